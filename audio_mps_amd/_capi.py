@@ -1,0 +1,93 @@
+"""ctypes binding of libcmps.so (include/cmps.h).  There is NO fallback: if the HIP library is missing
+or a symbol is absent this module raises, and everything built on it fails loudly."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcmps.so")
+
+CMPS_OK = 0
+CMPS_ERR_BAD_ARG = 1
+CMPS_ERR_UNSUPPORTED_D = 2
+CMPS_ERR_WORKSPACE = 3
+CMPS_ERR_HIP = 4
+CMPS_ERR_STATE = 5
+
+CMPS_WS_FWD_ONLY = 0
+CMPS_WS_TRAIN = 1
+
+CMPS_VARIANT_AUTO = 0
+CMPS_VARIANT_BLOCK = 1
+CMPS_VARIANT_WAVE = 2
+
+# every symbol include/cmps.h declares
+SYMBOLS = (
+    "cmps_version", "cmps_create", "cmps_destroy", "cmps_last_error", "cmps_set_variant",
+    "cmps_get_variant", "cmps_workspace_bytes", "cmps_set_params", "cmps_psi_loss_fwd",
+    "cmps_psi_loss_bwd", "cmps_psi_update_ancilla", "cmps_psi_states",
+)
+
+
+class CmpsError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libcmps error {code}: {message}")
+        self.code = code
+
+
+def _declare(lib):
+    c_int, c_float, c_double, c_size_t = ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_size_t
+    vp = ctypes.c_void_p
+    lib.cmps_version.argtypes = []
+    lib.cmps_version.restype = c_int
+    lib.cmps_create.argtypes = [c_int, ctypes.POINTER(vp)]
+    lib.cmps_create.restype = c_int
+    lib.cmps_destroy.argtypes = [vp]
+    lib.cmps_destroy.restype = c_int
+    lib.cmps_last_error.argtypes = [vp]
+    lib.cmps_last_error.restype = ctypes.c_char_p
+    lib.cmps_set_variant.argtypes = [vp, c_int]
+    lib.cmps_set_variant.restype = c_int
+    lib.cmps_get_variant.argtypes = [vp]
+    lib.cmps_get_variant.restype = c_int
+    lib.cmps_workspace_bytes.argtypes = [c_int, c_int, c_int, c_int]
+    lib.cmps_workspace_bytes.restype = c_size_t
+    lib.cmps_set_params.argtypes = [vp, vp, vp, vp, vp, vp, c_float, c_double, c_double, c_int, c_int,
+                                    c_int, vp, c_size_t, vp]
+    lib.cmps_set_params.restype = c_int
+    lib.cmps_psi_loss_fwd.argtypes = [vp, vp, c_int, c_int, vp, c_int, vp]
+    lib.cmps_psi_loss_fwd.restype = c_int
+    lib.cmps_psi_loss_bwd.argtypes = [vp, vp, c_int, c_int, vp, vp]
+    lib.cmps_psi_loss_bwd.restype = c_int
+    lib.cmps_psi_update_ancilla.argtypes = [vp, vp, vp, c_float, c_int, vp, vp]
+    lib.cmps_psi_update_ancilla.restype = c_int
+    lib.cmps_psi_states.argtypes = [vp, c_int, c_int, vp, vp]
+    lib.cmps_psi_states.restype = c_int
+
+
+_lib = None
+
+
+def load():
+    """Load libcmps.so (built in-tree by audio_mps_amd.build / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP library has not been built "
+            "(run `python -m audio_mps_amd.build` or `__graft_entry__.build()`); there is no CPU fallback")
+    lib = ctypes.CDLL(LIB_PATH)
+    missing = [s for s in SYMBOLS if not hasattr(lib, s)]
+    if missing:
+        raise ImportError(f"{LIB_PATH} lacks symbols {missing}")
+    _declare(lib)
+    _lib = lib
+    return lib
+
+
+def check(handle, code: int):
+    if code != CMPS_OK:
+        msg = load().cmps_last_error(handle)
+        raise CmpsError(code, msg.decode() if msg else "?")

@@ -1,0 +1,206 @@
+// C ABI of libcmps.so (see include/cmps.h for the contract and the reference lines each entry replaces).
+#include "../../include/cmps.h"
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "cmps_internal.h"
+
+using namespace cmps;
+
+struct cmps_handle_s {
+    int D = 0;
+    int variant_req = CMPS_VARIANT_AUTO;
+    bool params_set = false;
+    bool fwd_saved = false;
+    int saved_B = 0, saved_T = 0;
+    const float* saved_audio = nullptr;
+    float* saved_loss = nullptr;
+    Layout L{};
+    Dev P{};
+    char* ws = nullptr;
+    // time-table cache key: the table is rebuilt only when (workspace, N, dt) changes
+    char* tt_ws = nullptr;
+    int tt_N = -1;
+    float tt_dt = 0.f;
+    std::string err;
+};
+
+namespace {
+
+int fail(cmps_handle_t h, int code, const char* msg) {
+    if (h) h->err = msg;
+    return code;
+}
+
+int fail_hip(cmps_handle_t h, hipError_t e, const char* where) {
+    if (h) {
+        h->err = std::string(where) + ": " + hipGetErrorString(e);
+    }
+    return CMPS_ERR_HIP;
+}
+
+int resolve_variant(const cmps_handle_s* h) {
+    if (h->variant_req == CMPS_VARIANT_BLOCK) return CMPS_VARIANT_BLOCK;
+    if (h->variant_req == CMPS_VARIANT_WAVE) return h->D <= 32 ? CMPS_VARIANT_WAVE : CMPS_VARIANT_BLOCK;
+    return h->D <= 32 ? CMPS_VARIANT_WAVE : CMPS_VARIANT_BLOCK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cmps_version(void) { return 100; }
+
+int cmps_create(int D, cmps_handle_t* out) {
+    if (!out) return CMPS_ERR_BAD_ARG;
+    *out = nullptr;
+    if (D < 1 || D > 128) return CMPS_ERR_UNSUPPORTED_D;
+    cmps_handle_s* h = new (std::nothrow) cmps_handle_s();
+    if (!h) return CMPS_ERR_BAD_ARG;
+    h->D = D;
+    *out = h;
+    return CMPS_OK;
+}
+
+int cmps_destroy(cmps_handle_t h) {
+    delete h;
+    return CMPS_OK;
+}
+
+const char* cmps_last_error(cmps_handle_t h) { return h ? h->err.c_str() : "null handle"; }
+
+int cmps_set_variant(cmps_handle_t h, int variant) {
+    if (!h) return CMPS_ERR_BAD_ARG;
+    if (variant < CMPS_VARIANT_AUTO || variant > CMPS_VARIANT_WAVE)
+        return fail(h, CMPS_ERR_BAD_ARG, "cmps_set_variant: unknown variant");
+    if (variant == CMPS_VARIANT_WAVE && h->D > 32)
+        return fail(h, CMPS_ERR_UNSUPPORTED_D, "cmps_set_variant: the wave variant needs D <= 32");
+    h->variant_req = variant;
+    return CMPS_OK;
+}
+
+int cmps_get_variant(cmps_handle_t h) { return h ? resolve_variant(h) : 0; }
+
+size_t cmps_workspace_bytes(int D, int B, int T, int flags) {
+    if (D < 1 || D > 128 || B < 1 || T < 2) return 0;
+    return make_layout(D, B, T, flags).total;
+}
+
+int cmps_set_params(cmps_handle_t h, const float* R_re_dev, const float* R_im_dev,
+                    const float* freqs_dev, const float* psi0_re_dev, const float* psi0_im_dev,
+                    float A, double sigma, double delta_t, int T, int B_max, int flags,
+                    void* workspace_dev, size_t workspace_bytes, void* stream) {
+    if (!h) return CMPS_ERR_BAD_ARG;
+    if (!R_re_dev || !R_im_dev || !freqs_dev || !psi0_re_dev || !psi0_im_dev)
+        return fail(h, CMPS_ERR_BAD_ARG, "cmps_set_params: null parameter pointer");
+    if (T < 2 || B_max < 1) return fail(h, CMPS_ERR_BAD_ARG, "cmps_set_params: need T >= 2 and B_max >= 1");
+    if (!workspace_dev) return fail(h, CMPS_ERR_WORKSPACE, "cmps_set_params: null workspace");
+    Layout L = make_layout(h->D, B_max, T, flags);
+    if (workspace_bytes < L.total) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "cmps_set_params: workspace has %zu bytes, needs %zu", workspace_bytes, L.total);
+        return fail(h, CMPS_ERR_WORKSPACE, buf);
+    }
+    if (((uintptr_t)workspace_dev & 255) != 0)
+        return fail(h, CMPS_ERR_WORKSPACE, "cmps_set_params: workspace must be 256-byte aligned");
+    char* ws = static_cast<char*>(workspace_dev);
+    Dev P{};
+    P.D = L.D; P.DP = L.DP; P.B = B_max; P.T = T; P.N = L.N;
+    P.R = reinterpret_cast<float2*>(ws + L.off_R);
+    P.RT = reinterpret_cast<float2*>(ws + L.off_RT);
+    P.Q = reinterpret_cast<float2*>(ws + L.off_Q);
+    P.psi0 = reinterpret_cast<float2*>(ws + L.off_psi0);
+    P.freqs = reinterpret_cast<float*>(ws + L.off_freqs);
+    P.ttab = reinterpret_cast<float*>(ws + L.off_ttab);
+    P.dtk = reinterpret_cast<float*>(ws + L.off_dtk);
+    P.rho = reinterpret_cast<float2*>(ws + L.off_rho);
+    P.stash = (flags & CMPS_WS_TRAIN) ? reinterpret_cast<float2*>(ws + L.off_stash) : nullptr;
+    P.slabs = (flags & CMPS_WS_TRAIN) ? reinterpret_cast<float*>(ws + L.off_slabs) : nullptr;
+    P.sums = (flags & CMPS_WS_TRAIN) ? reinterpret_cast<float*>(ws + L.off_sums) : nullptr;
+    P.slab_floats = L.slab_floats;
+    P.A = A;
+    // model.py:312: `- self.delta_t * self.sigma**2` is a Python float (double), cast to complex64,
+    // multiplied in, then divided by 2. (exact halving)
+    P.c_half = (float)(-delta_t * sigma * sigma) / 2.0f;
+    const float dt = (float)delta_t;  // model.py:16
+    const bool rebuild = !(h->tt_ws == ws && h->tt_N == L.N && h->tt_dt == dt);
+    hipError_t e = launch_prep(P, R_re_dev, R_im_dev, freqs_dev, psi0_re_dev, psi0_im_dev, dt, rebuild,
+                               const_cast<float*>(P.ttab), const_cast<float*>(P.dtk),
+                               const_cast<float2*>(P.R), const_cast<float2*>(P.RT),
+                               const_cast<float2*>(P.Q), const_cast<float2*>(P.psi0),
+                               const_cast<float*>(P.freqs), const_cast<float2*>(P.rho),
+                               static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail_hip(h, e, "cmps_set_params");
+    h->tt_ws = ws; h->tt_N = L.N; h->tt_dt = dt;
+    h->L = L; h->P = P; h->ws = ws;
+    h->params_set = true;
+    h->fwd_saved = false;
+    return CMPS_OK;
+}
+
+int cmps_psi_loss_fwd(cmps_handle_t h, const float* audio_dev, int B, int T, float* loss_dev,
+                      int save_for_bwd, void* stream) {
+    if (!h) return CMPS_ERR_BAD_ARG;
+    if (!h->params_set) return fail(h, CMPS_ERR_STATE, "cmps_psi_loss_fwd: call cmps_set_params first");
+    if (!audio_dev || !loss_dev) return fail(h, CMPS_ERR_BAD_ARG, "cmps_psi_loss_fwd: null pointer");
+    if (T != h->L.T) return fail(h, CMPS_ERR_BAD_ARG, "cmps_psi_loss_fwd: T differs from cmps_set_params");
+    if (B < 1 || B > h->L.B) return fail(h, CMPS_ERR_BAD_ARG, "cmps_psi_loss_fwd: B outside [1, B_max]");
+    if (save_for_bwd && !(h->L.flags & CMPS_WS_TRAIN))
+        return fail(h, CMPS_ERR_WORKSPACE, "cmps_psi_loss_fwd: save_for_bwd needs a CMPS_WS_TRAIN workspace");
+    Dev P = h->P;
+    P.B = B;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = (resolve_variant(h) == CMPS_VARIANT_WAVE)
+                       ? launch_fwd_wave(P, audio_dev, loss_dev, save_for_bwd != 0, s)
+                       : launch_fwd_block(P, audio_dev, loss_dev, save_for_bwd != 0, s);
+    if (e != hipSuccess) return fail_hip(h, e, "cmps_psi_loss_fwd");
+    h->fwd_saved = save_for_bwd != 0;
+    h->saved_B = B; h->saved_T = T; h->saved_audio = audio_dev; h->saved_loss = loss_dev;
+    return CMPS_OK;
+}
+
+int cmps_psi_loss_bwd(cmps_handle_t h, const float* audio_dev, int B, int T, float* grad_dev, void* stream) {
+    if (!h) return CMPS_ERR_BAD_ARG;
+    if (!h->params_set || !h->fwd_saved)
+        return fail(h, CMPS_ERR_STATE, "cmps_psi_loss_bwd: needs cmps_psi_loss_fwd(save_for_bwd=1) first");
+    if (!audio_dev || !grad_dev) return fail(h, CMPS_ERR_BAD_ARG, "cmps_psi_loss_bwd: null pointer");
+    if (B != h->saved_B || T != h->saved_T || audio_dev != h->saved_audio)
+        return fail(h, CMPS_ERR_STATE, "cmps_psi_loss_bwd: audio / B / T differ from the forward call");
+    Dev P = h->P;
+    P.B = B;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = (resolve_variant(h) == CMPS_VARIANT_WAVE) ? launch_bwd_wave(P, audio_dev, s)
+                                                             : launch_bwd_block(P, audio_dev, s);
+    if (e != hipSuccess) return fail_hip(h, e, "cmps_psi_loss_bwd (scan)");
+    e = launch_reduce_finalize(P, h->saved_loss, grad_dev, s);
+    if (e != hipSuccess) return fail_hip(h, e, "cmps_psi_loss_bwd (reduce)");
+    return CMPS_OK;
+}
+
+int cmps_psi_update_ancilla(cmps_handle_t h, const float* psi_in_dev, const float* signal_dev, float t,
+                            int B, float* psi_out_dev, void* stream) {
+    if (!h) return CMPS_ERR_BAD_ARG;
+    if (!h->params_set) return fail(h, CMPS_ERR_STATE, "cmps_psi_update_ancilla: call cmps_set_params first");
+    if (!psi_in_dev || !signal_dev || !psi_out_dev || B < 1)
+        return fail(h, CMPS_ERR_BAD_ARG, "cmps_psi_update_ancilla: bad argument");
+    hipError_t e = launch_update_ancilla(h->P, psi_in_dev, signal_dev, t, B, psi_out_dev,
+                                         static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail_hip(h, e, "cmps_psi_update_ancilla");
+    return CMPS_OK;
+}
+
+int cmps_psi_states(cmps_handle_t h, int B, int T, float* psi_out_dev, void* stream) {
+    if (!h) return CMPS_ERR_BAD_ARG;
+    if (!h->params_set || !h->fwd_saved)
+        return fail(h, CMPS_ERR_STATE, "cmps_psi_states: needs cmps_psi_loss_fwd(save_for_bwd=1) first");
+    if (!psi_out_dev || B != h->saved_B || T != h->saved_T)
+        return fail(h, CMPS_ERR_BAD_ARG, "cmps_psi_states: bad argument");
+    hipError_t e = launch_states(h->P, B, psi_out_dev, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail_hip(h, e, "cmps_psi_states");
+    return CMPS_OK;
+}
+
+}  // extern "C"

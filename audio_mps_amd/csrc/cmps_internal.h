@@ -1,0 +1,111 @@
+// Internal declarations shared by the HIP translation units of libcmps.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace cmps {
+
+// ---------------------------------------------------------------------------------------------
+// Workspace layout (all offsets in bytes from the workspace base, every section 256-B aligned).
+//
+//   mats     : R [D][D] float2 | RT [D][D] float2 (RT[j][i] = R[i][j]) | Q [D][D] float2
+//              (Q = -(dt sigma^2 / 2) R^dagger R, Hermitian) | psi0 [D] float2 | freqs [D] float
+//   ttab     : t_k, k = 0..N          float32, sequential sum (model.py:16,266,281)
+//   dtk      : t_k - t_{k+1}          float32 (exact), k = 0..N-1
+//   rho      : [N][DP] float2         rho_k[d] = exp(i (fl(f_d t_k) - fl(f_d t_{k+1})))
+//   stash    : [B][N][DP] float2      un-normalised rotating-frame state y_k (TRAIN only)
+//   slabs    : [B][slab] float        per-clip gradient partials (TRAIN only)
+//   sums     : [slab] float           reduced partials
+// DP = D for the block variant; 32 for the wave variant (components >= D are zero padding).
+// ---------------------------------------------------------------------------------------------
+struct Layout {
+    int D, DP, B, T, N, flags;
+    size_t off_R, off_RT, off_Q, off_psi0, off_freqs, off_ttab, off_dtk, off_rho, off_stash,
+        off_slabs, off_sums, total;
+    size_t slab_floats;  // 4*DP*DP + 3*DP + 2
+};
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+inline int padded_D(int D) { return D <= 32 ? 32 : D; }
+
+inline Layout make_layout(int D, int B, int T, int flags) {
+    Layout L{};
+    L.D = D; L.B = B; L.T = T; L.N = T - 1; L.flags = flags;
+    // one layout serves both variants: tables are sized for the larger stride
+    L.DP = padded_D(D);
+    const size_t DP = (size_t)L.DP, N = (size_t)L.N;
+    size_t o = 0;
+    L.off_R = o;     o = align256(o + DP * DP * sizeof(float2));
+    L.off_RT = o;    o = align256(o + DP * DP * sizeof(float2));
+    L.off_Q = o;     o = align256(o + DP * DP * sizeof(float2));
+    L.off_psi0 = o;  o = align256(o + DP * sizeof(float2));
+    L.off_freqs = o; o = align256(o + DP * sizeof(float));
+    L.off_ttab = o;  o = align256(o + (N + 1) * sizeof(float));
+    L.off_dtk = o;   o = align256(o + (N + 64) * sizeof(float));
+    L.off_rho = o;   o = align256(o + (N + 1) * DP * sizeof(float2));
+    L.slab_floats = 4 * DP * DP + 3 * DP + 2;
+    L.off_stash = o;
+    L.off_slabs = o;
+    L.off_sums = o;
+    if (flags & 1) {
+        o = align256(o + (size_t)B * N * DP * sizeof(float2));
+        L.off_slabs = o; o = align256(o + (size_t)B * L.slab_floats * sizeof(float));
+        L.off_sums = o;  o = align256(o + L.slab_floats * sizeof(float));
+    }
+    L.total = o;
+    return L;
+}
+
+// Device-side view handed to the kernels by value.
+struct Dev {
+    int D, DP, B, T, N;
+    const float2* R;     // [DP][DP] row-major
+    const float2* RT;    // [DP][DP], RT[j][i] = R[i][j]
+    const float2* Q;     // [DP][DP] row-major, Hermitian
+    const float2* psi0;  // [DP]
+    const float* freqs;  // [DP]
+    const float* ttab;   // [N+1]
+    const float* dtk;    // [N]
+    const float2* rho;   // [N][DP]
+    float2* stash;       // [B][N][DP]
+    float* slabs;        // [B][slab]
+    float* sums;         // [slab]
+    size_t slab_floats;
+    float A;
+    float c_half;        // (float)(-delta_t * sigma^2) / 2   (model.py:312)
+};
+
+// ---- launchers (each returns the hipError_t of its launches) ----
+hipError_t launch_prep(const Dev& P, const float* R_re, const float* R_im, const float* freqs,
+                       const float* psi0_re, const float* psi0_im, float dt, bool rebuild_ttab,
+                       float* ttab, float* dtk, float2* R, float2* RT, float2* Q, float2* psi0,
+                       float* freqs_out, float2* rho, hipStream_t s);
+
+hipError_t launch_fwd_block(const Dev& P, const float* audio, float* loss, bool save, hipStream_t s);
+hipError_t launch_bwd_block(const Dev& P, const float* audio, hipStream_t s);
+hipError_t launch_fwd_wave(const Dev& P, const float* audio, float* loss, bool save, hipStream_t s);
+hipError_t launch_bwd_wave(const Dev& P, const float* audio, hipStream_t s);
+hipError_t launch_reduce_finalize(const Dev& P, const float* loss, float* grad_out, hipStream_t s);
+hipError_t launch_update_ancilla(const Dev& P, const float* psi_in, const float* signal, float t,
+                                 int B, float* psi_out, hipStream_t s);
+hipError_t launch_states(const Dev& P, int B, float* psi_out, hipStream_t s);
+
+// ---- small complex helpers (device) ----
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 cmul_conj_a(float2 a, float2 b) {  // conj(a) * b
+    return make_float2(a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ float2 cfma(float2 a, float2 b, float2 c) {  // a*b + c
+    return make_float2(fmaf(a.x, b.x, fmaf(-a.y, b.y, c.x)), fmaf(a.x, b.y, fmaf(a.y, b.x, c.y)));
+}
+__device__ __forceinline__ float2 cfma_conj_a(float2 a, float2 b, float2 c) {  // conj(a)*b + c
+    return make_float2(fmaf(a.x, b.x, fmaf(a.y, b.y, c.x)), fmaf(a.x, b.y, fmaf(-a.y, b.x, c.y)));
+}
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 cscale(float s, float2 a) { return make_float2(s * a.x, s * a.y); }
+
+}  // namespace cmps

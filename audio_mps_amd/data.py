@@ -1,0 +1,32 @@
+"""Input fixture of the reference: ``get_audio`` (data.py:6-45).  Only the synthetic ``damped_sine``
+branch (data.py:8-22) is on the hot path's boundary; the TFRecord branch (data.py:25-43) is a 'next' row
+ and raises."""
+from __future__ import annotations
+
+import numpy as np
+
+
+def damped_sine(batch: int, input_length: int, delta_t: float, seed: int = 0) -> np.ndarray:
+    """Gamma-delayed, exponentially damped 261.6 Hz sine, float32 [batch, input_length] (data.py:10-22).
+    delays ~ Gamma(alpha=2, beta=2/delay_time) with delay_time = input_length / 100 (data.py:13,15);
+    the reference draws them with tf.random_gamma, here a seeded numpy Generator."""
+    rng = np.random.default_rng(seed)
+    freq = 261.6            # Middle C (data.py:11)
+    decay_time = 0.1        # data.py:12
+    delay_time = input_length / 100
+    delays = rng.gamma(shape=2.0, scale=delay_time / 2.0, size=batch).astype(np.float32)
+    input_range = np.arange(input_length, dtype=np.float32)[None, :]
+    times = (input_range - delays[:, None]) * np.float32(delta_t)
+    wave = (np.float32(0.5) * (np.sign(times) + np.float32(1))
+            * np.sin(np.float32(2 * np.pi * freq) * times) * np.exp(-times / np.float32(decay_time)))
+    return wave.astype(np.float32)
+
+
+def get_audio(datadir, dataset, hps, sample_duration: int = 2 ** 16, seed: int = 0) -> np.ndarray:
+    """``get_audio(datadir, dataset, hps)`` (data.py:6); ``sample_duration`` is the reference's global
+    FLAGS.sample_duration (train.py:27, data.py:10)."""
+    if dataset == "damped_sine":
+        return damped_sine(hps.minibatch_size, sample_duration, hps.delta_t, seed=seed)
+    raise NotImplementedError(
+        f"dataset {dataset!r}: the TFRecord branch (data.py:25-43) is a 'next' row (SURVEY.md 8f); "
+        "the data blobs are absent from the reference (.MISSING_LARGE_BLOBS)")

@@ -1,0 +1,332 @@
+"""Host-side mirror of the reference's model surface for the pure-state path.
+
+Same class names, constructor arguments, hyper-parameter field names and attributes as
+/root/reference/model.py (CMPS :5-52, PsiCMPS :206-334) and the legacy ``AudioMPS`` surface that
+training_estimators.py:43-45 / follow_vae.py:45-51 call.  The reference builds a TensorFlow graph whose
+``.loss`` tensor is evaluated in a session and differentiated by ``AdamOptimizer.minimize``
+(train.py:89); here ``.loss`` launches the HIP scan (audio_mps_amd/csrc) and ``loss_and_grads()`` runs
+the forward + reverse kernels and applies the tiny host-side chain rule from the kernels' outputs
+(gradients w.r.t. the effective R, freqs, psi_0, A) to the raw variables (Rx, Ry, freqs, psi_x, psi_y, A).
+
+Out of scope on this surface ("next" rows): RhoCMPS / ``mixed=True``, sampling.
+They raise NotImplementedError rather than silently doing something else.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, fields
+from typing import Callable, Dict, Optional
+
+import numpy as np
+
+VARIABLE_NAMES = ("A", "Rx", "Ry", "freqs", "psi_x", "psi_y")
+
+
+# --------------------------------------------------------------------------------------------------
+# hyper-parameters: field names of tf.contrib.training.HParams at train.py:41-43
+# --------------------------------------------------------------------------------------------------
+@dataclass
+class HParams:
+    minibatch_size: int = 8
+    bond_dim: int = 8
+    delta_t: float = 1.0 / 16000
+    sigma: float = 0.0001
+    h_reg: float = 200.0 / (math.pi * 16000) ** 2
+    r_reg: float = 0.1
+    initial_rank: Optional[int] = None
+    A: float = 100.0
+    learning_rate: float = 0.001
+
+    def parse(self, spec: str) -> "HParams":
+        """``--hparams=name=value,...`` override (train.py:31,44)."""
+        if not spec:
+            return self
+        known = {f.name: f for f in fields(self)}
+        for item in spec.split(","):
+            if not item.strip():
+                continue
+            name, _, value = item.partition("=")
+            name = name.strip()
+            if name not in known:
+                raise ValueError(f"Unknown hyperparameter: {name}")
+            cur = getattr(self, name)
+            if name == "initial_rank":
+                setattr(self, name, None if value.strip() in ("None", "") else int(value))
+            elif isinstance(cur, int) and not isinstance(cur, bool):
+                setattr(self, name, int(value))
+            else:
+                setattr(self, name, float(value))
+        return self
+
+    def values(self) -> dict:
+        return {f.name: getattr(self, f.name) for f in fields(self)}
+
+
+def _f32(x):
+    return np.float32(x)
+
+
+def _rsqrt32(x) -> np.float32:
+    """tf.rsqrt(python_float): evaluated in float32 (model.py:36,38,49)."""
+    return np.float32(1) / np.sqrt(np.float32(x))
+
+
+def _normalize_psi_host(p: np.ndarray) -> np.ndarray:
+    """_normalize_psi with axis=None (model.py:327-334) for the D-vector psi_0 (tiny; host)."""
+    a = np.abs(p).astype(np.float32)
+    ss = np.sum(np.square(a), dtype=np.float32)
+    inv = np.float32(1) / np.sqrt(np.maximum(ss, np.float32(1e-12)))
+    return (p * np.complex64(inv)).astype(np.complex64)
+
+
+# --------------------------------------------------------------------------------------------------
+class CMPS:
+    """Continuous Matrix Product State: the trainable variables and the effective parameters
+    (model.py:5-52).  ``self.R`` (complex64 [D,D], diagonal removed as at model.py:42), ``self.freqs``,
+    ``self.A``, ``self.sigma`` are the attributes train.py:55-75 reads."""
+
+    def __init__(self, hparams, data_iterator=None, freqs_in=None, R_in=None, seed: int = 0):
+        self.hparams = hparams
+        self.bond_d = int(hparams.bond_dim)
+        self.batch_size = hparams.minibatch_size
+        self.h_reg = hparams.h_reg
+        self.r_reg = hparams.r_reg
+        self.delta_t = hparams.delta_t
+        self.dt = np.float32(hparams.delta_t)                     # model.py:16
+        self.sigma = hparams.sigma                                # model.py:21 (not trainable)
+        self.data_iterator = data_iterator
+        D = self.bond_d
+        rng = np.random.default_rng(seed)
+        self.variables: Dict[str, np.ndarray] = {}
+        self.variables["A"] = np.asarray(np.float32(hparams.A))   # model.py:19
+        # --- R (model.py:31-42)
+        if R_in is not None:
+            R_in = np.asarray(R_in)
+            if R_in.shape != (D, D):
+                raise ValueError(f"R_in must be [{D},{D}]")
+            self.variables["Rx"] = R_in.real.astype(np.float32)
+            self.variables["Ry"] = R_in.imag.astype(np.float32)
+            self._c_r = np.float32(1)
+        else:
+            self.variables["Rx"] = rng.standard_normal((D, D)).astype(np.float32)   # random_normal_initializer
+            self.variables["Ry"] = rng.standard_normal((D, D)).astype(np.float32)
+            self._c_r = _rsqrt32(self.r_reg)
+        # --- freqs (model.py:44-49)
+        if freqs_in is not None:
+            freqs_in = np.asarray(freqs_in, dtype=np.float32)
+            if freqs_in.shape != (D,):
+                raise ValueError(f"freqs_in must be [{D}]")
+            self.variables["freqs"] = freqs_in.copy()
+            self._c_h = np.float32(1)
+        else:
+            self.variables["freqs"] = rng.standard_normal(D).astype(np.float32)
+            self._c_h = _rsqrt32(self.h_reg)
+        self._rng = rng
+
+    # effective parameters, recomputed from the current variables ---------------------------------
+    @property
+    def A(self) -> np.float32:
+        return np.float32(self.variables["A"])
+
+    @property
+    def R(self) -> np.ndarray:
+        Rx = (self._c_r * self.variables["Rx"]).astype(np.float32) if self._c_r != 1 else self.variables["Rx"]
+        Ry = (self._c_r * self.variables["Ry"]).astype(np.float32) if self._c_r != 1 else self.variables["Ry"]
+        Z = (Rx + 1j * Ry).astype(np.complex64)                   # model.py:41
+        return (Z - np.diagonal(Z)[None, :]).astype(np.complex64)  # model.py:42 (row-vector broadcast)
+
+    @property
+    def freqs(self) -> np.ndarray:
+        f = self.variables["freqs"]
+        return (self._c_h * f).astype(np.float32) if self._c_h != 1 else f.astype(np.float32)
+
+    @property
+    def freqsc(self) -> np.ndarray:
+        return self.freqs.astype(np.complex64)                    # model.py:52
+
+
+# --------------------------------------------------------------------------------------------------
+class PsiCMPS(CMPS):
+    """Evolves the state (model.py:206-334).
+
+    ``data_iterator`` is the batch the loss is evaluated on: a float32 [B, T] numpy array or CUDA tensor,
+    or a zero-argument callable returning one (the eager stand-in for the TF input tensor that yields a
+    new batch per session.run).  ``backend`` is the scan implementation; the product has exactly one
+    (``HipScan``, the HIP kernels) and constructs it on first use -- tests may inject another object with
+    the same two methods to exercise the host logic without a GPU.
+    """
+
+    def __init__(self, hparams, psi_in=None, *args, backend=None, **kwargs):
+        super().__init__(hparams, *args, **kwargs)
+        D = self.bond_d
+        if psi_in is not None:
+            # the reference's branch is broken (undefined psi_x_in, model.py:214-216); a complex D-vector
+            psi_in = np.asarray(psi_in)
+            if psi_in.shape != (D,):
+                raise ValueError(f"psi_in must be [{D}]")
+            self.variables["psi_x"] = psi_in.real.astype(np.float32)
+            self.variables["psi_y"] = psi_in.imag.astype(np.float32)
+        else:
+            # initializer=None -> TF default glorot_uniform; 1-D [D]: limit sqrt(6 / (D + D))  (model.py:218-219)
+            lim = math.sqrt(6.0 / (2 * D))
+            self.variables["psi_x"] = self._rng.uniform(-lim, lim, D).astype(np.float32)
+            self.variables["psi_y"] = self._rng.uniform(-lim, lim, D).astype(np.float32)
+        self._backend = backend
+        self._last = None
+
+    # ---- attributes of the reference object ----
+    @property
+    def psi_0(self) -> np.ndarray:
+        p = (self.variables["psi_x"] + 1j * self.variables["psi_y"]).astype(np.complex64)   # model.py:221
+        return _normalize_psi_host(p)                                                        # model.py:222
+
+    @property
+    def loss(self) -> np.float32:
+        """PsiCMPS.loss (model.py:224-225, 267): mean over the batch of the per-clip loss."""
+        if self.data_iterator is None:
+            raise AttributeError("loss: the model was built without a data_iterator (model.py:224)")
+        per_clip = self.loss_per_clip()
+        return np.float32(np.mean(per_clip, dtype=np.float32))
+
+    # ---- backend plumbing ----
+    def _get_backend(self):
+        if self._backend is None:
+            from .scan import HipScan   # raises if libcmps.so or the GPU is missing: no fallback
+            self._backend = HipScan(self.bond_d)
+        return self._backend
+
+    def effective_params(self):
+        from .scan import EffectiveParams
+        return EffectiveParams(R=self.R, freqs=self.freqs, psi0=self.psi_0, A=float(self.A),
+                               sigma=float(self.sigma), delta_t=float(self.delta_t))
+
+    def _batch(self, data=None):
+        data = self.data_iterator if data is None else data
+        if callable(data):
+            data = data()
+        return data
+
+    def _to_device(self, data):
+        import torch
+        be = self._get_backend()
+        dev = getattr(be, "device", None)
+        if isinstance(data, torch.Tensor):
+            t = data.to(dtype=torch.float32)
+            if dev is not None:
+                t = t.to(dev)
+            return t.contiguous()
+        t = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32))
+        return t.to(dev) if dev is not None else t
+
+    # ---- the hot path ----
+    def loss_per_clip(self, data=None) -> np.ndarray:
+        """The fold carry ``loss`` [B] of model.py:265-266 (forward only)."""
+        audio = self._to_device(self._batch(data))
+        B, T = audio.shape
+        be = self._get_backend()
+        be.set_params(self.effective_params(), B, T, train=False)
+        return be.forward(audio, save_for_bwd=False).detach().cpu().numpy()
+
+    def grad_sums(self, data=None):
+        """Forward + reverse scan on this process's clips.  Returns (flat device/host buffer of SUMS over
+        clips as laid out by cmps_psi_loss_bwd, number of clips).  Used by loss_and_grads and by the
+        data-parallel trainer, which all-reduces the buffer before the chain rule."""
+        audio = self._to_device(self._batch(data))
+        B, T = audio.shape
+        be = self._get_backend()
+        be.set_params(self.effective_params(), B, T, train=True)
+        _, grad = be.loss_and_grad_sums(audio)
+        return grad, B
+
+    def chain_rule(self, flat_sums: np.ndarray, global_batch: int, with_reg: bool = False):
+        """Effective-parameter gradient sums -> (mean loss, gradients w.r.t. the raw variables).
+        Adjoint of model.py:36-42 (scaling + the row-broadcast diagonal removal), :49, :221-222, and
+        optionally the regularisers of train.py:55-60."""
+        from .scan import unpack_grad
+        D = self.bond_d
+        g = unpack_grad(np.asarray(flat_sums, dtype=np.float64), D)
+        invB = 1.0 / float(global_batch)
+        Rbar = g["Rbar"] * invB
+        fbar = g["fbar"] * invB
+        p0bar = g["psi0bar"] * invB
+        Abar = g["Abar"] * invB
+        loss = g["loss_sum"] * invB
+        if with_reg:
+            R = self.R.astype(np.complex128)
+            f = self.freqs.astype(np.float64)
+            loss = loss + self.h_reg * np.sum(f * f) + self.r_reg * np.sum((np.conj(R) * R).real)
+            fbar = fbar + 2.0 * self.h_reg * f
+            Rbar = Rbar + 2.0 * self.r_reg * R
+        Zbar = Rbar - np.diag(np.sum(Rbar, axis=0))               # adjoint of model.py:42
+        c_r, c_h = float(self._c_r), float(self._c_h)
+        p = (self.variables["psi_x"].astype(np.float64) + 1j * self.variables["psi_y"].astype(np.float64))
+        ss = float(np.sum(np.abs(p) ** 2))
+        m = max(ss, 1e-12)
+        inv = 1.0 / math.sqrt(m)
+        pbar = p0bar * inv
+        if ss > 1e-12:
+            inv_bar = float(np.sum((np.conj(p0bar) * p).real))
+            pbar = pbar + 2.0 * (inv_bar * (-0.5 * inv / m)) * p
+        grads = {
+            "A": np.asarray(np.float32(Abar)),
+            "Rx": (c_r * Zbar.real).astype(np.float32),
+            "Ry": (c_r * Zbar.imag).astype(np.float32),
+            "freqs": (c_h * fbar).astype(np.float32),
+            "psi_x": pbar.real.astype(np.float32),
+            "psi_y": pbar.imag.astype(np.float32),
+        }
+        return np.float32(loss), grads
+
+    def loss_and_grads(self, data=None, with_reg: bool = False):
+        """(loss, {variable: gradient}) of mean_b loss_b (+ train.py's regularisers if with_reg): what
+        ``AdamOptimizer.minimize`` obtains from TF (train.py:89)."""
+        flat, B = self.grad_sums(data)
+        host = flat.detach().cpu().numpy() if hasattr(flat, "detach") else np.asarray(flat)
+        self._last = host
+        return self.chain_rule(host, B, with_reg=with_reg)
+
+    # ---- other reference methods on this class ----
+    def _update_ancilla_psi(self, psi, signal, t):
+        """model.py:300-317 for a batch of states (used by the reference's testTrivialUpdateOfAncilla)."""
+        be = self._get_backend()
+        psi = np.asarray(psi, dtype=np.complex64)
+        be.set_params(self.effective_params(), psi.shape[0], 2, train=False)
+        return be.update_ancilla(psi, np.asarray(signal, dtype=np.float32), float(t))
+
+    def psi_evolve_with_data(self, data=None) -> np.ndarray:
+        """model.py:231-240: the normalised state after every step, [B, T-1, D]."""
+        audio = self._to_device(self._batch(data))
+        B, T = audio.shape
+        be = self._get_backend()
+        be.set_params(self.effective_params(), B, T, train=True)
+        be.forward(audio, save_for_bwd=True)
+        return be.states()
+
+    def sample(self, num_samples, length, temp=1):
+        raise NotImplementedError("PsiCMPS.sample (model.py:242-251) is a 'next' row (SURVEY.md 8f), not built yet")
+
+
+# --------------------------------------------------------------------------------------------------
+class RhoCMPS(CMPS):
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError("RhoCMPS (model.py:55-203) is a 'next' row (SURVEY.md 8f), not built yet")
+
+
+class AudioMPS(PsiCMPS):
+    """Legacy surface: ``AudioMPS(bond_d, dt, batch_size, data_iterator=..., mixed=...)``
+    (training_estimators.py:43-45; ``AudioMPS(bond_d, delta_t=..., data_iterator=...)`` in
+    notebooks/testing-AudioMPS.ipynb:268).  The class body no longer exists in the reference's model.py;
+    PsiCMPS is its successor, so this wraps PsiCMPS with train.py's remaining hyper-parameters."""
+
+    def __init__(self, bond_d, dt=None, batch_size=8, data_iterator=None, mixed=False, delta_t=None,
+                 hparams: Optional[HParams] = None, **kwargs):
+        if mixed:
+            raise NotImplementedError("AudioMPS(mixed=True) maps to RhoCMPS, a 'next' row (SURVEY.md 8f)")
+        if dt is None:
+            dt = delta_t
+        if dt is None:
+            raise TypeError("AudioMPS needs dt (or delta_t)")
+        hp = hparams if hparams is not None else HParams()
+        hp = HParams(**{**hp.values(), "bond_dim": int(bond_d), "delta_t": float(dt),
+                        "minibatch_size": int(batch_size)})
+        super().__init__(hp, data_iterator=data_iterator, **kwargs)

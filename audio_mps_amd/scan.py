@@ -1,0 +1,193 @@
+"""Host driver of the HIP scan: owns a libcmps handle and a device workspace (a torch uint8 tensor used
+purely as an allocation), and exposes the two operations the model needs.
+
+PyTorch appears here only as plumbing: device memory, the current HIP stream, host<->device copies.
+All arithmetic of the hot path happens in libcmps.so (audio_mps_amd/csrc/*.hip).
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _capi
+
+
+@dataclass
+class EffectiveParams:
+    """What CMPS.__init__ / PsiCMPS.__init__ hand to the scan (model.py:41-52, 221-222)."""
+    R: np.ndarray        # [D, D] complex64, after the diagonal removal of model.py:42
+    freqs: np.ndarray    # [D] float32
+    psi0: np.ndarray     # [D] complex64, normalised
+    A: float
+    sigma: float
+    delta_t: float
+
+
+def grad_size(D: int) -> int:
+    return 2 * D * D + 3 * D + 2
+
+
+def unpack_grad(flat, D: int):
+    """Flat buffer of cmps_psi_loss_bwd -> dict (sums over clips)."""
+    g = np.asarray(flat)
+    DD = D * D
+    return {
+        "Rbar": (g[:DD] + 1j * g[DD:2 * DD]).reshape(D, D),
+        "fbar": g[2 * DD:2 * DD + D],
+        "psi0bar": g[2 * DD + D:2 * DD + 2 * D] + 1j * g[2 * DD + 2 * D:2 * DD + 3 * D],
+        "Abar": g[2 * DD + 3 * D],
+        "loss_sum": g[2 * DD + 3 * D + 1],
+    }
+
+
+class HipScan:
+    """The MI355X backend: per-clip loss and parameter-gradient sums for a batch resident on the GPU."""
+
+    name = "hip"
+
+    def __init__(self, D: int, device: Optional[torch.device] = None, variant: int = _capi.CMPS_VARIANT_AUTO):
+        self._lib = _capi.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("HipScan needs a GPU (torch.cuda.is_available() is False); there is no CPU fallback")
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.D = int(D)
+        h = ctypes.c_void_p()
+        code = self._lib.cmps_create(self.D, ctypes.byref(h))
+        if code != _capi.CMPS_OK:
+            raise _capi.CmpsError(code, f"cmps_create(D={D}) failed")
+        self._h = h
+        _capi.check(self._h, self._lib.cmps_set_variant(self._h, int(variant)))
+        self._ws = None
+        self._ws_key = None
+        self._param_buf = torch.empty(2 * D * D + 3 * D, dtype=torch.float32, device=self.device)
+        self._param_host = torch.empty(2 * D * D + 3 * D, dtype=torch.float32).pin_memory()
+        self._param_evt = None
+        self._B = self._T = 0
+        self._audio = None
+        self._loss = None
+        self._grad = torch.empty(grad_size(D), dtype=torch.float32, device=self.device)
+
+    # ------------------------------------------------------------------
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._lib.cmps_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    @property
+    def variant(self) -> int:
+        return int(self._lib.cmps_get_variant(self._h))
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def workspace_bytes(self, B: int, T: int, train: bool) -> int:
+        return int(self._lib.cmps_workspace_bytes(self.D, B, T, _capi.CMPS_WS_TRAIN if train else _capi.CMPS_WS_FWD_ONLY))
+
+    def _ensure_ws(self, B: int, T: int, train: bool):
+        key = (B, T, train)
+        if self._ws_key != key:
+            nbytes = self.workspace_bytes(B, T, train)
+            if nbytes == 0:
+                raise ValueError(f"invalid shape for the scan: D={self.D}, B={B}, T={T}")
+            self._ws = None
+            self._ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+            self._ws_key = key
+        base = self._ws.data_ptr()
+        return (base + 255) // 256 * 256, self._ws.numel() - 256
+
+    # ------------------------------------------------------------------
+    def set_params(self, p: EffectiveParams, B: int, T: int, train: bool = True):
+        """cmps_set_params: upload the effective parameters and rebuild the derived tables."""
+        D = self.D
+        R = np.asarray(p.R)
+        if R.shape != (D, D):
+            raise ValueError(f"R must be [{D},{D}]")
+        if self._param_evt is not None:
+            self._param_evt.synchronize()  # the previous upload must have left the pinned buffer
+        host = self._param_host.numpy()
+        DD = D * D
+        host[:DD] = R.real.astype(np.float32).ravel()
+        host[DD:2 * DD] = R.imag.astype(np.float32).ravel()
+        host[2 * DD:2 * DD + D] = np.asarray(p.freqs, dtype=np.float32)
+        psi0 = np.asarray(p.psi0)
+        host[2 * DD + D:2 * DD + 2 * D] = psi0.real.astype(np.float32)
+        host[2 * DD + 2 * D:2 * DD + 3 * D] = psi0.imag.astype(np.float32)
+        self._param_buf.copy_(self._param_host, non_blocking=True)
+        self._param_evt = torch.cuda.Event()
+        self._param_evt.record(torch.cuda.current_stream(self.device))
+        ws_ptr, ws_bytes = self._ensure_ws(B, T, train)
+        base = self._param_buf.data_ptr()
+        f4 = 4
+        _capi.check(self._h, self._lib.cmps_set_params(
+            self._h, base, base + DD * f4, base + 2 * DD * f4, base + (2 * DD + D) * f4,
+            base + (2 * DD + 2 * D) * f4, float(p.A), float(p.sigma), float(p.delta_t), int(T), int(B),
+            _capi.CMPS_WS_TRAIN if train else _capi.CMPS_WS_FWD_ONLY, ws_ptr, ws_bytes, self._stream()))
+        self._B, self._T, self._train = B, T, train
+
+    def _check_audio(self, audio: torch.Tensor):
+        if not (isinstance(audio, torch.Tensor) and audio.is_cuda and audio.dtype == torch.float32
+                and audio.dim() == 2 and audio.is_contiguous()):
+            raise ValueError("audio must be a contiguous float32 CUDA tensor [B, T]")
+        B, T = audio.shape
+        if T != self._T or B > self._B:
+            raise ValueError(f"audio shape {tuple(audio.shape)} does not fit set_params(B={self._B}, T={self._T})")
+        return B, T
+
+    def forward(self, audio: torch.Tensor, save_for_bwd: bool = False) -> torch.Tensor:
+        """Per-clip loss [B] (device tensor): cmps_psi_loss_fwd."""
+        B, T = self._check_audio(audio)
+        if self._loss is None or self._loss.numel() != B:
+            self._loss = torch.empty(B, dtype=torch.float32, device=self.device)
+        _capi.check(self._h, self._lib.cmps_psi_loss_fwd(
+            self._h, audio.data_ptr(), B, T, self._loss.data_ptr(), 1 if save_for_bwd else 0, self._stream()))
+        self._audio = audio
+        return self._loss
+
+    def backward(self) -> torch.Tensor:
+        """Flat gradient sums [2D^2+3D+2] (device tensor): cmps_psi_loss_bwd after forward(save_for_bwd=True)."""
+        audio = self._audio
+        if audio is None:
+            raise RuntimeError("backward() needs forward(save_for_bwd=True) first")
+        B, T = audio.shape
+        _capi.check(self._h, self._lib.cmps_psi_loss_bwd(
+            self._h, audio.data_ptr(), B, T, self._grad.data_ptr(), self._stream()))
+        return self._grad
+
+    def loss_and_grad_sums(self, audio: torch.Tensor):
+        loss = self.forward(audio, save_for_bwd=True)
+        grad = self.backward()
+        return loss, grad
+
+    # ------------------------------------------------------------------
+    def update_ancilla(self, psi: np.ndarray, signal: np.ndarray, t: float) -> np.ndarray:
+        """PsiCMPS._update_ancilla_psi for a batch of states (host arrays in, host array out)."""
+        psi = np.asarray(psi, dtype=np.complex64)
+        B, D = psi.shape
+        if D != self.D:
+            raise ValueError("psi has the wrong bond dimension")
+        inter = np.stack([psi.real, psi.imag], axis=-1).astype(np.float32)
+        d_in = torch.from_numpy(np.ascontiguousarray(inter)).to(self.device)
+        d_sig = torch.from_numpy(np.ascontiguousarray(signal, dtype=np.float32)).to(self.device)
+        d_out = torch.empty_like(d_in)
+        _capi.check(self._h, self._lib.cmps_psi_update_ancilla(
+            self._h, d_in.data_ptr(), d_sig.data_ptr(), float(t), B, d_out.data_ptr(), self._stream()))
+        o = d_out.cpu().numpy()
+        return (o[..., 0] + 1j * o[..., 1]).astype(np.complex64)
+
+    def states(self) -> np.ndarray:
+        """Normalised lab-frame psi after every step, [B, T-1, D] complex64 (psi_evolve_with_data)."""
+        audio = self._audio
+        if audio is None:
+            raise RuntimeError("states() needs forward(save_for_bwd=True) first")
+        B, T = audio.shape
+        out = torch.empty((B, T - 1, self.D, 2), dtype=torch.float32, device=self.device)
+        _capi.check(self._h, self._lib.cmps_psi_states(self._h, B, T, out.data_ptr(), self._stream()))
+        o = out.cpu().numpy()
+        return (o[..., 0] + 1j * o[..., 1]).astype(np.complex64)

@@ -1,0 +1,122 @@
+/*
+ * cmps.h -- C ABI of libcmps.so: the MI355X (gfx950) implementation of audio-mps's per-timestep cMPS
+ * contraction scan (PsiCMPS log-likelihood forward and its gradient).
+ *
+ * The reference has no FFI: the path sits behind Python object attributes (PsiCMPS(...).loss,
+ * /root/reference/model.py:211-225, 257-334) and its gradient is produced by TensorFlow's autodiff
+ * (train.py:89).  Each entry point below names the reference lines it replaces.  All pointers named
+ * *_dev are DEVICE pointers owned by the caller; the library allocates no device memory, launches
+ * everything asynchronously on the caller's stream and never synchronises.  `stream` is a hipStream_t
+ * passed as void* (NULL = the default stream).  A handle must not be shared between host threads.
+ *
+ * Every function returns CMPS_OK (0) or a CMPS_ERR_* code; cmps_last_error(h) gives the message.
+ * NaN / Inf in the loss is NOT an error at this boundary (it propagates, as in the reference where
+ * only tests/test_model.py:113 looks at it).
+ */
+#ifndef CMPS_H_
+#define CMPS_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cmps_handle_s* cmps_handle_t;
+
+enum {
+    CMPS_OK = 0,
+    CMPS_ERR_BAD_ARG = 1,       /* null pointer, non-positive size, T < 2 ... */
+    CMPS_ERR_UNSUPPORTED_D = 2, /* bond dimension outside [1, 128] */
+    CMPS_ERR_WORKSPACE = 3,     /* workspace missing or smaller than cmps_workspace_bytes() */
+    CMPS_ERR_HIP = 4,           /* a HIP runtime call or kernel launch failed */
+    CMPS_ERR_STATE = 5          /* call order: set_params -> fwd(save_for_bwd=1) -> bwd */
+};
+
+/* workspace flags */
+enum {
+    CMPS_WS_FWD_ONLY = 0, /* loss only */
+    CMPS_WS_TRAIN = 1     /* forward + backward (adds the per-step state stash and gradient slabs) */
+};
+
+/* kernel variants (cmps_set_variant); AUTO picks the register-resident wave-per-clip kernel when the
+ * bond dimension has one and the block-per-clip kernel otherwise. */
+enum {
+    CMPS_VARIANT_AUTO = 0,
+    CMPS_VARIANT_BLOCK = 1, /* one workgroup per clip, any D <= 128 */
+    CMPS_VARIANT_WAVE = 2   /* one wavefront per clip, state and R in registers, D <= 32 */
+};
+
+/* Library version (major * 10000 + minor * 100 + patch). */
+int cmps_version(void);
+
+/* Replaces: construction of the model object's constant part, CMPS.__init__ (model.py:9-52).
+ * D = hparams.bond_dim. */
+int cmps_create(int D, cmps_handle_t* out);
+int cmps_destroy(cmps_handle_t h);
+const char* cmps_last_error(cmps_handle_t h);
+int cmps_set_variant(cmps_handle_t h, int variant);
+/* The variant the next launch will use (after AUTO resolution), CMPS_VARIANT_BLOCK or _WAVE. */
+int cmps_get_variant(cmps_handle_t h);
+
+/* Bytes of device workspace the caller must provide for bond dimension D, B clips of T samples.
+ * Returns 0 for invalid arguments. */
+size_t cmps_workspace_bytes(int D, int B, int T, int flags);
+
+/*
+ * Replaces: the parameter-derived constants that the TF graph rebuilds on every session.run --
+ * model.py:41-42 (complex R), :52 (freqsc), :304-305 / :321-322 (phases = exp(1j * freqsc * t) for every
+ * step, with t accumulated as a sequential float32 sum, model.py:16, 266, 281), :308 (adjoint(R)),
+ * :312 (-delta_t * sigma**2 / 2 factor), :221-222 (psi_0).
+ * Inputs are the EFFECTIVE parameters (after the rsqrt(reg) scaling and the diagonal removal of
+ * model.py:36-42, 49), float32, on the device:
+ *   R_re_dev, R_im_dev [D*D] row-major R[i][j];  freqs_dev [D];  psi0_re_dev, psi0_im_dev [D] (normalised).
+ * A = model.A (model.py:19), sigma (model.py:21), delta_t (model.py:15), T = samples per clip.
+ * Builds, on `stream`, inside `workspace_dev`: R^T, Q = -(delta_t sigma^2 / 2) R^dagger R, the float32
+ * time table t_k, and the per-step phase-rotation table.
+ */
+int cmps_set_params(cmps_handle_t h, const float* R_re_dev, const float* R_im_dev,
+                    const float* freqs_dev, const float* psi0_re_dev, const float* psi0_im_dev,
+                    float A, double sigma, double delta_t, int T, int B_max, int flags,
+                    void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/*
+ * Replaces: PsiCMPS._build_loss_psi (model.py:257-267) = tf.foldl of _psi_and_loss_update
+ * (model.py:276-282) over the T-1 increments, i.e. _update_ancilla_psi (:300-317), _inc_loss_psi
+ * (:293-294), _expectation (:319-325), _normalize_psi (:327-334) per step.
+ * audio_dev [B*T] row-major float32 clips (the `data_iterator` tensor);  loss_dev [B] receives the
+ * per-clip loss (the fold carry); PsiCMPS.loss is its mean (model.py:267).
+ * save_for_bwd != 0 stashes the per-step un-normalised state in the workspace (needs CMPS_WS_TRAIN).
+ */
+int cmps_psi_loss_fwd(cmps_handle_t h, const float* audio_dev, int B, int T, float* loss_dev,
+                      int save_for_bwd, void* stream);
+
+/*
+ * Replaces: the reverse while-loop that tf.train.AdamOptimizer.minimize builds (train.py:89,
+ * training_estimators.py:68) for d(sum_b loss_b)/d(effective parameters).
+ * Must follow cmps_psi_loss_fwd(..., save_for_bwd=1) on the same audio, B, T and stream.
+ * grad_dev [2*D*D + 3*D + 2] receives SUMS over the B clips (divide by the global batch for the mean):
+ *   dR_re [D*D], dR_im [D*D] (row-major, dL/dRe R[i][j], dL/dIm R[i][j]), dfreqs [D],
+ *   dpsi0_re [D], dpsi0_im [D], dA, sum_b loss_b.
+ */
+int cmps_psi_loss_bwd(cmps_handle_t h, const float* audio_dev, int B, int T, float* grad_dev,
+                      void* stream);
+
+/*
+ * Replaces: PsiCMPS._update_ancilla_psi (model.py:300-317), one step in the lab frame.
+ * psi_in_dev / psi_out_dev [B*D*2] interleaved (re, im); signal_dev [B]; t = time of the step.
+ */
+int cmps_psi_update_ancilla(cmps_handle_t h, const float* psi_in_dev, const float* signal_dev,
+                            float t, int B, float* psi_out_dev, void* stream);
+
+/*
+ * Replaces: PsiCMPS.psi_evolve_with_data (model.py:231-240): the normalised lab-frame state after
+ * every step, psi_out_dev [B*(T-1)*D*2] interleaved (re, im), reconstructed from the stash written by
+ * cmps_psi_loss_fwd(..., save_for_bwd=1).
+ */
+int cmps_psi_states(cmps_handle_t h, int B, int T, float* psi_out_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CMPS_H_ */

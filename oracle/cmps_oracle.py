@@ -1,0 +1,437 @@
+"""CPU restatement (numpy) of audio-mps's PsiCMPS log-likelihood scan and its gradient.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``oracle/`` is part of the product: only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it, and only as the
+checker.  The product path (``audio_mps_amd``) never imports this module and has no CPU fallback.
+
+PARITY UNPINNED.  The reference arithmetic lives in TensorFlow 1.x (``requirements.txt:1``, unpinned),
+which is not importable here (ordinary ``ModuleNotFoundError``; no wheel, no network), and the
+reference's own tests (``tests/test_model.py``) hold structural invariants only -- no golden vectors,
+no known-answer values.  This file therefore restates ``model.py`` op for op from its text, in the
+same dtypes (float32 / complex64), the same operation order, with sequential fp32 ``t += dt`` and
+``loss += ...`` accumulation and plain ``log(1 + z)``.  What pins it instead: the reference's six
+invariants (tests/test_oracle_invariants.py), a float64 twin (``dtype="f64"``) and central
+finite-difference gradient checks in float64.
+
+Every function cites the reference lines it follows (paths relative to /root/reference).
+
+The backward pass has no reference source (it is produced by ``tf.train.AdamOptimizer.minimize``,
+``train.py:89``); ``psi_loss_and_grads`` is the op-by-op reverse-mode adjoint of the forward below,
+i.e. what a while-loop autodiff would compute, in the same dtype as the forward.
+Cotangent convention for a complex value z: zbar = dL/dRe(z) + 1j * dL/dIm(z), so that
+dL = Re(conj(zbar) * dz).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+
+
+# --------------------------------------------------------------------------------------------
+# hyper-parameters (train.py:41-43; tests/test_model.py:13-14)
+# --------------------------------------------------------------------------------------------
+@dataclass
+class HParams:
+    """Field names are the reference's (``tf.contrib.training.HParams`` at train.py:41-43)."""
+    minibatch_size: int = 8
+    bond_dim: int = 8
+    delta_t: float = 1.0 / 16000
+    sigma: float = 0.0001
+    h_reg: float = 200.0 / (math.pi * 16000) ** 2
+    r_reg: float = 0.1
+    initial_rank: Optional[int] = None
+    A: float = 100.0
+    learning_rate: float = 0.001
+
+
+def _dt(dtype):
+    if dtype == "f32":
+        return np.float32, np.complex64
+    if dtype == "f64":
+        return np.float64, np.complex128
+    raise ValueError(dtype)
+
+
+# --------------------------------------------------------------------------------------------
+# raw (trainable) variables and their initialisation
+# --------------------------------------------------------------------------------------------
+@dataclass
+class Variables:
+    """The trainable set of PsiCMPS: A, Rx, Ry, freqs (model.py:19,32-39,46-49), psi_x, psi_y
+    (model.py:218-219).  ``scaled_R`` / ``scaled_freqs`` record which initialisation branch was taken:
+    on the random-init branch the effective value is rsqrt(reg) * variable (model.py:36-39,49)."""
+    A: np.ndarray
+    Rx: np.ndarray
+    Ry: np.ndarray
+    freqs: np.ndarray
+    psi_x: np.ndarray
+    psi_y: np.ndarray
+    scaled_R: bool = True
+    scaled_freqs: bool = True
+
+    NAMES = ("A", "Rx", "Ry", "freqs", "psi_x", "psi_y")
+
+    def copy(self):
+        return Variables(*(np.array(getattr(self, n), copy=True) for n in self.NAMES),
+                         scaled_R=self.scaled_R, scaled_freqs=self.scaled_freqs)
+
+    def astype(self, real):
+        return Variables(*(np.asarray(getattr(self, n), dtype=real) for n in self.NAMES),
+                         scaled_R=self.scaled_R, scaled_freqs=self.scaled_freqs)
+
+
+def init_variables(hp: HParams, seed: int = 0, R_in=None, freqs_in=None, psi_in=None) -> Variables:
+    """Initial values by the reference's rules, from a numpy Generator (TF's own RNG streams are not
+    reproducible outside TF).
+    Rx, Ry, freqs: ``tf.random_normal_initializer`` (std 1)            model.py:36-39,49
+    R_in / freqs_in: variables initialised to the given arrays          model.py:31-33,44-46
+    psi_x, psi_y: ``initializer=None`` -> TF default glorot-uniform; for a 1-D [D] variable the limit
+    is sqrt(6 / (D + D)) (legacy graph shows +-0.7746 at D=5)           model.py:218-219
+    psi_in: the reference's branch is broken (undefined psi_x_in, model.py:214-216); treated here as
+    complex D-vector -> real / imaginary parts.
+    """
+    D = hp.bond_dim
+    rng = np.random.default_rng(seed)
+    A = np.float32(hp.A)
+    nRx = rng.standard_normal((D, D)).astype(np.float32)
+    nRy = rng.standard_normal((D, D)).astype(np.float32)
+    nf = rng.standard_normal(D).astype(np.float32)
+    lim = math.sqrt(6.0 / (2 * D))
+    px = rng.uniform(-lim, lim, D).astype(np.float32)
+    py = rng.uniform(-lim, lim, D).astype(np.float32)
+    scaled_R = R_in is None
+    scaled_f = freqs_in is None
+    if R_in is not None:
+        R_in = np.asarray(R_in)
+        nRx, nRy = R_in.real.astype(np.float32), R_in.imag.astype(np.float32)
+    if freqs_in is not None:
+        nf = np.asarray(freqs_in, dtype=np.float32)
+    if psi_in is not None:
+        psi_in = np.asarray(psi_in)
+        px, py = psi_in.real.astype(np.float32), psi_in.imag.astype(np.float32)
+    return Variables(np.asarray(A), nRx, nRy, nf, px, py, scaled_R=scaled_R, scaled_freqs=scaled_f)
+
+
+# --------------------------------------------------------------------------------------------
+# a1: CMPS.__init__ (model.py:9-52) -- effective parameters
+# --------------------------------------------------------------------------------------------
+def _rsqrt(x, real):
+    """tf.rsqrt on a scalar constant: 1/sqrt(x) evaluated in the working dtype."""
+    x = real(x)
+    return real(1) / np.sqrt(x)
+
+
+def effective_params(hp: HParams, var: Variables, dtype="f32"):
+    """Returns (R [D,D] complex, freqs [D] real, c_r, c_h).   model.py:31-52
+    R = complex(Rx, Ry); R -= matrix_diag_part(R) -- the subtraction broadcasts the diagonal as a ROW
+    vector: R[i, j] = Z[i, j] - Z[j, j]  (model.py:41-42)."""
+    real, cplx = _dt(dtype)
+    c_r = _rsqrt(hp.r_reg, real) if var.scaled_R else real(1)
+    c_h = _rsqrt(hp.h_reg, real) if var.scaled_freqs else real(1)
+    Rx = c_r * var.Rx.astype(real) if var.scaled_R else var.Rx.astype(real)
+    Ry = c_r * var.Ry.astype(real) if var.scaled_R else var.Ry.astype(real)
+    Z = (Rx + 1j * Ry).astype(cplx)
+    R = (Z - np.diagonal(Z)[None, :]).astype(cplx)
+    freqs = c_h * var.freqs.astype(real) if var.scaled_freqs else var.freqs.astype(real)
+    return R, freqs.astype(real), c_r, c_h
+
+
+# --------------------------------------------------------------------------------------------
+# a8: PsiCMPS._normalize_psi (model.py:327-334)
+# --------------------------------------------------------------------------------------------
+def normalize_psi(x, axis=None, epsilon=1e-12, dtype="f32"):
+    real, cplx = _dt(dtype)
+    a = np.abs(x).astype(real)                                   # tf.abs of complex -> hypot
+    square_sum = np.sum(np.square(a), axis=axis, keepdims=True, dtype=real)
+    x_inv_norm = real(1) / np.sqrt(np.maximum(square_sum, real(epsilon)))   # tf.rsqrt
+    return (x * x_inv_norm.astype(cplx)).astype(cplx)
+
+
+def psi_0(var: Variables, dtype="f32"):
+    """a2: PsiCMPS.__init__ (model.py:221-222): normalise complex(psi_x, psi_y) over all of D."""
+    real, cplx = _dt(dtype)
+    p = (var.psi_x.astype(real) + 1j * var.psi_y.astype(real)).astype(cplx)
+    return normalize_psi(p, axis=None, dtype=dtype).reshape(-1)
+
+
+# --------------------------------------------------------------------------------------------
+# a5 / a7 / a6: the step pieces (model.py:300-317, 319-325, 293-294)
+# --------------------------------------------------------------------------------------------
+def _phases(freqs, t, dtype):
+    """phases = tf.exp(1j * freqsc * t_c) (model.py:304-305, 321-322): the imaginary argument is the
+    working-precision product fl(freqs * t); exp of a purely imaginary complex number."""
+    real, cplx = _dt(dtype)
+    freqsc = freqs.astype(cplx)
+    t_c = cplx(t)
+    return np.exp(cplx(1j) * freqsc * t_c).astype(cplx)
+
+
+def update_ancilla_psi(psi, signal, t, R, freqs, A, hp: HParams, dtype="f32"):
+    """PsiCMPS._update_ancilla_psi (model.py:300-317).  psi [B,D] complex, signal [B] real, t scalar."""
+    real, cplx = _dt(dtype)
+    s = (signal.astype(real) / real(A)).astype(cplx)              # model.py:303
+    phases = _phases(freqs, real(t), dtype)                       # :304-305
+    Upsi = psi * np.conj(phases)                                  # :306
+    Rdag = np.conj(R.T)                                           # :308
+    RUpsi = (Upsi @ R.T).astype(cplx)                             # :309  einsum('bc,ac->ab')
+    RdagRUpsi = (RUpsi @ Rdag.T).astype(cplx)                     # :310
+    cc = cplx(-hp.delta_t * hp.sigma ** 2)                        # python float64 product, then cast
+    delta_Upsi = cc * RdagRUpsi / cplx(2.0)                       # :312
+    delta_Upsi = delta_Upsi + s[:, None] * RUpsi                  # :313
+    delta_psi = phases * delta_Upsi                               # :315
+    return (psi + delta_psi).astype(cplx)                         # :317
+
+
+def expectation(psi, t, R, freqs, dtype="f32"):
+    """PsiCMPS._expectation (model.py:319-325): 2 Re <U| R |U>, U = psi * conj(phases)."""
+    real, cplx = _dt(dtype)
+    phases = _phases(freqs, real(t), dtype)
+    Upsi = psi * np.conj(phases)
+    RU = (Upsi @ R.T).astype(cplx)
+    ex = np.sum(np.conj(Upsi) * RU, axis=1)                       # einsum('ab,bc,ac->a')
+    return (real(2) * ex.real).astype(real)
+
+
+def inc_loss_psi(psi, signal, t, R, freqs, A, dtype="f32"):
+    """PsiCMPS._inc_loss_psi (model.py:293-294): -log(1. + e * signal / A), plain log(1+z)."""
+    real, _ = _dt(dtype)
+    e = expectation(psi, t, R, freqs, dtype)
+    z = (e * signal.astype(real)) / real(A)
+    return (-np.log(real(1) + z)).astype(real)
+
+
+# --------------------------------------------------------------------------------------------
+# a3 / a4: PsiCMPS._build_loss_psi and the fold (model.py:257-267, 276-282)
+# --------------------------------------------------------------------------------------------
+def time_table(delta_t, N, dtype="f32"):
+    """t_0 = 0, t_{k+1} = t_k + dt accumulated sequentially in the working dtype
+    (model.py:16 ``self.dt = tf.constant(delta_t, tf.float32)``; :266 initial 0.; :281 ``t += self.dt``)."""
+    real, _ = _dt(dtype)
+    t = np.empty(N + 1, dtype=real)
+    acc = real(0)
+    dt = real(delta_t)
+    for k in range(N + 1):
+        t[k] = acc
+        acc = real(acc + dt)
+    return t
+
+
+def psi_loss_per_clip(hp: HParams, var: Variables, data, dtype="f32", return_states=False):
+    """Per-clip loss [B] (the fold carry of model.py:265-266); ``mean`` of it is PsiCMPS.loss (:267).
+    With return_states=True also returns the normalised psi after each step, [B, N, D]
+    (what PsiCMPS.psi_evolve_with_data / _psi_update, model.py:231-240, 269-274, produce)."""
+    real, cplx = _dt(dtype)
+    data = np.asarray(data, dtype=real)
+    B, T = data.shape
+    R, freqs, _, _ = effective_params(hp, var, dtype)
+    A = real(var.A)
+    incs = (data[:, 1:] - data[:, :-1]).astype(real)              # model.py:263
+    psi = np.tile(psi_0(var, dtype)[None, :], (B, 1)).astype(cplx)  # :260
+    loss = np.zeros(B, dtype=real)
+    t = real(0)
+    dt = real(hp.delta_t)
+    states = [] if return_states else None
+    for k in range(T - 1):                                        # tf.foldl, :265
+        x = incs[:, k]
+        psi = update_ancilla_psi(psi, x, t, R, freqs, A, hp, dtype)          # :278
+        loss = (loss + inc_loss_psi(psi, x, t, R, freqs, A, dtype)).astype(real)  # :279
+        psi = normalize_psi(psi, axis=1, dtype=dtype)                          # :280
+        t = real(t + dt)                                                       # :281
+        if return_states:
+            states.append(psi)
+    if return_states:
+        return loss, np.stack(states, axis=1)
+    return loss
+
+
+def psi_loss(hp, var, data, dtype="f32"):
+    """PsiCMPS.loss = reduce_mean over the batch (model.py:267)."""
+    real, _ = _dt(dtype)
+    per = psi_loss_per_clip(hp, var, data, dtype)
+    return real(np.mean(per, dtype=real))
+
+
+# --------------------------------------------------------------------------------------------
+# a10: total loss of train.py:55-60
+# --------------------------------------------------------------------------------------------
+def regularisers(hp: HParams, var: Variables, dtype="f32"):
+    real, _ = _dt(dtype)
+    R, freqs, _, _ = effective_params(hp, var, dtype)
+    h_l2sqnorm = np.sum(np.square(freqs), dtype=real)             # train.py:55
+    r_l2sqnorm = np.sum((np.conj(R) * R).real, dtype=real)        # train.py:56
+    return real(hp.h_reg) * h_l2sqnorm + real(hp.r_reg) * r_l2sqnorm
+
+
+def total_loss(hp, var, data, dtype="f32"):
+    real, _ = _dt(dtype)
+    return real(psi_loss(hp, var, data, dtype) + regularisers(hp, var, dtype))
+
+
+# --------------------------------------------------------------------------------------------
+# a9: gradients (no reference source; reverse-mode adjoint of the forward above)
+# --------------------------------------------------------------------------------------------
+@dataclass
+class Grads:
+    """Gradients of mean_b loss_b (+ regularisers if requested) w.r.t. the raw variables, plus the
+    intermediate gradients w.r.t. the effective parameters (what the HIP kernels emit)."""
+    A: np.ndarray
+    Rx: np.ndarray
+    Ry: np.ndarray
+    freqs: np.ndarray
+    psi_x: np.ndarray
+    psi_y: np.ndarray
+    loss: float = 0.0
+    per_clip: Optional[np.ndarray] = None
+    eff: dict = field(default_factory=dict)   # Rbar [D,D] complex, fbar [D], psi0bar [D] complex, Abar
+
+    def flat(self):
+        return np.concatenate([np.ravel(getattr(self, n)) for n in Variables.NAMES])
+
+
+def psi_loss_and_grads(hp: HParams, var: Variables, data, dtype="f32", with_reg=False) -> Grads:
+    real, cplx = _dt(dtype)
+    data = np.asarray(data, dtype=real)
+    B, T = data.shape
+    N = T - 1
+    D = hp.bond_dim
+    R, freqs, c_r, c_h = effective_params(hp, var, dtype)
+    A = real(var.A)
+    Rdag_T = np.conj(R)                       # adjoint(R) transposed
+    cc = cplx(-hp.delta_t * hp.sigma ** 2)
+    incs = (data[:, 1:] - data[:, :-1]).astype(real)
+    p0 = psi_0(var, dtype)
+    psi = np.tile(p0[None, :], (B, 1)).astype(cplx)
+    loss = np.zeros(B, dtype=real)
+    t = real(0)
+    dt = real(hp.delta_t)
+    tape_psi = np.empty((N, B, D), dtype=cplx)
+    tape_t = np.empty(N, dtype=real)
+    # ---------------- forward (identical op order to psi_loss_per_clip) ----------------
+    for k in range(N):
+        tape_psi[k] = psi
+        tape_t[k] = t
+        x = incs[:, k]
+        psi = update_ancilla_psi(psi, x, t, R, freqs, A, hp, dtype)
+        loss = (loss + inc_loss_psi(psi, x, t, R, freqs, A, dtype)).astype(real)
+        psi = normalize_psi(psi, axis=1, dtype=dtype)
+        t = real(t + dt)
+    # ---------------- reverse ----------------
+    g = np.zeros((B, D), dtype=cplx)          # cotangent of the carried (normalised) psi
+    lbar = real(1) / real(B)                  # d mean / d loss_b
+    Rbar = np.zeros((D, D), dtype=cplx)
+    fbar = np.zeros(D, dtype=real)
+    Abar = real(0)
+    eps = real(1e-12)
+    for k in range(N - 1, -1, -1):
+        psi_k = tape_psi[k]
+        tk = tape_t[k]
+        x = incs[:, k]
+        # recompute the step's intermediates (same ops as the forward)
+        s_r = (x / A).astype(real)
+        s = s_r.astype(cplx)
+        ph = _phases(freqs, tk, dtype)
+        U = psi_k * np.conj(ph)
+        V = (U @ R.T).astype(cplx)
+        W = (V @ Rdag_T).astype(cplx)
+        delta = cc * W / cplx(2.0) + s[:, None] * V
+        psi_p = (psi_k + ph * delta).astype(cplx)
+        Up = psi_p * np.conj(ph)
+        RVp = (Up @ R.T).astype(cplx)
+        ex = np.sum(np.conj(Up) * RVp, axis=1)
+        e = (real(2) * ex.real).astype(real)
+        ex_ = (e * x).astype(real)
+        z = (ex_ / A).astype(real)
+        a = np.abs(psi_p).astype(real)
+        ss = np.sum(np.square(a), axis=1, keepdims=True, dtype=real)
+        m = np.maximum(ss, eps)
+        inv = (real(1) / np.sqrt(m)).astype(real)
+        # --- normalise:  psi_next = psi_p * inv
+        psi_p_bar = g * inv.astype(cplx)
+        inv_bar = np.sum((np.conj(g) * psi_p).real, axis=1, keepdims=True).astype(real)
+        m_bar = inv_bar * (real(-0.5) * inv / m)
+        ss_bar = np.where(ss > eps, m_bar, real(0)).astype(real)
+        psi_p_bar = psi_p_bar + (real(2) * ss_bar).astype(cplx) * psi_p
+        # --- loss increment: l = -log(1 + z), z = (e * x) / A
+        z_bar = (-lbar / (real(1) + z)).astype(real)
+        Abar = real(Abar + np.sum(z_bar * (-ex_ / (A * A)), dtype=real))
+        e_bar = (z_bar * x / A).astype(real)
+        ex_bar = (real(2) * e_bar).astype(cplx)
+        Up_bar = ex_bar[:, None] * RVp
+        RVp_bar = ex_bar[:, None] * Up
+        Up_bar = Up_bar + RVp_bar @ np.conj(R)
+        Rbar = Rbar + (np.conj(Up.T) @ RVp_bar).T
+        psi_p_bar = psi_p_bar + Up_bar * ph
+        ph_bar = np.conj(np.sum(Up_bar * np.conj(psi_p), axis=0))
+        # --- psi_p = psi_k + ph * delta
+        g_new = psi_p_bar.copy()
+        ph_bar = ph_bar + np.sum(psi_p_bar * np.conj(delta), axis=0)
+        delta_bar = psi_p_bar * np.conj(ph)
+        # --- delta = cc * W / 2 + s * V
+        s_bar = np.sum((delta_bar * np.conj(V)).real, axis=1).astype(real)
+        V_bar = delta_bar * s[:, None]
+        W_bar = delta_bar * (np.conj(cc) / cplx(2.0))
+        # --- W = V @ conj(R)
+        V_bar = V_bar + W_bar @ R.T
+        Rbar = Rbar + np.conj(np.conj(V.T) @ W_bar)
+        # --- V = U @ R.T
+        U_bar = V_bar @ np.conj(R)
+        Rbar = Rbar + (np.conj(U.T) @ V_bar).T
+        # --- U = psi_k * conj(ph)
+        g_new = g_new + U_bar * ph
+        ph_bar = ph_bar + np.conj(np.sum(U_bar * np.conj(psi_k), axis=0))
+        # --- s = x / A
+        Abar = real(Abar + np.sum(s_bar * (-x / (A * A)), dtype=real))
+        # --- ph = exp(1j * f * t)
+        w_bar = ph_bar * np.conj(ph)
+        fbar = (fbar + tk * w_bar.imag).astype(real)
+        g = g_new.astype(cplx)
+    # psi_0 tiled over the batch
+    psi0_bar = np.sum(g, axis=0)
+    eff = {"Rbar": Rbar.copy(), "fbar": fbar.copy(), "psi0bar": psi0_bar.copy(), "Abar": real(Abar)}
+    if with_reg:                                                   # train.py:55-60
+        fbar = fbar + real(2 * hp.h_reg) * freqs
+        Rbar = Rbar + cplx(2 * hp.r_reg) * R
+    # R[i,j] = Z[i,j] - Z[j,j]   (model.py:42)  ->  Zbar = Rbar - diag(colsum(Rbar))
+    Zbar = Rbar - np.diag(np.sum(Rbar, axis=0))
+    gRx = (c_r * Zbar.real).astype(real)
+    gRy = (c_r * Zbar.imag).astype(real)
+    gf = (c_h * fbar).astype(real)
+    # psi_0 = p * rsqrt(max(sum |p|^2, eps))
+    p = (var.psi_x.astype(real) + 1j * var.psi_y.astype(real)).astype(cplx)
+    ss0 = np.sum(np.square(np.abs(p).astype(real)), dtype=real)
+    m0 = max(ss0, eps)
+    inv0 = real(1) / np.sqrt(m0)
+    p_bar = psi0_bar * cplx(inv0)
+    inv0_bar = real(np.sum((np.conj(psi0_bar) * p).real, dtype=real))
+    m0_bar = inv0_bar * (real(-0.5) * inv0 / m0)
+    if ss0 > eps:
+        p_bar = p_bar + cplx(2 * m0_bar) * p
+    total = real(np.mean(loss, dtype=real))
+    if with_reg:
+        total = real(total + regularisers(hp, var, dtype))
+    return Grads(A=np.asarray(real(Abar)), Rx=gRx, Ry=gRy, freqs=gf,
+                 psi_x=p_bar.real.astype(real), psi_y=p_bar.imag.astype(real),
+                 loss=total, per_clip=loss, eff=eff)
+
+
+# --------------------------------------------------------------------------------------------
+# input fixture: the damped sine of data.py:8-22
+# --------------------------------------------------------------------------------------------
+def damped_sine(batch, input_length, delta_t, seed=0):
+    """data.py:8-22: gamma(alpha=2, rate=2/delay_time)-delayed, exponentially damped 261.6 Hz sine,
+    float32 [batch, input_length].  The reference draws the delays with tf.random_gamma; here a numpy
+    Generator with an explicit seed (TF's stream is not reproducible outside TF)."""
+    rng = np.random.default_rng(seed)
+    freq = 261.6
+    decay_time = 0.1
+    delay_time = input_length / 100
+    delays = rng.gamma(shape=2.0, scale=delay_time / 2.0, size=batch).astype(np.float32)
+    input_range = np.arange(input_length, dtype=np.float32)[None, :]
+    times = (input_range - delays[:, None]) * np.float32(delta_t)
+    two_pi_f = np.float32(2 * np.pi * freq)
+    wave = (np.float32(0.5) * (np.sign(times) + np.float32(1))
+            * np.sin(two_pi_f * times) * np.exp(-times / np.float32(decay_time)))
+    return wave.astype(np.float32)
