@@ -78,6 +78,9 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: the HIP library has not been built "
             "(run `python -m audio_mps_amd.build` or `__graft_entry__.build()`); there is no CPU fallback")
+    # The device buffers and streams handed to libcmps come from PyTorch's HIP runtime, so libcmps must bind to
+    # that same libamdhip64 instance: import torch first so its runtime is the one already loaded.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     missing = [s for s in SYMBOLS if not hasattr(lib, s)]
     if missing:

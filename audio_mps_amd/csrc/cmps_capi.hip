@@ -15,7 +15,7 @@ struct cmps_handle_s {
     int variant_req = CMPS_VARIANT_AUTO;
     bool params_set = false;
     bool fwd_saved = false;
-    int saved_B = 0, saved_T = 0;
+    int saved_B = 0, saved_T = 0, saved_variant = 0;
     const float* saved_audio = nullptr;
     float* saved_loss = nullptr;
     Layout L{};
@@ -118,6 +118,7 @@ int cmps_set_params(cmps_handle_t h, const float* R_re_dev, const float* R_im_de
     P.dtk = reinterpret_cast<float*>(ws + L.off_dtk);
     P.rho = reinterpret_cast<float2*>(ws + L.off_rho);
     P.stash = (flags & CMPS_WS_TRAIN) ? reinterpret_cast<float2*>(ws + L.off_stash) : nullptr;
+    P.scal = (flags & CMPS_WS_TRAIN) ? reinterpret_cast<float*>(ws + L.off_scal) : nullptr;
     P.slabs = (flags & CMPS_WS_TRAIN) ? reinterpret_cast<float*>(ws + L.off_slabs) : nullptr;
     P.sums = (flags & CMPS_WS_TRAIN) ? reinterpret_cast<float*>(ws + L.off_sums) : nullptr;
     P.slab_floats = L.slab_floats;
@@ -153,12 +154,14 @@ int cmps_psi_loss_fwd(cmps_handle_t h, const float* audio_dev, int B, int T, flo
     Dev P = h->P;
     P.B = B;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipError_t e = (resolve_variant(h) == CMPS_VARIANT_WAVE)
+    const int variant = resolve_variant(h);
+    hipError_t e = (variant == CMPS_VARIANT_WAVE)
                        ? launch_fwd_wave(P, audio_dev, loss_dev, save_for_bwd != 0, s)
                        : launch_fwd_block(P, audio_dev, loss_dev, save_for_bwd != 0, s);
     if (e != hipSuccess) return fail_hip(h, e, "cmps_psi_loss_fwd");
     h->fwd_saved = save_for_bwd != 0;
     h->saved_B = B; h->saved_T = T; h->saved_audio = audio_dev; h->saved_loss = loss_dev;
+    h->saved_variant = variant;
     return CMPS_OK;
 }
 
@@ -172,8 +175,9 @@ int cmps_psi_loss_bwd(cmps_handle_t h, const float* audio_dev, int B, int T, flo
     Dev P = h->P;
     P.B = B;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipError_t e = (resolve_variant(h) == CMPS_VARIANT_WAVE) ? launch_bwd_wave(P, audio_dev, s)
-                                                             : launch_bwd_block(P, audio_dev, s);
+    // the stash layout belongs to the variant that wrote it
+    hipError_t e = (h->saved_variant == CMPS_VARIANT_WAVE) ? launch_bwd_wave(P, audio_dev, s)
+                                                           : launch_bwd_block(P, audio_dev, s);
     if (e != hipSuccess) return fail_hip(h, e, "cmps_psi_loss_bwd (scan)");
     e = launch_reduce_finalize(P, h->saved_loss, grad_dev, s);
     if (e != hipSuccess) return fail_hip(h, e, "cmps_psi_loss_bwd (reduce)");

@@ -1,13 +1,33 @@
 // Wave-per-clip kernels (the hot path for D <= 32): one 64-lane wavefront owns one clip for the whole
-// scan.  The ancilla state and the three D x D matrices (R, R^dagger, Q) live in registers; the only
-// HBM traffic is the audio stream (coalesced 256-B chunks), the per-step rotation table (cache
-// resident) and, when training, the per-step state stash.
+// scan.  Measured on MI355X (scripts/ubench/issue_rate.hip): a lone wave issues one VALU instruction per
+// ~5.3 cycles whether it is v_fma_f32 or v_pk_fma_f32, dependent accumulation chains cost nothing extra,
+// and the fp32 MFMA shares the fp32 ALUs with the VALU (no overlap).  The kernels are therefore
+// instruction-issue bound; the design minimises instruction count and keeps every memory latency off the
+// instruction stream.
 //
 // Lane layout (DP = 32, smaller D zero-padded): lane l = (i = l & 31, h = l >> 5).
-//   * every lane holds component i of each state vector as one float2 (both halves hold the same value)
-//   * lane (i, h) holds columns 16h .. 16h+15 of row i of R, R^dagger and Q  (3 x 16 float2)
-//   * a mat-vec is: broadcast the vector through LDS (each half reads its 16 entries with ds_read_b128),
-//     16 complex FMAs per lane, one cross-half add.
+//   * SPLIT layout of a complex D-vector X: ONE float per lane, x = h ? Im X_i : Re X_i.
+//   * where a lane needs the whole complex number it holds the pair (own, osig) with
+//       osig = h ? -Re X_i : Im X_i,   i.e. the pair is X_i in half 0 and -i X_i in half 1.
+//     Multiplying such pairs by an ordinary complex scalar (the rotation rho) is plain complex pair
+//     arithmetic in every lane; products between two lane-held vectors use the split form:
+//     sum over all 64 lanes of a_own * b_own = Re(a^dagger b).
+//   * lane (i, h) holds columns 16h..16h+15 of row i of each matrix as 16 (re, im) pairs (32 VGPRs).
+//     mat-vec: the vector is broadcast through LDS (4-byte write per lane, 8 x ds_read_b128 per half),
+//     32 v_pk_fma_f32 per lane -- a complex multiply-accumulate is two packed FMAs that use op_sel /
+//     neg_lo on the SAME register pair -- then ONE v_permlane32_swap + ONE add combines the two halves
+//     and lands the result directly in the split layout.
+//   * wave reductions: 4 fused DPP adds inside 16-lane rows + 2 row_bcast adds + v_readlane.
+//   * per-step tables (rotation rho_k, and in the reverse sweep the stashed state y_k) are staged in LDS
+//     one 64-step chunk at a time; the next chunk is prefetched into registers while the current one is
+//     consumed, so the inner loops contain no global loads and wait on no memory latency.
+//   * everything uniform across lanes and off the serial chain (x/A, (e x)/A, log(1+z), 1/(1+z), ...) is
+//     evaluated once per 64 steps, one step per lane, in the reference's operation order, and fetched per
+//     step with v_readlane.  The float32 loss accumulation stays strictly sequential in time (model.py:279).
+//   * backward: R y and R^dagger y only enter as their sum, so one mat-vec with H = R + R^dagger replaces
+//     two; the three rank-1 gradient updates per step are six v_mfma_f32_32x32x2_f32 (exact fp32; K = 2 is
+//     {real, imaginary}; the split layout IS the MFMA operand layout); the part of the adjoint that does not
+//     depend on the incoming cotangent is computed one step ahead, off the serial chain.
 // Recurrence and adjoint: see the header of cmps_block.hip (same arithmetic, same reference lines).
 #include "cmps_internal.h"
 
@@ -15,106 +35,277 @@ namespace cmps {
 
 namespace {
 
-constexpr int DPW = 32;        // padded bond dimension of this variant
-constexpr int WAVES = 4;       // waves (clips) per workgroup: one per SIMD of a CU
+constexpr int DPW = 32;    // padded bond dimension of this variant
+constexpr int WAVES = 4;   // waves (clips) per workgroup: one per SIMD of a CU
+constexpr int CH = 64;     // steps per chunk
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ v2f mk2(float a, float b) { v2f r; r.x = a; r.y = b; return r; }
+__device__ __forceinline__ v2f ld2(const float2* p) { const float2 t = *p; return mk2(t.x, t.y); }
+__device__ __forceinline__ v2f lo2(v4f q) { return __builtin_shufflevector(q, q, 0, 1); }
+__device__ __forceinline__ v2f hi2(v4f q) { return __builtin_shufflevector(q, q, 2, 3); }
+
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+
+// ---- packed complex multiply-accumulate: acc += a * b  =  [a * Re b]  +  [i a * Im b] ----
+__device__ __forceinline__ void pkmul_bl(v2f& acc, v2f a, v2f b) {   // acc = (a.x, a.y) * (b.x, b.x)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void pkfma_bl(v2f& acc, v2f a, v2f b) {   // acc += (a.x, a.y) * (b.x, b.x)
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void pkfma_bh(v2f& acc, v2f a, v2f b) {   // acc += (-a.y, a.x) * (b.y, b.y)
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void pkfma_bh_conj(v2f& acc, v2f a, v2f b) {  // acc += (a.y, -a.x) * (b.y, b.y)
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ v2f cmul2(v2f a, v2f b) {            // a * b
+    v2f acc;
+    pkmul_bl(acc, a, b);
+    pkfma_bh(acc, a, b);
+    return acc;
+}
+__device__ __forceinline__ v2f cmul2_conj_b(v2f a, v2f b) {     // a * conj(b) = a*Re b - i a*Im b
+    v2f acc;
+    pkmul_bl(acc, a, b);
+    pkfma_bh_conj(acc, a, b);
+    return acc;
+}
+
+// this half's 16 columns of (M v): one dependent chain of 32 packed ops (chains are free, see header)
+__device__ __forceinline__ v2f chain16(const v2f (&M)[16], const v4f (&q)[8]) {
+    v2f acc;
+    pkmul_bl(acc, M[0], lo2(q[0]));
+    pkfma_bh(acc, M[0], lo2(q[0]));
+#pragma unroll
+    for (int m = 1; m < 16; ++m) {
+        const v2f b = (m & 1) ? hi2(q[m >> 1]) : lo2(q[m >> 1]);
+        pkfma_bl(acc, M[m], b);
+        pkfma_bh(acc, M[m], b);
+    }
+    return acc;
+}
 
 __device__ __forceinline__ float rdlane(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
-// sum over the 32 lanes of each half (both halves hold the same values -> same result everywhere)
-__device__ __forceinline__ float sum32(float v) {
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 8, 64);
-    v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 1, 64);
-    return v;
+// ---- cross-half: (partial.x, partial.y) of both halves -> split-layout total ----
+__device__ __forceinline__ float swapadd(float px, float py) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(px), __float_as_uint(py), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);     // half 0: sum of x's; half 1: sum of y's
+}
+// split value x -> osig (see header): half 0 gets the partner's value, half 1 minus the partner's value
+__device__ __forceinline__ float osig_of(float x, bool hbit) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return hbit ? -__uint_as_float(r[0]) : __uint_as_float(r[1]);
 }
 
-__device__ __forceinline__ float2 xhalf_add(float2 v) {  // add the partner half's partial sum
-    return make_float2(v.x + __shfl_xor(v.x, 32, 64), v.y + __shfl_xor(v.y, 32, 64));
+// ---- wave reduction ----
+template <int CTRL>
+__device__ __forceinline__ float dpp_add_row(float x) {
+    return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float sum64(float x) {   // sum over all 64 lanes, uniform (SGPR) result
+    x = dpp_add_row<0xB1>(x);    // quad_perm [1,0,3,2]
+    x = dpp_add_row<0x4E>(x);    // quad_perm [2,3,0,1]
+    x = dpp_add_row<0x141>(x);   // row_half_mirror
+    x = dpp_add_row<0x140>(x);   // row_mirror        -> every lane holds its 16-lane row's sum
+    // row_bcast15 into rows 1,3 then row_bcast31 into rows 2,3 (the s_nop covers the VALU-write -> DPP-read
+    // hazard, which hipcc does not see inside an asm statement)
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(x));
+    return rdlane(x, 63);
 }
 
-// write one vector (component i from the lanes of half 0) and read back this half's 16 entries
-__device__ __forceinline__ void bcast16(float2* buf, float2 mine, int i, int h, float2 (&out)[16]) {
-    if (h == 0) buf[i] = mine;
-    __builtin_amdgcn_wave_barrier();
-    const float4* p = reinterpret_cast<const float4*>(buf + 16 * h);
+__device__ __forceinline__ float rsq_nr(float m) {   // 1/sqrt(m): v_rsq_f32 + one Newton step
+    const float r = __builtin_amdgcn_rsqf(m);
+    return r * (1.5f - 0.5f * m * r * r);
+}
+
+// ---- LDS traffic of the inner loops, hidden from hipcc's waitcnt bookkeeping on purpose ----
+// broadcast: every lane writes its 4-byte split value; this half then reads its 16 complex entries.
+// Optionally also reads one 8-byte table entry (rho).  Outputs are valid only after lds_wait*.
+__device__ __forceinline__ void bcast_issue(unsigned wr, unsigned rd, float mine, v4f (&o)[8]) {
+    asm volatile("ds_write_b32 %8, %9\n\t"
+                 "ds_read_b128 %0, %10\n\tds_read_b128 %1, %10 offset:16\n\t"
+                 "ds_read_b128 %2, %10 offset:32\n\tds_read_b128 %3, %10 offset:48\n\t"
+                 "ds_read_b128 %4, %10 offset:64\n\tds_read_b128 %5, %10 offset:80\n\t"
+                 "ds_read_b128 %6, %10 offset:96\n\tds_read_b128 %7, %10 offset:112"
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
+                 : "v"(wr), "v"(mine), "v"(rd) : "memory");
+}
+__device__ __forceinline__ void bcast_issue_tab(unsigned wr, unsigned rd, float mine, unsigned tab,
+                                                v4f (&o)[8], v2f& t) {
+    asm volatile("ds_write_b32 %9, %10\n\t"
+                 "ds_read_b128 %0, %11\n\tds_read_b128 %1, %11 offset:16\n\t"
+                 "ds_read_b128 %2, %11 offset:32\n\tds_read_b128 %3, %11 offset:48\n\t"
+                 "ds_read_b128 %4, %11 offset:64\n\tds_read_b128 %5, %11 offset:80\n\t"
+                 "ds_read_b128 %6, %11 offset:96\n\tds_read_b128 %7, %11 offset:112\n\t"
+                 "ds_read_b64 %8, %12"
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]),
+                   "=&v"(t)
+                 : "v"(wr), "v"(mine), "v"(rd), "v"(tab) : "memory");
+}
+// row read (no write): this half's 16 entries of a staged vector, the lane's own split value, one table entry
+__device__ __forceinline__ void row_issue(unsigned rd, unsigned own_addr, unsigned tab, v4f (&o)[8], float& own, v2f& t) {
+    asm volatile("ds_read_b128 %0, %10\n\tds_read_b128 %1, %10 offset:16\n\t"
+                 "ds_read_b128 %2, %10 offset:32\n\tds_read_b128 %3, %10 offset:48\n\t"
+                 "ds_read_b128 %4, %10 offset:64\n\tds_read_b128 %5, %10 offset:80\n\t"
+                 "ds_read_b128 %6, %10 offset:96\n\tds_read_b128 %7, %10 offset:112\n\t"
+                 "ds_read_b32 %8, %11\n\tds_read_b64 %9, %12"
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]),
+                   "=&v"(own), "=&v"(t)
+                 : "v"(rd), "v"(own_addr), "v"(tab) : "memory");
+}
+// LDS operations of one wave complete in order, so "at most N outstanding" retires everything issued
+// before the last N; extra operations hipcc may have in flight only make the wait stricter.
+template <int N>
+__device__ __forceinline__ void lds_wait(v4f (&o)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(%8)"
+                 : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(o[4]), "+v"(o[5]), "+v"(o[6]), "+v"(o[7])
+                 : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lds_wait_t(v4f (&o)[8], v2f& t) {
+    asm volatile("s_waitcnt lgkmcnt(%9)"
+                 : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(o[4]), "+v"(o[5]), "+v"(o[6]), "+v"(o[7]), "+v"(t)
+                 : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lds_wait_row(v4f (&o)[8], float& own, v2f& t) {
+    asm volatile("s_waitcnt lgkmcnt(%10)"
+                 : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(o[4]), "+v"(o[5]), "+v"(o[6]), "+v"(o[7]),
+                   "+v"(own), "+v"(t)
+                 : "n"(N) : "memory");
+}
+
+// ---- chunk staging: 64 table rows of 256 B (= 1024 float4) global -> registers -> LDS ----
+__device__ __forceinline__ void stage_load(const float4* __restrict__ tab, int row0, int max_row, int lane,
+                                           v4f (&r)[16]) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const float4 t = p[q];
-        out[2 * q] = make_float2(t.x, t.y);
-        out[2 * q + 1] = make_float2(t.z, t.w);
+    for (int q = 0; q < 16; ++q) {
+        const int e = q * 64 + lane;
+        int row = row0 + (e >> 4);
+        row = row < max_row ? row : max_row;
+        const float4 t = tab[(size_t)row * 16 + (e & 15)];
+        r[q] = v4f{t.x, t.y, t.z, t.w};
     }
-    __builtin_amdgcn_wave_barrier();
 }
-
-__device__ __forceinline__ float2 mv16(const float2 (&M)[16], const float2 (&v)[16]) {
-    float2 acc0 = make_float2(0.f, 0.f), acc1 = make_float2(0.f, 0.f);
+__device__ __forceinline__ void stage_commit(float4* lds, int lane, const v4f (&r)[16]) {
 #pragma unroll
-    for (int m = 0; m < 16; m += 2) {
-        acc0 = cfma(M[m], v[m], acc0);
-        acc1 = cfma(M[m + 1], v[m + 1], acc1);
-    }
-    return cadd(acc0, acc1);
+    for (int q = 0; q < 16; ++q) lds[q * 64 + lane] = make_float4(r[q].x, r[q].y, r[q].z, r[q].w);
 }
 
 }  // namespace
+
+// per-chunk scalar stash: [B][NC][2][64] floats: n_k (true |y_k|^2), e_k, one step per lane
+__device__ __forceinline__ size_t scal_off(int b, int NC, int c) { return ((size_t)b * NC + c) * 128; }
 
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64 * WAVES, 1) void k_fwd_wave(Dev P, const float* __restrict__ audio,
                                                             float* __restrict__ loss_out, int save) {
-    __shared__ __attribute__((aligned(16))) float2 lds[WAVES][2][DPW];
+    __shared__ __attribute__((aligned(16))) float4 stR[WAVES][CH * 16];   // rho rows of the current chunk
+    __shared__ __attribute__((aligned(16))) float2 bcU[WAVES][DPW], bcY[WAVES][DPW];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i = lane & 31, h = lane >> 5;
+    const bool hb = h != 0;
     const int b = blockIdx.x * WAVES + w;
     if (b >= P.B) return;  // whole wave exits together; no workgroup barriers are used below
-    const int N = P.N, T = P.T;
-    float2* bufU = lds[w][0];
-    float2* bufY = lds[w][1];
+    const int N = P.N, T = P.T, NC = (N + CH - 1) / CH;
 
-    float2 MR[16], MQ[16];
+    v2f MR[16], MQ[16];
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
-        MR[m] = P.R[i * DPW + 16 * h + m];
-        MQ[m] = P.Q[i * DPW + 16 * h + m];
+        MR[m] = ld2(&P.R[i * DPW + 16 * h + m]);
+        MQ[m] = ld2(&P.Q[i * DPW + 16 * h + m]);
     }
+    const unsigned aUw = lds_addr(&bcU[w][0]) + i * 8 + h * 4, aUr = lds_addr(&bcU[w][0]) + h * 128;
+    const unsigned aYw = lds_addr(&bcY[w][0]) + i * 8 + h * 4, aYr = lds_addr(&bcY[w][0]) + h * 128;
+    const unsigned aRho = lds_addr(&stR[w][0]) + i * 8;
+    const float4* rho4 = reinterpret_cast<const float4*>(P.rho);
     const float* xrow = audio + (size_t)b * T;
-    float2* st = save ? P.stash + (size_t)b * N * DPW : nullptr;
-    float2 u = P.psi0[i];
+    float* st = save ? reinterpret_cast<float*>(P.stash + (size_t)b * N * DPW) + 2 * i + h : nullptr;
+    float* sc = save ? P.scal + scal_off(b, NC, 0) : nullptr;
+    const float A = P.A;
+
+    // chunk 0: tables and increments
+    v4f sr[16];
+    stage_load(rho4, 0, N, lane, sr);
+    float xa0 = lane < T ? xrow[lane] : 0.f;
+    float xa1 = lane + 1 < T ? xrow[lane + 1] : 0.f;
+    stage_commit(stR[w], lane, sr);
+
+    const float2 p0 = P.psi0[i];
+    float u = hb ? p0.y : p0.x;
     float loss = 0.f;
-    float incv = 0.f, sv = 0.f;
-    float2 rho_next = P.rho[i];
-    for (int k = 0; k < N; ++k) {
-        if ((k & 63) == 0) {  // next 64 increments, one per lane (model.py:263, :303)
-            const int idx = k + lane;
-            const float a0 = idx < T ? xrow[idx] : 0.f;
-            const float a1 = idx + 1 < T ? xrow[idx + 1] : 0.f;
-            incv = a1 - a0;
-            sv = incv / P.A;
+    v4f qu[8];
+    v2f rho;
+    bcast_issue_tab(aUw, aUr, u, aRho, qu, rho);                 // broadcast of u_0 and rho_0 in flight
+    for (int c = 0; c < NC; ++c) {
+        const int kbeg = c * CH;
+        const int cnt = (N - kbeg) < CH ? (N - kbeg) : CH;
+        const float incv = xa1 - xa0;                            // model.py:263, one step per lane
+        const float sv = incv / A;                               // model.py:303
+        {   // prefetch the next chunk (clamped at the end: a harmless reload)
+            const int cn = c + 1 < NC ? c + 1 : NC - 1;
+            stage_load(rho4, cn * CH, N, lane, sr);
+            const int idx = cn * CH + lane;
+            xa0 = idx < T ? xrow[idx] : 0.f;
+            xa1 = idx + 1 < T ? xrow[idx + 1] : 0.f;
         }
-        const float x = rdlane(incv, k & 63);
-        const float s = rdlane(sv, k & 63);
-        const float2 rho = rho_next;
-        rho_next = P.rho[(size_t)(k + 1) * DPW + i];  // table has N+1 rows
-        float2 ub[16];
-        bcast16(bufU, u, i, h, ub);
-        const float2 v = xhalf_add(mv16(MR, ub));
-        const float2 q = xhalf_add(mv16(MQ, ub));
-        const float2 y = make_float2(u.x + q.x + s * v.x, u.y + q.y + s * v.y);
-        float2 yb[16];
-        bcast16(bufY, y, i, h, yb);
-        const float2 r = xhalf_add(mv16(MR, yb));
-        const float e = 2.0f * sum32(y.x * r.x + y.y * r.y);
-        const float n = sum32(y.x * y.x + y.y * y.y);
-        const float z = (e * x) / P.A;
-        loss += -logf(1.0f + z);
-        if (st && h == 0) st[(size_t)k * DPW + i] = y;
-        const float inv = 1.0f / sqrtf(fmaxf(n, 1e-12f));
-        u = cmul(rho, cscale(inv, y));
+        float evec = 0.f, nvec = 1.f;
+        for (int kk = 0; kk < cnt; ++kk) {
+            const float s = rdlane(sv, kk);
+            // ---- serial chain: y = u + Q u + s R u ----
+            lds_wait_t<0>(qu, rho);
+            const v2f av = chain16(MR, qu);
+            const v2f aq = chain16(MQ, qu);
+            const v2f wp = aq + s * av;
+            const float y = u + swapadd(wp.x, wp.y);
+            v4f qy[8];
+            bcast_issue(aYw, aYr, y, qy);                        // for e_k only: off the chain
+            const float n = sum64(y * y);
+            const float inv = rsq_nr(fmaxf(n, 1e-12f));          // model.py:332
+            const float yo = osig_of(y, hb);
+            const v2f un = cmul2(inv * mk2(y, yo), rho);         // u_{k+1} = rho_k * y / sqrt(n)
+            u = un.x;
+            // next step's broadcast goes out before the off-chain work so its latency is covered
+            const int kn = kk + 1 < CH ? kk + 1 : 0;             // (row 0 of the next chunk is read after commit)
+            if (kk + 1 < cnt) {
+                bcast_issue_tab(aUw, aUr, u, aRho + kn * 256, qu, rho);
+                lds_wait<10>(qy);
+            } else {
+                lds_wait<0>(qy);
+            }
+            // ---- off the chain: e_k = 2 Re(y^dagger R y) ----
+            const v2f ar = chain16(MR, qy);
+            const float e = 2.0f * sum64(y * swapadd(ar.x, ar.y));   // model.py:325
+            evec = (lane == kk) ? e : evec;
+            nvec = (lane == kk) ? n : nvec;
+            if (st) st[(size_t)(kbeg + kk) * (2 * DPW)] = y;
+        }
+        // loss increments of this chunk in the reference's operation order (model.py:294), then the
+        // sequential float32 accumulation of model.py:279 in time order
+        const float z = (evec * incv) / A;
+        const float lv = -logf(1.0f + z);
+        for (int j = 0; j < cnt; ++j) loss += rdlane(lv, j);
+        if (sc) {
+            sc[(size_t)c * 128 + lane] = nvec;
+            sc[(size_t)c * 128 + 64 + lane] = evec;
+        }
+        if (c + 1 < NC) {
+            stage_commit(stR[w], lane, sr);
+            bcast_issue_tab(aUw, aUr, u, aRho, qu, rho);         // first step of the next chunk
+        }
     }
     if (lane == 0) loss_out[b] = loss;
 }
@@ -122,136 +313,203 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_fwd_wave(Dev P, const float* 
 // ------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------
+namespace {
+
+// Everything about step j that does not depend on the incoming cotangent (split layout, see header).
+struct Pre {
+    float yh;      // yhat_j = y_j / sqrt(max(n_j, 1e-12))           (split)
+    float yho;     // its osig
+    float yhp;     // yhat_j, or 0 when n_j <= 1e-12 (the projection term vanishes)
+    float un;      // u_{j+1} = rho_j yhat_j                          (split)
+    float uno;     // its osig
+    float pre;     // 2 ebar_j ((R + R^dagger) y_j)                   (split)
+    v2f rho;       // rho_j
+    float inv, s, ten, dtk;   // 1/sqrt(max(n_j,1e-12)), x_j/A, 2 ebar_j n_j, t_j - t_{j+1}
+};
+
+}  // namespace
+
 __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* __restrict__ audio) {
-    __shared__ __attribute__((aligned(16))) float2 lds[WAVES][3][DPW];
+    __shared__ __attribute__((aligned(16))) float4 stY[WAVES][CH * 16];   // stashed y rows of the current chunk
+    __shared__ __attribute__((aligned(16))) float4 stR[WAVES][CH * 16];   // rho rows of the current chunk
+    __shared__ __attribute__((aligned(16))) float2 bcB[WAVES][DPW];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i = lane & 31, h = lane >> 5;
+    const bool hb = h != 0;
     const int b = blockIdx.x * WAVES + w;
     if (b >= P.B) return;
-    const int N = P.N, T = P.T;
-    float2* bufY = lds[w][0];
-    float2* bufYb = lds[w][1];
-    float2* bufU = lds[w][2];
-    const float2 zero = make_float2(0.f, 0.f);
+    const int N = P.N, T = P.T, NC = (N + CH - 1) / CH;
 
-    float2 MR[16], MRd[16], MQ[16];
+    v2f MRd[16], MQ[16], MH[16];
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
-        MR[m] = P.R[i * DPW + 16 * h + m];
-        const float2 rt = P.RT[i * DPW + 16 * h + m];  // R[16h+m][i]
-        MRd[m] = make_float2(rt.x, -rt.y);
-        MQ[m] = P.Q[i * DPW + 16 * h + m];
+        const v2f r = ld2(&P.R[i * DPW + 16 * h + m]);
+        const v2f rt = ld2(&P.RT[i * DPW + 16 * h + m]);   // R[16h+m][i]
+        MRd[m] = mk2(rt.x, -rt.y);                          // R^dagger[i][16h+m]
+        MH[m] = mk2(r.x + rt.x, r.y - rt.y);                // (R + R^dagger)[i][16h+m]
+        MQ[m] = ld2(&P.Q[i * DPW + 16 * h + m]);
     }
-    float2 Rb[16], Qb[16];
-#pragma unroll
-    for (int m = 0; m < 16; ++m) Rb[m] = Qb[m] = zero;
+    v16f Rre = {}, Rim = {}, Qre = {}, Qim = {};
 
+    const unsigned aBw = lds_addr(&bcB[w][0]) + i * 8 + h * 4, aBr = lds_addr(&bcB[w][0]) + h * 128;
+    const unsigned aYrow = lds_addr(&stY[w][0]) + h * 128, aYown = lds_addr(&stY[w][0]) + i * 8 + h * 4;
+    const unsigned aRho = lds_addr(&stR[w][0]) + i * 8;
+    const float4* rho4 = reinterpret_cast<const float4*>(P.rho);
+    const float4* sty4 = reinterpret_cast<const float4*>(P.stash + (size_t)b * N * DPW);
     const float* xrow = audio + (size_t)b * T;
-    const float2* st = P.stash + (size_t)b * N * DPW;
-    const float A = P.A, invA2 = 1.0f / (A * A);
-    float facc = 0.f, Abar = 0.f;
-    float2 g = zero;
+    const float* sc = P.scal + scal_off(b, NC, 0);
+    const float A = P.A;
 
-    float2 y = st[(size_t)(N - 1) * DPW + i];
-    float nraw = sum32(y.x * y.x + y.y * y.y);
-    float inv = 1.0f / sqrtf(fmaxf(nraw, 1e-12f));
-    float2 yhat = cscale(inv, y);
-    float2 rho = P.rho[(size_t)(N - 1) * DPW + i];
-    float2 unext = cmul(rho, yhat);
-    // prefetched for the step's second half: y_{k-1}, rho_{k-1}
-    float2 yprev_n = N >= 2 ? st[(size_t)(N - 2) * DPW + i] : zero;
-    float2 rhoprev_n = N >= 2 ? P.rho[(size_t)(N - 2) * DPW + i] : make_float2(1.f, 0.f);
+    float facc = 0.f;   // per lane: sum_k dtk * g_osig * u_own   (the two halves are added at the end)
+    float accS = 0.f;   // per lane: sum_k s_k d_own u_own
+    float accA = 0.f;   // per lane (one step per lane): sum_k zbar_k (e_k x_k)
 
-    float incv = 0.f, sv = 0.f, dtv = 0.f;
-    int chunk = -1;
-    for (int k = N - 1; k >= 0; --k) {
-        if ((k >> 6) != chunk) {
-            chunk = k >> 6;
-            const int idx = (chunk << 6) + lane;
-            const float a0 = idx < T ? xrow[idx] : 0.f;
-            const float a1 = idx + 1 < T ? xrow[idx + 1] : 0.f;
-            incv = a1 - a0;
-            sv = incv / A;
-            dtv = P.dtk[idx];  // padded to N + 64 entries
-        }
-        const float x = rdlane(incv, k & 63);
-        const float s = rdlane(sv, k & 63);
-        const float dtk = rdlane(dtv, k & 63);
-        const float2 yprev = yprev_n, rhoprev = rhoprev_n;
-        if (k >= 2) {
-            yprev_n = st[(size_t)(k - 2) * DPW + i];
-            rhoprev_n = P.rho[(size_t)(k - 2) * DPW + i];
-        }
-        facc += dtk * (g.y * unext.x - g.x * unext.y);
-        const float2 yhb = cmul_conj_a(rho, g);
-        const float dot = sum32(yhat.x * yhb.x + yhat.y * yhb.y);
-        float2 ybar;
-        if (nraw > 1e-12f)
-            ybar = make_float2((yhb.x - yhat.x * dot) * inv, (yhb.y - yhat.y * dot) * inv);
-        else
-            ybar = cscale(inv, yhb);
-        float2 yb[16];
-        bcast16(bufY, y, i, h, yb);
-        const float2 r = xhalf_add(mv16(MR, yb));
-        const float2 a = xhalf_add(mv16(MRd, yb));
-        const float e = 2.0f * sum32(y.x * r.x + y.y * r.y);
-        const float ex = e * x;
+    // chunk vectors (one step per lane) of the chunk the "pre" stage is working in
+    float sv = 0.f, dtv = 0.f, invv = 1.f, invokv = 0.f, tev = 0.f, tenv = 0.f;
+    float ra0, ra1, rdt, rnv, rev;   // raw prefetched values of the next chunk
+    v4f sry[16], srr[16];
+    auto chunk_load = [&](int c) {
+        stage_load(sty4, c * CH, N - 1, lane, sry);
+        stage_load(rho4, c * CH, N, lane, srr);
+        const int idx = c * CH + lane;
+        ra0 = idx < T ? xrow[idx] : 0.f;
+        ra1 = idx + 1 < T ? xrow[idx + 1] : 0.f;
+        rdt = P.dtk[idx];                 // padded to N + 64 entries
+        rnv = sc[(size_t)c * 128 + lane];
+        rev = sc[(size_t)c * 128 + 64 + lane];
+    };
+    auto chunk_commit = [&](int c) {
+        stage_commit(stY[w], lane, sry);
+        stage_commit(stR[w], lane, srr);
+        const int idx = c * CH + lane;
+        const float inc = ra1 - ra0;
+        sv = inc / A;
+        dtv = rdt;
+        const float nv = rnv, ev = rev;
+        invv = rsq_nr(fmaxf(nv, 1e-12f));
+        invokv = nv > 1e-12f ? invv : 0.f;
+        const float ex = ev * inc;                      // model.py:294 operation order
         const float z = ex / A;
         const float zbar = -1.0f / (1.0f + z);
-        const float ebar = zbar * x / A;
-        Abar += zbar * (-ex * invA2);
-        const float te = 2.0f * ebar;
-        ybar.x += te * (r.x + a.x);
-        ybar.y += te * (r.y + a.y);
-        float2 ybb[16];
-        bcast16(bufYb, ybar, i, h, ybb);
-        const float2 bq = xhalf_add(mv16(MQ, ybb));
-        const float2 d = xhalf_add(mv16(MRd, ybb));
-        // u_k
-        float2 uk, yhatp = zero;
-        float nprev = 1.f, invp = 1.f;
-        if (k > 0) {
-            nprev = sum32(yprev.x * yprev.x + yprev.y * yprev.y);
-            invp = 1.0f / sqrtf(fmaxf(nprev, 1e-12f));
-            yhatp = cscale(invp, yprev);
-            uk = cmul(rhoprev, yhatp);
-        } else {
-            uk = P.psi0[i];
-        }
-        const float sbar = sum32(d.x * uk.x + d.y * uk.y);
-        Abar += sbar * (-x * invA2);
-        float2 ukb[16];
-        bcast16(bufU, uk, i, h, ukb);
-#pragma unroll
-        for (int m = 0; m < 16; ++m) {
-            const float2 yj = yb[m], uj = ukb[m];
-            const float2 o1 = make_float2(y.x * yj.x + y.y * yj.y, y.y * yj.x - y.x * yj.y);
-            const float2 o2 = make_float2(ybar.x * uj.x + ybar.y * uj.y, ybar.y * uj.x - ybar.x * uj.y);
-            Rb[m].x += te * o1.x + s * o2.x;
-            Rb[m].y += te * o1.y + s * o2.y;
-            Qb[m].x += o2.x;
-            Qb[m].y += o2.y;
-        }
-        g = make_float2(ybar.x + bq.x + s * d.x, ybar.y + bq.y + s * d.y);
-        y = yprev; nraw = nprev; inv = invp; yhat = yhatp; unext = uk; rho = rhoprev;
+        const float ebar = zbar * inc / A;
+        tev = 2.0f * ebar;
+        tenv = tev * nv;
+        if (idx < N) accA += zbar * ex;
+    };
+
+    // the off-chain stage for step j; its LDS reads were issued earlier by row_issue
+    auto make_pre = [&](int jj, v4f (&qy)[8], float yown, v2f rho) -> Pre {
+        Pre S;
+        S.rho = rho;
+        S.s = rdlane(sv, jj);
+        S.dtk = rdlane(dtv, jj);
+        S.inv = rdlane(invv, jj);
+        S.ten = rdlane(tenv, jj);
+        const float te = rdlane(tev, jj);
+        const float invok = rdlane(invokv, jj);
+        const v2f ah = chain16(MH, qy);
+        S.pre = te * swapadd(ah.x, ah.y);
+        S.yh = S.inv * yown;
+        S.yhp = invok * yown;
+        S.yho = osig_of(S.yh, hb);
+        const v2f un = cmul2(mk2(S.yh, S.yho), rho);
+        S.un = un.x;
+        S.uno = un.y;
+        return S;
+    };
+
+    const int cl = (N - 1) / CH;
+    chunk_load(cl);
+    chunk_commit(cl);
+    v4f qy[8], qc[8];
+    float yown;
+    v2f rho_j;
+    Pre S;
+    {
+        const int jj = (N - 1) & (CH - 1);
+        row_issue(aYrow + jj * 256, aYown + jj * 256, aRho + jj * 256, qy, yown, rho_j);
+        lds_wait_row<0>(qy, yown, rho_j);
+        S = make_pre(jj, qy, yown, rho_j);
     }
+    float g = 0.f, go = 0.f;                      // cotangent of u_{k+1}: split value and its osig
+    const float2 p0 = P.psi0[i];
+    const float u0 = hb ? p0.y : p0.x, u0o = hb ? -p0.x : p0.y;
+
+    // one step of the serial chain (step k = the step S describes), given u_k (split + osig)
+    auto chain_step = [&](const Pre& S, float uk, float uko, bool have_pre, int jjn) -> Pre {
+        // ---- chain, scalar part ----
+        facc += S.dtk * (go * S.un);
+        const v2f yhbp = cmul2_conj_b(mk2(g, go), S.rho);              // conj(rho_k) g
+        const float yhb = yhbp.x;
+        const float dot = sum64(S.yhp * yhb);
+        const float ybar = (yhb - dot * S.yhp) * S.inv + S.pre;
+        bcast_issue(aBw, aBr, ybar, qc);
+        // ---- off-chain: pre of step k-1 (gives u_k) ----
+        Pre Sn = S;
+        if (have_pre) {
+            lds_wait_row<9>(qy, yown, rho_j);
+            Sn = make_pre(jjn, qy, yown, rho_j);
+            uk = Sn.un;
+            uko = Sn.uno;
+        }
+        // ---- chain, mat-vec part: g_k = ybar + Q ybar + s R^dagger ybar ----
+        lds_wait<0>(qc);
+        const v2f aq = chain16(MQ, qc);
+        const v2f ad = chain16(MRd, qc);
+        const float sd = S.s * swapadd(ad.x, ad.y);
+        accS += sd * uk;
+        g = ybar + swapadd(aq.x, aq.y) + sd;
+        go = osig_of(g, hb);
+        // ---- rank-1 gradient updates (A: rows i, B: columns j; K = {re, im}) ----
+        //   Rbar += 2 ebar y y^dagger + s ybar u^dagger ;  Qbar += ybar u^dagger
+        //   Re(a b^dagger): A = a (split), B = b (split);  Im(a b^dagger): A = a (split), B = -b_osig
+        //   (the sign of the Im tiles is applied once at the end)
+        const float a1 = S.ten * S.yh;           // 2 ebar n yhat  (y y^dagger = n yhat yhat^dagger)
+        const float a2 = S.s * ybar;
+        Rre = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, S.yh, Rre, 0, 0, 0);
+        Rim = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, S.yho, Rim, 0, 0, 0);
+        Qre = __builtin_amdgcn_mfma_f32_32x32x2f32(ybar, uk, Qre, 0, 0, 0);
+        Qim = __builtin_amdgcn_mfma_f32_32x32x2f32(ybar, uko, Qim, 0, 0, 0);
+        Rre = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, uk, Rre, 0, 0, 0);
+        Rim = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, uko, Rim, 0, 0, 0);
+        return Sn;
+    };
+
+    // pre index j runs N-2 .. 0 chunk by chunk; the chain handles step j+1 in the same iteration
+    for (int c = cl; c >= 0; --c) {
+        const int jlo = c * CH;
+        const int jhi = (N - 2) < (jlo + CH - 1) ? (N - 2) : (jlo + CH - 1);
+        chunk_load(c > 0 ? c - 1 : 0);               // prefetch into registers (clamped: harmless reload)
+        for (int j = jhi; j >= jlo; --j) {
+            const int jj = j & (CH - 1);
+            row_issue(aYrow + jj * 256, aYown + jj * 256, aRho + jj * 256, qy, yown, rho_j);
+            S = chain_step(S, 0.f, 0.f, true, jj);
+        }
+        if (c > 0) chunk_commit(c - 1);
+    }
+    S = chain_step(S, u0, u0o, false, 0);            // step 0: u_0 = psi_0
+
+    // ---------------- per-clip slab ----------------
     float* slab = P.slabs + (size_t)b * P.slab_floats;
     constexpr int DD = DPW * DPW;
 #pragma unroll
-    for (int m = 0; m < 16; ++m) {
-        const int o = i * DPW + 16 * h + m;
-        slab[o] = Rb[m].x;
-        slab[DD + o] = Rb[m].y;
-        slab[2 * DD + o] = Qb[m].x;
-        slab[3 * DD + o] = Qb[m].y;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;   // C/D layout of the 32x32 MFMA: column = lane & 31
+        const int o = row * DPW + i;
+        slab[o] = Rre[r];
+        slab[DD + o] = -Rim[r];
+        slab[2 * DD + o] = Qre[r];
+        slab[3 * DD + o] = -Qim[r];
     }
-    if (h == 0) {
-        slab[4 * DD + i] = facc;
-        slab[4 * DD + DPW + i] = g.x;
-        slab[4 * DD + 2 * DPW + i] = g.y;
-    }
+    const float sumS = sum64(accS);
+    const float sumA = sum64(accA);
+    // fbar_i = sum_k dtk Im(g conj(u)) = sum over both halves of g_osig * u_own (the sign lives in osig)
+    const float ftot = swapadd(facc, facc);               // half 0: f(h=0) + f(h=1)
+    slab[4 * DD + (hb ? 2 * DPW : DPW) + i] = g;          // cotangent of psi_0: re in [DPW, 2DPW), im in [2DPW, 3DPW)
+    if (!hb) slab[4 * DD + i] = ftot;
     if (lane == 0) {
-        slab[4 * DD + 3 * DPW] = Abar;
+        // Abar = sum_k zbar_k (-(e x)_k / A^2) + sum_k sbar_k (-x_k / A^2),  s_k = x_k / A
+        slab[4 * DD + 3 * DPW] = -(sumA / (A * A)) - sumS / A;
         slab[4 * DD + 3 * DPW + 1] = 0.f;
     }
 }

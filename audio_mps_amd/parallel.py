@@ -1,0 +1,83 @@
+"""Data parallelism over the batch axis: one process per GPU, one collective per optimiser step.
+
+The reference is single-process (no distributed code at all).  The scan shards naturally
+because clips are independent given the parameters (model.py:260; the only cross-clip op is the final
+reduce_mean, model.py:267): rank r owns clips [r*B/W, (r+1)*B/W), parameters are replicated, and the
+only exchange is ONE all-reduce(sum) of the flat buffer the reverse kernel emits
+(2 D^2 + 3 D + 2 floats: dR, dfreqs, dpsi0, dA, sum loss) plus the local clip count -- 8.6 KB at D=32.
+On ROCm the "nccl" backend of torch.distributed IS RCCL (over xGMI inside a node); "gloo" is used for the
+CPU tests.  The message is latency-bound, so nothing is bucketed or overlapped: it is a single call.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+class DataParallel:
+    def __init__(self, backend: Optional[str] = None, device: Optional[torch.device] = None):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.device = device
+        self._own_group = False
+        if self.world_size > 1:
+            if backend is None:
+                backend = "nccl" if (device is not None and torch.device(device).type == "cuda") else "gloo"
+            self.backend = backend
+            if not dist.is_initialized():
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29500")
+                kwargs = {}
+                if backend == "nccl" and device is not None:
+                    kwargs["device_id"] = torch.device(device)
+                dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world_size, **kwargs)
+                self._own_group = True
+        else:
+            self.backend = None
+
+    # -- sharding ---------------------------------------------------------------------------------
+    def shard(self, global_batch: int) -> Tuple[int, int]:
+        """(first clip, number of clips) of this rank; the remainder goes to the lowest ranks."""
+        W, r = self.world_size, self.rank
+        base, rem = divmod(int(global_batch), W)
+        count = base + (1 if r < rem else 0)
+        start = r * base + min(r, rem)
+        return start, count
+
+    # -- the one collective -----------------------------------------------------------------------
+    def allreduce_sums(self, flat: torch.Tensor, local_clips: int) -> Tuple[np.ndarray, int]:
+        """Sum the per-rank gradient/loss sums and clip counts over all ranks.
+        flat: [G] float32 tensor on this rank's device (or CPU for gloo).  Returns (host float64 [G], B_global)."""
+        if self.world_size == 1:
+            return flat.detach().cpu().numpy().astype(np.float64), int(local_clips)
+        buf = torch.empty(flat.numel() + 1, dtype=torch.float32, device=flat.device)
+        buf[:-1] = flat
+        buf[-1] = float(local_clips)
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        host = buf.detach().cpu().numpy().astype(np.float64)
+        return host[:-1], int(round(host[-1]))
+
+    def barrier(self):
+        if self.world_size > 1:
+            if self.backend == "nccl" and self.device is not None:
+                dist.barrier(device_ids=[torch.device(self.device).index])
+            else:
+                dist.barrier()
+
+    def max_over_ranks(self, value: float) -> float:
+        if self.world_size == 1:
+            return float(value)
+        dev = self.device if self.backend == "nccl" else "cpu"
+        t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self._own_group and dist.is_initialized():
+            dist.destroy_process_group()
+            self._own_group = False

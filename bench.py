@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: audio samples/s for forward + backward of the PsiCMPS scan.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one complete optimiser step on one batch of synthetic audio already resident in HBM:
+parameter upload + table rebuild, forward scan, reverse scan, slab reduction, (one RCCL all-reduce of the
+gradient sums when N > 1), chain rule and Adam on the host.  Workload at every N: BASELINE.json configs[2]
+per GPU -- D=32, T=16000, batch 1024 per GPU (configs[3] = the same per GPU on 8 GPUs), so scaling is weak.
+Inputs: the reference's damped sine (data.py:8-22) plus white noise, parameters by the reference's
+initialisation rules (model.py:36-39, 49, 218-219) with train.py:41-43 hyper-parameters, seed 0.
+
+Rank 0 prints ONE JSON line; `roofline` describes the dominant kernel (the reverse scan), `cpu_baseline`
+is the plain-C restatement (oracle/cmps_oracle.c) timed on this host's cores on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 vector peak == fp32-input MFMA peak (dense)
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec peak
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--bond-dim", type=int, default=32)
+    p.add_argument("--T", type=int, default=16000)
+    p.add_argument("--batch-per-gpu", type=int, default=1024)
+    p.add_argument("--variant", type=int, default=0, help="0 auto, 1 block-per-clip, 2 wave-per-clip")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-clips", type=int, default=0, help="clips in the CPU sample (0 = 8 per core)")
+    return p.parse_args()
+
+
+def cpu_baseline(D, T, hp_values, seed):
+    """Times oracle/cmps_oracle.c (kind 'port': the reference itself is TensorFlow 1.x and cannot run here)
+    on a bounded sample of the same workload: forward + backward, float32, OpenMP over clips."""
+    from oracle import cmps_oracle as O, c_oracle as C
+    cores = os.cpu_count() or 1
+    hp = O.HParams(**hp_values)
+    var = O.init_variables(hp, seed=0)
+    R, f, _, _ = O.effective_params(hp, var)
+    p0 = O.psi_0(var)
+    clips = ARGS.cpu_clips if ARGS.cpu_clips > 0 else 8 * cores
+    data = make_audio_host(clips, T, hp.delta_t, seed)
+    C.psi_scan(data[:cores], R, f, p0, var.A, hp.delta_t, hp.sigma, "f32", want_grad=True, nthreads=cores)  # warm
+    t0 = time.perf_counter()
+    out = C.psi_scan(data, R, f, p0, var.A, hp.delta_t, hp.sigma, "f32", want_grad=True, nthreads=cores)
+    dt = time.perf_counter() - t0
+    assert np.all(np.isfinite(out["loss_per_clip"]))
+    return {"value": clips * T / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"{clips} clips of T={T}, D={D}, fwd+bwd, float32, {cores} OpenMP threads, {dt:.2f} s"}, out
+
+
+def make_audio_host(B, T, delta_t, seed, noise=0.02):
+    from audio_mps_amd.data import damped_sine
+    rng = np.random.default_rng(seed + 12345)
+    x = damped_sine(B, T, delta_t, seed=seed)
+    return (x + noise * rng.standard_normal(x.shape)).astype(np.float32)
+
+
+def main():
+    import torch
+    from audio_mps_amd import HParams, PsiCMPS
+    from audio_mps_amd.parallel import DataParallel
+    from audio_mps_amd.scan import HipScan
+    from audio_mps_amd.train import Trainer
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != ARGS.gpus:
+        if world == 1 and ARGS.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dp = DataParallel(device=dev)
+
+    D, T, B = ARGS.bond_dim, ARGS.T, ARGS.batch_per_gpu
+    hp = HParams(minibatch_size=B * world, bond_dim=D)          # train.py:41-43 defaults otherwise
+    config_id = 3
+    audio_host = make_audio_host(B, T, hp.delta_t, seed=1000 * config_id + rank)
+    audio = torch.from_numpy(audio_host).to(dev)                 # resident in HBM before the timed region
+    backend = HipScan(D, device=dev, variant=ARGS.variant)
+    model = PsiCMPS(hp, seed=0, backend=backend)
+    trainer = Trainer(model, hp, dp)
+
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    fwd_ms, bwd_ms = [], []
+
+    def step(timed):
+        # same sequence as Trainer.step, with HIP events around the two scan launches
+        be = model._get_backend()
+        be.set_params(model.effective_params(), B, T, train=True)
+        ev[0].record()
+        be.forward(audio, save_for_bwd=True)
+        ev[1].record()
+        flat = be.backward()
+        ev[2].record()
+        host, b_global = dp.allreduce_sums(flat, B)              # D2H copy synchronises the stream
+        total, grads = model.chain_rule(host, b_global, with_reg=True)
+        trainer.opt.apply_gradients(model.variables, grads)
+        if timed:
+            fwd_ms.append(ev[0].elapsed_time(ev[1]))
+            bwd_ms.append(ev[1].elapsed_time(ev[2]))
+        return host[-1] / b_global
+
+    for _ in range(ARGS.warmup):
+        step(False)
+    dp.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = 0.0
+    for _ in range(ARGS.steps):
+        last = step(True)
+    torch.cuda.synchronize()
+    dp.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = dp.max_over_ranks(elapsed)
+    if not np.isfinite(last):
+        raise SystemExit(f"non-finite loss {last}")
+
+    if rank == 0:
+        N = T - 1
+        ms_per_step = 1e3 * elapsed / ARGS.steps
+        value = world * B * T * ARGS.steps / elapsed
+        t_bwd = float(np.mean(bwd_ms)) * 1e-3
+        t_fwd = float(np.mean(fwd_ms)) * 1e-3
+        flops_bwd = 56.0 * D * D * B * N                         # 56 D^2 per (clip, sample)
+        flops_fwd = 24.0 * D * D * B * N
+        bytes_alg = 8.0 * B * T                                  # 4 B read forward + 4 B read in the reverse sweep
+        out = {
+            "metric": "audio samples/sec (fwd+bwd) at D=32, T=16000",
+            "value": value, "unit": "samples/s", "n_gpus": world, "steps": ARGS.steps, "warmup": ARGS.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[2]: PsiCMPS fwd+bwd scan, D={D}, T={T}, batch {B} per GPU"
+                                   f" (global {B * world}), damped sine + noise, full optimiser step",
+                       "parallelism": f"dp{world}", "kernel_variant": int(backend.variant)},
+            "roofline": {"bound": "mfma", "kernel": "k_bwd_wave (reverse scan)" if backend.variant == 2 else "k_bwd_block",
+                         "achieved": flops_bwd / t_bwd / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": flops_bwd / t_bwd / 1e12 / FP32_PEAK_TFLOPS, "traffic": None,
+                         "note": "fp32: the f32-input MFMA peak equals the fp32 vector peak (157.3 TFLOP/s); "
+                                 "the scan is compute/latency-bound, not HBM-bound (10 D^2 flop per byte)",
+                         "launch_ms": t_bwd * 1e3,
+                         "fwd_kernel": {"achieved": flops_fwd / t_fwd / 1e12, "frac": flops_fwd / t_fwd / 1e12 / FP32_PEAK_TFLOPS,
+                                        "launch_ms": t_fwd * 1e3},
+                         "hbm": {"achieved": bytes_alg / (t_fwd + t_bwd) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": bytes_alg / (t_fwd + t_bwd) / 1e9 / HBM_PEAK_GBS}},
+            "final_loss": float(last),
+        }
+        if not ARGS.no_cpu_baseline and world == 1:
+            cb, _ = cpu_baseline(D, T, hp.values(), seed=1000 * config_id)
+            out["cpu_baseline"] = cb
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    dp.barrier()
+    dp.close()
+
+
+if __name__ == "__main__":
+    ARGS = parse_args()
+    main()
