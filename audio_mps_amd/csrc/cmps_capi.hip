@@ -133,7 +133,7 @@ int cmps_set_params(cmps_handle_t h, const float* R_re_dev, const float* R_im_de
                                const_cast<float2*>(P.R), const_cast<float2*>(P.RT),
                                const_cast<float2*>(P.Q), const_cast<float2*>(P.psi0),
                                const_cast<float*>(P.freqs), const_cast<float2*>(P.rho),
-                               static_cast<hipStream_t>(stream));
+                               reinterpret_cast<double2*>(ws + L.off_rfix), static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail_hip(h, e, "cmps_set_params");
     h->tt_ws = ws; h->tt_N = L.N; h->tt_dt = dt;
     h->L = L; h->P = P; h->ws = ws;

@@ -13,7 +13,8 @@ namespace cmps {
 //              (Q = -(dt sigma^2 / 2) R^dagger R, Hermitian) | psi0 [D] float2 | freqs [D] float
 //   ttab     : t_k, k = 0..N          float32, sequential sum (model.py:16,266,281)
 //   dtk      : t_k - t_{k+1}          float32 (exact), k = 0..N-1
-//   rho      : [N][DP] float2         rho_k[d] = exp(i (fl(f_d t_k) - fl(f_d t_{k+1})))
+//   rho      : [N+1][DP] float2       rho_k[d] = exp(i (fl(f_d t_k) - fl(f_d t_{k+1}))), drift-corrected (cmps_prep.hip)
+//   rfix     : [2][NC][DP] double2    scratch of the drift correction
 //   stash    : [B][N][DP] float2      un-normalised rotating-frame state y_k (TRAIN only)
 //   scal     : [B][NC][2][64] float   per 64-step chunk: |y_k|^2 and e_k, one step per lane (wave variant)
 //   slabs    : [B][slab] float        per-clip gradient partials (TRAIN only)
@@ -22,8 +23,8 @@ namespace cmps {
 // ---------------------------------------------------------------------------------------------
 struct Layout {
     int D, DP, B, T, N, flags;
-    size_t off_R, off_RT, off_Q, off_psi0, off_freqs, off_ttab, off_dtk, off_rho, off_stash,
-        off_scal, off_slabs, off_sums, total;
+    size_t off_R, off_RT, off_Q, off_psi0, off_freqs, off_ttab, off_dtk, off_rho, off_rfix,
+        off_stash, off_scal, off_slabs, off_sums, total;
     size_t slab_floats;  // 4*DP*DP + 3*DP + 2
 };
 
@@ -46,6 +47,7 @@ inline Layout make_layout(int D, int B, int T, int flags) {
     L.off_ttab = o;  o = align256(o + (N + 1) * sizeof(float));
     L.off_dtk = o;   o = align256(o + (N + 64) * sizeof(float));
     L.off_rho = o;   o = align256(o + (N + 1) * DP * sizeof(float2));
+    L.off_rfix = o;  o = align256(o + ((N + 63) / 64) * DP * 2 * sizeof(double2));
     L.slab_floats = 4 * DP * DP + 3 * DP + 2;
     L.off_stash = o;
     L.off_scal = o;
@@ -85,7 +87,7 @@ struct Dev {
 hipError_t launch_prep(const Dev& P, const float* R_re, const float* R_im, const float* freqs,
                        const float* psi0_re, const float* psi0_im, float dt, bool rebuild_ttab,
                        float* ttab, float* dtk, float2* R, float2* RT, float2* Q, float2* psi0,
-                       float* freqs_out, float2* rho, hipStream_t s);
+                       float* freqs_out, float2* rho, double2* rfix, hipStream_t s);
 
 hipError_t launch_fwd_block(const Dev& P, const float* audio, float* loss, bool save, hipStream_t s);
 hipError_t launch_bwd_block(const Dev& P, const float* audio, hipStream_t s);

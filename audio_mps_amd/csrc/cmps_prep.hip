@@ -52,38 +52,87 @@ __global__ void k_pack(int D, int DP, const float* __restrict__ R_re, const floa
     }
 }
 
-// rho_k[d] = phi_k[d] * conj(phi_{k+1}[d]) with phi_k[d] = exp(i * fl32(f_d * t_k))  (model.py:305:
-// the argument of the exponential is the float32 product).  The two float32 angles are subtracted
-// exactly in double and the rotation is evaluated in double, then rounded once.
-__global__ void k_rho(int D, int DP, int N, const float* __restrict__ freqs,
-                      const float* __restrict__ ttab, float2* __restrict__ rho) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (size_t)(N + 1) * DP) return;
-    const int k = (int)(idx / DP), d = (int)(idx % DP);
-    float2 out = make_float2(1.f, 0.f);
-    if (d < D && k < N) {
-        const float f = freqs[d];
-        const float th0 = __fmul_rn(f, ttab[k]);
-        const float th1 = __fmul_rn(f, ttab[k + 1]);
-        const double del = (double)th0 - (double)th1;
-        double sn, cs;
-        sincos(del, &sn, &cs);
-        out = make_float2((float)cs, (float)sn);
+// rho_k[d] = phi_k[d] * conj(phi_{k+1}[d]) with phi_k[d] = exp(i * fl32(f_d * t_k))  (model.py:305: the
+// argument of the exponential is the float32 product).  The two float32 angles are subtracted exactly in
+// double, the rotation is evaluated in double and rounded once to float32.
+//
+// Rounding rho_k to float32 leaves a phase (and modulus) error of ~3e-8 per step.  In the reference the state
+// lives in the lab frame and is re-expressed with phases_k at every step, so table errors telescope; in the
+// rotating frame used here they would accumulate as a random walk over the clip (~4e-6 rad after 16000 steps),
+// which measurably shifts the log-likelihood (~1.5e-5 relative, the same for every clip).  So the table is
+// built with error feedback at chunk granularity: the LAST entry of every 64-step chunk is replaced by
+// fl32(target / actual), where actual is the exact (double) product of the float32 entries so far and target
+// is exp(-i fl32(f t_{k+1})), making the accumulated rotation exact at every chunk boundary.
+//
+// pass 1: one thread per (chunk, d): raw entries, the exact product of the chunk's entries but the last,
+//         and the target accumulated rotation at the end of the chunk.
+__global__ void k_rho_raw(int D, int DP, int N, const float* __restrict__ freqs, const float* __restrict__ ttab,
+                          float2* __restrict__ rho, double2* __restrict__ prod, double2* __restrict__ target) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int NC = (N + 63) / 64;
+    if (idx >= NC * DP) return;
+    const int c = idx / DP, d = idx % DP;
+    const int k0 = c * 64, k1 = (k0 + 64 < N ? k0 + 64 : N);     // steps [k0, k1)
+    double pr = 1.0, pi = 0.0;
+    const float f = d < D ? freqs[d] : 0.f;
+    for (int k = k0; k < k1; ++k) {
+        float2 out = make_float2(1.f, 0.f);
+        if (d < D) {
+            const float th0 = __fmul_rn(f, ttab[k]);
+            const float th1 = __fmul_rn(f, ttab[k + 1]);
+            double sn, cs;
+            sincos((double)th0 - (double)th1, &sn, &cs);
+            out = make_float2((float)cs, (float)sn);
+        }
+        rho[(size_t)k * DP + d] = out;
+        if (k < k1 - 1) {
+            const double nr = pr * (double)out.x - pi * (double)out.y;
+            pi = pr * (double)out.y + pi * (double)out.x;
+            pr = nr;
+        }
     }
-    rho[idx] = out;
+    if (c == NC - 1) rho[(size_t)N * DP + d] = make_float2(1.f, 0.f);   // row N: padding read by prefetches
+    prod[idx] = make_double2(pr, pi);
+    double sn = 0.0, cs = 1.0;
+    if (d < D) sincos(-(double)__fmul_rn(f, ttab[k1]), &sn, &cs);
+    target[idx] = make_double2(cs, sn);
+}
+// pass 2: one thread per d, sequential over chunks (a few hundred iterations of double arithmetic).
+__global__ void k_rho_fix(int DP, int N, float2* __restrict__ rho, const double2* __restrict__ prod,
+                          const double2* __restrict__ target) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= DP) return;
+    const int NC = (N + 63) / 64;
+    double ar = 1.0, ai = 0.0;   // exact accumulated rotation of the float32 table so far
+    for (int c = 0; c < NC; ++c) {
+        const int klast = (c * 64 + 64 < N ? c * 64 + 64 : N) - 1;
+        const double2 p = prod[c * DP + d], t = target[c * DP + d];
+        const double br = ar * p.x - ai * p.y, bi = ar * p.y + ai * p.x;     // before the chunk's last entry
+        const double den = br * br + bi * bi;
+        const double lr = (t.x * br + t.y * bi) / den, li = (t.y * br - t.x * bi) / den;   // target / actual
+        const float2 last = make_float2((float)lr, (float)li);
+        rho[(size_t)klast * DP + d] = last;
+        ar = br * (double)last.x - bi * (double)last.y;
+        ai = br * (double)last.y + bi * (double)last.x;
+    }
 }
 
 hipError_t launch_prep(const Dev& P, const float* R_re, const float* R_im, const float* freqs,
                        const float* psi0_re, const float* psi0_im, float dt, bool rebuild_ttab,
                        float* ttab, float* dtk, float2* R, float2* RT, float2* Q, float2* psi0,
-                       float* freqs_out, float2* rho, hipStream_t s) {
+                       float* freqs_out, float2* rho, double2* rfix, hipStream_t s) {
     if (rebuild_ttab) hipLaunchKernelGGL(k_ttable, dim3(1), dim3(64), 0, s, dt, P.N, ttab, dtk);
     const int n = P.DP * P.DP;
     hipLaunchKernelGGL(k_pack, dim3((n + 255) / 256), dim3(256), 0, s, P.D, P.DP, R_re, R_im, freqs,
                        psi0_re, psi0_im, P.c_half, R, RT, Q, psi0, freqs_out);
-    const size_t m = (size_t)(P.N + 1) * P.DP;
-    hipLaunchKernelGGL(k_rho, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, P.D, P.DP, P.N,
-                       freqs_out, ttab, rho);
+    const int NC = (P.N + 63) / 64;
+    const int m = NC * P.DP;
+    double2* prod = rfix;
+    double2* target = rfix + m;
+    hipLaunchKernelGGL(k_rho_raw, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, s, P.D, P.DP, P.N,
+                       (const float*)freqs_out, (const float*)ttab, rho, prod, target);
+    hipLaunchKernelGGL(k_rho_fix, dim3((unsigned)((P.DP + 63) / 64)), dim3(64), 0, s, P.DP, P.N, rho,
+                       (const double2*)prod, (const double2*)target);
     return hipGetLastError();
 }
 

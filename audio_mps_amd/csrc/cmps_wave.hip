@@ -78,18 +78,48 @@ __device__ __forceinline__ v2f cmul2_conj_b(v2f a, v2f b) {     // a * conj(b) =
     return acc;
 }
 
-// this half's 16 columns of (M v): one dependent chain of 32 packed ops (chains are free, see header)
-__device__ __forceinline__ v2f chain16(const v2f (&M)[16], const v4f (&q)[8]) {
+// ---- mat-vec cores.  One asm statement per 8 complex multiply-accumulates (16 packed instructions):
+// hipcc pads every asm statement boundary with an s_nop, which costs a full issue slot for a lone wave, so
+// the chains are emitted as a few large blocks.  Dependent accumulation inside a block is free (see header).
+// operand numbering: CM(acc, m, b): acc += M_m * b   (complex, two packed FMAs)
+#define CM_FIRST(acc, m, b)                                                                   \
+    "v_pk_mul_f32 %" #acc ", %" #m ", %" #b " op_sel:[0,0] op_sel_hi:[1,0]\n\t"                 \
+    "v_pk_fma_f32 %" #acc ", %" #m ", %" #b ", %" #acc " op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]\n\t"
+#define CM(acc, m, b)                                                                         \
+    "v_pk_fma_f32 %" #acc ", %" #m ", %" #b ", %" #acc " op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"   \
+    "v_pk_fma_f32 %" #acc ", %" #m ", %" #b ", %" #acc " op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]\n\t"
+
+// this half's 16 columns of (M v), one chain
+__device__ __forceinline__ v2f mv1(const v2f (&M)[16], const v4f (&q)[8]) {
     v2f acc;
-    pkmul_bl(acc, M[0], lo2(q[0]));
-    pkfma_bh(acc, M[0], lo2(q[0]));
-#pragma unroll
-    for (int m = 1; m < 16; ++m) {
-        const v2f b = (m & 1) ? hi2(q[m >> 1]) : lo2(q[m >> 1]);
-        pkfma_bl(acc, M[m], b);
-        pkfma_bh(acc, M[m], b);
-    }
+    asm(CM_FIRST(0, 1, 9) CM(0, 2, 10) CM(0, 3, 11) CM(0, 4, 12) CM(0, 5, 13) CM(0, 6, 14) CM(0, 7, 15) CM(0, 8, 16)
+        : "=&v"(acc)
+        : "v"(M[0]), "v"(M[1]), "v"(M[2]), "v"(M[3]), "v"(M[4]), "v"(M[5]), "v"(M[6]), "v"(M[7]),
+          "v"(lo2(q[0])), "v"(hi2(q[0])), "v"(lo2(q[1])), "v"(hi2(q[1])), "v"(lo2(q[2])), "v"(hi2(q[2])),
+          "v"(lo2(q[3])), "v"(hi2(q[3])));
+    asm(CM(0, 1, 9) CM(0, 2, 10) CM(0, 3, 11) CM(0, 4, 12) CM(0, 5, 13) CM(0, 6, 14) CM(0, 7, 15) CM(0, 8, 16)
+        : "+v"(acc)
+        : "v"(M[8]), "v"(M[9]), "v"(M[10]), "v"(M[11]), "v"(M[12]), "v"(M[13]), "v"(M[14]), "v"(M[15]),
+          "v"(lo2(q[4])), "v"(hi2(q[4])), "v"(lo2(q[5])), "v"(hi2(q[5])), "v"(lo2(q[6])), "v"(hi2(q[6])),
+          "v"(lo2(q[7])), "v"(hi2(q[7])));
     return acc;
+}
+// two matrices applied to the same vector, chains interleaved
+__device__ __forceinline__ void mv2(const v2f (&MA)[16], const v2f (&MB)[16], const v4f (&q)[8], v2f& accA, v2f& accB) {
+    asm(CM_FIRST(0, 2, 18) CM_FIRST(1, 10, 18) CM(0, 3, 19) CM(1, 11, 19) CM(0, 4, 20) CM(1, 12, 20) CM(0, 5, 21) CM(1, 13, 21)
+        CM(0, 6, 22) CM(1, 14, 22) CM(0, 7, 23) CM(1, 15, 23) CM(0, 8, 24) CM(1, 16, 24) CM(0, 9, 25) CM(1, 17, 25)
+        : "=&v"(accA), "=&v"(accB)
+        : "v"(MA[0]), "v"(MA[1]), "v"(MA[2]), "v"(MA[3]), "v"(MA[4]), "v"(MA[5]), "v"(MA[6]), "v"(MA[7]),
+          "v"(MB[0]), "v"(MB[1]), "v"(MB[2]), "v"(MB[3]), "v"(MB[4]), "v"(MB[5]), "v"(MB[6]), "v"(MB[7]),
+          "v"(lo2(q[0])), "v"(hi2(q[0])), "v"(lo2(q[1])), "v"(hi2(q[1])), "v"(lo2(q[2])), "v"(hi2(q[2])),
+          "v"(lo2(q[3])), "v"(hi2(q[3])));
+    asm(CM(0, 2, 18) CM(1, 10, 18) CM(0, 3, 19) CM(1, 11, 19) CM(0, 4, 20) CM(1, 12, 20) CM(0, 5, 21) CM(1, 13, 21)
+        CM(0, 6, 22) CM(1, 14, 22) CM(0, 7, 23) CM(1, 15, 23) CM(0, 8, 24) CM(1, 16, 24) CM(0, 9, 25) CM(1, 17, 25)
+        : "+v"(accA), "+v"(accB)
+        : "v"(MA[8]), "v"(MA[9]), "v"(MA[10]), "v"(MA[11]), "v"(MA[12]), "v"(MA[13]), "v"(MA[14]), "v"(MA[15]),
+          "v"(MB[8]), "v"(MB[9]), "v"(MB[10]), "v"(MB[11]), "v"(MB[12]), "v"(MB[13]), "v"(MB[14]), "v"(MB[15]),
+          "v"(lo2(q[4])), "v"(hi2(q[4])), "v"(lo2(q[5])), "v"(hi2(q[5])), "v"(lo2(q[6])), "v"(hi2(q[6])),
+          "v"(lo2(q[7])), "v"(hi2(q[7])));
 }
 
 __device__ __forceinline__ float rdlane(float v, int lane) {
@@ -267,8 +297,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_fwd_wave(Dev P, const float* 
             const float s = rdlane(sv, kk);
             // ---- serial chain: y = u + Q u + s R u ----
             lds_wait_t<0>(qu, rho);
-            const v2f av = chain16(MR, qu);
-            const v2f aq = chain16(MQ, qu);
+            v2f av, aq;
+            mv2(MR, MQ, qu, av, aq);
             const v2f wp = aq + s * av;
             const float y = u + swapadd(wp.x, wp.y);
             v4f qy[8];
@@ -278,21 +308,19 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_fwd_wave(Dev P, const float* 
             const float yo = osig_of(y, hb);
             const v2f un = cmul2(inv * mk2(y, yo), rho);         // u_{k+1} = rho_k * y / sqrt(n)
             u = un.x;
-            // next step's broadcast goes out before the off-chain work so its latency is covered
-            const int kn = kk + 1 < CH ? kk + 1 : 0;             // (row 0 of the next chunk is read after commit)
-            if (kk + 1 < cnt) {
-                bcast_issue_tab(aUw, aUr, u, aRho + kn * 256, qu, rho);
-                lds_wait<10>(qy);
-            } else {
-                lds_wait<0>(qy);
-            }
+            // next step's broadcast goes out before the off-chain work so its latency is covered (after the
+            // last step of a chunk it is a dummy: the tables are re-staged first and it is issued again)
+            const int kn = kk + 1 < CH ? kk + 1 : 0;
+            bcast_issue_tab(aUw, aUr, u, aRho + kn * 256, qu, rho);
+            lds_wait<10>(qy);
             // ---- off the chain: e_k = 2 Re(y^dagger R y) ----
-            const v2f ar = chain16(MR, qy);
+            const v2f ar = mv1(MR, qy);
             const float e = 2.0f * sum64(y * swapadd(ar.x, ar.y));   // model.py:325
             evec = (lane == kk) ? e : evec;
             nvec = (lane == kk) ? n : nvec;
             if (st) st[(size_t)(kbeg + kk) * (2 * DPW)] = y;
         }
+        lds_wait_t<0>(qu, rho);                                  // retire the dummy broadcast
         // loss increments of this chunk in the reference's operation order (model.py:294), then the
         // sequential float32 accumulation of model.py:279 in time order
         const float z = (evec * incv) / A;
@@ -407,7 +435,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
         S.ten = rdlane(tenv, jj);
         const float te = rdlane(tev, jj);
         const float invok = rdlane(invokv, jj);
-        const v2f ah = chain16(MH, qy);
+        const v2f ah = mv1(MH, qy);
         S.pre = te * swapadd(ah.x, ah.y);
         S.yh = S.inv * yown;
         S.yhp = invok * yown;
@@ -454,8 +482,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
         }
         // ---- chain, mat-vec part: g_k = ybar + Q ybar + s R^dagger ybar ----
         lds_wait<0>(qc);
-        const v2f aq = chain16(MQ, qc);
-        const v2f ad = chain16(MRd, qc);
+        v2f aq, ad;
+        mv2(MQ, MRd, qc, aq, ad);
         const float sd = S.s * swapadd(ad.x, ad.y);
         accS += sd * uk;
         g = ybar + swapadd(aq.x, aq.y) + sd;

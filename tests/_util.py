@@ -41,3 +41,86 @@ def rel_inf(a, b):
     a = np.asarray(a, dtype=np.complex128 if np.iscomplexobj(a) or np.iscomplexobj(b) else np.float64)
     b = np.asarray(b, dtype=a.dtype)
     return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+# ---------------------------------------------------------------------------------------------------
+# golden fixtures
+# ---------------------------------------------------------------------------------------------------
+import glob
+import os
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLDEN_DIR, name + ".npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+def golden_hparams(g, cls):
+    """hyper-parameters of a fixture as an instance of ``cls`` (the product's or the oracle's HParams)."""
+    kw = {}
+    for k in ("minibatch_size", "bond_dim", "delta_t", "sigma", "h_reg", "r_reg", "initial_rank", "A", "learning_rate"):
+        v = g["hp_" + k].item()
+        if k in ("minibatch_size", "bond_dim"):
+            v = int(v)
+        if k == "initial_rank":
+            v = None if v == -1 else int(v)
+        kw[k] = v
+    return cls(**kw)
+
+
+def golden_oracle_variables(g):
+    return O.Variables(*(np.array(g["var_" + k]) for k in O.Variables.NAMES),
+                       scaled_R=bool(g["scaled_R"]), scaled_freqs=bool(g["scaled_freqs"]))
+
+
+def model_from_golden(g, backend=None):
+    """The product's PsiCMPS holding exactly the fixture's raw variables."""
+    from audio_mps_amd import HParams, PsiCMPS
+    hp = golden_hparams(g, HParams)
+    D = hp.bond_dim
+    kw = {}
+    if not bool(g["scaled_R"]):
+        kw["R_in"] = (g["var_Rx"] + 1j * g["var_Ry"]).astype(np.complex64)
+    if not bool(g["scaled_freqs"]):
+        kw["freqs_in"] = g["var_freqs"].astype(np.float32)
+    m = PsiCMPS(hp, data_iterator=g["data"], backend=backend, **kw)
+    for k in O.Variables.NAMES:
+        m.variables[k] = np.array(g["var_" + k], dtype=np.float32)
+    assert m.variables["Rx"].shape == (D, D)
+    return m
+
+
+class OracleBackend:
+    """A stand-in for HipScan built on the oracle, used ONLY by CPU tests of the host logic (chain rule, Adam,
+    trainer, data-parallel reduction).  Same two methods, host tensors instead of device tensors."""
+    name = "oracle"
+    device = None
+
+    def __init__(self, D, dtype="f32"):
+        self.D, self.dtype = D, dtype
+
+    def set_params(self, p, B, T, train=True):
+        self.p = p
+
+    def _run(self, audio, want_grad):
+        import torch
+        a = audio.numpy() if isinstance(audio, torch.Tensor) else np.asarray(audio)
+        return C.psi_scan(a, self.p.R, self.p.freqs, self.p.psi0, self.p.A, self.p.delta_t, self.p.sigma,
+                          self.dtype, want_grad=want_grad, nthreads=2)
+
+    def forward(self, audio, save_for_bwd=False):
+        import torch
+        self._audio = audio
+        return torch.from_numpy(self._run(audio, False)["loss_per_clip"].astype(np.float32))
+
+    def loss_and_grad_sums(self, audio):
+        import torch
+        out = self._run(audio, True)
+        return (torch.from_numpy(out["loss_per_clip"].astype(np.float32)),
+                torch.from_numpy(out["grad"].astype(np.float32)))

@@ -1,0 +1,56 @@
+"""The C-ABI library builds (hipcc cross-compiles gfx950 without a GPU), loads, and exports every symbol that
+include/cmps.h declares.  No compute call is made here (that needs a GPU: tests marked gpu)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "cmps.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cmps_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported(hip_lib):
+    from audio_mps_amd import _capi
+    names = declared_symbols()
+    assert len(names) >= 12
+    assert sorted(_capi.SYMBOLS) == names
+    for n in names:
+        assert hasattr(hip_lib, n), n
+
+
+def test_host_only_entry_points(hip_lib):
+    from audio_mps_amd import _capi
+    assert hip_lib.cmps_version() >= 100
+    h = ctypes.c_void_p()
+    assert hip_lib.cmps_create(0, ctypes.byref(h)) == _capi.CMPS_ERR_UNSUPPORTED_D
+    assert hip_lib.cmps_create(129, ctypes.byref(h)) == _capi.CMPS_ERR_UNSUPPORTED_D
+    assert hip_lib.cmps_create(32, ctypes.byref(h)) == _capi.CMPS_OK and h.value
+    assert hip_lib.cmps_get_variant(h) == _capi.CMPS_VARIANT_WAVE
+    assert hip_lib.cmps_set_variant(h, _capi.CMPS_VARIANT_BLOCK) == _capi.CMPS_OK
+    assert hip_lib.cmps_get_variant(h) == _capi.CMPS_VARIANT_BLOCK
+    assert hip_lib.cmps_set_variant(h, 7) == _capi.CMPS_ERR_BAD_ARG
+    assert b"unknown variant" in hip_lib.cmps_last_error(h)
+    # call order is enforced before anything touches the device
+    assert hip_lib.cmps_psi_loss_fwd(h, None, 1, 2, None, 0, None) == _capi.CMPS_ERR_STATE
+    assert hip_lib.cmps_psi_loss_bwd(h, None, 1, 2, None, None) == _capi.CMPS_ERR_STATE
+    assert hip_lib.cmps_destroy(h) == _capi.CMPS_OK
+    h64 = ctypes.c_void_p()
+    assert hip_lib.cmps_create(64, ctypes.byref(h64)) == _capi.CMPS_OK
+    assert hip_lib.cmps_get_variant(h64) == _capi.CMPS_VARIANT_BLOCK
+    assert hip_lib.cmps_set_variant(h64, _capi.CMPS_VARIANT_WAVE) == _capi.CMPS_ERR_UNSUPPORTED_D
+    hip_lib.cmps_destroy(h64)
+
+
+def test_workspace_bytes(hip_lib):
+    from audio_mps_amd import _capi
+    assert hip_lib.cmps_workspace_bytes(0, 1, 16, 0) == 0
+    assert hip_lib.cmps_workspace_bytes(32, 1, 1, 0) == 0
+    fwd = hip_lib.cmps_workspace_bytes(32, 1024, 16000, _capi.CMPS_WS_FWD_ONLY)
+    trn = hip_lib.cmps_workspace_bytes(32, 1024, 16000, _capi.CMPS_WS_TRAIN)
+    assert 4_000_000 < fwd < 8_000_000                     # rotation table 4.1 MB + small tables
+    stash = 1024 * 15999 * 32 * 8
+    assert stash < trn < stash * 1.05                     # the per-step state stash dominates (4.2 GB at C3)

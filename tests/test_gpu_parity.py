@@ -1,0 +1,262 @@
+"""Parity of the HIP path (through the C ABI, include/cmps.h) against the oracle, on a real MI355X.
+
+Tolerances (stated once, used everywhere below):
+  * per-clip log-likelihood: |hip - oracle_f32| <= 1e-5 * max(|oracle_f32|, 1)   (BASELINE north_star: 1e-5 relative).
+    The floor of 1 covers clips whose loss is a small difference of large partial sums; there two float32
+    evaluations that differ only in summation order already differ by ~1e-4 relative.
+  * gradients: max |hip - oracle_f32| <= 1e-4 * max |oracle_f32| per tensor (observed ~3e-6).
+Both kernel variants are exercised: the wave-per-clip kernels (D <= 32, the hot path) and the block-per-clip
+kernels (any D <= 128).
+"""
+import ctypes
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cmps_oracle as O
+from oracle import c_oracle as C
+from _util import (c_oracle_run, golden_names, load_golden, make_audio, model_from_golden, oracle_hparams,
+                   oracle_variables, rel_inf)
+
+pytestmark = pytest.mark.gpu
+
+LOSS_RTOL = 1e-5
+GRAD_RTOL = 1e-4
+BLOCK, WAVE = 1, 2
+
+
+def _scan(D, variant):
+    from audio_mps_amd.scan import HipScan
+    return HipScan(D, variant=variant)
+
+
+def _model(D, T, B, variant, sigma=1e-4, seed=0, rscale=None, **hpkw):
+    from audio_mps_amd import HParams, PsiCMPS
+    hp = HParams(minibatch_size=B, bond_dim=D, sigma=sigma, **hpkw)
+    audio = make_audio(B, T, hp.delta_t, seed)
+    m = PsiCMPS(hp, data_iterator=audio, seed=seed, backend=_scan(D, variant))
+    if rscale is not None:
+        m.variables["Rx"] *= np.float32(rscale)
+        m.variables["Ry"] *= np.float32(rscale)
+    return m, audio
+
+
+def _check_against_oracle(m, audio, nthreads=0, loss_rtol=LOSS_RTOL, grad_rtol=GRAD_RTOL):
+    from audio_mps_amd.scan import unpack_grad
+    D = m.bond_d
+    per = m.loss_per_clip()
+    flat, B = m.grad_sums()
+    flat = flat.cpu().numpy()
+    ref = c_oracle_run(m, audio, "f32", nthreads=nthreads)
+    assert np.all(np.isfinite(per))
+    err = np.max(np.abs(per - ref["loss_per_clip"]) / np.maximum(np.abs(ref["loss_per_clip"]), 1.0))
+    assert err <= loss_rtol, f"loss rel err {err}"
+    g, gr = unpack_grad(flat, D), C.unpack_grad(ref["grad"], D)
+    for k in ("Rbar", "fbar", "psi0bar", "Abar"):
+        e = rel_inf(g[k], gr[k])
+        assert e <= grad_rtol, f"{k} rel err {e}"
+    assert abs(g["loss_sum"] - gr["loss_sum"]) <= loss_rtol * max(abs(gr["loss_sum"]), B)
+    return per, flat
+
+
+# ---------------------------------------------------------------------------------------------------
+# golden fixtures and oracle parity over shapes / variants
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("variant", [BLOCK, WAVE])
+@pytest.mark.parametrize("name", golden_names())
+def test_golden(name, variant):
+    from audio_mps_amd.scan import unpack_grad
+    g = load_golden(name)
+    D = int(g["hp_bond_dim"])
+    m = model_from_golden(g, backend=_scan(D, variant))
+    per = m.loss_per_clip()
+    scale = np.maximum(np.abs(g["loss_per_clip_f32"]), 1.0)
+    assert np.max(np.abs(per - g["loss_per_clip_f32"]) / scale) <= LOSS_RTOL
+    loss, grads = m.loss_and_grads()
+    assert abs(float(loss) - float(g["loss_f32"])) <= LOSS_RTOL * max(1.0, abs(float(g["loss_f32"])))
+    for k in O.Variables.NAMES:
+        assert rel_inf(grads[k], g[f"grad_{k}_f32"]) <= GRAD_RTOL, k
+    eff = unpack_grad(m._last, D)
+    B = g["data"].shape[0]
+    assert rel_inf(eff["Rbar"] / B, g["eff_Rbar_f32"]) <= GRAD_RTOL
+    assert rel_inf(eff["fbar"] / B, g["eff_fbar_f32"]) <= GRAD_RTOL
+
+
+@pytest.mark.parametrize("D,T,B,sigma,variant", [
+    (4, 256, 8, 1e-4, WAVE), (4, 256, 8, 1e-4, BLOCK),            # BASELINE configs[0] shape
+    (8, 300, 5, 1e-4, WAVE),                                      # train.py default bond_dim, ragged B
+    (7, 256, 8, 1.0, WAVE), (7, 256, 8, 1.0, BLOCK),              # odd D, sigma = 1 (dissipator visible)
+    (16, 1000, 16, 1e-4, WAVE), (16, 1000, 16, 1e-4, BLOCK),
+    (32, 2000, 12, 1e-4, WAVE), (32, 700, 6, 1e-4, BLOCK),
+    (32, 500, 4, 1.0, WAVE),
+    (33, 200, 3, 1e-4, BLOCK), (64, 300, 4, 1e-4, BLOCK), (128, 100, 2, 1e-4, BLOCK),   # D > 32: block variant
+])
+def test_oracle_parity(D, T, B, sigma, variant):
+    rscale = 0.1 if sigma == 1.0 else None
+    m, audio = _model(D, T, B, variant, sigma=sigma, seed=D + T, rscale=rscale)
+    _check_against_oracle(m, audio)
+
+
+@pytest.mark.parametrize("T", [2, 3, 64, 65, 66, 129, 193])
+def test_chunk_boundaries(T):
+    """T - 1 steps around the 64-step chunking of the wave kernels (1, 2, 63, 64, 65, 128, 192 steps)."""
+    m, audio = _model(32, T, 5, WAVE, seed=T)
+    _check_against_oracle(m, audio)
+
+
+def test_single_clip_and_non_multiple_of_four():
+    for B in (1, 2, 3, 7):
+        m, audio = _model(16, 130, B, WAVE, seed=B)
+        _check_against_oracle(m, audio)
+
+
+def test_config2_full_size():
+    """BASELINE configs[1]: D=16, T=4096, batch=256, full size against the C oracle."""
+    m, audio = _model(16, 4096, 256, WAVE, seed=2)
+    _check_against_oracle(m, audio, nthreads=16)
+
+
+def test_config3_reduced_batch():
+    """BASELINE configs[2] at full T = 16000, D = 32, on a reduced batch the oracle finishes in seconds."""
+    m, audio = _model(32, 16000, 32, WAVE, seed=3)
+    _check_against_oracle(m, audio, nthreads=16)
+
+
+def test_variants_agree():
+    m1, audio = _model(32, 1500, 9, WAVE, seed=5)
+    m2, _ = _model(32, 1500, 9, BLOCK, seed=5)
+    p1, p2 = m1.loss_per_clip(), m2.loss_per_clip()
+    assert np.max(np.abs(p1 - p2) / np.maximum(np.abs(p2), 1.0)) <= LOSS_RTOL
+    f1 = m1.grad_sums()[0].cpu().numpy()
+    f2 = m2.grad_sums()[0].cpu().numpy()
+    assert rel_inf(f1[:2 * 32 * 32], f2[:2 * 32 * 32]) <= GRAD_RTOL
+
+
+# ---------------------------------------------------------------------------------------------------
+# size-independent properties at BASELINE's full size (configs[2]: D=32, T=16000, B=1024)
+# ---------------------------------------------------------------------------------------------------
+def test_full_size_properties():
+    from audio_mps_amd import HParams, PsiCMPS
+    D, T, B = 32, 16000, 1024
+    hp = HParams(minibatch_size=B, bond_dim=D)
+    base = make_audio(64, T, hp.delta_t, 9)
+    audio = np.concatenate([base] * (B // 64), axis=0)           # 16 copies of 64 distinct clips
+    m = PsiCMPS(hp, seed=0, backend=_scan(D, WAVE))
+    per = m.loss_per_clip(audio)
+    assert per.shape == (B,) and np.all(np.isfinite(per))
+    # (1) determinism / independence of clips: identical clips give bit-identical losses wherever they sit
+    np.testing.assert_array_equal(per.reshape(B // 64, 64), np.tile(per[:64], (B // 64, 1)))
+    # (2) the reduced loss and gradient SUMS are additive over a split of the batch
+    full = m.grad_sums(audio)[0].cpu().numpy().astype(np.float64)
+    h1 = m.grad_sums(audio[:512])[0].cpu().numpy().astype(np.float64)
+    h2 = m.grad_sums(audio[512:])[0].cpu().numpy().astype(np.float64)
+    assert rel_inf(h1 + h2, full) <= 2e-5
+    assert abs(full[-1] - per.astype(np.float64).sum()) <= 1e-5 * abs(full[-1])
+    # (3) against the oracle on the 64 distinct clips
+    ref = c_oracle_run(m, base, "f32", want_grad=False, nthreads=16)
+    assert np.max(np.abs(per[:64] - ref["loss_per_clip"]) / np.maximum(np.abs(ref["loss_per_clip"]), 1.0)) <= LOSS_RTOL
+
+
+def test_gradient_is_directional_derivative():
+    """d/deps loss(R + eps dR) from two forward scans == <grad, dR> from the reverse scan (fp32, loose)."""
+    m, audio = _model(16, 400, 8, WAVE, seed=21)
+    loss0, grads = m.loss_and_grads()
+    rng = np.random.default_rng(0)
+    d = {k: rng.standard_normal(np.shape(v)).astype(np.float32) for k, v in m.variables.items()}
+    eps = 1e-3
+    base = {k: v.copy() for k, v in m.variables.items()}
+    vals = []
+    for sgn in (+1, -1):
+        for k in base:
+            m.variables[k] = (base[k] + sgn * eps * d[k]).astype(np.float32)
+        vals.append(float(np.mean(m.loss_per_clip().astype(np.float64))))
+    fd = (vals[0] - vals[1]) / (2 * eps)
+    an = sum(float(np.sum(grads[k].astype(np.float64) * d[k])) for k in base)
+    assert abs(fd - an) <= 2e-2 * max(abs(an), 1e-3), (fd, an)
+
+
+# ---------------------------------------------------------------------------------------------------
+# the reference's own invariants (tests/test_model.py), now on the HIP path
+# ---------------------------------------------------------------------------------------------------
+REF_TEST_HP = dict(r_reg=2 / (math.pi * 16000), h_reg=2 / (math.pi * 16000) ** 2)   # tests/test_model.py:13-14
+
+
+@pytest.mark.parametrize("variant", [BLOCK, WAVE])
+def test_loss_not_nan(variant):
+    """TestPsiCMPS.testLossNotNaN (tests/test_model.py:107-113)."""
+    m, _ = _model(7, 2 ** 8, 8, variant, **REF_TEST_HP)
+    assert not np.isnan(m.loss)
+
+
+@pytest.mark.parametrize("variant", [BLOCK, WAVE])
+def test_psi_evolved_with_data_remains_normalized(variant):
+    """TestPsiCMPS.testPsiEvolvedWithDataRemainsNormalized (tests/test_model.py:115-122)."""
+    m, audio = _model(7, 2 ** 8, 8, variant, **REF_TEST_HP)
+    psi = m.psi_evolve_with_data()
+    assert psi.shape == (8, 2 ** 8 - 1, 7)
+    np.testing.assert_allclose(np.linalg.norm(psi, axis=-1), np.ones(psi.shape[:2]), rtol=1e-5)
+    _, ref = O.psi_loss_per_clip(oracle_hparams(m.hparams), oracle_variables(m), audio, return_states=True)
+    assert np.max(np.abs(psi - ref)) < 2e-4        # |R| ~ 1e3 with these hparams: states decorrelate slowly
+
+
+def test_trivial_update_of_ancilla():
+    """TestPsiCMPS.testTrivialUpdateOfAncilla (tests/test_model.py:124-138)."""
+    from audio_mps_amd import HParams, PsiCMPS
+    hp = HParams(minibatch_size=8, bond_dim=7, **REF_TEST_HP)
+    m = PsiCMPS(hp, freqs_in=np.zeros(7, np.float32), R_in=np.zeros((7, 7), np.complex64), backend=_scan(7, 0))
+    signal = np.random.rand(8).astype(np.float32)
+    stack = np.stack(8 * [m.psi_0])
+    out = m._update_ancilla_psi(stack, signal, 0.0)
+    np.testing.assert_allclose(out, stack, rtol=1e-6)
+
+
+def test_update_ancilla_matches_oracle():
+    m, _ = _model(16, 8, 4, 0, sigma=1.0, seed=4, rscale=0.1)
+    rng = np.random.default_rng(1)
+    psi = (rng.standard_normal((4, 16)) + 1j * rng.standard_normal((4, 16))).astype(np.complex64)
+    sig = rng.standard_normal(4).astype(np.float32)
+    ohp, ov = oracle_hparams(m.hparams), oracle_variables(m)
+    R, f, _, _ = O.effective_params(ohp, ov)
+    ref = O.update_ancilla_psi(psi, sig, 0.37, R, f, ov.A, ohp)
+    out = m._update_ancilla_psi(psi, sig, 0.37)
+    assert np.max(np.abs(out - ref)) <= 1e-5 * np.max(np.abs(ref))
+
+
+# ---------------------------------------------------------------------------------------------------
+# error behaviour at the ABI
+# ---------------------------------------------------------------------------------------------------
+def test_error_codes_and_nan_propagation():
+    from audio_mps_amd import _capi
+    from audio_mps_amd.scan import HipScan
+    lib = _capi.load()
+    sc = HipScan(8)
+    m, audio = _model(8, 64, 4, 0)
+    # backward before forward
+    with pytest.raises(_capi.CmpsError) as ei:
+        sc.set_params(m.effective_params(), 4, 64, train=True)
+        sc._audio = torch.zeros((4, 64), device=sc.device)
+        sc.backward()
+    assert ei.value.code == _capi.CMPS_ERR_STATE
+    # save_for_bwd with a forward-only workspace
+    sc.set_params(m.effective_params(), 4, 64, train=False)
+    with pytest.raises(_capi.CmpsError) as ei:
+        sc.forward(torch.zeros((4, 64), device=sc.device), save_for_bwd=True)
+    assert ei.value.code == _capi.CMPS_ERR_WORKSPACE
+    # workspace too small
+    h = ctypes.c_void_p()
+    assert lib.cmps_create(8, ctypes.byref(h)) == 0
+    buf = torch.zeros(1024, dtype=torch.uint8, device=sc.device)
+    p = sc._param_buf.data_ptr()
+    rc = lib.cmps_set_params(h, p, p, p, p, p, 100.0, 1e-4, 1 / 16000, 64, 4, 1, buf.data_ptr(), 1024, None)
+    assert rc == _capi.CMPS_ERR_WORKSPACE and b"workspace" in lib.cmps_last_error(h)
+    lib.cmps_destroy(h)
+    # NaN is not an error at the boundary: it propagates into the loss like in the reference
+    bad = audio.copy()
+    bad[1, 10] = np.nan
+    per = m.loss_per_clip(bad)
+    assert np.isnan(per[1]) and np.all(np.isfinite(per[[0, 2, 3]]))
+    # 1 + z <= 0 gives NaN / inf (plain log(1 + z), model.py:294), again without an error
+    big = (audio * 1e6).astype(np.float32)
+    assert not np.all(np.isfinite(m.loss_per_clip(big)))

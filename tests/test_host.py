@@ -1,0 +1,134 @@
+"""CPU tests of the host-side mirror (audio_mps_amd.model / train): hyper-parameters, effective parameters,
+the chain rule from kernel outputs to raw-variable gradients, Adam, the trainer, checkpoint/resume.
+The scan itself is supplied by the oracle-backed stand-in (tests/_util.OracleBackend): these tests exercise
+the host logic only -- the HIP path has its own parity tests (-m gpu)."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from audio_mps_amd import HParams, CMPS, PsiCMPS, AudioMPS, RhoCMPS
+from audio_mps_amd.train import AdamOptimizer, Trainer
+from audio_mps_amd.data import get_audio
+from oracle import cmps_oracle as O
+from _util import (OracleBackend, golden_names, load_golden, model_from_golden, oracle_hparams, oracle_variables,
+                   rel_inf, make_audio)
+
+
+def test_hparams_defaults_and_parse():
+    hp = HParams()                                           # train.py:41-43
+    assert hp.minibatch_size == 8 and hp.bond_dim == 8 and hp.A == 100.0 and hp.sigma == 1e-4
+    assert hp.r_reg == 0.1 and hp.learning_rate == 1e-3 and hp.initial_rank is None
+    assert hp.h_reg == pytest.approx(200 / (math.pi * 16000) ** 2)
+    hp.parse("bond_dim=32,minibatch_size=64,learning_rate=0.3")   # train.py:31,44
+    assert (hp.bond_dim, hp.minibatch_size, hp.learning_rate) == (32, 64, 0.3)
+    with pytest.raises(ValueError):
+        HParams().parse("no_such=1")
+
+
+def test_effective_parameters_match_oracle():
+    hp = HParams(bond_dim=7, r_reg=2 / (math.pi * 16000), h_reg=2 / (math.pi * 16000) ** 2)
+    m = PsiCMPS(hp, seed=3, backend=OracleBackend(7))
+    R, f, _, _ = O.effective_params(oracle_hparams(hp), oracle_variables(m))
+    np.testing.assert_array_equal(m.R, R)
+    np.testing.assert_array_equal(m.freqs, f)
+    np.testing.assert_array_equal(m.psi_0, O.psi_0(oracle_variables(m)))
+    np.testing.assert_allclose(np.diagonal(m.R), 0, atol=1e-6)      # tests/test_model.py:19-25
+    assert abs(np.linalg.norm(m.psi_0) - 1) < 1e-6
+
+
+def test_R_in_freqs_in_branches():
+    D = 2
+    hp = HParams(bond_dim=D, sigma=1.0, A=1.0)
+    R = np.array([[0, 1], [0, 0]], dtype=np.complex64)              # tests/test_model.py:147-151
+    f = np.array([10.0, -10.0], dtype=np.float32)
+    m = PsiCMPS(hp, R_in=R, freqs_in=f, backend=OracleBackend(D))
+    np.testing.assert_array_equal(m.R, R - np.diagonal(R)[None, :])
+    np.testing.assert_array_equal(m.freqs, f)
+    with pytest.raises(ValueError):
+        CMPS(hp, R_in=np.zeros((3, 3)))
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_loss_and_chain_rule_match_golden(name):
+    """PsiCMPS.loss / loss_and_grads through the host chain rule == the oracle's own end-to-end gradients."""
+    g = load_golden(name)
+    m = model_from_golden(g, backend=OracleBackend(int(g["hp_bond_dim"])))
+    loss, grads = m.loss_and_grads()
+    assert abs(float(loss) - float(g["loss_f32"])) <= 2e-5 * max(1.0, abs(float(g["loss_f32"])))
+    for k in O.Variables.NAMES:
+        assert rel_inf(grads[k], g[f"grad_{k}_f32"]) < 2e-4, k
+    assert abs(float(m.loss) - float(g["loss_f32"])) <= 2e-5 * max(1.0, abs(float(g["loss_f32"])))
+
+
+def test_regularised_gradients_match_oracle():
+    hp = HParams(minibatch_size=3, bond_dim=5, sigma=0.7, A=3.0)
+    m = PsiCMPS(hp, seed=1, backend=OracleBackend(5))
+    m.variables["Rx"] *= np.float32(0.3)
+    m.variables["Ry"] *= np.float32(0.3)
+    data = make_audio(3, 60, hp.delta_t, 2, noise=0.05)
+    total, grads = m.loss_and_grads(data, with_reg=True)
+    ref = O.psi_loss_and_grads(oracle_hparams(hp), oracle_variables(m).astype(np.float64), data, "f64", with_reg=True)
+    assert abs(float(total) - float(ref.loss)) < 1e-4 * abs(float(ref.loss))
+    for k in O.Variables.NAMES:
+        assert rel_inf(grads[k], getattr(ref, k)) < 1e-3, k
+
+
+def test_adam_matches_formula():
+    opt = AdamOptimizer(learning_rate=1e-3)
+    v = {k: np.ones(3, np.float32) for k in ("A", "Rx", "Ry", "freqs", "psi_x", "psi_y")}
+    g = {k: np.full(3, 0.5, np.float32) for k in v}
+    opt.apply_gradients(v, g)
+    # t = 1: m = 0.1 g, v = 0.001 g^2, lr_t = lr sqrt(1-b2)/(1-b1) -> step = lr * g / (|g| + eps*...) ~ lr
+    lr_t = 1e-3 * math.sqrt(1 - 0.999) / (1 - 0.9)
+    expect = 1 - lr_t * (0.1 * 0.5) / (math.sqrt(0.001 * 0.25) + 1e-8)
+    np.testing.assert_allclose(v["Rx"], expect, rtol=1e-6)
+
+
+def test_trainer_decreases_loss_and_checkpoints(tmp_path):
+    hp = HParams(minibatch_size=4, bond_dim=4, learning_rate=0.01)
+    data = make_audio(4, 80, hp.delta_t, 3)
+    m = PsiCMPS(hp, data_iterator=data, seed=0, backend=OracleBackend(4))
+    tr = Trainer(m, hp)
+    first = tr.step()["total_loss"]
+    for _ in range(5):
+        last = tr.step()["total_loss"]
+    assert np.isfinite(last) and last < first
+    path = os.path.join(tmp_path, "ckpt", "model.ckpt.npz")
+    tr.save(path)
+    m2 = PsiCMPS(hp, data_iterator=data, seed=9, backend=OracleBackend(4))
+    tr2 = Trainer(m2, hp)
+    assert tr2.restore(path) and tr2.global_step == tr.global_step
+    for k in m.variables:
+        np.testing.assert_array_equal(m.variables[k], m2.variables[k])
+    assert tr2.step()["total_loss"] == pytest.approx(tr.step()["total_loss"], rel=1e-6)
+
+
+def test_audiomps_surface():
+    """training_estimators.py:43-45: AudioMPS(bond_d, dt, batch_size, data_iterator=data, mixed=discr).loss"""
+    data = make_audio(4, 64, 0.001, 1)
+    a = AudioMPS(4, 0.001, 4, data_iterator=data, mixed=False, backend=OracleBackend(4))
+    assert a.bond_d == 4 and a.delta_t == 0.001 and np.isfinite(a.loss)
+    with pytest.raises(NotImplementedError):
+        AudioMPS(4, 0.001, 4, data_iterator=data, mixed=True)
+    with pytest.raises(NotImplementedError):
+        RhoCMPS(HParams())
+
+
+def test_get_audio():
+    hp = HParams(minibatch_size=8)
+    d = get_audio(None, "damped_sine", hp, sample_duration=2 ** 8)   # tests/test_data.py:12-16
+    assert d.shape == (8, 256) and d.dtype == np.float32
+    with pytest.raises(NotImplementedError):
+        get_audio("./data", "guitar", hp)
+
+
+def test_product_has_no_cpu_fallback():
+    """Without a GPU the product must refuse to compute rather than silently use something else."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    m = PsiCMPS(HParams(bond_dim=4), data_iterator=make_audio(2, 16, 1 / 16000, 0))
+    with pytest.raises(RuntimeError):
+        _ = m.loss

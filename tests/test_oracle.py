@@ -1,0 +1,126 @@
+"""CPU tests of the oracle itself: the reference's own invariants (tests/test_model.py, tests/test_data.py
+of /root/reference) restated on the restatement, the two oracle implementations against each other, the
+float64 twin, finite-difference gradients, and the committed golden fixtures."""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import cmps_oracle as O
+from oracle import c_oracle as C
+from _util import golden_names, load_golden, golden_hparams, golden_oracle_variables, rel_inf
+
+# tests/test_model.py:13-14
+TEST_HP = O.HParams(minibatch_size=8, bond_dim=7, delta_t=1 / 16000, sigma=0.0001, initial_rank=None, A=100.0,
+                    h_reg=2 / (math.pi * 16000) ** 2, r_reg=2 / (math.pi * 16000))
+SAMPLE_DURATION = 2 ** 8    # tests/test_model.py:9
+
+
+def test_R_has_no_diagonal_elements():
+    """TestCMPS.testRHasNoDiagonalElements (tests/test_model.py:19-25)."""
+    var = O.init_variables(TEST_HP, seed=0)
+    R, _, _, _ = O.effective_params(TEST_HP, var)
+    np.testing.assert_allclose(np.diagonal(R), np.zeros(TEST_HP.bond_dim), atol=1e-6)
+    # the quirk of model.py:42: every column j is shifted by -Z[j, j]
+    Z = (O._rsqrt(TEST_HP.r_reg, np.float32) * (var.Rx + 1j * var.Ry)).astype(np.complex64)
+    np.testing.assert_allclose(R, Z - np.diagonal(Z)[None, :], rtol=1e-6)
+
+
+def test_data_shape():
+    """TestGetAudio.testCorrectShape (tests/test_data.py:12-16)."""
+    d = O.damped_sine(TEST_HP.minibatch_size, SAMPLE_DURATION, TEST_HP.delta_t, seed=0)
+    assert d.shape == (TEST_HP.minibatch_size, SAMPLE_DURATION) and d.dtype == np.float32
+
+
+def test_loss_not_nan():
+    """TestPsiCMPS.testLossNotNaN (tests/test_model.py:107-113)."""
+    var = O.init_variables(TEST_HP, seed=0)
+    data = O.damped_sine(TEST_HP.minibatch_size, SAMPLE_DURATION, TEST_HP.delta_t, seed=1)
+    assert not np.isnan(O.psi_loss(TEST_HP, var, data))
+
+
+def test_psi_evolved_with_data_remains_normalized():
+    """TestPsiCMPS.testPsiEvolvedWithDataRemainsNormalized (tests/test_model.py:115-122)."""
+    var = O.init_variables(TEST_HP, seed=0)
+    data = O.damped_sine(TEST_HP.minibatch_size, SAMPLE_DURATION, TEST_HP.delta_t, seed=1)
+    _, states = O.psi_loss_per_clip(TEST_HP, var, data, return_states=True)
+    assert states.shape == (TEST_HP.minibatch_size, SAMPLE_DURATION - 1, TEST_HP.bond_dim)
+    np.testing.assert_allclose(np.linalg.norm(states, axis=-1), np.ones(states.shape[:2]), rtol=1e-5)
+
+
+def test_trivial_update_of_ancilla():
+    """TestPsiCMPS.testTrivialUpdateOfAncilla (tests/test_model.py:124-138): H = R = 0 leaves psi unchanged."""
+    D, B = TEST_HP.bond_dim, TEST_HP.minibatch_size
+    var = O.init_variables(TEST_HP, seed=0, R_in=np.zeros((D, D), np.complex64), freqs_in=np.zeros(D, np.float32))
+    R, f, _, _ = O.effective_params(TEST_HP, var)
+    psi0 = np.tile(O.psi_0(var)[None], (B, 1))
+    signal = np.random.default_rng(0).random(B).astype(np.float32)
+    out = O.update_ancilla_psi(psi0, signal, 0.0, R, f, var.A, TEST_HP)
+    np.testing.assert_allclose(out, psi0, rtol=1e-6)
+
+
+@pytest.mark.parametrize("D,T,B,sigma", [(4, 64, 3, 1e-4), (7, 100, 4, 1.0), (16, 80, 2, 1e-4)])
+def test_c_oracle_matches_numpy_oracle(D, T, B, sigma):
+    hp = O.HParams(minibatch_size=B, bond_dim=D, sigma=sigma)
+    var = O.init_variables(hp, seed=D)
+    if sigma == 1.0:
+        var.Rx *= 0.1
+        var.Ry *= 0.1
+    data = O.damped_sine(B, T, hp.delta_t, seed=D + 1)
+    for dtype, tol in (("f32", 2e-5), ("f64", 1e-9)):
+        v = var if dtype == "f32" else var.astype(np.float64)
+        g = O.psi_loss_and_grads(hp, v, data, dtype)
+        R, f, _, _ = O.effective_params(hp, v, dtype)
+        c = C.psi_scan(data, R, f, O.psi_0(v, dtype), v.A, hp.delta_t, hp.sigma, dtype, want_grad=True, want_states=True)
+        scale = max(1.0, np.abs(g.per_clip).max())
+        assert np.abs(c["loss_per_clip"] - g.per_clip).max() / scale < tol
+        cg = C.unpack_grad(c["grad"], D)
+        for k in ("Rbar", "fbar", "psi0bar"):
+            assert rel_inf(np.asarray(cg[k]) / B, g.eff[k]) < 20 * tol, k
+        _, states = O.psi_loss_per_clip(hp, v, data, dtype, return_states=True)
+        assert np.abs(c["states"] - states).max() < 50 * tol
+
+
+def test_float64_gradients_match_finite_differences():
+    hp = O.HParams(minibatch_size=2, bond_dim=3, sigma=0.7, A=3.0)
+    var = O.init_variables(hp, seed=1)
+    var.Rx *= 0.3
+    var.Ry *= 0.3
+    data = (O.damped_sine(2, 21, hp.delta_t, seed=2)
+            + 0.05 * np.random.default_rng(5).standard_normal((2, 21))).astype(np.float32)
+    v64 = var.astype(np.float64)
+    g = O.psi_loss_and_grads(hp, v64, data, "f64", with_reg=True)
+    f = lambda v: float(O.total_loss(hp, v, data, "f64"))
+    for name in O.Variables.NAMES:
+        arr = getattr(v64, name)
+        ga = np.asarray(getattr(g, name))
+        for idx in np.ndindex(arr.shape):
+            h = 1e-6 * max(1.0, abs(float(arr[idx])))
+            vp, vm = v64.copy(), v64.copy()
+            getattr(vp, name)[idx] += h
+            getattr(vm, name)[idx] -= h
+            fd = (f(vp) - f(vm)) / (2 * h)
+            assert abs(fd - float(ga[idx])) <= 1e-6 * max(1e-3, abs(fd)), (name, idx, fd, float(ga[idx]))
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_oracle_reproduces_golden(name):
+    """The committed vectors are what the oracle computes today (numpy / libm differences allowed for)."""
+    g = load_golden(name)
+    hp = golden_hparams(g, O.HParams)
+    var = golden_oracle_variables(g)
+    out = O.psi_loss_and_grads(hp, var, g["data"], "f32")
+    scale = np.maximum(np.abs(g["loss_per_clip_f32"]), 1.0)
+    assert np.max(np.abs(out.per_clip - g["loss_per_clip_f32"]) / scale) < 2e-6
+    for k in O.Variables.NAMES:
+        assert rel_inf(getattr(out, k), g[f"grad_{k}_f32"]) < 1e-4, k
+    # the C restatement against the same vectors
+    R, f, _, _ = O.effective_params(hp, var)
+    c = C.psi_scan(g["data"], R, f, O.psi_0(var), var.A, hp.delta_t, hp.sigma, "f32", want_grad=True)
+    assert np.max(np.abs(c["loss_per_clip"] - g["loss_per_clip_f32"]) / scale) < 2e-5
+    cg = C.unpack_grad(c["grad"], hp.bond_dim)
+    B = g["data"].shape[0]
+    assert rel_inf(cg["Rbar"] / B, g["eff_Rbar_f32"]) < 1e-4
+    assert rel_inf(cg["fbar"] / B, g["eff_fbar_f32"]) < 1e-4
+    # float64 twin stays close (it is a sanity bound, not the parity target)
+    assert np.max(np.abs(g["loss_per_clip_f64"] - g["loss_per_clip_f32"]) / scale) < 1e-3
