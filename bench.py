@@ -41,7 +41,7 @@ def parse_args():
     p.add_argument("--batch-per-gpu", type=int, default=1024)
     p.add_argument("--variant", type=int, default=0, help="0 auto, 1 block-per-clip, 2 wave-per-clip")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-clips", type=int, default=0, help="clips in the CPU sample (0 = 8 per core)")
+    p.add_argument("--cpu-clips", type=int, default=0, help="clips in the CPU sample (0 = 8 per thread)")
     return p.parse_args()
 
 
@@ -49,7 +49,12 @@ def cpu_baseline(D, T, hp_values, seed):
     """Times oracle/cmps_oracle.c (kind 'port': the reference itself is TensorFlow 1.x and cannot run here)
     on a bounded sample of the same workload: forward + backward, float32, OpenMP over clips."""
     from oracle import cmps_oracle as O, c_oracle as C
-    cores = os.cpu_count() or 1
+    # the GPU box gives one GPU's share of the host: use the affinity mask, capped at 16 threads
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))
     hp = O.HParams(**hp_values)
     var = O.init_variables(hp, seed=0)
     R, f, _, _ = O.effective_params(hp, var)
@@ -63,6 +68,27 @@ def cpu_baseline(D, T, hp_values, seed):
     assert np.all(np.isfinite(out["loss_per_clip"]))
     return {"value": clips * T / dt, "unit": "samples/s", "cores": cores, "kind": "port",
             "sample": f"{clips} clips of T={T}, D={D}, fwd+bwd, float32, {cores} OpenMP threads, {dt:.2f} s"}, out
+
+
+def profiled_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary (profiles/*pmc_summary.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate passes of this same command, FETCH doubled as
+    MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950).  None if no profile is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as fh:
+            d = json.load(fh)["kernels"]
+        for name, c in d.items():
+            if kernel in name:
+                dv = c["derived"]
+                return {"bytes": dv["hbm_read_bytes_per_launch_corrected"] + dv["hbm_write_bytes_per_launch"],
+                        "source": os.path.relpath(files[-1], ROOT)}
+    except Exception:
+        return None
+    return None
 
 
 def make_audio_host(B, T, delta_t, seed, noise=0.02):
@@ -144,6 +170,8 @@ def main():
         flops_bwd = 56.0 * D * D * B * N                         # 56 D^2 per (clip, sample)
         flops_fwd = 24.0 * D * D * B * N
         bytes_alg = 8.0 * B * T                                  # 4 B read forward + 4 B read in the reverse sweep
+        traffic = profiled_traffic("k_bwd_wave" if backend.variant == 2 else "k_bwd_block") \
+            if (D, T, B) == (32, 16000, 1024) else None
         out = {
             "metric": "audio samples/sec (fwd+bwd) at D=32, T=16000",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": ARGS.steps, "warmup": ARGS.warmup,
@@ -154,7 +182,10 @@ def main():
                        "parallelism": f"dp{world}", "kernel_variant": int(backend.variant)},
             "roofline": {"bound": "mfma", "kernel": "k_bwd_wave (reverse scan)" if backend.variant == 2 else "k_bwd_block",
                          "achieved": flops_bwd / t_bwd / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": flops_bwd / t_bwd / 1e12 / FP32_PEAK_TFLOPS, "traffic": None,
+                         "frac": flops_bwd / t_bwd / 1e12 / FP32_PEAK_TFLOPS,
+                         "traffic": (lambda t: t["bytes"] if t else None)(traffic),
+                         "traffic_source": traffic["source"] if traffic else None,
+                         "algorithmic_bytes": 4.0 * B * T,
                          "note": "fp32: the f32-input MFMA peak equals the fp32 vector peak (157.3 TFLOP/s); "
                                  "the scan is compute/latency-bound, not HBM-bound (10 D^2 flop per byte)",
                          "launch_ms": t_bwd * 1e3,
