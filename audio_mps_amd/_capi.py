@@ -6,7 +6,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcmps.so")
+LIB_PATH = os.environ.get("CMPS_LIB") or os.path.join(_HERE, "lib", "libcmps.so")   # CMPS_LIB: diagnostic builds
 
 CMPS_OK = 0
 CMPS_ERR_BAD_ARG = 1

@@ -118,6 +118,7 @@ int cmps_set_params(cmps_handle_t h, const float* R_re_dev, const float* R_im_de
     P.dtk = reinterpret_cast<float*>(ws + L.off_dtk);
     P.rho = reinterpret_cast<float2*>(ws + L.off_rho);
     P.stash = (flags & CMPS_WS_TRAIN) ? reinterpret_cast<float2*>(ws + L.off_stash) : nullptr;
+    P.hst = (flags & CMPS_WS_TRAIN) ? reinterpret_cast<float*>(ws + L.off_hst) : nullptr;
     P.scal = (flags & CMPS_WS_TRAIN) ? reinterpret_cast<float*>(ws + L.off_scal) : nullptr;
     P.slabs = (flags & CMPS_WS_TRAIN) ? reinterpret_cast<float*>(ws + L.off_slabs) : nullptr;
     P.sums = (flags & CMPS_WS_TRAIN) ? reinterpret_cast<float*>(ws + L.off_sums) : nullptr;

@@ -16,6 +16,7 @@ namespace cmps {
 //   rho      : [N+1][DP] float2       rho_k[d] = exp(i (fl(f_d t_k) - fl(f_d t_{k+1}))), drift-corrected (cmps_prep.hip)
 //   rfix     : [2][NC][DP] double2    scratch of the drift correction
 //   stash    : [B][N][DP] float2      un-normalised rotating-frame state y_k (TRAIN only)
+//   hst      : [B][N][64] float       (R + R^dagger) y_k in split layout (TRAIN, wave variant)
 //   scal     : [B][NC][2][64] float   per 64-step chunk: |y_k|^2 and e_k, one step per lane (wave variant)
 //   slabs    : [B][slab] float        per-clip gradient partials (TRAIN only)
 //   sums     : [slab] float           reduced partials
@@ -24,7 +25,7 @@ namespace cmps {
 struct Layout {
     int D, DP, B, T, N, flags;
     size_t off_R, off_RT, off_Q, off_psi0, off_freqs, off_ttab, off_dtk, off_rho, off_rfix,
-        off_stash, off_scal, off_slabs, off_sums, total;
+        off_stash, off_hst, off_scal, off_slabs, off_sums, total;
     size_t slab_floats;  // 4*DP*DP + 3*DP + 2
 };
 
@@ -50,11 +51,14 @@ inline Layout make_layout(int D, int B, int T, int flags) {
     L.off_rfix = o;  o = align256(o + ((N + 63) / 64) * DP * 2 * sizeof(double2));
     L.slab_floats = 4 * DP * DP + 3 * DP + 2;
     L.off_stash = o;
+    L.off_hst = o;
     L.off_scal = o;
     L.off_slabs = o;
     L.off_sums = o;
     if (flags & 1) {
         o = align256(o + (size_t)B * N * DP * sizeof(float2));
+        L.off_hst = o;
+        if (D <= 32) o = align256(o + (size_t)B * N * 64 * sizeof(float));
         L.off_scal = o;  o = align256(o + (size_t)B * ((N + 63) / 64) * 128 * sizeof(float));
         L.off_slabs = o; o = align256(o + (size_t)B * L.slab_floats * sizeof(float));
         L.off_sums = o;  o = align256(o + L.slab_floats * sizeof(float));
@@ -75,6 +79,7 @@ struct Dev {
     const float* dtk;    // [N]
     const float2* rho;   // [N][DP]
     float2* stash;       // [B][N][DP]
+    float* hst;          // [B][N][64]   (wave variant)
     float* scal;         // [B][NC][2][64]
     float* slabs;        // [B][slab]
     float* sums;         // [slab]

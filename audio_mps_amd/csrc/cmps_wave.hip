@@ -18,17 +18,23 @@
 //     neg_lo on the SAME register pair -- then ONE v_permlane32_swap + ONE add combines the two halves
 //     and lands the result directly in the split layout.
 //   * wave reductions: 4 fused DPP adds inside 16-lane rows + 2 row_bcast adds + v_readlane.
-//   * per-step tables (rotation rho_k, and in the reverse sweep the stashed state y_k) are staged in LDS
-//     one 64-step chunk at a time; the next chunk is prefetched into registers while the current one is
-//     consumed, so the inner loops contain no global loads and wait on no memory latency.
+//   * per-step tables (rotation rho_k, and in the reverse sweep the stashed y_k and H y_k) are staged in LDS
+//     one chunk (64 / 32 steps) at a time; the next chunk is prefetched into registers while the current one
+//     is consumed, so the inner loops contain no global loads and wait on no memory latency.
+//   * the LDS round trip of a broadcast is ~350 cycles when four waves share the LDS: the forward keeps only
+//     ONE of them on its serial chain (u -> y), starts the FMAs on the first half of the reads, and runs the
+//     mat-vec that only feeds the loss (H y, e = y^dagger H y) one step late, reading y back from LDS.
 //   * everything uniform across lanes and off the serial chain (x/A, (e x)/A, log(1+z), 1/(1+z), ...) is
 //     evaluated once per 64 steps, one step per lane, in the reference's operation order, and fetched per
 //     step with v_readlane.  The float32 loss accumulation stays strictly sequential in time (model.py:279).
-//   * backward: R y and R^dagger y only enter as their sum, so one mat-vec with H = R + R^dagger replaces
-//     two; the three rank-1 gradient updates per step are six v_mfma_f32_32x32x2_f32 (exact fp32; K = 2 is
+//   * backward: R y and R^dagger y only enter as their sum H y (H = R + R^dagger), which the forward already
+//     computes for e = y^dagger H y and stashes, so the reverse step has TWO mat-vecs (Q ybar, R^dagger ybar);
+//     the three rank-1 gradient updates per step are six v_mfma_f32_32x32x2_f32 (exact fp32; K = 2 is
 //     {real, imaginary}; the split layout IS the MFMA operand layout); the part of the adjoint that does not
 //     depend on the incoming cotangent is computed one step ahead, off the serial chain.
 // Recurrence and adjoint: see the header of cmps_block.hip (same arithmetic, same reference lines).
+#include <type_traits>
+
 #include "cmps_internal.h"
 
 namespace cmps {
@@ -37,7 +43,8 @@ namespace {
 
 constexpr int DPW = 32;    // padded bond dimension of this variant
 constexpr int WAVES = 4;   // waves (clips) per workgroup: one per SIMD of a CU
-constexpr int CH = 64;     // steps per chunk
+constexpr int CH = 64;     // steps per chunk of per-step scalars (one step per lane); forward table staging
+constexpr int CHB = 32;    // steps per staged chunk in the reverse sweep (three tables share the LDS)
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -104,8 +111,9 @@ __device__ __forceinline__ v2f mv1(const v2f (&M)[16], const v4f (&q)[8]) {
           "v"(lo2(q[7])), "v"(hi2(q[7])));
     return acc;
 }
-// two matrices applied to the same vector, chains interleaved
-__device__ __forceinline__ void mv2(const v2f (&MA)[16], const v2f (&MB)[16], const v4f (&q)[8], v2f& accA, v2f& accB) {
+// two matrices applied to the same vector, chains interleaved; in two halves so that the first can start as
+// soon as the first four broadcast reads have landed
+__device__ __forceinline__ void mv2_lo(const v2f (&MA)[16], const v2f (&MB)[16], const v4f (&q)[8], v2f& accA, v2f& accB) {
     asm(CM_FIRST(0, 2, 18) CM_FIRST(1, 10, 18) CM(0, 3, 19) CM(1, 11, 19) CM(0, 4, 20) CM(1, 12, 20) CM(0, 5, 21) CM(1, 13, 21)
         CM(0, 6, 22) CM(1, 14, 22) CM(0, 7, 23) CM(1, 15, 23) CM(0, 8, 24) CM(1, 16, 24) CM(0, 9, 25) CM(1, 17, 25)
         : "=&v"(accA), "=&v"(accB)
@@ -113,6 +121,8 @@ __device__ __forceinline__ void mv2(const v2f (&MA)[16], const v2f (&MB)[16], co
           "v"(MB[0]), "v"(MB[1]), "v"(MB[2]), "v"(MB[3]), "v"(MB[4]), "v"(MB[5]), "v"(MB[6]), "v"(MB[7]),
           "v"(lo2(q[0])), "v"(hi2(q[0])), "v"(lo2(q[1])), "v"(hi2(q[1])), "v"(lo2(q[2])), "v"(hi2(q[2])),
           "v"(lo2(q[3])), "v"(hi2(q[3])));
+}
+__device__ __forceinline__ void mv2_hi(const v2f (&MA)[16], const v2f (&MB)[16], const v4f (&q)[8], v2f& accA, v2f& accB) {
     asm(CM(0, 2, 18) CM(1, 10, 18) CM(0, 3, 19) CM(1, 11, 19) CM(0, 4, 20) CM(1, 12, 20) CM(0, 5, 21) CM(1, 13, 21)
         CM(0, 6, 22) CM(1, 14, 22) CM(0, 7, 23) CM(1, 15, 23) CM(0, 8, 24) CM(1, 16, 24) CM(0, 9, 25) CM(1, 17, 25)
         : "+v"(accA), "+v"(accB)
@@ -143,6 +153,9 @@ __device__ __forceinline__ float dpp_add_row(float x) {
     return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float sum64(float x) {   // sum over all 64 lanes, uniform (SGPR) result
+#ifdef ABL_NO_REDUCE
+    return rdlane(x, 63);
+#endif
     x = dpp_add_row<0xB1>(x);    // quad_perm [1,0,3,2]
     x = dpp_add_row<0x4E>(x);    // quad_perm [2,3,0,1]
     x = dpp_add_row<0x141>(x);   // row_half_mirror
@@ -160,8 +173,8 @@ __device__ __forceinline__ float rsq_nr(float m) {   // 1/sqrt(m): v_rsq_f32 + o
 }
 
 // ---- LDS traffic of the inner loops, hidden from hipcc's waitcnt bookkeeping on purpose ----
-// broadcast: every lane writes its 4-byte split value; this half then reads its 16 complex entries.
-// Optionally also reads one 8-byte table entry (rho).  Outputs are valid only after lds_wait*.
+// broadcast: every lane writes its 4-byte split value; this half then reads its 16 complex entries and one
+// 8-byte table entry (rho).  Outputs are valid only after a matching lds_wait*.
 __device__ __forceinline__ void bcast_issue(unsigned wr, unsigned rd, float mine, v4f (&o)[8]) {
     asm volatile("ds_write_b32 %8, %9\n\t"
                  "ds_read_b128 %0, %10\n\tds_read_b128 %1, %10 offset:16\n\t"
@@ -183,16 +196,22 @@ __device__ __forceinline__ void bcast_issue_tab(unsigned wr, unsigned rd, float 
                    "=&v"(t)
                  : "v"(wr), "v"(mine), "v"(rd), "v"(tab) : "memory");
 }
-// row read (no write): this half's 16 entries of a staged vector, the lane's own split value, one table entry
-__device__ __forceinline__ void row_issue(unsigned rd, unsigned own_addr, unsigned tab, v4f (&o)[8], float& own, v2f& t) {
-    asm volatile("ds_read_b128 %0, %10\n\tds_read_b128 %1, %10 offset:16\n\t"
-                 "ds_read_b128 %2, %10 offset:32\n\tds_read_b128 %3, %10 offset:48\n\t"
-                 "ds_read_b128 %4, %10 offset:64\n\tds_read_b128 %5, %10 offset:80\n\t"
-                 "ds_read_b128 %6, %10 offset:96\n\tds_read_b128 %7, %10 offset:112\n\t"
-                 "ds_read_b32 %8, %11\n\tds_read_b64 %9, %12"
-                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]),
-                   "=&v"(own), "=&v"(t)
-                 : "v"(rd), "v"(own_addr), "v"(tab) : "memory");
+// row read (no write): this half's 16 entries of a vector written earlier
+__device__ __forceinline__ void rows_issue(unsigned rd, v4f (&o)[8]) {
+    asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\t"
+                 "ds_read_b128 %2, %8 offset:32\n\tds_read_b128 %3, %8 offset:48\n\t"
+                 "ds_read_b128 %4, %8 offset:64\n\tds_read_b128 %5, %8 offset:80\n\t"
+                 "ds_read_b128 %6, %8 offset:96\n\tds_read_b128 %7, %8 offset:112"
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
+                 : "v"(rd) : "memory");
+}
+__device__ __forceinline__ void lds_write32(unsigned wr, float v) {
+    asm volatile("ds_write_b32 %0, %1" : : "v"(wr), "v"(v) : "memory");
+}
+// the lane's own entries of the staged rows of one step: y (4 B), H y (4 B), rho (8 B)
+__device__ __forceinline__ void own_issue(unsigned ay, unsigned ah, unsigned ar, float& y, float& hh, v2f& t) {
+    asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %4\n\tds_read_b64 %2, %5"
+                 : "=&v"(y), "=&v"(hh), "=&v"(t) : "v"(ay), "v"(ah), "v"(ar) : "memory");
 }
 // LDS operations of one wave complete in order, so "at most N outstanding" retires everything issued
 // before the last N; extra operations hipcc may have in flight only make the wait stricter.
@@ -203,24 +222,35 @@ __device__ __forceinline__ void lds_wait(v4f (&o)[8]) {
                  : "n"(N) : "memory");
 }
 template <int N>
-__device__ __forceinline__ void lds_wait_t(v4f (&o)[8], v2f& t) {
-    asm volatile("s_waitcnt lgkmcnt(%9)"
-                 : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(o[4]), "+v"(o[5]), "+v"(o[6]), "+v"(o[7]), "+v"(t)
+__device__ __forceinline__ void lds_wait_lo(v4f (&o)[8]) {     // first four reads of a broadcast
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]) : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lds_wait_hi(v4f (&o)[8]) {     // last four reads
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(o[4]), "+v"(o[5]), "+v"(o[6]), "+v"(o[7]) : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lds_wait_hi_t(v4f (&o)[8], v2f& t) {   // last four reads + table entry
+    asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(o[4]), "+v"(o[5]), "+v"(o[6]), "+v"(o[7]), "+v"(t) : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lds_wait_all(v4f (&a)[8], v4f (&b)[8], v2f& t) {
+    asm volatile("s_waitcnt lgkmcnt(%17)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+                   "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]), "+v"(t)
                  : "n"(N) : "memory");
 }
 template <int N>
-__device__ __forceinline__ void lds_wait_row(v4f (&o)[8], float& own, v2f& t) {
-    asm volatile("s_waitcnt lgkmcnt(%10)"
-                 : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(o[4]), "+v"(o[5]), "+v"(o[6]), "+v"(o[7]),
-                   "+v"(own), "+v"(t)
-                 : "n"(N) : "memory");
+__device__ __forceinline__ void lds_wait_own(float& y, float& hh, v2f& t) {
+    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(y), "+v"(hh), "+v"(t) : "n"(N) : "memory");
 }
 
-// ---- chunk staging: 64 table rows of 256 B (= 1024 float4) global -> registers -> LDS ----
+// ---- chunk staging: 4*NQ table rows of 256 B (16 float4 each) global -> registers -> LDS ----
+template <int NQ>
 __device__ __forceinline__ void stage_load(const float4* __restrict__ tab, int row0, int max_row, int lane,
-                                           v4f (&r)[16]) {
+                                           v4f (&r)[NQ]) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
+    for (int q = 0; q < NQ; ++q) {
         const int e = q * 64 + lane;
         int row = row0 + (e >> 4);
         row = row < max_row ? row : max_row;
@@ -228,9 +258,10 @@ __device__ __forceinline__ void stage_load(const float4* __restrict__ tab, int r
         r[q] = v4f{t.x, t.y, t.z, t.w};
     }
 }
-__device__ __forceinline__ void stage_commit(float4* lds, int lane, const v4f (&r)[16]) {
+template <int NQ>
+__device__ __forceinline__ void stage_commit(float4* lds, int lane, const v4f (&r)[NQ]) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) lds[q * 64 + lane] = make_float4(r[q].x, r[q].y, r[q].z, r[q].w);
+    for (int q = 0; q < NQ; ++q) lds[q * 64 + lane] = make_float4(r[q].x, r[q].y, r[q].z, r[q].w);
 }
 
 // The four waves of a workgroup run the same instruction stream at the same pace; started together they hit
@@ -244,16 +275,28 @@ __device__ __forceinline__ void stagger(int w) {
 
 }  // namespace
 
+#ifdef ABL_NO_WAIT
+#define ABL_WAIT(a)
+#else
+#define ABL_WAIT(a) a
+#endif
+#ifdef ABL_NO_MV1
+#define ABL_MV1(a, b) b
+#else
+#define ABL_MV1(a, b) a
+#endif
+
 // per-chunk scalar stash: [B][NC][2][64] floats: n_k (true |y_k|^2), e_k, one step per lane
 __device__ __forceinline__ size_t scal_off(int b, int NC, int c) { return ((size_t)b * NC + c) * 128; }
 
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
+template <bool SAVE>
 __global__ __launch_bounds__(64 * WAVES, 1) void k_fwd_wave(Dev P, const float* __restrict__ audio,
-                                                            float* __restrict__ loss_out, int save) {
+                                                            float* __restrict__ loss_out) {
     __shared__ __attribute__((aligned(16))) float4 stR[WAVES][CH * 16];   // rho rows of the current chunk
-    __shared__ __attribute__((aligned(16))) float2 bcU[WAVES][DPW], bcY[WAVES][DPW];
+    __shared__ __attribute__((aligned(16))) float2 bcU[WAVES][DPW], bcY[WAVES][2][DPW];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i = lane & 31, h = lane >> 5;
     const bool hb = h != 0;
@@ -262,86 +305,113 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_fwd_wave(Dev P, const float* 
     const int N = P.N, T = P.T, NC = (N + CH - 1) / CH;
     stagger(w);
 
-    v2f MR[16], MQ[16];
+    v2f MR[16], MQ[16], MH[16];
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
         MR[m] = ld2(&P.R[i * DPW + 16 * h + m]);
+        const v2f rt = ld2(&P.RT[i * DPW + 16 * h + m]);   // R[16h+m][i]
+        MH[m] = mk2(MR[m].x + rt.x, MR[m].y - rt.y);        // (R + R^dagger)[i][16h+m]
         MQ[m] = ld2(&P.Q[i * DPW + 16 * h + m]);
     }
     const unsigned aUw = lds_addr(&bcU[w][0]) + i * 8 + h * 4, aUr = lds_addr(&bcU[w][0]) + h * 128;
-    const unsigned aYw = lds_addr(&bcY[w][0]) + i * 8 + h * 4, aYr = lds_addr(&bcY[w][0]) + h * 128;
+    const unsigned aYw = lds_addr(&bcY[w][0][0]) + i * 8 + h * 4, aYr = lds_addr(&bcY[w][0][0]) + h * 128;
     const unsigned aRho = lds_addr(&stR[w][0]) + i * 8;
     const float4* rho4 = reinterpret_cast<const float4*>(P.rho);
     const float* xrow = audio + (size_t)b * T;
-    float* st = save ? reinterpret_cast<float*>(P.stash + (size_t)b * N * DPW) + 2 * i + h : nullptr;
-    float* sc = save ? P.scal + scal_off(b, NC, 0) : nullptr;
+    float* st = SAVE ? reinterpret_cast<float*>(P.stash + (size_t)b * N * DPW) + 2 * i + h : nullptr;
+    float* sth = SAVE ? P.hst + (size_t)b * N * 64 + lane : nullptr;
+    float* sc = SAVE ? P.scal + scal_off(b, NC, 0) : nullptr;
     const float A = P.A;
 
     // chunk 0: tables and increments
     v4f sr[16];
-    stage_load(rho4, 0, N, lane, sr);
+    stage_load<16>(rho4, 0, N, lane, sr);
     float xa0 = lane < T ? xrow[lane] : 0.f;
     float xa1 = lane + 1 < T ? xrow[lane + 1] : 0.f;
-    stage_commit(stR[w], lane, sr);
+    stage_commit<16>(stR[w], lane, sr);
 
     const float2 p0 = P.psi0[i];
     float u = hb ? p0.y : p0.x;
     float loss = 0.f;
-    v4f qu[8];
+    v4f qu[8], qy[8];
     v2f rho;
+    float evec = 0.f, nvec = 1.f, yprev = 0.f;
+    int kbeg = 0;
+
     bcast_issue_tab(aUw, aUr, u, aRho, qu, rho);                 // broadcast of u_0 and rho_0 in flight
     for (int c = 0; c < NC; ++c) {
-        const int kbeg = c * CH;
+        kbeg = c * CH;
         const int cnt = (N - kbeg) < CH ? (N - kbeg) : CH;
         const float incv = xa1 - xa0;                            // model.py:263, one step per lane
         const float sv = incv / A;                               // model.py:303
         {   // prefetch the next chunk (clamped at the end: a harmless reload)
             const int cn = c + 1 < NC ? c + 1 : NC - 1;
-            stage_load(rho4, cn * CH, N, lane, sr);
+            stage_load<16>(rho4, cn * CH, N, lane, sr);
             const int idx = cn * CH + lane;
             xa0 = idx < T ? xrow[idx] : 0.f;
             xa1 = idx + 1 < T ? xrow[idx + 1] : 0.f;
         }
-        float evec = 0.f, nvec = 1.f;
-        for (int kk = 0; kk < cnt; ++kk) {
-            const float s = rdlane(sv, kk);
-            // ---- serial chain: y = u + Q u + s R u ----
-            lds_wait_t<0>(qu, rho);
-            v2f av, aq;
-            mv2(MR, MQ, qu, av, aq);
-            const v2f wp = aq + s * av;
-            const float y = u + swapadd(wp.x, wp.y);
-            v4f qy[8];
-            bcast_issue(aYw, aYr, y, qy);                        // for e_k only: off the chain
-            const float n = sum64(y * y);
-            const float inv = rsq_nr(fmaxf(n, 1e-12f));          // model.py:332
-            const float yo = osig_of(y, hb);
-            const v2f un = cmul2(inv * mk2(y, yo), rho);         // u_{k+1} = rho_k * y / sqrt(n)
-            u = un.x;
-            // next step's broadcast goes out before the off-chain work so its latency is covered (after the
-            // last step of a chunk it is a dummy: the tables are re-staged first and it is issued again)
-            const int kn = kk + 1 < CH ? kk + 1 : 0;
-            bcast_issue_tab(aUw, aUr, u, aRho + kn * 256, qu, rho);
-            lds_wait<10>(qy);
-            // ---- off the chain: e_k = 2 Re(y^dagger R y) ----
-            const v2f ar = mv1(MR, qy);
-            const float e = 2.0f * sum64(y * swapadd(ar.x, ar.y));   // model.py:325
-            evec = (lane == kk) ? e : evec;
-            nvec = (lane == kk) ? n : nvec;
-            if (st) st[(size_t)(kbeg + kk) * (2 * DPW)] = y;
+        evec = 0.f;
+        nvec = 1.f;
+#define FWD_STEP(KK, PENDING)                                                                                  \
+        {                                                                                                      \
+            const int kk_ = (KK);                                                                              \
+            const float s = rdlane(sv, kk_);                                                                   \
+            if (PENDING) rows_issue(aYr + ((kk_ - 1) & 1) * 256, qy);   /* y_{k-1} back from LDS (8 ops) */     \
+            /* ---- serial chain: y = u + Q u + s R u ---- */                                                  \
+            ABL_WAIT(lds_wait_lo<(PENDING) ? 13 : 5>(qu);)                                                     \
+            v2f av, aq;                                                                                        \
+            mv2_lo(MR, MQ, qu, av, aq);                                                                        \
+            ABL_WAIT(lds_wait_hi_t<(PENDING) ? 8 : 0>(qu, rho);)                                               \
+            mv2_hi(MR, MQ, qu, av, aq);                                                                        \
+            const v2f wp = aq + s * av;                                                                        \
+            const float y = u + swapadd(wp.x, wp.y);                                                           \
+            lds_write32(aYw + (kk_ & 1) * 256, y);                       /* 1 op */                             \
+            const float n = sum64(y * y);                                                                      \
+            const float inv = rsq_nr(fmaxf(n, 1e-12f));                  /* model.py:332 */                     \
+            const float yo = osig_of(y, hb);                                                                   \
+            const v2f un = cmul2(inv * mk2(y, yo), rho);                 /* u_{k+1} = rho_k y / sqrt(n) */      \
+            u = un.x;                                                                                          \
+            /* next step's broadcast (after the last step of a chunk it is a dummy, retired by the flush) */   \
+            const int kn = kk_ + 1 < CH ? kk_ + 1 : 0;                                                         \
+            bcast_issue_tab(aUw, aUr, u, aRho + kn * 256, qu, rho);      /* 10 ops */                           \
+            if (PENDING) {                                                                                     \
+                /* ---- off the chain, one step late: e_{k-1} = y^dagger H y (model.py:325) ---- */             \
+                lds_wait<11>(qy);                                                                              \
+                ABL_MV1(const v2f ah = mv1(MH, qy);, const v2f ah = lo2(qy[0]) + hi2(qy[7]);)                                                                    \
+                const float hs = swapadd(ah.x, ah.y);                                                          \
+                const float e = sum64(yprev * hs);                                                             \
+                evec = (lane == kk_ - 1) ? e : evec;                                                           \
+                if (SAVE) sth[(size_t)(kbeg + kk_ - 1) * 64] = hs;                                             \
+            }                                                                                                  \
+            nvec = (lane == kk_) ? n : nvec;                                                                   \
+            if (SAVE) st[(size_t)(kbeg + kk_) * (2 * DPW)] = y;                                                \
+            yprev = y;                                                                                         \
         }
-        lds_wait_t<0>(qu, rho);                                  // retire the dummy broadcast
+        FWD_STEP(0, false)
+        for (int kk = 1; kk < cnt; ++kk) FWD_STEP(kk, true)
+#undef FWD_STEP
+        {   // flush: the loss mat-vec of the chunk's last step; also retires the dummy broadcast
+            const int kl = cnt - 1;
+            rows_issue(aYr + (kl & 1) * 256, qy);
+            lds_wait_all<0>(qy, qu, rho);
+            const v2f ah = mv1(MH, qy);
+            const float hs = swapadd(ah.x, ah.y);
+            const float e = sum64(yprev * hs);
+            evec = (lane == kl) ? e : evec;
+            if (SAVE) sth[(size_t)(kbeg + kl) * 64] = hs;
+        }
         // loss increments of this chunk in the reference's operation order (model.py:294), then the
         // sequential float32 accumulation of model.py:279 in time order
         const float z = (evec * incv) / A;
         const float lv = -logf(1.0f + z);
         for (int j = 0; j < cnt; ++j) loss += rdlane(lv, j);
-        if (sc) {
+        if (SAVE) {
             sc[(size_t)c * 128 + lane] = nvec;
             sc[(size_t)c * 128 + 64 + lane] = evec;
         }
         if (c + 1 < NC) {
-            stage_commit(stR[w], lane, sr);
+            stage_commit<16>(stR[w], lane, sr);
             bcast_issue_tab(aUw, aUr, u, aRho, qu, rho);         // first step of the next chunk
         }
     }
@@ -363,13 +433,15 @@ struct Pre {
     float pre;     // 2 ebar_j ((R + R^dagger) y_j)                   (split)
     v2f rho;       // rho_j
     float inv, s, ten, dtk;   // 1/sqrt(max(n_j,1e-12)), x_j/A, 2 ebar_j n_j, t_j - t_{j+1}
+    float rad;     // 2 ebar_j e_j = Re(u_j^dagger g_j), the radial derivative at u_j (Euler: e is homogeneous of degree 2)
 };
 
 }  // namespace
 
 __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* __restrict__ audio) {
-    __shared__ __attribute__((aligned(16))) float4 stY[WAVES][CH * 16];   // stashed y rows of the current chunk
-    __shared__ __attribute__((aligned(16))) float4 stR[WAVES][CH * 16];   // rho rows of the current chunk
+    __shared__ __attribute__((aligned(16))) float4 stY[WAVES][CHB * 16];   // stashed y rows of the staged chunk
+    __shared__ __attribute__((aligned(16))) float4 stH[WAVES][CHB * 16];   // stashed H y rows
+    __shared__ __attribute__((aligned(16))) float4 stR[WAVES][CHB * 16];   // rho rows
     __shared__ __attribute__((aligned(16))) float2 bcB[WAVES][DPW];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i = lane & 31, h = lane >> 5;
@@ -379,22 +451,22 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
     const int N = P.N, T = P.T, NC = (N + CH - 1) / CH;
     stagger(w);
 
-    v2f MRd[16], MQ[16], MH[16];
+    v2f MRd[16], MQ[16];
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
-        const v2f r = ld2(&P.R[i * DPW + 16 * h + m]);
         const v2f rt = ld2(&P.RT[i * DPW + 16 * h + m]);   // R[16h+m][i]
         MRd[m] = mk2(rt.x, -rt.y);                          // R^dagger[i][16h+m]
-        MH[m] = mk2(r.x + rt.x, r.y - rt.y);                // (R + R^dagger)[i][16h+m]
         MQ[m] = ld2(&P.Q[i * DPW + 16 * h + m]);
     }
     v16f Rre = {}, Rim = {}, Qre = {}, Qim = {};
 
     const unsigned aBw = lds_addr(&bcB[w][0]) + i * 8 + h * 4, aBr = lds_addr(&bcB[w][0]) + h * 128;
-    const unsigned aYrow = lds_addr(&stY[w][0]) + h * 128, aYown = lds_addr(&stY[w][0]) + i * 8 + h * 4;
+    const unsigned aYown = lds_addr(&stY[w][0]) + i * 8 + h * 4;
+    const unsigned aHown = lds_addr(&stH[w][0]) + lane * 4;
     const unsigned aRho = lds_addr(&stR[w][0]) + i * 8;
     const float4* rho4 = reinterpret_cast<const float4*>(P.rho);
     const float4* sty4 = reinterpret_cast<const float4*>(P.stash + (size_t)b * N * DPW);
+    const float4* sth4 = reinterpret_cast<const float4*>(P.hst + (size_t)b * N * 64);
     const float* xrow = audio + (size_t)b * T;
     const float* sc = P.scal + scal_off(b, NC, 0);
     const float A = P.A;
@@ -403,13 +475,11 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
     float accS = 0.f;   // per lane: sum_k s_k d_own u_own
     float accA = 0.f;   // per lane (one step per lane): sum_k zbar_k (e_k x_k)
 
-    // chunk vectors (one step per lane) of the chunk the "pre" stage is working in
-    float sv = 0.f, dtv = 0.f, invv = 1.f, invokv = 0.f, tev = 0.f, tenv = 0.f;
-    float ra0, ra1, rdt, rnv, rev;   // raw prefetched values of the next chunk
-    v4f sry[16], srr[16];
-    auto chunk_load = [&](int c) {
-        stage_load(sty4, c * CH, N - 1, lane, sry);
-        stage_load(rho4, c * CH, N, lane, srr);
+    // per-step scalars, one step per lane, of the 64-step chunk the "pre" stage is working in
+    float sv = 0.f, dtv = 0.f, invv = 1.f, invokv = 0.f, tev = 0.f, tenv = 0.f, radv = 0.f;
+    float ra0 = 0.f, ra1 = 0.f, rdt = 0.f, rnv = 1.f, rev = 0.f;   // raw prefetched values of the next chunk
+    v4f sry[8], srh[8], srr[8];
+    auto scal_load = [&](int c) {
         const int idx = c * CH + lane;
         ra0 = idx < T ? xrow[idx] : 0.f;
         ra1 = idx + 1 < T ? xrow[idx + 1] : 0.f;
@@ -417,9 +487,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
         rnv = sc[(size_t)c * 128 + lane];
         rev = sc[(size_t)c * 128 + 64 + lane];
     };
-    auto chunk_commit = [&](int c) {
-        stage_commit(stY[w], lane, sry);
-        stage_commit(stR[w], lane, srr);
+    auto scal_commit = [&](int c) {
         const int idx = c * CH + lane;
         const float inc = ra1 - ra0;
         sv = inc / A;
@@ -433,11 +501,23 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
         const float ebar = zbar * inc / A;
         tev = 2.0f * ebar;
         tenv = tev * nv;
+        radv = tev * ev;
         if (idx < N) accA += zbar * ex;
     };
+    auto stage_load_all = [&](int hh) {
+        stage_load<8>(sty4, hh * CHB, N - 1, lane, sry);
+        stage_load<8>(sth4, hh * CHB, N - 1, lane, srh);
+        stage_load<8>(rho4, hh * CHB, N, lane, srr);
+    };
+    auto stage_commit_all = [&]() {
+        stage_commit<8>(stY[w], lane, sry);
+        stage_commit<8>(stH[w], lane, srh);
+        stage_commit<8>(stR[w], lane, srr);
+    };
 
-    // the off-chain stage for step j; its LDS reads were issued earlier by row_issue
-    auto make_pre = [&](int jj, v4f (&qy)[8], float yown, v2f rho) -> Pre {
+    // the off-chain stage for step j; its LDS reads were issued earlier by own_issue
+    auto make_pre = [&](int j, float yown, float hown, v2f rho) -> Pre {
+        const int jj = j & (CH - 1);
         Pre S;
         S.rho = rho;
         S.s = rdlane(sv, jj);
@@ -446,8 +526,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
         S.ten = rdlane(tenv, jj);
         const float te = rdlane(tev, jj);
         const float invok = rdlane(invokv, jj);
-        const v2f ah = mv1(MH, qy);
-        S.pre = te * swapadd(ah.x, ah.y);
+        S.rad = rdlane(radv, jj);
+        S.pre = te * hown;
         S.yh = S.inv * yown;
         S.yhp = invok * yown;
         S.yho = osig_of(S.yh, hb);
@@ -457,44 +537,57 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
         return S;
     };
 
-    const int cl = (N - 1) / CH;
-    chunk_load(cl);
-    chunk_commit(cl);
-    v4f qy[8], qc[8];
-    float yown;
+    const int hl = (N - 1) / CHB;
+    stage_load_all(hl);
+    scal_load(hl >> 1);
+    stage_commit_all();
+    scal_commit(hl >> 1);
+    v4f qc[8];
+    float yown, hown;
     v2f rho_j;
     Pre S;
     {
-        const int jj = (N - 1) & (CH - 1);
-        row_issue(aYrow + jj * 256, aYown + jj * 256, aRho + jj * 256, qy, yown, rho_j);
-        lds_wait_row<0>(qy, yown, rho_j);
-        S = make_pre(jj, qy, yown, rho_j);
+        const int jr = (N - 1) & (CHB - 1);
+        own_issue(aYown + jr * 256, aHown + jr * 256, aRho + jr * 256, yown, hown, rho_j);
+        lds_wait_own<0>(yown, hown, rho_j);
+        S = make_pre(N - 1, yown, hown, rho_j);
     }
     float g = 0.f, go = 0.f;                      // cotangent of u_{k+1}: split value and its osig
     const float2 p0 = P.psi0[i];
     const float u0 = hb ? p0.y : p0.x, u0o = hb ? -p0.x : p0.y;
 
-    // one step of the serial chain (step k = the step S describes), given u_k (split + osig)
-    auto chain_step = [&](const Pre& S, float uk, float uko, bool have_pre, int jjn) -> Pre {
+    // one step of the serial chain (step k = the step S describes); with have_pre, the pre stage of step
+    // k-1 (index jn) runs in its shadow and supplies u_k.
+    // The normalisation adjoint needs dot = Re(yhat_k^dagger conj(rho_k) g) = Re(u_{k+1}^dagger g_{k+1}), the radial
+    // derivative at u_{k+1}.  Everything downstream of u_{k+1} is scale invariant except the loss term of step
+    // k+1, which is homogeneous of degree 2 in u_{k+1}, so dot = 2 e_{k+1} ebar_{k+1} exactly (rad_next).  Using
+    // it keeps the 144-cycle wave reduction off the serial chain; `exact` (once per staged chunk) does the real
+    // projection so that rounding in the radial direction cannot accumulate over the clip.
+    float rad_next = 0.f;                         // no step N: g_N = 0
+    auto chain_step = [&](const Pre& S, float uk, float uko, auto have_pre, int jn, bool exact) -> Pre {
         // ---- chain, scalar part ----
         facc += S.dtk * (go * S.un);
         const v2f yhbp = cmul2_conj_b(mk2(g, go), S.rho);              // conj(rho_k) g
         const float yhb = yhbp.x;
-        const float dot = sum64(S.yhp * yhb);
+        float dot = rad_next;
+        if (exact) dot = sum64(S.yhp * yhb);
+        rad_next = S.rad;
         const float ybar = (yhb - dot * S.yhp) * S.inv + S.pre;
-        bcast_issue(aBw, aBr, ybar, qc);
+        bcast_issue(aBw, aBr, ybar, qc);                               // 9 ops
         // ---- off-chain: pre of step k-1 (gives u_k) ----
         Pre Sn = S;
-        if (have_pre) {
-            lds_wait_row<9>(qy, yown, rho_j);
-            Sn = make_pre(jjn, qy, yown, rho_j);
+        if constexpr (decltype(have_pre)::value) {
+            lds_wait_own<9>(yown, hown, rho_j);
+            Sn = make_pre(jn, yown, hown, rho_j);
             uk = Sn.un;
             uko = Sn.uno;
         }
         // ---- chain, mat-vec part: g_k = ybar + Q ybar + s R^dagger ybar ----
-        lds_wait<0>(qc);
+        lds_wait_lo<4>(qc);
         v2f aq, ad;
-        mv2(MQ, MRd, qc, aq, ad);
+        mv2_lo(MQ, MRd, qc, aq, ad);
+        lds_wait_hi<0>(qc);
+        mv2_hi(MQ, MRd, qc, aq, ad);
         const float sd = S.s * swapadd(ad.x, ad.y);
         accS += sd * uk;
         g = ybar + swapadd(aq.x, aq.y) + sd;
@@ -514,19 +607,23 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
         return Sn;
     };
 
-    // pre index j runs N-2 .. 0 chunk by chunk; the chain handles step j+1 in the same iteration
-    for (int c = cl; c >= 0; --c) {
-        const int jlo = c * CH;
-        const int jhi = (N - 2) < (jlo + CH - 1) ? (N - 2) : (jlo + CH - 1);
-        chunk_load(c > 0 ? c - 1 : 0);               // prefetch into registers (clamped: harmless reload)
+    // pre index j runs N-2 .. 0, one staged chunk (32 steps) at a time; the chain handles step j+1 in the
+    // same iteration; per-step scalars are re-derived whenever j enters a new 64-step chunk
+    for (int hh = hl; hh >= 0; --hh) {
+        const int jlo = hh * CHB;
+        const int jhi = (N - 2) < (jlo + CHB - 1) ? (N - 2) : (jlo + CHB - 1);
+        stage_load_all(hh > 0 ? hh - 1 : 0);          // prefetch into registers (clamped: harmless reload)
+        const bool new_scal = (hh & 1) == 0 && hh > 0;
+        if (new_scal) scal_load((hh >> 1) - 1);
         for (int j = jhi; j >= jlo; --j) {
-            const int jj = j & (CH - 1);
-            row_issue(aYrow + jj * 256, aYown + jj * 256, aRho + jj * 256, qy, yown, rho_j);
-            S = chain_step(S, 0.f, 0.f, true, jj);
+            const int jr = j & (CHB - 1);
+            own_issue(aYown + jr * 256, aHown + jr * 256, aRho + jr * 256, yown, hown, rho_j);
+            S = chain_step(S, 0.f, 0.f, std::true_type{}, j, j == jhi);
         }
-        if (c > 0) chunk_commit(c - 1);
+        if (hh > 0) stage_commit_all();
+        if (new_scal) scal_commit((hh >> 1) - 1);
     }
-    S = chain_step(S, u0, u0o, false, 0);            // step 0: u_0 = psi_0
+    S = chain_step(S, u0, u0o, std::false_type{}, 0, true);      // step 0: u_0 = psi_0
 
     // ---------------- per-clip slab ----------------
     float* slab = P.slabs + (size_t)b * P.slab_floats;
@@ -555,7 +652,10 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
 
 hipError_t launch_fwd_wave(const Dev& P, const float* audio, float* loss, bool save, hipStream_t s) {
     const unsigned nb = (unsigned)((P.B + WAVES - 1) / WAVES);
-    hipLaunchKernelGGL(k_fwd_wave, dim3(nb), dim3(64 * WAVES), 0, s, P, audio, loss, save ? 1 : 0);
+    if (save)
+        hipLaunchKernelGGL(k_fwd_wave<true>, dim3(nb), dim3(64 * WAVES), 0, s, P, audio, loss);
+    else
+        hipLaunchKernelGGL(k_fwd_wave<false>, dim3(nb), dim3(64 * WAVES), 0, s, P, audio, loss);
     return hipGetLastError();
 }
 

@@ -1,0 +1,15 @@
+#!/usr/bin/env python3
+"""Diagnostic: build libcmps variants with ablation flags (results wrong, timing informative) and time the scans."""
+import os, sys, subprocess
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from audio_mps_amd import build
+variants = {"base": [], "no_wait": ["-DABL_NO_WAIT"], "no_wait_no_mv1_no_reduce": ["-DABL_NO_WAIT", "-DABL_NO_REDUCE", "-DABL_NO_MV1"]}
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+for name, flags in variants.items():
+    lib = os.path.join(ROOT, "gpurun_out", f"libcmps_{name}.so")
+    subprocess.run([build._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", lib] + flags
+                   + [os.path.join(build.CSRC, s) for s in build.SOURCES], check=True)
+    env = dict(os.environ, CMPS_LIB=lib)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "time_kernels.py")], env=env, capture_output=True, text=True).stdout
+    print("==", name); print("\n".join(l for l in out.splitlines() if "median" in l))

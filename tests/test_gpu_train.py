@@ -38,3 +38,35 @@ def test_trainer_tracks_oracle_trainer(tmp_path):
 def test_smoke_entry():
     import __graft_entry__ as ge
     ge.smoke()
+
+
+def test_nccl_single_rank_collectives(tmp_path):
+    """The RCCL code path of audio_mps_amd.parallel (backend "nccl" = RCCL on ROCm) with a one-rank group on
+    this box's GPU: init with device_id, all-reduce of the flat gradient buffer, barrier, max-over-ranks."""
+    import subprocess
+    import sys
+    import textwrap
+    code = textwrap.dedent("""
+        import os, sys, socket
+        sys.path.insert(0, %r)
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        import torch, torch.distributed as dist
+        from audio_mps_amd.parallel import DataParallel
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+        dp = DataParallel.__new__(DataParallel)
+        dp.rank, dp.world_size, dp.local_rank, dp.device, dp.backend, dp._own_group = 0, 2, 0, dev, "nccl", False
+        dp.world_size = 2          # take the collective branch although the group has one rank
+        flat = torch.arange(10, dtype=torch.float32, device=dev)
+        host, nb = dp.allreduce_sums(flat, 7)
+        assert nb == 7 and host.tolist() == list(range(10)), (nb, host)
+        dp.barrier()
+        assert dp.max_over_ranks(1.5) == 1.5
+        dist.destroy_process_group()
+        print("OK")
+    """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
