@@ -311,7 +311,15 @@ __global__ void k_states(Dev P, float* __restrict__ psi_out) {
     const size_t row = blockIdx.x;  // b * N + k
     const int k = (int)(row % N), i = threadIdx.x;
     const bool act = i < D;
-    const float2 y = act ? P.stash[row * DP + i] : make_float2(0.f, 0.f);
+    float2 y = make_float2(0.f, 0.f);
+    if (act) {
+        if (P.stash_layout == 1) {   // wave variant: 64 lanes x (y own, H y own); re on lane i, im on lane i + 32
+            const float* r = P.hst + row * 128;
+            y = make_float2(r[2 * i], r[2 * (i + 32)]);
+        } else {
+            y = P.stash[row * DP + i];
+        }
+    }
     float n = act ? (y.x * y.x + y.y * y.y) : 0.f;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off, 64);

@@ -16,7 +16,7 @@ namespace cmps {
 //   rho      : [N+1][DP] float2       rho_k[d] = exp(i (fl(f_d t_k) - fl(f_d t_{k+1}))), drift-corrected (cmps_prep.hip)
 //   rfix     : [2][NC][DP] double2    scratch of the drift correction
 //   stash    : [B][N][DP] float2      un-normalised rotating-frame state y_k (TRAIN only)
-//   hst      : [B][N][64] float       (R + R^dagger) y_k in split layout (TRAIN, wave variant)
+//   hst      : [B][N][64][2] float    wave variant's stash: per lane (y_k own, ((R + R^dagger) y_k) own), 512 B per step
 //   scal     : [B][NC][2][64] float   per 64-step chunk: |y_k|^2 and e_k, one step per lane (wave variant)
 //   slabs    : [B][slab] float        per-clip gradient partials (TRAIN only)
 //   sums     : [slab] float           reduced partials
@@ -58,7 +58,7 @@ inline Layout make_layout(int D, int B, int T, int flags) {
     if (flags & 1) {
         o = align256(o + (size_t)B * N * DP * sizeof(float2));
         L.off_hst = o;
-        if (D <= 32) o = align256(o + (size_t)B * N * 64 * sizeof(float));
+        if (D <= 32) o = align256(o + (size_t)B * N * 128 * sizeof(float));
         L.off_scal = o;  o = align256(o + (size_t)B * ((N + 63) / 64) * 128 * sizeof(float));
         L.off_slabs = o; o = align256(o + (size_t)B * L.slab_floats * sizeof(float));
         L.off_sums = o;  o = align256(o + L.slab_floats * sizeof(float));
@@ -79,7 +79,8 @@ struct Dev {
     const float* dtk;    // [N]
     const float2* rho;   // [N][DP]
     float2* stash;       // [B][N][DP]
-    float* hst;          // [B][N][64]   (wave variant)
+    float* hst;          // [B][N][64][2] (wave variant)
+    int stash_layout;    // 0: stash [B][N][DP] float2 (block variant)  1: hst rows (wave variant)
     float* scal;         // [B][NC][2][64]
     float* slabs;        // [B][slab]
     float* sums;         // [slab]

@@ -44,6 +44,7 @@ namespace {
 constexpr int DPW = 32;    // padded bond dimension of this variant
 constexpr int WAVES = 4;   // waves (clips) per workgroup: one per SIMD of a CU
 constexpr int CH = 64;     // steps per chunk of per-step scalars (one step per lane); forward table staging
+constexpr int PE_LD = 65;  // row stride (floats) of the forward's per-lane product buffer: conflict-free both ways
 constexpr int CHB = 32;    // steps per staged chunk in the reverse sweep (three tables share the LDS)
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -208,10 +209,11 @@ __device__ __forceinline__ void rows_issue(unsigned rd, v4f (&o)[8]) {
 __device__ __forceinline__ void lds_write32(unsigned wr, float v) {
     asm volatile("ds_write_b32 %0, %1" : : "v"(wr), "v"(v) : "memory");
 }
-// the lane's own entries of the staged rows of one step: y (4 B), H y (4 B), rho (8 B)
-__device__ __forceinline__ void own_issue(unsigned ay, unsigned ah, unsigned ar, float& y, float& hh, v2f& t) {
-    asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %4\n\tds_read_b64 %2, %5"
-                 : "=&v"(y), "=&v"(hh), "=&v"(t) : "v"(ay), "v"(ah), "v"(ar) : "memory");
+// what the reverse step's off-chain stage reads: the lane's own (y, H y) of the staged row (8 B), rho (8 B), and
+// the step's scalar row (2 x 16 B, the same address for every lane)
+__device__ __forceinline__ void own_issue(unsigned ay, unsigned ar, unsigned as, v2f& yh, v2f& t, v4f& c0, v4f& c1) {
+    asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %6 offset:16"
+                 : "=&v"(yh), "=&v"(t), "=&v"(c0), "=&v"(c1) : "v"(ay), "v"(ar), "v"(as) : "memory");
 }
 // LDS operations of one wave complete in order, so "at most N outstanding" retires everything issued
 // before the last N; extra operations hipcc may have in flight only make the wait stricter.
@@ -241,8 +243,8 @@ __device__ __forceinline__ void lds_wait_all(v4f (&a)[8], v4f (&b)[8], v2f& t) {
                  : "n"(N) : "memory");
 }
 template <int N>
-__device__ __forceinline__ void lds_wait_own(float& y, float& hh, v2f& t) {
-    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(y), "+v"(hh), "+v"(t) : "n"(N) : "memory");
+__device__ __forceinline__ void lds_wait_own(v2f& yh, v2f& t, v4f& c0, v4f& c1) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(yh), "+v"(t), "+v"(c0), "+v"(c1) : "n"(N) : "memory");
 }
 
 // ---- chunk staging: 4*NQ table rows of 256 B (16 float4 each) global -> registers -> LDS ----
@@ -255,6 +257,19 @@ __device__ __forceinline__ void stage_load(const float4* __restrict__ tab, int r
         int row = row0 + (e >> 4);
         row = row < max_row ? row : max_row;
         const float4 t = tab[(size_t)row * 16 + (e & 15)];
+        r[q] = v4f{t.x, t.y, t.z, t.w};
+    }
+}
+// same for 512-B rows (32 float4 each): 2*NQ rows
+template <int NQ>
+__device__ __forceinline__ void stage_load512(const float4* __restrict__ tab, int row0, int max_row, int lane,
+                                              v4f (&r)[NQ]) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int e = q * 64 + lane;
+        int row = row0 + (e >> 5);
+        row = row < max_row ? row : max_row;
+        const float4 t = tab[(size_t)row * 32 + (e & 31)];
         r[q] = v4f{t.x, t.y, t.z, t.w};
     }
 }
@@ -297,10 +312,11 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_fwd_wave(Dev P, const float* 
                                                             float* __restrict__ loss_out) {
     __shared__ __attribute__((aligned(16))) float4 stR[WAVES][CH * 16];   // rho rows of the current chunk
     __shared__ __attribute__((aligned(16))) float2 bcU[WAVES][DPW], bcY[WAVES][2][DPW];
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __shared__ float pe[WAVES][64 * PE_LD];   // per-lane products y_own * (H y)_own, row = lane, column = step
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int i = lane & 31, h = lane >> 5;
     const bool hb = h != 0;
-    const int b = blockIdx.x * WAVES + w;
+    const int b = blockIdx.x * WAVES + w;      // wave-uniform (SGPR): the per-clip base addresses stay scalar
     if (b >= P.B) return;  // whole wave exits together; no workgroup barriers are used below
     const int N = P.N, T = P.T, NC = (N + CH - 1) / CH;
     stagger(w);
@@ -316,10 +332,12 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_fwd_wave(Dev P, const float* 
     const unsigned aUw = lds_addr(&bcU[w][0]) + i * 8 + h * 4, aUr = lds_addr(&bcU[w][0]) + h * 128;
     const unsigned aYw = lds_addr(&bcY[w][0][0]) + i * 8 + h * 4, aYr = lds_addr(&bcY[w][0][0]) + h * 128;
     const unsigned aRho = lds_addr(&stR[w][0]) + i * 8;
+    const unsigned aPEw = lds_addr(&pe[w][0]) + lane * (PE_LD * 4);   // + 4 * step
+    const unsigned aPEr = lds_addr(&pe[w][0]) + lane * 4;             // + row * PE_LD * 4 (immediate offsets)
     const float4* rho4 = reinterpret_cast<const float4*>(P.rho);
     const float* xrow = audio + (size_t)b * T;
-    float* st = SAVE ? reinterpret_cast<float*>(P.stash + (size_t)b * N * DPW) + 2 * i + h : nullptr;
-    float* sth = SAVE ? P.hst + (size_t)b * N * 64 + lane : nullptr;
+    // stash row of step k: 64 lanes x (y_k own, (H y_k) own) = 512 B, written by ONE 8-byte-per-lane store
+    float2* st = SAVE ? reinterpret_cast<float2*>(P.hst + (size_t)b * N * 128) : nullptr;   // uniform base
     float* sc = SAVE ? P.scal + scal_off(b, NC, 0) : nullptr;
     const float A = P.A;
 
@@ -351,7 +369,6 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_fwd_wave(Dev P, const float* 
             xa0 = idx < T ? xrow[idx] : 0.f;
             xa1 = idx + 1 < T ? xrow[idx + 1] : 0.f;
         }
-        evec = 0.f;
         nvec = 1.f;
 #define FWD_STEP(KK, PENDING)                                                                                  \
         {                                                                                                      \
@@ -368,7 +385,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_fwd_wave(Dev P, const float* 
             const float y = u + swapadd(wp.x, wp.y);                                                           \
             lds_write32(aYw + (kk_ & 1) * 256, y);                       /* 1 op */                             \
             const float n = sum64(y * y);                                                                      \
-            const float inv = rsq_nr(fmaxf(n, 1e-12f));                  /* model.py:332 */                     \
+            const float inv = __builtin_amdgcn_rsqf(fmaxf(n, 1e-12f));   /* model.py:332 (v_rsq_f32: 1 ulp) */  \
             const float yo = osig_of(y, hb);                                                                   \
             const v2f un = cmul2(inv * mk2(y, yo), rho);                 /* u_{k+1} = rho_k y / sqrt(n) */      \
             u = un.x;                                                                                          \
@@ -380,12 +397,10 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_fwd_wave(Dev P, const float* 
                 lds_wait<11>(qy);                                                                              \
                 ABL_MV1(const v2f ah = mv1(MH, qy);, const v2f ah = lo2(qy[0]) + hi2(qy[7]);)                                                                    \
                 const float hs = swapadd(ah.x, ah.y);                                                          \
-                const float e = sum64(yprev * hs);                                                             \
-                evec = (lane == kk_ - 1) ? e : evec;                                                           \
-                if (SAVE) sth[(size_t)(kbeg + kk_ - 1) * 64] = hs;                                             \
+                lds_write32(aPEw + (kk_ - 1) * 4, yprev * hs);           /* summed over lanes at chunk end */    \
+                if (SAVE) st[(size_t)(kbeg + kk_ - 1) * 64 + lane] = make_float2(yprev, hs);                   \
             }                                                                                                  \
             nvec = (lane == kk_) ? n : nvec;                                                                   \
-            if (SAVE) st[(size_t)(kbeg + kk_) * (2 * DPW)] = y;                                                \
             yprev = y;                                                                                         \
         }
         FWD_STEP(0, false)
@@ -397,9 +412,23 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_fwd_wave(Dev P, const float* 
             lds_wait_all<0>(qy, qu, rho);
             const v2f ah = mv1(MH, qy);
             const float hs = swapadd(ah.x, ah.y);
-            const float e = sum64(yprev * hs);
-            evec = (lane == kl) ? e : evec;
-            if (SAVE) sth[(size_t)(kbeg + kl) * 64] = hs;
+            lds_write32(aPEw + kl * 4, yprev * hs);
+            if (SAVE) st[(size_t)(kbeg + kl) * 64 + lane] = make_float2(yprev, hs);
+        }
+        // e_k = y^dagger H y = sum over the 64 lanes of the stored products: lane k sums column k
+        {
+            const float* col = &pe[w][lane];
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int l = 0; l < 64; l += 4) {
+                a0 += col[(l + 0) * PE_LD];
+                a1 += col[(l + 1) * PE_LD];
+                a2 += col[(l + 2) * PE_LD];
+                a3 += col[(l + 3) * PE_LD];
+            }
+            evec = (a0 + a1) + (a2 + a3);
+            (void)aPEr;
         }
         // loss increments of this chunk in the reference's operation order (model.py:294), then the
         // sequential float32 accumulation of model.py:279 in time order
@@ -439,14 +468,14 @@ struct Pre {
 }  // namespace
 
 __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* __restrict__ audio) {
-    __shared__ __attribute__((aligned(16))) float4 stY[WAVES][CHB * 16];   // stashed y rows of the staged chunk
-    __shared__ __attribute__((aligned(16))) float4 stH[WAVES][CHB * 16];   // stashed H y rows
+    __shared__ __attribute__((aligned(16))) float4 stY[WAVES][CHB * 32];   // stashed (y, H y) rows of the staged chunk
     __shared__ __attribute__((aligned(16))) float4 stR[WAVES][CHB * 16];   // rho rows
+    __shared__ __attribute__((aligned(16))) float4 scl[WAVES][CH * 2];     // per-step scalars, one 32-B row per step
     __shared__ __attribute__((aligned(16))) float2 bcB[WAVES][DPW];
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int i = lane & 31, h = lane >> 5;
     const bool hb = h != 0;
-    const int b = blockIdx.x * WAVES + w;
+    const int b = blockIdx.x * WAVES + w;      // wave-uniform
     if (b >= P.B) return;
     const int N = P.N, T = P.T, NC = (N + CH - 1) / CH;
     stagger(w);
@@ -461,12 +490,11 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
     v16f Rre = {}, Rim = {}, Qre = {}, Qim = {};
 
     const unsigned aBw = lds_addr(&bcB[w][0]) + i * 8 + h * 4, aBr = lds_addr(&bcB[w][0]) + h * 128;
-    const unsigned aYown = lds_addr(&stY[w][0]) + i * 8 + h * 4;
-    const unsigned aHown = lds_addr(&stH[w][0]) + lane * 4;
+    const unsigned aYown = lds_addr(&stY[w][0]) + lane * 8;
     const unsigned aRho = lds_addr(&stR[w][0]) + i * 8;
+    const unsigned aScl = lds_addr(&scl[w][0]);
     const float4* rho4 = reinterpret_cast<const float4*>(P.rho);
-    const float4* sty4 = reinterpret_cast<const float4*>(P.stash + (size_t)b * N * DPW);
-    const float4* sth4 = reinterpret_cast<const float4*>(P.hst + (size_t)b * N * 64);
+    const float4* sty4 = reinterpret_cast<const float4*>(P.hst + (size_t)b * N * 128);
     const float* xrow = audio + (size_t)b * T;
     const float* sc = P.scal + scal_off(b, NC, 0);
     const float A = P.A;
@@ -475,10 +503,11 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
     float accS = 0.f;   // per lane: sum_k s_k d_own u_own
     float accA = 0.f;   // per lane (one step per lane): sum_k zbar_k (e_k x_k)
 
-    // per-step scalars, one step per lane, of the 64-step chunk the "pre" stage is working in
-    float sv = 0.f, dtv = 0.f, invv = 1.f, invokv = 0.f, tev = 0.f, tenv = 0.f, radv = 0.f;
+    // per-step scalars of the 64-step chunk the "pre" stage is working in: computed one step per lane, then
+    // written to LDS as one 32-B row per step (s, dtk, inv, ten | te, invok, rad, -) so that a step fetches all
+    // of them with two broadcast reads instead of seven v_readlane
     float ra0 = 0.f, ra1 = 0.f, rdt = 0.f, rnv = 1.f, rev = 0.f;   // raw prefetched values of the next chunk
-    v4f sry[8], srh[8], srr[8];
+    v4f sry[16], srr[8];
     auto scal_load = [&](int c) {
         const int idx = c * CH + lane;
         ra0 = idx < T ? xrow[idx] : 0.f;
@@ -490,43 +519,40 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
     auto scal_commit = [&](int c) {
         const int idx = c * CH + lane;
         const float inc = ra1 - ra0;
-        sv = inc / A;
-        dtv = rdt;
+        const float sv = inc / A;
         const float nv = rnv, ev = rev;
-        invv = rsq_nr(fmaxf(nv, 1e-12f));
-        invokv = nv > 1e-12f ? invv : 0.f;
+        const float invv = rsq_nr(fmaxf(nv, 1e-12f));
+        const float invokv = nv > 1e-12f ? invv : 0.f;
         const float ex = ev * inc;                      // model.py:294 operation order
         const float z = ex / A;
         const float zbar = -1.0f / (1.0f + z);
         const float ebar = zbar * inc / A;
-        tev = 2.0f * ebar;
-        tenv = tev * nv;
-        radv = tev * ev;
+        const float tev = 2.0f * ebar;
+        scl[w][2 * lane] = make_float4(sv, rdt, invv, tev * nv);
+        scl[w][2 * lane + 1] = make_float4(tev, invokv, tev * ev, 0.f);
         if (idx < N) accA += zbar * ex;
     };
     auto stage_load_all = [&](int hh) {
-        stage_load<8>(sty4, hh * CHB, N - 1, lane, sry);
-        stage_load<8>(sth4, hh * CHB, N - 1, lane, srh);
+        stage_load512<16>(sty4, hh * CHB, N - 1, lane, sry);
         stage_load<8>(rho4, hh * CHB, N, lane, srr);
     };
     auto stage_commit_all = [&]() {
-        stage_commit<8>(stY[w], lane, sry);
-        stage_commit<8>(stH[w], lane, srh);
+        stage_commit<16>(stY[w], lane, sry);
         stage_commit<8>(stR[w], lane, srr);
     };
 
     // the off-chain stage for step j; its LDS reads were issued earlier by own_issue
-    auto make_pre = [&](int j, float yown, float hown, v2f rho) -> Pre {
-        const int jj = j & (CH - 1);
+    auto make_pre = [&](v2f yh2, v2f rho, v4f c0, v4f c1) -> Pre {
+        const float yown = yh2.x, hown = yh2.y;
         Pre S;
         S.rho = rho;
-        S.s = rdlane(sv, jj);
-        S.dtk = rdlane(dtv, jj);
-        S.inv = rdlane(invv, jj);
-        S.ten = rdlane(tenv, jj);
-        const float te = rdlane(tev, jj);
-        const float invok = rdlane(invokv, jj);
-        S.rad = rdlane(radv, jj);
+        S.s = c0.x;
+        S.dtk = c0.y;
+        S.inv = c0.z;
+        S.ten = c0.w;
+        const float te = c1.x;
+        const float invok = c1.y;
+        S.rad = c1.z;
         S.pre = te * hown;
         S.yh = S.inv * yown;
         S.yhp = invok * yown;
@@ -543,14 +569,14 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
     stage_commit_all();
     scal_commit(hl >> 1);
     v4f qc[8];
-    float yown, hown;
-    v2f rho_j;
+    v2f yh_j, rho_j;
+    v4f c0_j, c1_j;
     Pre S;
     {
-        const int jr = (N - 1) & (CHB - 1);
-        own_issue(aYown + jr * 256, aHown + jr * 256, aRho + jr * 256, yown, hown, rho_j);
-        lds_wait_own<0>(yown, hown, rho_j);
-        S = make_pre(N - 1, yown, hown, rho_j);
+        const int jr = (N - 1) & (CHB - 1), jc = (N - 1) & (CH - 1);
+        own_issue(aYown + jr * 512, aRho + jr * 256, aScl + jc * 32, yh_j, rho_j, c0_j, c1_j);
+        lds_wait_own<0>(yh_j, rho_j, c0_j, c1_j);
+        S = make_pre(yh_j, rho_j, c0_j, c1_j);
     }
     float g = 0.f, go = 0.f;                      // cotangent of u_{k+1}: split value and its osig
     const float2 p0 = P.psi0[i];
@@ -577,8 +603,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
         // ---- off-chain: pre of step k-1 (gives u_k) ----
         Pre Sn = S;
         if constexpr (decltype(have_pre)::value) {
-            lds_wait_own<9>(yown, hown, rho_j);
-            Sn = make_pre(jn, yown, hown, rho_j);
+            lds_wait_own<9>(yh_j, rho_j, c0_j, c1_j);
+            Sn = make_pre(yh_j, rho_j, c0_j, c1_j);
             uk = Sn.un;
             uko = Sn.uno;
         }
@@ -616,8 +642,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
         const bool new_scal = (hh & 1) == 0 && hh > 0;
         if (new_scal) scal_load((hh >> 1) - 1);
         for (int j = jhi; j >= jlo; --j) {
-            const int jr = j & (CHB - 1);
-            own_issue(aYown + jr * 256, aHown + jr * 256, aRho + jr * 256, yown, hown, rho_j);
+            const int jr = j & (CHB - 1), jc = j & (CH - 1);
+            own_issue(aYown + jr * 512, aRho + jr * 256, aScl + jc * 32, yh_j, rho_j, c0_j, c1_j);
             S = chain_step(S, 0.f, 0.f, std::true_type{}, j, j == jhi);
         }
         if (hh > 0) stage_commit_all();
