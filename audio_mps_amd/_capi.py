@@ -26,7 +26,7 @@ CMPS_VARIANT_WAVE = 2
 SYMBOLS = (
     "cmps_version", "cmps_create", "cmps_destroy", "cmps_last_error", "cmps_set_variant",
     "cmps_get_variant", "cmps_workspace_bytes", "cmps_set_params", "cmps_psi_loss_fwd",
-    "cmps_psi_loss_bwd", "cmps_psi_update_ancilla", "cmps_psi_states",
+    "cmps_psi_loss_bwd", "cmps_psi_update_ancilla", "cmps_psi_states", "cmps_psi_sample",
 )
 
 
@@ -64,6 +64,8 @@ def _declare(lib):
     lib.cmps_psi_update_ancilla.restype = c_int
     lib.cmps_psi_states.argtypes = [vp, c_int, c_int, vp, vp]
     lib.cmps_psi_states.restype = c_int
+    lib.cmps_psi_sample.argtypes = [vp, vp, c_int, c_int, vp, vp]
+    lib.cmps_psi_sample.restype = c_int
 
 
 _lib = None

@@ -340,6 +340,45 @@ __global__ void k_states(Dev P, float* __restrict__ psi_out) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// PsiCMPS.sample (model.py:242-251, 284-291), general D: one workgroup per sample path.
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(NT) void k_sample_block(Dev P, const float* __restrict__ noise, int length,
+                                                     float* __restrict__ out) {
+    extern __shared__ float2 sh[];
+    const int D = P.D, DP = P.DP;
+    float2* su = sh;
+    float* red = reinterpret_cast<float*>(sh + D);
+    const int b = blockIdx.x, t = threadIdx.x;
+    const bool act = t < D;
+    float2 u = act ? P.psi0[t] : make_float2(0.f, 0.f);
+    float samp = 0.f;
+    for (int k = 0; k < length; ++k) {
+        if (act) su[t] = u;
+        __syncthreads();
+        float2 v = make_float2(0.f, 0.f), q = make_float2(0.f, 0.f);
+        if (act) {
+            for (int j = 0; j < D; ++j) {
+                const float2 uj = su[j];
+                v = cfma(P.RT[j * DP + t], uj, v);
+                q = cfma_conj_a(P.Q[j * DP + t], uj, q);
+            }
+        }
+        const float e = 2.0f * block_sum<NT>(act ? (u.x * v.x + u.y * v.y) : 0.f, red);   // model.py:319-325
+        const float inc = e * P.dt + noise[(size_t)b * length + k];                        // :286
+        samp += inc;                                                                       // :287
+        const float s = inc / P.A;                                                         // :288, :303
+        const float2 y = make_float2(u.x + q.x + s * v.x, u.y + q.y + s * v.y);
+        const float n = block_sum<NT>(act ? (y.x * y.x + y.y * y.y) : 0.f, red);
+        const float inv = 1.0f / sqrtf(fmaxf(n, 1e-12f));                                  // :289
+        if (act) u = cmul(P.rho[(size_t)k * DP + t], cscale(inv, y));
+        if (t == 0) out[(size_t)b * length + k] = P.A * samp;                              // :251
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
@@ -376,6 +415,15 @@ hipError_t launch_update_ancilla(const Dev& P, const float* psi_in, const float*
                                  int B, float* psi_out, hipStream_t s) {
     const size_t shm = (size_t)2 * P.D * sizeof(float2);
     hipLaunchKernelGGL(k_update_ancilla, dim3(B), dim3(round64(P.D)), shm, s, P, psi_in, signal, t, psi_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_sample_block(const Dev& P, const float* noise, int n, int length, float* out, hipStream_t s) {
+    const size_t shm = (size_t)P.D * sizeof(float2) + 64;
+    if (P.D <= 64)
+        hipLaunchKernelGGL(k_sample_block<64>, dim3(n), dim3(64), shm, s, P, noise, length, out);
+    else
+        hipLaunchKernelGGL(k_sample_block<128>, dim3(n), dim3(128), shm, s, P, noise, length, out);
     return hipGetLastError();
 }
 

@@ -128,6 +128,7 @@ int cmps_set_params(cmps_handle_t h, const float* R_re_dev, const float* R_im_de
     // multiplied in, then divided by 2. (exact halving)
     P.c_half = (float)(-delta_t * sigma * sigma) / 2.0f;
     const float dt = (float)delta_t;  // model.py:16
+    P.dt = dt;
     const bool rebuild = !(h->tt_ws == ws && h->tt_N == L.N && h->tt_dt == dt);
     hipError_t e = launch_prep(P, R_re_dev, R_im_dev, freqs_dev, psi0_re_dev, psi0_im_dev, dt, rebuild,
                                const_cast<float*>(P.ttab), const_cast<float*>(P.dtk),
@@ -206,6 +207,20 @@ int cmps_psi_states(cmps_handle_t h, int B, int T, float* psi_out_dev, void* str
         return fail(h, CMPS_ERR_BAD_ARG, "cmps_psi_states: bad argument");
     hipError_t e = launch_states(h->P, B, psi_out_dev, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail_hip(h, e, "cmps_psi_states");
+    return CMPS_OK;
+}
+
+int cmps_psi_sample(cmps_handle_t h, const float* noise_dev, int n, int length, float* out_dev, void* stream) {
+    if (!h) return CMPS_ERR_BAD_ARG;
+    if (!h->params_set) return fail(h, CMPS_ERR_STATE, "cmps_psi_sample: call cmps_set_params first");
+    if (!noise_dev || !out_dev || n < 1 || length < 1)
+        return fail(h, CMPS_ERR_BAD_ARG, "cmps_psi_sample: bad argument");
+    if (length > h->L.N)
+        return fail(h, CMPS_ERR_BAD_ARG, "cmps_psi_sample: length exceeds T - 1 of cmps_set_params (the per-step tables)");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = (resolve_variant(h) == CMPS_VARIANT_WAVE) ? launch_sample_wave(h->P, noise_dev, n, length, out_dev, s)
+                                                             : launch_sample_block(h->P, noise_dev, n, length, out_dev, s);
+    if (e != hipSuccess) return fail_hip(h, e, "cmps_psi_sample");
     return CMPS_OK;
 }
 

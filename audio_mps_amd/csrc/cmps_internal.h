@@ -15,8 +15,9 @@ namespace cmps {
 //   dtk      : t_k - t_{k+1}          float32 (exact), k = 0..N-1
 //   rho      : [N+1][DP] float2       rho_k[d] = exp(i (fl(f_d t_k) - fl(f_d t_{k+1}))), drift-corrected (cmps_prep.hip)
 //   rfix     : [2][NC][DP] double2    scratch of the drift correction
-//   stash    : [B][N][DP] float2      un-normalised rotating-frame state y_k (TRAIN only)
-//   hst      : [B][N][64][2] float    wave variant's stash: per lane (y_k own, ((R + R^dagger) y_k) own), 512 B per step
+//   stash    : [B][N][DP] float2      un-normalised rotating-frame state y_k (TRAIN only; block variant)
+//   hst      : [B][N][64][2] float    wave variant's stash (same region as `stash`): per lane (y_k own,
+//                                     ((R + R^dagger) y_k) own), 512 B per step
 //   scal     : [B][NC][2][64] float   per 64-step chunk: |y_k|^2 and e_k, one step per lane (wave variant)
 //   slabs    : [B][slab] float        per-clip gradient partials (TRAIN only)
 //   sums     : [slab] float           reduced partials
@@ -56,9 +57,11 @@ inline Layout make_layout(int D, int B, int T, int flags) {
     L.off_slabs = o;
     L.off_sums = o;
     if (flags & 1) {
-        o = align256(o + (size_t)B * N * DP * sizeof(float2));
-        L.off_hst = o;
-        if (D <= 32) o = align256(o + (size_t)B * N * 128 * sizeof(float));
+        // the two variants never run on the same stash: their layouts share one region
+        size_t stash_bytes = (size_t)B * N * DP * sizeof(float2);
+        if (D <= 32 && stash_bytes < (size_t)B * N * 128 * sizeof(float)) stash_bytes = (size_t)B * N * 128 * sizeof(float);
+        L.off_hst = L.off_stash;
+        o = align256(o + stash_bytes);
         L.off_scal = o;  o = align256(o + (size_t)B * ((N + 63) / 64) * 128 * sizeof(float));
         L.off_slabs = o; o = align256(o + (size_t)B * L.slab_floats * sizeof(float));
         L.off_sums = o;  o = align256(o + L.slab_floats * sizeof(float));
@@ -86,6 +89,7 @@ struct Dev {
     float* sums;         // [slab]
     size_t slab_floats;
     float A;
+    float dt;            // (float)delta_t (model.py:16; also the python-float factor of model.py:286)
     float c_half;        // (float)(-delta_t * sigma^2) / 2   (model.py:312)
 };
 
@@ -103,6 +107,8 @@ hipError_t launch_reduce_finalize(const Dev& P, const float* loss, float* grad_o
 hipError_t launch_update_ancilla(const Dev& P, const float* psi_in, const float* signal, float t,
                                  int B, float* psi_out, hipStream_t s);
 hipError_t launch_states(const Dev& P, int B, float* psi_out, hipStream_t s);
+hipError_t launch_sample_wave(const Dev& P, const float* noise, int n, int length, float* out, hipStream_t s);
+hipError_t launch_sample_block(const Dev& P, const float* noise, int n, int length, float* out, hipStream_t s);
 
 // ---- small complex helpers (device) ----
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {

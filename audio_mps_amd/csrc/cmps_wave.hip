@@ -676,12 +676,83 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// sampling: PsiCMPS.sample = tf.scan of _psi_and_sample_update (model.py:242-251, 284-291)
+//   increment = 2 Re(u^dagger R u) * delta_t + noise_k;  sample += increment;  psi <- update(psi, increment);  normalise
+// One wavefront per sample path, same layout and mat-vec as the forward scan; here both wave reductions sit on
+// the serial chain (the increment feeds the update), so this kernel is latency-bound by construction.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * WAVES, 1) void k_sample_wave(Dev P, const float* __restrict__ noise, int n_paths,
+                                                               int length, float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float4 stR[WAVES][CH * 16];
+    __shared__ __attribute__((aligned(16))) float2 bcU[WAVES][DPW];
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const bool hb = h != 0;
+    const int b = blockIdx.x * WAVES + w;
+    if (b >= n_paths) return;
+    const int N = length, NC = (N + CH - 1) / CH;
+    v2f MR[16], MQ[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        MR[m] = ld2(&P.R[i * DPW + 16 * h + m]);
+        MQ[m] = ld2(&P.Q[i * DPW + 16 * h + m]);
+    }
+    const unsigned aUw = lds_addr(&bcU[w][0]) + i * 8 + h * 4, aUr = lds_addr(&bcU[w][0]) + h * 128;
+    const unsigned aRho = lds_addr(&stR[w][0]) + i * 8;
+    const float4* rho4 = reinterpret_cast<const float4*>(P.rho);
+    const float* nrow = noise + (size_t)b * length;
+    float* orow = out + (size_t)b * length;
+    const float A = P.A, dt = P.dt;
+    const float2 p0 = P.psi0[i];
+    float u = hb ? p0.y : p0.x;
+    float samp = 0.f;                                    // model.py:244 batch_zeros
+    v4f sr[16], qu[8];
+    v2f rho;
+    for (int c = 0; c < NC; ++c) {
+        const int kbeg = c * CH;
+        const int cnt = (N - kbeg) < CH ? (N - kbeg) : CH;
+        stage_load<16>(rho4, kbeg, P.N, lane, sr);
+        const float nz = kbeg + lane < N ? nrow[kbeg + lane] : 0.f;
+        stage_commit<16>(stR[w], lane, sr);
+        float svec = 0.f;
+        for (int kk = 0; kk < cnt; ++kk) {
+            bcast_issue_tab(aUw, aUr, u, aRho + kk * 256, qu, rho);
+            lds_wait_lo<5>(qu);
+            v2f av, aq;
+            mv2_lo(MR, MQ, qu, av, aq);
+            lds_wait_hi_t<0>(qu, rho);
+            mv2_hi(MR, MQ, qu, av, aq);
+            const float vs = swapadd(av.x, av.y), qs = swapadd(aq.x, aq.y);
+            const float e = 2.0f * sum64(u * vs);                    // _expectation (model.py:319-325)
+            const float inc = e * dt + rdlane(nz, kk);               // model.py:286
+            samp += inc;                                             // :287
+            svec = (lane == kk) ? samp : svec;
+            const float s = inc / A;                                 // :288 -> :303
+            const float y = u + (qs + s * vs);
+            const float n = sum64(y * y);
+            const float inv = rsq_nr(fmaxf(n, 1e-12f));              // :289
+            const float yo = osig_of(y, hb);
+            const v2f un = cmul2(inv * mk2(y, yo), rho);
+            u = un.x;
+        }
+        if (lane < cnt) orow[kbeg + lane] = A * svec;                // model.py:251
+    }
+}
+
 hipError_t launch_fwd_wave(const Dev& P, const float* audio, float* loss, bool save, hipStream_t s) {
     const unsigned nb = (unsigned)((P.B + WAVES - 1) / WAVES);
     if (save)
         hipLaunchKernelGGL(k_fwd_wave<true>, dim3(nb), dim3(64 * WAVES), 0, s, P, audio, loss);
     else
         hipLaunchKernelGGL(k_fwd_wave<false>, dim3(nb), dim3(64 * WAVES), 0, s, P, audio, loss);
+    return hipGetLastError();
+}
+
+hipError_t launch_sample_wave(const Dev& P, const float* noise, int n, int length, float* out, hipStream_t s) {
+    const unsigned nb = (unsigned)((n + WAVES - 1) / WAVES);
+    hipLaunchKernelGGL(k_sample_wave, dim3(nb), dim3(64 * WAVES), 0, s, P, noise, n, length, out);
     return hipGetLastError();
 }
 

@@ -8,7 +8,7 @@ training_estimators.py:43-45 / follow_vae.py:45-51 call.  The reference builds a
 the forward + reverse kernels and applies the tiny host-side chain rule from the kernels' outputs
 (gradients w.r.t. the effective R, freqs, psi_0, A) to the raw variables (Rx, Ry, freqs, psi_x, psi_y, A).
 
-Out of scope on this surface ("next" rows): RhoCMPS / ``mixed=True``, sampling.
+Out of scope on this surface ("next" rows): RhoCMPS / ``mixed=True``.
 They raise NotImplementedError rather than silently doing something else.
 """
 from __future__ import annotations
@@ -302,8 +302,20 @@ class PsiCMPS(CMPS):
         be.forward(audio, save_for_bwd=True)
         return be.states()
 
-    def sample(self, num_samples, length, temp=1):
-        raise NotImplementedError("PsiCMPS.sample (model.py:242-251) is a 'next' row (SURVEY.md 8f), not built yet")
+    def sample(self, num_samples, length, temp=1, seed=None, noise=None):
+        """model.py:242-251: waveforms [num_samples, length] = A * running sum of the sampled increments.
+        The Gaussian noise (stddev sigma * sqrt(temp * delta_t), model.py:246) is drawn on the host with a numpy
+        Generator (``seed``), or passed in as ``noise`` [length, num_samples] like the reference's tensor."""
+        if noise is None:
+            rng = np.random.default_rng(seed)
+            std = float(self.sigma) * math.sqrt(temp * float(self.delta_t))
+            noise = (std * rng.standard_normal((length, num_samples))).astype(np.float32)
+        noise = np.asarray(noise, dtype=np.float32)
+        if noise.shape != (length, num_samples):
+            raise ValueError(f"noise must be [{length}, {num_samples}]")
+        be = self._get_backend()
+        be.set_params(self.effective_params(), num_samples, length + 1, train=False)
+        return be.sample(noise)
 
 
 # --------------------------------------------------------------------------------------------------

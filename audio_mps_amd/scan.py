@@ -191,3 +191,13 @@ class HipScan:
         _capi.check(self._h, self._lib.cmps_psi_states(self._h, B, T, out.data_ptr(), self._stream()))
         o = out.cpu().numpy()
         return (o[..., 0] + 1j * o[..., 1]).astype(np.complex64)
+
+    def sample(self, noise: np.ndarray) -> np.ndarray:
+        """PsiCMPS.sample for pre-drawn noise [length, n] (the reference's layout) -> waveforms [n, length]."""
+        noise = np.asarray(noise, dtype=np.float32)
+        length, n = noise.shape
+        d_noise = torch.from_numpy(np.ascontiguousarray(noise.T)).to(self.device)
+        d_out = torch.empty((n, length), dtype=torch.float32, device=self.device)
+        _capi.check(self._h, self._lib.cmps_psi_sample(self._h, d_noise.data_ptr(), n, length, d_out.data_ptr(),
+                                                       self._stream()))
+        return d_out.cpu().numpy()

@@ -116,6 +116,15 @@ int cmps_psi_update_ancilla(cmps_handle_t h, const float* psi_in_dev, const floa
  */
 int cmps_psi_states(cmps_handle_t h, int B, int T, float* psi_out_dev, void* stream);
 
+/*
+ * Replaces: PsiCMPS.sample's tf.scan of _psi_and_sample_update (model.py:242-251, 284-291) for pre-drawn noise
+ * (the reference draws it with tf.random_normal([length, n], stddev = sigma * sqrt(temp * delta_t)), model.py:246).
+ * noise_dev [n * length] row-major [path][step] (transposed w.r.t. the reference so that a path reads contiguous
+ * memory); out_dev [n * length] receives A * (running sum of the increments), i.e. `self.A * transpose(samples)`.
+ * Needs cmps_set_params with T >= length + 1 (the per-step time/phase tables); any workspace flags.
+ */
+int cmps_psi_sample(cmps_handle_t h, const float* noise_dev, int n, int length, float* out_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,7 +10,7 @@ reference's own tests (``tests/test_model.py``) hold structural invariants only 
 no known-answer values.  This file therefore restates ``model.py`` op for op from its text, in the
 same dtypes (float32 / complex64), the same operation order, with sequential fp32 ``t += dt`` and
 ``loss += ...`` accumulation and plain ``log(1 + z)``.  What pins it instead: the reference's six
-invariants (tests/test_oracle_invariants.py), a float64 twin (``dtype="f64"``) and central
+invariants (tests/test_oracle.py), a float64 twin (``dtype="f64"``) and central
 finite-difference gradient checks in float64.
 
 Every function cites the reference lines it follows (paths relative to /root/reference).
@@ -415,6 +415,46 @@ def psi_loss_and_grads(hp: HParams, var: Variables, data, dtype="f32", with_reg=
     return Grads(A=np.asarray(real(Abar)), Rx=gRx, Ry=gRy, freqs=gf,
                  psi_x=p_bar.real.astype(real), psi_y=p_bar.imag.astype(real),
                  loss=total, per_clip=loss, eff=eff)
+
+
+# --------------------------------------------------------------------------------------------
+# next row: PsiCMPS.sample  (model.py:242-251, 284-291)
+# --------------------------------------------------------------------------------------------
+def sample_noise(hp: HParams, num_samples, length, temp=1.0, seed=0):
+    """noise = tf.random_normal([length, num_samples], stddev=sigma*sqrt(temp*delta_t)) (model.py:246); a seeded
+    numpy Generator stands in for TF's stream.  Returned as [length, num_samples] float32 like the reference."""
+    rng = np.random.default_rng(seed)
+    std = hp.sigma * np.sqrt(temp * hp.delta_t)
+    return (std * rng.standard_normal((length, num_samples))).astype(np.float32)
+
+
+def psi_sample(hp: HParams, var: Variables, noise, dtype="f32", return_states=False):
+    """PsiCMPS.sample given the pre-drawn noise [length, num_samples]: tf.scan of _psi_and_sample_update
+    (model.py:284-291) from (psi_0 stacked, zeros, 0.), returning A * transpose(samples)  [num_samples, length]."""
+    real, cplx = _dt(dtype)
+    noise = np.asarray(noise, dtype=real)
+    length, n = noise.shape
+    R, freqs, _, _ = effective_params(hp, var, dtype)
+    A = real(var.A)
+    psi = np.tile(psi_0(var, dtype)[None, :], (n, 1)).astype(cplx)          # model.py:245
+    sample = np.zeros(n, dtype=real)                                        # :244
+    t = real(0)
+    dt = real(hp.delta_t)
+    out = np.empty((length, n), dtype=real)
+    states = []
+    for k in range(length):
+        increment = (expectation(psi, t, R, freqs, dtype) * real(hp.delta_t) + noise[k]).astype(real)   # :286
+        sample = (sample + increment).astype(real)                                                     # :287
+        psi = update_ancilla_psi(psi, increment, t, R, freqs, A, hp, dtype)                            # :288
+        psi = normalize_psi(psi, axis=1, dtype=dtype)                                                  # :289
+        t = real(t + dt)                                                                               # :290
+        out[k] = sample
+        if return_states:
+            states.append(psi)
+    res = (A * out.T).astype(real)                                                                     # :251
+    if return_states:
+        return res, np.stack(states, axis=1)
+    return res
 
 
 # --------------------------------------------------------------------------------------------

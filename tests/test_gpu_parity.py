@@ -260,3 +260,37 @@ def test_error_codes_and_nan_propagation():
     # 1 + z <= 0 gives NaN / inf (plain log(1 + z), model.py:294), again without an error
     big = (audio * 1e6).astype(np.float32)
     assert not np.all(np.isfinite(m.loss_per_clip(big)))
+
+
+# ---------------------------------------------------------------------------------------------------
+# next row: PsiCMPS.sample
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("variant", [BLOCK, WAVE])
+def test_sampling_two_level_system(variant):
+    """TestPsiCMPS.testSampling (tests/test_model.py:140-158): R = [[0,1],[0,0]], freqs = [w, -w], sigma = 1, A = 1."""
+    from audio_mps_amd import HParams, PsiCMPS
+    hp = HParams(minibatch_size=8, bond_dim=2, delta_t=1 / 16000, sigma=1, A=1.0,
+                 h_reg=2 / (math.pi * 16000) ** 2, r_reg=2 / (math.pi * 16000) ** 2)
+    R = np.array([[0, 1], [0, 0]], dtype=np.complex64)
+    freqs = np.array([10.0, -10.0], dtype=np.float32)
+    qubit = PsiCMPS(hp, R_in=R, freqs_in=freqs, backend=_scan(2, variant))
+    waveform = qubit.sample(num_samples=2, length=512, seed=3)
+    assert waveform.shape == (2, 512) and np.all(np.isfinite(waveform))
+    noise = O.sample_noise(oracle_hparams(hp), 2, 512, seed=5)
+    ref = O.psi_sample(oracle_hparams(hp), oracle_variables(qubit), noise)
+    out = qubit.sample(2, 512, noise=noise)
+    assert np.max(np.abs(out - ref)) <= 1e-5 * max(1.0, np.max(np.abs(ref)))
+
+
+@pytest.mark.parametrize("D,length,n,variant", [(8, 300, 5, WAVE), (32, 700, 9, WAVE), (32, 130, 3, BLOCK), (48, 100, 2, BLOCK)])
+def test_sampling_matches_oracle(D, length, n, variant):
+    from audio_mps_amd import HParams, PsiCMPS
+    hp = HParams(minibatch_size=n, bond_dim=D, sigma=1.0, A=10.0)
+    m = PsiCMPS(hp, seed=D, backend=_scan(D, variant))
+    m.variables["Rx"] *= np.float32(0.05)
+    m.variables["Ry"] *= np.float32(0.05)
+    noise = O.sample_noise(oracle_hparams(hp), n, length, temp=0.5, seed=D)
+    ref = O.psi_sample(oracle_hparams(hp), oracle_variables(m), noise)
+    out = m.sample(n, length, noise=noise)
+    assert out.shape == (n, length)
+    assert np.max(np.abs(out - ref)) <= 2e-5 * max(1.0, np.max(np.abs(ref)))

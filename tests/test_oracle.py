@@ -124,3 +124,17 @@ def test_oracle_reproduces_golden(name):
     assert rel_inf(cg["fbar"] / B, g["eff_fbar_f32"]) < 1e-4
     # float64 twin stays close (it is a sanity bound, not the parity target)
     assert np.max(np.abs(g["loss_per_clip_f64"] - g["loss_per_clip_f32"]) / scale) < 1e-3
+
+
+def test_sampling_shape_and_twin():
+    """TestPsiCMPS.testSampling (tests/test_model.py:140-158): the two-level system; shape (2, 512)."""
+    hp = O.HParams(minibatch_size=8, bond_dim=2, delta_t=1 / 16000, sigma=1, A=1.0,
+                   h_reg=2 / (math.pi * 16000) ** 2, r_reg=2 / (math.pi * 16000) ** 2)
+    var = O.init_variables(hp, seed=0, R_in=np.array([[0, 1], [0, 0]], dtype=np.complex64),
+                           freqs_in=np.array([10.0, -10.0], dtype=np.float32))
+    noise = O.sample_noise(hp, 2, 512, seed=1)
+    w, states = O.psi_sample(hp, var, noise, return_states=True)
+    assert w.shape == (2, 512) and np.all(np.isfinite(w))
+    np.testing.assert_allclose(np.linalg.norm(states, axis=-1), 1.0, rtol=1e-5)
+    w64 = O.psi_sample(hp, var.astype(np.float64), noise, "f64")
+    assert np.max(np.abs(w - w64)) < 1e-5
