@@ -50,6 +50,9 @@ constexpr int CHB = 32;    // steps per staged chunk in the reverse sweep (three
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v16f __attribute__((ext_vector_type(16)));
+typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ v2f mk2(float a, float b) { v2f r; r.x = a; r.y = b; return r; }
 __device__ __forceinline__ v2f ld2(const float2* p) { const float2 t = *p; return mk2(t.x, t.y); }
@@ -590,7 +593,42 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
     // it keeps the 144-cycle wave reduction off the serial chain; `exact` (once per staged chunk) does the real
     // projection so that rounding in the radial direction cannot accumulate over the clip.
     float rad_next = 0.f;                         // no step N: g_N = 0
-    auto chain_step = [&](const Pre& S, float uk, float uko, auto have_pre, int jn, bool exact) -> Pre {
+    // Rank-1 updates, two forms.  Immediate: six exact-fp32 v_mfma_f32_32x32x2_f32 (the fp32 MFMA shares the fp32
+    // ALUs with the VALU, so each blocks the wave for 64 cycles).  Recorded: the seven operand values of the
+    // step are split into bf16 hi (truncation) + bf16 lo (rounded remainder) and packed into slot P of per-lane
+    // K-fragments; after eight steps 18 v_mfma_f32_32x32x16_bf16 (hi*hi + hi*lo + lo*hi per product; K = 8 steps x
+    // {re, im}; error ~2^-17 per product) accumulate them into the same fp32 tiles.  The bf16 MFMA runs on the
+    // matrix pipe beside the VALU and is issued once per eight steps.
+    unsigned fH[7][4], fL[7][4];      // K-fragments: value v, register r holds slots 2r (low half) and 2r+1 (high half)
+    float fsave[7];
+    auto record = [&](auto slot, const float (&val)[7]) {
+        constexpr int PSLOT = decltype(slot)::value;
+        if constexpr (PSLOT & 1) {
+#pragma unroll
+            for (int v = 0; v < 7; ++v) fsave[v] = val[v];
+        } else {
+#pragma unroll
+            for (int v = 0; v < 7; ++v) {
+                const unsigned xe = __float_as_uint(val[v]), xo = __float_as_uint(fsave[v]);
+                fH[v][PSLOT >> 1] = __builtin_amdgcn_perm(xo, xe, 0x07060302u);
+                v2f lo;
+                lo.x = val[v] - __uint_as_float(xe & 0xFFFF0000u);
+                lo.y = fsave[v] - __uint_as_float(xo & 0xFFFF0000u);
+                fL[v][PSLOT >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf2));
+            }
+        }
+    };
+    auto flush_octet = [&]() {
+        auto frag = [&](const unsigned (&f)[4]) { return __builtin_bit_cast(bf8, v4u{f[0], f[1], f[2], f[3]}); };
+        auto mf = [&](v16f& acc, int ia, int ib) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(fH[ia]), frag(fH[ib]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(fH[ia]), frag(fL[ib]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(fL[ia]), frag(fH[ib]), acc, 0, 0, 0);
+        };
+        // values: 0 a1 = 2 ebar n yhat, 1 ybar, 2 a2 = s ybar | 3 yhat, 4 yhat_osig, 5 u_k, 6 u_k_osig
+        mf(Rre, 0, 3); mf(Rim, 0, 4); mf(Qre, 1, 5); mf(Qim, 1, 6); mf(Rre, 2, 5); mf(Rim, 2, 6);
+    };
+    auto chain_step = [&](const Pre& S, float uk, float uko, auto have_pre, int jn, bool exact, auto slot) -> Pre {
         // ---- chain, scalar part ----
         facc += S.dtk * (go * S.un);
         const v2f yhbp = cmul2_conj_b(mk2(g, go), S.rho);              // conj(rho_k) g
@@ -624,12 +662,17 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
         //   (the sign of the Im tiles is applied once at the end)
         const float a1 = S.ten * S.yh;           // 2 ebar n yhat  (y y^dagger = n yhat yhat^dagger)
         const float a2 = S.s * ybar;
-        Rre = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, S.yh, Rre, 0, 0, 0);
-        Rim = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, S.yho, Rim, 0, 0, 0);
-        Qre = __builtin_amdgcn_mfma_f32_32x32x2f32(ybar, uk, Qre, 0, 0, 0);
-        Qim = __builtin_amdgcn_mfma_f32_32x32x2f32(ybar, uko, Qim, 0, 0, 0);
-        Rre = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, uk, Rre, 0, 0, 0);
-        Rim = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, uko, Rim, 0, 0, 0);
+        if constexpr (decltype(slot)::value < 0) {
+            Rre = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, S.yh, Rre, 0, 0, 0);
+            Rim = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, S.yho, Rim, 0, 0, 0);
+            Qre = __builtin_amdgcn_mfma_f32_32x32x2f32(ybar, uk, Qre, 0, 0, 0);
+            Qim = __builtin_amdgcn_mfma_f32_32x32x2f32(ybar, uko, Qim, 0, 0, 0);
+            Rre = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, uk, Rre, 0, 0, 0);
+            Rim = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, uko, Rim, 0, 0, 0);
+        } else {
+            const float val[7] = {a1, ybar, a2, S.yh, S.yho, uk, uko};
+            record(slot, val);
+        }
         return Sn;
     };
 
@@ -641,15 +684,30 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
         stage_load_all(hh > 0 ? hh - 1 : 0);          // prefetch into registers (clamped: harmless reload)
         const bool new_scal = (hh & 1) == 0 && hh > 0;
         if (new_scal) scal_load((hh >> 1) - 1);
-        for (int j = jhi; j >= jlo; --j) {
+        int j = jhi;
+        // steps above the first aligned octet (top chunk only): immediate fp32 updates
+        for (; j >= jlo && (j & 7) != 7; --j) {
             const int jr = j & (CHB - 1), jc = j & (CH - 1);
             own_issue(aYown + jr * 512, aRho + jr * 256, aScl + jc * 32, yh_j, rho_j, c0_j, c1_j);
-            S = chain_step(S, 0.f, 0.f, std::true_type{}, j, j == jhi);
+            S = chain_step(S, 0.f, 0.f, std::true_type{}, j, j == jhi, std::integral_constant<int, -1>{});
         }
+        // aligned octets: slot = j & 7, updates recorded and applied once per octet
+#define BWD_STEP8(P)                                                                                          \
+        {                                                                                                     \
+            const int jq = j - (7 - (P));                                                                     \
+            const int jr = jq & (CHB - 1), jc = jq & (CH - 1);                                                \
+            own_issue(aYown + jr * 512, aRho + jr * 256, aScl + jc * 32, yh_j, rho_j, c0_j, c1_j);            \
+            S = chain_step(S, 0.f, 0.f, std::true_type{}, jq, jq == jhi, std::integral_constant<int, (P)>{}); \
+        }
+        for (; j >= jlo; j -= 8) {
+            BWD_STEP8(7) BWD_STEP8(6) BWD_STEP8(5) BWD_STEP8(4) BWD_STEP8(3) BWD_STEP8(2) BWD_STEP8(1) BWD_STEP8(0)
+            flush_octet();
+        }
+#undef BWD_STEP8
         if (hh > 0) stage_commit_all();
         if (new_scal) scal_commit((hh >> 1) - 1);
     }
-    S = chain_step(S, u0, u0o, std::false_type{}, 0, true);      // step 0: u_0 = psi_0
+    S = chain_step(S, u0, u0o, std::false_type{}, 0, true, std::integral_constant<int, -1>{});   // step 0: u_0 = psi_0
 
     // ---------------- per-clip slab ----------------
     float* slab = P.slabs + (size_t)b * P.slab_floats;
