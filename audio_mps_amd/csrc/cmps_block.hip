@@ -226,11 +226,23 @@ __global__ __launch_bounds__(NT) void k_bwd_block(Dev P, const float* __restrict
 //   Rbar += c_half R (Qbar + Qbar^dagger)       (from Q = c_half R^dagger R)
 // grad_out: dR_re [D*D] | dR_im [D*D] | dfreqs [D] | dpsi0_re [D] | dpsi0_im [D] | dA | sum loss
 // ------------------------------------------------------------------------------------------------
-__global__ void k_reduce_slabs(Dev P, float* __restrict__ sums) {
+// two passes, fixed summation order (deterministic): RPART row-groups of clips, then the groups
+constexpr int RPART = 32;
+__global__ void k_reduce_slabs(Dev P, float* __restrict__ part) {
+    const size_t col = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= P.slab_floats) return;
+    const int g = blockIdx.y;
+    const int per = (P.B + RPART - 1) / RPART;
+    const int b0 = g * per, b1 = (b0 + per < P.B) ? b0 + per : P.B;
+    double acc = 0.0;
+    for (int b = b0; b < b1; ++b) acc += (double)P.slabs[(size_t)b * P.slab_floats + col];
+    reinterpret_cast<double*>(part)[(size_t)g * P.slab_floats + col] = acc;
+}
+__global__ void k_reduce_parts(Dev P, const float* __restrict__ part, float* __restrict__ sums) {
     const size_t col = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= P.slab_floats) return;
     double acc = 0.0;
-    for (int b = 0; b < P.B; ++b) acc += (double)P.slabs[(size_t)b * P.slab_floats + col];
+    for (int g = 0; g < RPART; ++g) acc += reinterpret_cast<const double*>(part)[(size_t)g * P.slab_floats + col];
     sums[col] = (float)acc;
 }
 
@@ -406,7 +418,9 @@ hipError_t launch_bwd_block(const Dev& P, const float* audio, hipStream_t s) {
 
 hipError_t launch_reduce_finalize(const Dev& P, const float* loss, float* grad_out, hipStream_t s) {
     const unsigned nb = (unsigned)((P.slab_floats + 255) / 256);
-    hipLaunchKernelGGL(k_reduce_slabs, dim3(nb), dim3(256), 0, s, P, P.sums);
+    float* part = P.sums + ((P.slab_floats + 63) / 64) * 64;          // RPART x slab doubles behind the sums
+    hipLaunchKernelGGL(k_reduce_slabs, dim3(nb, RPART), dim3(256), 0, s, P, part);
+    hipLaunchKernelGGL(k_reduce_parts, dim3(nb), dim3(256), 0, s, P, (const float*)part, P.sums);
     hipLaunchKernelGGL(k_finalize, dim3(8), dim3(256), 0, s, P, (const float*)P.sums, loss, grad_out);
     return hipGetLastError();
 }

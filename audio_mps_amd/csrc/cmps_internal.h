@@ -20,7 +20,7 @@ namespace cmps {
 //                                     ((R + R^dagger) y_k) own), 512 B per step
 //   scal     : [B][NC][2][64] float   per 64-step chunk: |y_k|^2 and e_k, one step per lane (wave variant)
 //   slabs    : [B][slab] float        per-clip gradient partials (TRAIN only)
-//   sums     : [slab] float           reduced partials
+//   sums     : [slab] float           reduced partials, followed by [32][slab] double first-pass partial sums
 // DP = D for the block variant; 32 for the wave variant (components >= D are zero padding).
 // ---------------------------------------------------------------------------------------------
 struct Layout {
@@ -64,7 +64,7 @@ inline Layout make_layout(int D, int B, int T, int flags) {
         o = align256(o + stash_bytes);
         L.off_scal = o;  o = align256(o + (size_t)B * ((N + 63) / 64) * 128 * sizeof(float));
         L.off_slabs = o; o = align256(o + (size_t)B * L.slab_floats * sizeof(float));
-        L.off_sums = o;  o = align256(o + L.slab_floats * sizeof(float));
+        L.off_sums = o;  o = align256(o + (L.slab_floats + 64) * sizeof(float) + 32 * L.slab_floats * sizeof(double));
     }
     L.total = o;
     return L;

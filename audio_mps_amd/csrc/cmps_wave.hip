@@ -618,18 +618,38 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
             }
         }
     };
-    auto flush_octet = [&]() {
+    // values: 0 a1 = 2 ebar n yhat, 1 ybar, 2 a2 = s ybar | 3 yhat, 4 yhat_osig, 5 u_k, 6 u_k_osig
+    // The 18 MFMAs of a finished octet (6 groups of 3) are issued at six points of the NEXT step (slot 7 writes no
+    // fragment register), each behind enough VALU work that the matrix pipe is free again: back to back they
+    // would hold the in-order wave for 18 x 32 cycles.
+    bool pend = false;                // a finished octet's fragments are waiting to be applied
+    auto mf_group = [&](auto gsel) {
+        constexpr int G = decltype(gsel)::value;
         auto frag = [&](const unsigned (&f)[4]) { return __builtin_bit_cast(bf8, v4u{f[0], f[1], f[2], f[3]}); };
         auto mf = [&](v16f& acc, int ia, int ib) {
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(fH[ia]), frag(fH[ib]), acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(fH[ia]), frag(fL[ib]), acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(fL[ia]), frag(fH[ib]), acc, 0, 0, 0);
         };
-        // values: 0 a1 = 2 ebar n yhat, 1 ybar, 2 a2 = s ybar | 3 yhat, 4 yhat_osig, 5 u_k, 6 u_k_osig
-        mf(Rre, 0, 3); mf(Rim, 0, 4); mf(Qre, 1, 5); mf(Qim, 1, 6); mf(Rre, 2, 5); mf(Rim, 2, 6);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (G == 0) mf(Rre, 0, 3);
+        if constexpr (G == 1) mf(Rim, 0, 4);
+        if constexpr (G == 2) mf(Qre, 1, 5);
+        if constexpr (G == 3) mf(Qim, 1, 6);
+        if constexpr (G == 4) mf(Rre, 2, 5);
+        if constexpr (G == 5) mf(Rim, 2, 6);
+        __builtin_amdgcn_sched_barrier(0);
     };
+    auto flush_octet = [&]() {
+        mf_group(std::integral_constant<int, 0>{}); mf_group(std::integral_constant<int, 1>{});
+        mf_group(std::integral_constant<int, 2>{}); mf_group(std::integral_constant<int, 3>{});
+        mf_group(std::integral_constant<int, 4>{}); mf_group(std::integral_constant<int, 5>{});
+        pend = false;
+    };
+#define MF_HOOK(G) if constexpr (decltype(slot)::value == 7) { if (pend) mf_group(std::integral_constant<int, (G)>{}); }
     auto chain_step = [&](const Pre& S, float uk, float uko, auto have_pre, int jn, bool exact, auto slot) -> Pre {
         // ---- chain, scalar part ----
+        MF_HOOK(0)
         facc += S.dtk * (go * S.un);
         const v2f yhbp = cmul2_conj_b(mk2(g, go), S.rho);              // conj(rho_k) g
         const float yhb = yhbp.x;
@@ -638,6 +658,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
         rad_next = S.rad;
         const float ybar = (yhb - dot * S.yhp) * S.inv + S.pre;
         bcast_issue(aBw, aBr, ybar, qc);                               // 9 ops
+        MF_HOOK(1)
         // ---- off-chain: pre of step k-1 (gives u_k) ----
         Pre Sn = S;
         if constexpr (decltype(have_pre)::value) {
@@ -647,15 +668,19 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
             uko = Sn.uno;
         }
         // ---- chain, mat-vec part: g_k = ybar + Q ybar + s R^dagger ybar ----
+        MF_HOOK(2)
         lds_wait_lo<4>(qc);
         v2f aq, ad;
         mv2_lo(MQ, MRd, qc, aq, ad);
+        MF_HOOK(3)
         lds_wait_hi<0>(qc);
         mv2_hi(MQ, MRd, qc, aq, ad);
+        MF_HOOK(4)
         const float sd = S.s * swapadd(ad.x, ad.y);
         accS += sd * uk;
         g = ybar + swapadd(aq.x, aq.y) + sd;
         go = osig_of(g, hb);
+        if constexpr (decltype(slot)::value == 7) { if (pend) { mf_group(std::integral_constant<int, 5>{}); pend = false; } }
         // ---- rank-1 gradient updates (A: rows i, B: columns j; K = {re, im}) ----
         //   Rbar += 2 ebar y y^dagger + s ybar u^dagger ;  Qbar += ybar u^dagger
         //   Re(a b^dagger): A = a (split), B = b (split);  Im(a b^dagger): A = a (split), B = -b_osig
@@ -701,13 +726,15 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
         }
         for (; j >= jlo; j -= 8) {
             BWD_STEP8(7) BWD_STEP8(6) BWD_STEP8(5) BWD_STEP8(4) BWD_STEP8(3) BWD_STEP8(2) BWD_STEP8(1) BWD_STEP8(0)
-            flush_octet();
+            pend = true;                               // applied during the next step (or by the final flush)
         }
 #undef BWD_STEP8
         if (hh > 0) stage_commit_all();
         if (new_scal) scal_commit((hh >> 1) - 1);
     }
+    if (pend) flush_octet();
     S = chain_step(S, u0, u0o, std::false_type{}, 0, true, std::integral_constant<int, -1>{});   // step 0: u_0 = psi_0
+#undef MF_HOOK
 
     // ---------------- per-clip slab ----------------
     float* slab = P.slabs + (size_t)b * P.slab_floats;
