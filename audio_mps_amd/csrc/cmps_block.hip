@@ -271,11 +271,13 @@ __global__ void k_finalize(Dev P, const float* __restrict__ sums, const float* _
         grad_out[2 * D * D + D + d] = sums[4 * DD + DP + d];
         grad_out[2 * D * D + 2 * D + d] = sums[4 * DD + 2 * DP + d];
     }
-    if (tid == 0) {
-        grad_out[2 * D * D + 3 * D] = sums[4 * DD + 3 * DP];
+    if (tid == 0) grad_out[2 * D * D + 3 * D] = sums[4 * DD + 3 * DP];
+    if (blockIdx.x == 0 && threadIdx.x < 64) {      // sum_b loss_b: one wave, strided partials then a fixed-order tree
         double ls = 0.0;
-        for (int b = 0; b < P.B; ++b) ls += (double)loss[b];
-        grad_out[2 * D * D + 3 * D + 1] = (float)ls;
+        for (int b = threadIdx.x; b < P.B; b += 64) ls += (double)loss[b];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ls += __shfl_xor(ls, off, 64);
+        if (threadIdx.x == 0) grad_out[2 * D * D + 3 * D + 1] = (float)ls;
     }
 }
 

@@ -104,9 +104,11 @@ __global__ void k_rho_fix(int DP, int N, float2* __restrict__ rho, const double2
     if (d >= DP) return;
     const int NC = (N + 63) / 64;
     double ar = 1.0, ai = 0.0;   // exact accumulated rotation of the float32 table so far
+    double2 p = prod[d], t = target[d];
     for (int c = 0; c < NC; ++c) {
         const int klast = (c * 64 + 64 < N ? c * 64 + 64 : N) - 1;
-        const double2 p = prod[c * DP + d], t = target[c * DP + d];
+        const int cn = c + 1 < NC ? c + 1 : c;                               // next chunk's inputs: off the dependent chain
+        const double2 pn = prod[cn * DP + d], tn = target[cn * DP + d];
         const double br = ar * p.x - ai * p.y, bi = ar * p.y + ai * p.x;     // before the chunk's last entry
         const double den = br * br + bi * bi;
         const double lr = (t.x * br + t.y * bi) / den, li = (t.y * br - t.x * bi) / den;   // target / actual
@@ -114,6 +116,8 @@ __global__ void k_rho_fix(int DP, int N, float2* __restrict__ rho, const double2
         rho[(size_t)klast * DP + d] = last;
         ar = br * (double)last.x - bi * (double)last.y;
         ai = br * (double)last.y + bi * (double)last.x;
+        p = pn;
+        t = tn;
     }
 }
 
