@@ -1,6 +1,7 @@
-"""Input fixture of the reference: ``get_audio`` (data.py:6-45).  Only the synthetic ``damped_sine``
-branch (data.py:8-22) is on the hot path's boundary; the TFRecord branch (data.py:25-43) is a 'next' row
- and raises."""
+"""Input side of the reference: ``get_audio`` (data.py:6-45).  The synthetic ``damped_sine`` branch (data.py:8-22)
+is the fixture the reference's model tests use; the TFRecord branch (data.py:25-43) is served by
+``audio_mps_amd.tfrecord`` (pure Python reader; the reference's data blobs themselves are absent,
+.MISSING_LARGE_BLOBS)."""
 from __future__ import annotations
 
 import numpy as np
@@ -27,6 +28,11 @@ def get_audio(datadir, dataset, hps, sample_duration: int = 2 ** 16, seed: int =
     FLAGS.sample_duration (train.py:27, data.py:10)."""
     if dataset == "damped_sine":
         return damped_sine(hps.minibatch_size, sample_duration, hps.delta_t, seed=seed)
-    raise NotImplementedError(
-        f"dataset {dataset!r}: the TFRecord branch (data.py:25-43) is a 'next' row (SURVEY.md 8f); "
-        "the data blobs are absent from the reference (.MISSING_LARGE_BLOBS)")
+    # data.py:25-43: f"{datadir}/{dataset}.tfrecords" -> "audio" FixedLenFeature -> batch -> shuffle(24) -> repeat.
+    # Returns a zero-argument callable yielding the next batch (the eager stand-in for iterator.get_next()).
+    import os
+    from .tfrecord import audio_batches
+    path = os.path.join(str(datadir), f"{dataset}.tfrecords")
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"{path} (the reference's data blobs are not distributed: .MISSING_LARGE_BLOBS)")
+    return audio_batches(path, hps.minibatch_size, sample_duration, seed=seed, order="data")

@@ -120,8 +120,38 @@ def test_get_audio():
     hp = HParams(minibatch_size=8)
     d = get_audio(None, "damped_sine", hp, sample_duration=2 ** 8)   # tests/test_data.py:12-16
     assert d.shape == (8, 256) and d.dtype == np.float32
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(FileNotFoundError):
         get_audio("./data", "guitar", hp)
+
+
+def test_tfrecord_pipeline(tmp_path):
+    """data.py:25-43 / training_estimators.py:76-95 on a small file written like make-small-dataset.py:18-32."""
+    from audio_mps_amd import tfrecord as tfr
+    assert tfr.crc32c(b"123456789") == 0xE3069283                  # CRC-32C check value
+    rng = np.random.default_rng(0)
+    clips = rng.standard_normal((10, 64)).astype(np.float32)
+    path = os.path.join(tmp_path, "guitar.tfrecords")
+    tfr.write_audio_tfrecord(path, clips)
+    recs = [tfr.parse_example(r)["audio"] for r in tfr.read_records(path, verify=True)]
+    np.testing.assert_array_equal(np.stack(recs), clips)
+    hp = HParams(minibatch_size=4)
+    nxt = get_audio(str(tmp_path), "guitar", hp, sample_duration=64, seed=1)     # batch(4) -> shuffle(24) -> repeat
+    seen = [nxt() for _ in range(6)]                               # two epochs of 3 batches (4 + 4 + 2 clips)
+    assert sorted(b.shape[0] for b in seen[:3]) == [2, 4, 4]
+    first = np.concatenate(seen[:3])
+    assert sorted(map(tuple, first.round(4).tolist())) == sorted(map(tuple, clips.round(4).tolist()))
+    est = tfr.audio_batches(path, 4, 64, seed=2, order="estimator")  # shuffle(24).repeat().batch(4)
+    b = [est() for _ in range(5)]
+    assert all(x.shape == (4, 64) for x in b)
+    with pytest.raises(ValueError):                                # FixedLenFeature([T]) rejects other lengths (data.py:32)
+        get_audio(str(tmp_path), "guitar", hp, sample_duration=32)()
+    # corruption is detected when verification is on
+    raw = bytearray(open(path, "rb").read())
+    raw[40] ^= 0xFF
+    bad = os.path.join(tmp_path, "bad.tfrecords")
+    open(bad, "wb").write(bytes(raw))
+    with pytest.raises(IOError):
+        list(tfr.read_records(bad, verify=True))
 
 
 def test_product_has_no_cpu_fallback():
@@ -132,3 +162,24 @@ def test_product_has_no_cpu_fallback():
     m = PsiCMPS(HParams(bond_dim=4), data_iterator=make_audio(2, 16, 1 / 16000, 0))
     with pytest.raises(RuntimeError):
         _ = m.loss
+
+
+def test_estimator_surface(tmp_path):
+    """training_estimators.py: audiomps(...) -> model_fn (loss, Adam 1e-3) -> Estimator.train with checkpoints."""
+    from audio_mps_amd import tfrecord as tfr
+    from audio_mps_amd.training_estimators import Estimator, build_input_fns, build_parser
+    args = build_parser().parse_args([])
+    assert (args.bond_d, args.dt, args.batch_size, args.viz_steps, args.max_steps, args.discr) == (10, 0.001, 32, 1, 5001, False)
+    clips = make_audio(12, 48, 0.001, 4)
+    path = os.path.join(tmp_path, "pitch_30.tfrecords")
+    tfr.write_audio_tfrecord(path, clips)
+    input_fn = build_input_fns(path, 4, sample_duration=48, seed=0)
+    params = dict(bond_d=4, dt=0.001, batch_size=4, discr=False)
+    est = Estimator(params, model_dir=os.path.join(tmp_path, "m"), save_checkpoints_steps=2,
+                    model_kw={"backend": OracleBackend(4), "seed": 0})
+    est.train(input_fn, steps=4)
+    assert est.global_step == 4 and np.isfinite(est.last_loss)
+    est2 = Estimator(params, model_dir=os.path.join(tmp_path, "m"), model_kw={"backend": OracleBackend(4), "seed": 5})
+    assert est2.global_step == 4
+    for k in est.model.variables:
+        np.testing.assert_array_equal(est.model.variables[k], est2.model.variables[k])
