@@ -294,3 +294,40 @@ def test_sampling_matches_oracle(D, length, n, variant):
     out = m.sample(n, length, noise=noise)
     assert out.shape == (n, length)
     assert np.max(np.abs(out - ref)) <= 2e-5 * max(1.0, np.max(np.abs(ref)))
+
+
+@pytest.mark.parametrize("variant", [BLOCK, WAVE])
+def test_normalisation_floor_branch(variant):
+    """`tf.maximum(square_sum, 1e-12)` (model.py:332): a step whose update annihilates the state (I + s R) u = 0.
+    Two-level system, R = [[0, a], [a, 0]] (eigenvalues +-a), psi_0 = the +a eigenvector, first increment x = -A/a."""
+    from audio_mps_amd import HParams, PsiCMPS
+    a, A = 2.0, 4.0
+    hp = HParams(minibatch_size=3, bond_dim=2, sigma=0.0, A=A)
+    R = np.array([[0, a], [a, 0]], dtype=np.complex64)
+    m = PsiCMPS(hp, R_in=R, freqs_in=np.array([3.0, -5.0], dtype=np.float32),
+                psi_in=np.array([1, 1], dtype=np.complex64), backend=_scan(2, variant))
+    T = 40
+    audio = make_audio(3, T, hp.delta_t, 77, noise=0.05)
+    audio[1, 0] = 0.0
+    audio[1, 1] = -A / a            # clip 1: s R u = -u at step 0  ->  |y|^2 = 0 <= 1e-12
+    ref = c_oracle_run(m, audio, "f32")
+    per = m.loss_per_clip(audio)
+    assert np.all(np.isfinite(ref["loss_per_clip"])) and np.all(np.isfinite(per))
+    assert np.max(np.abs(per - ref["loss_per_clip"])) <= 1e-5 * max(1.0, np.max(np.abs(ref["loss_per_clip"])))
+    from audio_mps_amd.scan import unpack_grad
+    flat = m.grad_sums(audio)[0].cpu().numpy()
+    g, gr = unpack_grad(flat, 2), C.unpack_grad(ref["grad"], 2)
+    for k in ("Rbar", "fbar", "psi0bar", "Abar"):
+        assert rel_inf(g[k], gr[k]) <= 1e-3, k
+
+
+def test_more_clips_than_simds():
+    """B = 1030 (> 1024 waves, not a multiple of 4): several rounds of workgroups per CU."""
+    m, audio = _model(32, 130, 1030, WAVE, seed=11)
+    per = m.loss_per_clip()
+    ref = c_oracle_run(m, audio, "f32", want_grad=True, nthreads=16)
+    assert np.max(np.abs(per - ref["loss_per_clip"]) / np.maximum(np.abs(ref["loss_per_clip"]), 1.0)) <= LOSS_RTOL
+    from audio_mps_amd.scan import unpack_grad
+    g, gr = unpack_grad(m.grad_sums()[0].cpu().numpy(), 32), C.unpack_grad(ref["grad"], 32)
+    for k in ("Rbar", "fbar", "psi0bar", "Abar"):
+        assert rel_inf(g[k], gr[k]) <= GRAD_RTOL, k
