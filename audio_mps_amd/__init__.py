@@ -5,6 +5,6 @@ training_estimators.py) and drives hand-written HIP kernels (csrc/) through the 
 Importing the package does not touch the GPU; the HIP library is loaded on first use and there is no
 CPU fallback.
 """
-from .model import HParams, CMPS, PsiCMPS, RhoCMPS, AudioMPS  # noqa: F401
+from .model import HParams, CMPS, PsiCMPS, RhoCMPS, AudioMPS, LegacyAudioMPS  # noqa: F401
 
-__all__ = ["HParams", "CMPS", "PsiCMPS", "RhoCMPS", "AudioMPS"]
+__all__ = ["HParams", "CMPS", "PsiCMPS", "RhoCMPS", "AudioMPS", "LegacyAudioMPS"]

@@ -27,6 +27,7 @@ SYMBOLS = (
     "cmps_version", "cmps_create", "cmps_destroy", "cmps_last_error", "cmps_set_variant",
     "cmps_get_variant", "cmps_workspace_bytes", "cmps_set_params", "cmps_psi_loss_fwd",
     "cmps_psi_loss_bwd", "cmps_psi_update_ancilla", "cmps_psi_states", "cmps_psi_sample",
+    "cmps_legacy_set_params", "cmps_legacy_loss_fwd", "cmps_legacy_loss_bwd",
 )
 
 
@@ -66,6 +67,12 @@ def _declare(lib):
     lib.cmps_psi_states.restype = c_int
     lib.cmps_psi_sample.argtypes = [vp, vp, c_int, c_int, vp, vp]
     lib.cmps_psi_sample.restype = c_int
+    lib.cmps_legacy_set_params.argtypes = [vp, vp, vp, vp, c_double, c_int, c_int, c_int, vp, c_size_t, vp]
+    lib.cmps_legacy_set_params.restype = c_int
+    lib.cmps_legacy_loss_fwd.argtypes = [vp, vp, c_int, c_int, vp, c_int, vp]
+    lib.cmps_legacy_loss_fwd.restype = c_int
+    lib.cmps_legacy_loss_bwd.argtypes = [vp, vp, c_int, c_int, vp, vp]
+    lib.cmps_legacy_loss_bwd.restype = c_int
 
 
 _lib = None

@@ -418,11 +418,16 @@ hipError_t launch_bwd_block(const Dev& P, const float* audio, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_reduce_finalize(const Dev& P, const float* loss, float* grad_out, hipStream_t s) {
+hipError_t launch_reduce_only(const Dev& P, hipStream_t s) {
     const unsigned nb = (unsigned)((P.slab_floats + 255) / 256);
     float* part = P.sums + ((P.slab_floats + 63) / 64) * 64;          // RPART x slab doubles behind the sums
     hipLaunchKernelGGL(k_reduce_slabs, dim3(nb, RPART), dim3(256), 0, s, P, part);
     hipLaunchKernelGGL(k_reduce_parts, dim3(nb), dim3(256), 0, s, P, (const float*)part, P.sums);
+    return hipGetLastError();
+}
+
+hipError_t launch_reduce_finalize(const Dev& P, const float* loss, float* grad_out, hipStream_t s) {
+    (void)launch_reduce_only(P, s);
     hipLaunchKernelGGL(k_finalize, dim3(8), dim3(256), 0, s, P, (const float*)P.sums, loss, grad_out);
     return hipGetLastError();
 }

@@ -14,6 +14,7 @@ struct cmps_handle_s {
     int D = 0;
     int variant_req = CMPS_VARIANT_AUTO;
     bool params_set = false;
+    bool legacy = false;       // the tables currently hold the legacy AudioMPS arithmetic (cmps_legacy_set_params)
     bool fwd_saved = false;
     int saved_B = 0, saved_T = 0, saved_variant = 0;
     const float* saved_audio = nullptr;
@@ -112,6 +113,7 @@ int cmps_set_params(cmps_handle_t h, const float* R_re_dev, const float* R_im_de
     P.R = reinterpret_cast<float2*>(ws + L.off_R);
     P.RT = reinterpret_cast<float2*>(ws + L.off_RT);
     P.Q = reinterpret_cast<float2*>(ws + L.off_Q);
+    P.QT = reinterpret_cast<float2*>(ws + L.off_QT);
     P.psi0 = reinterpret_cast<float2*>(ws + L.off_psi0);
     P.freqs = reinterpret_cast<float*>(ws + L.off_freqs);
     P.ttab = reinterpret_cast<float*>(ws + L.off_ttab);
@@ -140,6 +142,7 @@ int cmps_set_params(cmps_handle_t h, const float* R_re_dev, const float* R_im_de
     h->tt_ws = ws; h->tt_N = L.N; h->tt_dt = dt;
     h->L = L; h->P = P; h->ws = ws;
     h->params_set = true;
+    h->legacy = false;
     h->fwd_saved = false;
     return CMPS_OK;
 }
@@ -147,7 +150,7 @@ int cmps_set_params(cmps_handle_t h, const float* R_re_dev, const float* R_im_de
 int cmps_psi_loss_fwd(cmps_handle_t h, const float* audio_dev, int B, int T, float* loss_dev,
                       int save_for_bwd, void* stream) {
     if (!h) return CMPS_ERR_BAD_ARG;
-    if (!h->params_set) return fail(h, CMPS_ERR_STATE, "cmps_psi_loss_fwd: call cmps_set_params first");
+    if (!h->params_set || h->legacy) return fail(h, CMPS_ERR_STATE, "cmps_psi_loss_fwd: call cmps_set_params first");
     if (!audio_dev || !loss_dev) return fail(h, CMPS_ERR_BAD_ARG, "cmps_psi_loss_fwd: null pointer");
     if (T != h->L.T) return fail(h, CMPS_ERR_BAD_ARG, "cmps_psi_loss_fwd: T differs from cmps_set_params");
     if (B < 1 || B > h->L.B) return fail(h, CMPS_ERR_BAD_ARG, "cmps_psi_loss_fwd: B outside [1, B_max]");
@@ -170,7 +173,7 @@ int cmps_psi_loss_fwd(cmps_handle_t h, const float* audio_dev, int B, int T, flo
 
 int cmps_psi_loss_bwd(cmps_handle_t h, const float* audio_dev, int B, int T, float* grad_dev, void* stream) {
     if (!h) return CMPS_ERR_BAD_ARG;
-    if (!h->params_set || !h->fwd_saved)
+    if (!h->params_set || !h->fwd_saved || h->legacy)
         return fail(h, CMPS_ERR_STATE, "cmps_psi_loss_bwd: needs cmps_psi_loss_fwd(save_for_bwd=1) first");
     if (!audio_dev || !grad_dev) return fail(h, CMPS_ERR_BAD_ARG, "cmps_psi_loss_bwd: null pointer");
     if (B != h->saved_B || T != h->saved_T || audio_dev != h->saved_audio)
@@ -221,6 +224,78 @@ int cmps_psi_sample(cmps_handle_t h, const float* noise_dev, int n, int length, 
     hipError_t e = (resolve_variant(h) == CMPS_VARIANT_WAVE) ? launch_sample_wave(h->P, noise_dev, n, length, out_dev, s)
                                                              : launch_sample_block(h->P, noise_dev, n, length, out_dev, s);
     if (e != hipSuccess) return fail_hip(h, e, "cmps_psi_sample");
+    return CMPS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// legacy AudioMPS arithmetic
+// ---------------------------------------------------------------------------------------------------
+int cmps_legacy_set_params(cmps_handle_t h, const float* R_dev, const float* Q_re_dev, const float* Q_im_dev,
+                           double delta_t, int T, int B_max, int flags, void* workspace_dev, size_t workspace_bytes,
+                           void* stream) {
+    if (!h) return CMPS_ERR_BAD_ARG;
+    if (!R_dev || !Q_re_dev || !Q_im_dev) return fail(h, CMPS_ERR_BAD_ARG, "cmps_legacy_set_params: null parameter pointer");
+    if (T < 2 || B_max < 1) return fail(h, CMPS_ERR_BAD_ARG, "cmps_legacy_set_params: need T >= 2 and B_max >= 1");
+    if (!workspace_dev) return fail(h, CMPS_ERR_WORKSPACE, "cmps_legacy_set_params: null workspace");
+    Layout L = make_layout(h->D, B_max, T, flags);
+    if (workspace_bytes < L.total) return fail(h, CMPS_ERR_WORKSPACE, "cmps_legacy_set_params: workspace too small");
+    if (((uintptr_t)workspace_dev & 255) != 0)
+        return fail(h, CMPS_ERR_WORKSPACE, "cmps_legacy_set_params: workspace must be 256-byte aligned");
+    char* ws = static_cast<char*>(workspace_dev);
+    Dev P{};
+    P.D = L.D; P.DP = L.DP; P.B = B_max; P.T = T; P.N = L.N;
+    P.R = reinterpret_cast<float2*>(ws + L.off_R);
+    P.RT = reinterpret_cast<float2*>(ws + L.off_RT);
+    P.Q = reinterpret_cast<float2*>(ws + L.off_Q);
+    P.QT = reinterpret_cast<float2*>(ws + L.off_QT);
+    P.stash = (flags & CMPS_WS_TRAIN) ? reinterpret_cast<float2*>(ws + L.off_stash) : nullptr;
+    P.slabs = (flags & CMPS_WS_TRAIN) ? reinterpret_cast<float*>(ws + L.off_slabs) : nullptr;
+    P.sums = (flags & CMPS_WS_TRAIN) ? reinterpret_cast<float*>(ws + L.off_sums) : nullptr;
+    P.slab_floats = L.slab_floats;
+    P.dt = (float)delta_t;
+    hipError_t e = launch_pack_legacy(P, R_dev, Q_re_dev, Q_im_dev, const_cast<float2*>(P.R), const_cast<float2*>(P.RT),
+                                      const_cast<float2*>(P.Q), const_cast<float2*>(P.QT), static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail_hip(h, e, "cmps_legacy_set_params");
+    h->L = L; h->P = P; h->ws = ws;
+    h->tt_ws = nullptr;               // the time table of the PsiCMPS mode is no longer valid for this workspace
+    h->params_set = true;
+    h->legacy = true;
+    h->fwd_saved = false;
+    return CMPS_OK;
+}
+
+int cmps_legacy_loss_fwd(cmps_handle_t h, const float* audio_dev, int B, int T, float* loss_dev, int save_for_bwd,
+                         void* stream) {
+    if (!h) return CMPS_ERR_BAD_ARG;
+    if (!h->params_set || !h->legacy) return fail(h, CMPS_ERR_STATE, "cmps_legacy_loss_fwd: call cmps_legacy_set_params first");
+    if (!audio_dev || !loss_dev) return fail(h, CMPS_ERR_BAD_ARG, "cmps_legacy_loss_fwd: null pointer");
+    if (T != h->L.T || B < 1 || B > h->L.B) return fail(h, CMPS_ERR_BAD_ARG, "cmps_legacy_loss_fwd: shape differs from set_params");
+    if (save_for_bwd && !(h->L.flags & CMPS_WS_TRAIN))
+        return fail(h, CMPS_ERR_WORKSPACE, "cmps_legacy_loss_fwd: save_for_bwd needs a CMPS_WS_TRAIN workspace");
+    Dev P = h->P;
+    P.B = B;
+    hipError_t e = launch_fwd_legacy(P, audio_dev, loss_dev, save_for_bwd != 0, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail_hip(h, e, "cmps_legacy_loss_fwd");
+    h->fwd_saved = save_for_bwd != 0;
+    h->saved_B = B; h->saved_T = T; h->saved_audio = audio_dev; h->saved_loss = loss_dev;
+    return CMPS_OK;
+}
+
+int cmps_legacy_loss_bwd(cmps_handle_t h, const float* audio_dev, int B, int T, float* grad_dev, void* stream) {
+    if (!h) return CMPS_ERR_BAD_ARG;
+    if (!h->params_set || !h->legacy || !h->fwd_saved)
+        return fail(h, CMPS_ERR_STATE, "cmps_legacy_loss_bwd: needs cmps_legacy_loss_fwd(save_for_bwd=1) first");
+    if (!audio_dev || !grad_dev) return fail(h, CMPS_ERR_BAD_ARG, "cmps_legacy_loss_bwd: null pointer");
+    if (B != h->saved_B || T != h->saved_T || audio_dev != h->saved_audio)
+        return fail(h, CMPS_ERR_STATE, "cmps_legacy_loss_bwd: audio / B / T differ from the forward call");
+    Dev P = h->P;
+    P.B = B;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = launch_bwd_legacy(P, audio_dev, s);
+    if (e != hipSuccess) return fail_hip(h, e, "cmps_legacy_loss_bwd (scan)");
+    e = launch_reduce_only(P, s);
+    if (e == hipSuccess) e = launch_finalize_legacy(P, h->saved_loss, grad_dev, s);
+    if (e != hipSuccess) return fail_hip(h, e, "cmps_legacy_loss_bwd (reduce)");
     return CMPS_OK;
 }
 

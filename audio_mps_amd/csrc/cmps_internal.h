@@ -25,7 +25,7 @@ namespace cmps {
 // ---------------------------------------------------------------------------------------------
 struct Layout {
     int D, DP, B, T, N, flags;
-    size_t off_R, off_RT, off_Q, off_psi0, off_freqs, off_ttab, off_dtk, off_rho, off_rfix,
+    size_t off_R, off_RT, off_Q, off_QT, off_psi0, off_freqs, off_ttab, off_dtk, off_rho, off_rfix,
         off_stash, off_hst, off_scal, off_slabs, off_sums, total;
     size_t slab_floats;  // 4*DP*DP + 3*DP + 2
 };
@@ -44,6 +44,7 @@ inline Layout make_layout(int D, int B, int T, int flags) {
     L.off_R = o;     o = align256(o + DP * DP * sizeof(float2));
     L.off_RT = o;    o = align256(o + DP * DP * sizeof(float2));
     L.off_Q = o;     o = align256(o + DP * DP * sizeof(float2));
+    L.off_QT = o;    o = align256(o + DP * DP * sizeof(float2));
     L.off_psi0 = o;  o = align256(o + DP * sizeof(float2));
     L.off_freqs = o; o = align256(o + DP * sizeof(float));
     L.off_ttab = o;  o = align256(o + (N + 1) * sizeof(float));
@@ -75,7 +76,8 @@ struct Dev {
     int D, DP, B, T, N;
     const float2* R;     // [DP][DP] row-major
     const float2* RT;    // [DP][DP], RT[j][i] = R[i][j]
-    const float2* Q;     // [DP][DP] row-major, Hermitian
+    const float2* Q;     // [DP][DP] row-major, Hermitian (legacy mode: general complex)
+    const float2* QT;    // [DP][DP] transpose of Q (legacy mode only)
     const float2* psi0;  // [DP]
     const float* freqs;  // [DP]
     const float* ttab;   // [N+1]
@@ -107,6 +109,12 @@ hipError_t launch_reduce_finalize(const Dev& P, const float* loss, float* grad_o
 hipError_t launch_update_ancilla(const Dev& P, const float* psi_in, const float* signal, float t,
                                  int B, float* psi_out, hipStream_t s);
 hipError_t launch_states(const Dev& P, int B, float* psi_out, hipStream_t s);
+hipError_t launch_reduce_only(const Dev& P, hipStream_t s);
+hipError_t launch_pack_legacy(const Dev& P, const float* Rr, const float* Qre, const float* Qim, float2* R,
+                              float2* RT, float2* Q, float2* QT, hipStream_t s);
+hipError_t launch_fwd_legacy(const Dev& P, const float* audio, float* loss, bool save, hipStream_t s);
+hipError_t launch_bwd_legacy(const Dev& P, const float* audio, hipStream_t s);
+hipError_t launch_finalize_legacy(const Dev& P, const float* loss, float* grad_out, hipStream_t s);
 hipError_t launch_sample_wave(const Dev& P, const float* noise, int n, int length, float* out, hipStream_t s);
 hipError_t launch_sample_block(const Dev& P, const float* noise, int n, int length, float* out, hipStream_t s);
 

@@ -324,14 +324,111 @@ class RhoCMPS(CMPS):
         raise NotImplementedError("RhoCMPS (model.py:55-203) is a 'next' row (SURVEY.md 8f), not built yet")
 
 
+class LegacyAudioMPS:
+    """The legacy ``AudioMPS`` arithmetic (reconstructed from logging/graph.pbtxt): real
+    variables H, R [D,D] (glorot-uniform), H_s = tril(H) + tril(H)^T, psi_0 = e_0,
+    loss = mean_b sum_k (x_k - 2 Re<psi|R|psi>)^2 / 2 evaluated BEFORE the update,
+    psi' = psi + dt (-i H_s - R^T R / 2) psi + dt x R psi, normalised.  Trained with Adam(1e-3) on the bare loss
+    (training_estimators.py:64-68)."""
+
+    VARIABLE_NAMES = ("H", "R")
+
+    def __init__(self, bond_d, dt, batch_size=8, data_iterator=None, seed: int = 0, backend=None):
+        self.bond_d = int(bond_d)
+        self.delta_t = float(dt)
+        self.batch_size = batch_size
+        self.data_iterator = data_iterator
+        rng = np.random.default_rng(seed)
+        lim = math.sqrt(6.0 / (2 * self.bond_d))            # glorot_uniform, graph.pbtxt:9076-9114
+        self.variables: Dict[str, np.ndarray] = {
+            "H": rng.uniform(-lim, lim, (self.bond_d, self.bond_d)).astype(np.float32),
+            "R": rng.uniform(-lim, lim, (self.bond_d, self.bond_d)).astype(np.float32)}
+        self._backend = backend
+
+    def _get_backend(self):
+        if self._backend is None:
+            from .scan import HipScan
+            self._backend = HipScan(self.bond_d)
+        return self._backend
+
+    @property
+    def H_s(self) -> np.ndarray:
+        L = np.tril(self.variables["H"])
+        return (L + L.T).astype(np.float32)                  # graph.pbtxt:9442-9605
+
+    @property
+    def Q(self) -> np.ndarray:
+        R = self.variables["R"]
+        RtR = (R.T @ R).astype(np.float32)                   # MatMul transpose_a, :13041
+        return ((np.complex64(-1j) * self.H_s.astype(np.complex64) - (RtR / np.float32(2)).astype(np.complex64))
+                * np.complex64(np.float32(self.delta_t))).astype(np.complex64)
+
+    def _audio(self, data):
+        import torch
+        data = self.data_iterator if data is None else data
+        if callable(data):
+            data = data()
+        be = self._get_backend()
+        t = data if isinstance(data, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32))
+        return t.to(be.device, dtype=torch.float32).contiguous()
+
+    def loss_per_clip(self, data=None) -> np.ndarray:
+        audio = self._audio(data)
+        be = self._get_backend()
+        be.legacy_set_params(self.variables["R"], self.Q, self.delta_t, audio.shape[0], audio.shape[1], train=False)
+        return be.legacy_forward(audio).detach().cpu().numpy()
+
+    @property
+    def loss(self) -> np.float32:
+        return np.float32(np.mean(self.loss_per_clip(), dtype=np.float32))
+
+    def grad_sums(self, data=None):
+        audio = self._audio(data)
+        be = self._get_backend()
+        be.legacy_set_params(self.variables["R"], self.Q, self.delta_t, audio.shape[0], audio.shape[1], train=True)
+        be.legacy_forward(audio, save_for_bwd=True)
+        return be.legacy_backward(), audio.shape[0]
+
+    def chain_rule(self, flat_sums, global_batch: int, with_reg: bool = False):
+        """(dQ, dR_direct) sums -> gradients w.r.t. H and R  (adjoint of Q = dt (-i H_s - R^T R / 2), H_s = L + L^T)."""
+        D = self.bond_d
+        g = np.asarray(flat_sums, dtype=np.float64) / float(global_batch)
+        DD = D * D
+        Qbar = (g[:DD] + 1j * g[DD:2 * DD]).reshape(D, D)
+        Rdir = g[2 * DD:3 * DD].reshape(D, D)
+        loss = g[3 * DD]
+        dt = float(np.float32(self.delta_t))
+        R = self.variables["R"].astype(np.float64)
+        Hs_bar = -dt * Qbar.imag
+        M_bar = -(dt / 2.0) * Qbar.real
+        gR = Rdir + R @ (M_bar + M_bar.T)
+        gH = np.tril(Hs_bar + Hs_bar.T)
+        return np.float32(loss), {"H": gH.astype(np.float32), "R": gR.astype(np.float32)}
+
+    def loss_and_grads(self, data=None, with_reg: bool = False):
+        flat, B = self.grad_sums(data)
+        return self.chain_rule(flat.detach().cpu().numpy(), B)
+
+
 class AudioMPS(PsiCMPS):
     """Legacy surface: ``AudioMPS(bond_d, dt, batch_size, data_iterator=..., mixed=...)``
     (training_estimators.py:43-45; ``AudioMPS(bond_d, delta_t=..., data_iterator=...)`` in
     notebooks/testing-AudioMPS.ipynb:268).  The class body no longer exists in the reference's model.py;
     PsiCMPS is its successor, so this wraps PsiCMPS with train.py's remaining hyper-parameters."""
 
+    def __new__(cls, *args, arithmetic: str = "psi", **kwargs):
+        # arithmetic="legacy": the model this surface originally named (LegacyAudioMPS, SURVEY Appendix A)
+        if arithmetic == "legacy":
+            kwargs.pop("mixed", None)
+            dt = kwargs.pop("delta_t", None)
+            if dt is not None and len(args) < 2:
+                kwargs["dt"] = dt
+            kwargs.pop("hparams", None)
+            return LegacyAudioMPS(*args, **kwargs)
+        return super().__new__(cls)
+
     def __init__(self, bond_d, dt=None, batch_size=8, data_iterator=None, mixed=False, delta_t=None,
-                 hparams: Optional[HParams] = None, **kwargs):
+                 hparams: Optional[HParams] = None, arithmetic: str = "psi", **kwargs):
         if mixed:
             raise NotImplementedError("AudioMPS(mixed=True) maps to RhoCMPS, a 'next' row (SURVEY.md 8f)")
         if dt is None:

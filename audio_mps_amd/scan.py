@@ -201,3 +201,38 @@ class HipScan:
         _capi.check(self._h, self._lib.cmps_psi_sample(self._h, d_noise.data_ptr(), n, length, d_out.data_ptr(),
                                                        self._stream()))
         return d_out.cpu().numpy()
+
+    # ------------------------------------------------------------------
+    # legacy AudioMPS arithmetic
+    # ------------------------------------------------------------------
+    def legacy_set_params(self, R: np.ndarray, Q: np.ndarray, delta_t: float, B: int, T: int, train: bool = True):
+        D = self.D
+        DD = D * D
+        buf = torch.from_numpy(np.concatenate([np.asarray(R, dtype=np.float32).ravel(),
+                                               np.asarray(Q).real.astype(np.float32).ravel(),
+                                               np.asarray(Q).imag.astype(np.float32).ravel()])).to(self.device)
+        self._legacy_buf = buf
+        ws_ptr, ws_bytes = self._ensure_ws(B, T, train)
+        base = buf.data_ptr()
+        _capi.check(self._h, self._lib.cmps_legacy_set_params(
+            self._h, base, base + DD * 4, base + 2 * DD * 4, float(delta_t), int(T), int(B),
+            _capi.CMPS_WS_TRAIN if train else _capi.CMPS_WS_FWD_ONLY, ws_ptr, ws_bytes, self._stream()))
+        self._B, self._T, self._train = B, T, train
+
+    def legacy_forward(self, audio: torch.Tensor, save_for_bwd: bool = False) -> torch.Tensor:
+        B, T = self._check_audio(audio)
+        if self._loss is None or self._loss.numel() != B:
+            self._loss = torch.empty(B, dtype=torch.float32, device=self.device)
+        _capi.check(self._h, self._lib.cmps_legacy_loss_fwd(
+            self._h, audio.data_ptr(), B, T, self._loss.data_ptr(), 1 if save_for_bwd else 0, self._stream()))
+        self._audio = audio
+        return self._loss
+
+    def legacy_backward(self) -> torch.Tensor:
+        audio = self._audio
+        B, T = audio.shape
+        if getattr(self, "_legacy_grad", None) is None:
+            self._legacy_grad = torch.empty(3 * self.D * self.D + 1, dtype=torch.float32, device=self.device)
+        _capi.check(self._h, self._lib.cmps_legacy_loss_bwd(
+            self._h, audio.data_ptr(), B, T, self._legacy_grad.data_ptr(), self._stream()))
+        return self._legacy_grad

@@ -125,6 +125,21 @@ int cmps_psi_states(cmps_handle_t h, int B, int T, float* psi_out_dev, void* str
  */
 int cmps_psi_sample(cmps_handle_t h, const float* noise_dev, int n, int length, float* out_dev, void* stream);
 
+/*
+ * Legacy `AudioMPS` arithmetic (the model training_estimators.py:43-45 was written for; its class body is gone from
+ * model.py, its training graph survives in logging/graph.pbtxt: psi_0 = e_0, loss += (x - 2 Re<psi|R|psi>)^2 / 2 before
+ * the update, psi' = psi + Q psi + dt x R psi, Q = dt (-i H_s - R^T R / 2), graph.pbtxt:10585-14847).
+ * R_dev [D*D] real row-major; Q_re_dev, Q_im_dev [D*D] (Q is built by the caller from H and R).
+ * cmps_legacy_loss_fwd / _bwd mirror cmps_psi_loss_fwd / _bwd; grad_dev [3*D*D + 1] receives sums over clips of
+ *   dQ_re [D*D], dQ_im [D*D], dR (the direct real-R part) [D*D], sum_b loss_b.
+ */
+int cmps_legacy_set_params(cmps_handle_t h, const float* R_dev, const float* Q_re_dev, const float* Q_im_dev,
+                           double delta_t, int T, int B_max, int flags, void* workspace_dev, size_t workspace_bytes,
+                           void* stream);
+int cmps_legacy_loss_fwd(cmps_handle_t h, const float* audio_dev, int B, int T, float* loss_dev, int save_for_bwd,
+                         void* stream);
+int cmps_legacy_loss_bwd(cmps_handle_t h, const float* audio_dev, int B, int T, float* grad_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

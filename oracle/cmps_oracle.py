@@ -475,3 +475,98 @@ def damped_sine(batch, input_length, delta_t, seed=0):
     wave = (np.float32(0.5) * (np.sign(times) + np.float32(1))
             * np.sin(two_pi_f * times) * np.exp(-times / np.float32(decay_time)))
     return wave.astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------------
+# next row: the legacy AudioMPS arithmetic, reconstructed in SURVEY Appendix A from the
+# serialized training graph logging/graph.pbtxt (the class body no longer exists in model.py).
+#   variables H, R: real float32 [D,D], glorot-uniform                          graph.pbtxt:9032-9303, 9632-9903
+#   H_s = band_part(H,-1,0) + band_part(H,-1,0)^T                               :9442-9605
+#   psi_0 = one_hot(0, D) as complex64, per clip                                :10585-10742
+#   step:  e = 2 Re(conj(psi) . R_c psi)   on the normalised pre-update psi      :11857-12661
+#          loss += (x - e)^2 / 2                                                 :12685-12819
+#          Q = dt (-i H_s - R^T R / 2);  psi' = psi + Q psi + dt x (R psi)       :12982-14323
+#          psi = psi' rsqrt(max(sum |psi'|^2, 1e-12))                            :14350-14594
+#   result mean_b(loss)                                                          :14811-14847
+# --------------------------------------------------------------------------------------------
+def legacy_init(D, seed=0):
+    """H, R glorot-uniform (limit sqrt(6 / (2 D)))."""
+    rng = np.random.default_rng(seed)
+    lim = math.sqrt(6.0 / (2 * D))
+    return (rng.uniform(-lim, lim, (D, D)).astype(np.float32), rng.uniform(-lim, lim, (D, D)).astype(np.float32))
+
+
+def legacy_Q(H, R, dt, dtype="f32"):
+    real, cplx = _dt(dtype)
+    H = np.asarray(H, dtype=real)
+    R = np.asarray(R, dtype=real)
+    L = np.tril(H)
+    Hs = (L + L.T).astype(real)
+    RtR = (R.T @ R).astype(real)
+    Q = (cplx(-1j) * Hs.astype(cplx) - (RtR / real(2)).astype(cplx)) * cplx(real(dt))
+    return Q.astype(cplx), Hs
+
+
+def legacy_loss_and_grads(H, R, dt, data, dtype="f32"):
+    """Returns dict(loss, per_clip, gH, gR, Qbar, Rcbar): mean_b loss and its gradients (reverse-mode adjoint)."""
+    real, cplx = _dt(dtype)
+    data = np.asarray(data, dtype=real)
+    B, T = data.shape
+    N = T - 1
+    H = np.asarray(H, dtype=real)
+    R = np.asarray(R, dtype=real)
+    D = R.shape[0]
+    Q, _ = legacy_Q(H, R, dt, dtype)
+    Rc = R.astype(cplx)
+    incs = (data[:, 1:] - data[:, :-1]).astype(real)
+    psi = np.zeros((B, D), dtype=cplx)
+    psi[:, 0] = 1
+    loss = np.zeros(B, dtype=real)
+    tape = np.empty((N, B, D), dtype=cplx)
+    dtr = real(dt)
+    eps = real(1e-12)
+    for k in range(N):
+        tape[k] = psi
+        x = incs[:, k]
+        v = (psi @ Rc.T).astype(cplx)
+        e = (real(2) * np.sum(np.conj(psi) * v, axis=1).real).astype(real)
+        loss = (loss + np.square(x - e) / real(2)).astype(real)
+        y = (psi + psi @ Q.T + (dtr * x)[:, None].astype(cplx) * v).astype(cplx)
+        ss = np.sum(np.square(np.abs(y).astype(real)), axis=1, keepdims=True, dtype=real)
+        psi = (y * (real(1) / np.sqrt(np.maximum(ss, eps))).astype(cplx)).astype(cplx)
+    g = np.zeros((B, D), dtype=cplx)
+    Qbar = np.zeros((D, D), dtype=cplx)
+    Rcbar = np.zeros((D, D), dtype=cplx)
+    lbar = real(1) / real(B)
+    for k in range(N - 1, -1, -1):
+        p = tape[k]
+        x = incs[:, k]
+        v = (p @ Rc.T).astype(cplx)
+        e = (real(2) * np.sum(np.conj(p) * v, axis=1).real).astype(real)
+        c = (dtr * x).astype(real)
+        y = (p + p @ Q.T + c[:, None].astype(cplx) * v).astype(cplx)
+        ss = np.sum(np.square(np.abs(y).astype(real)), axis=1, keepdims=True, dtype=real)
+        m = np.maximum(ss, eps)
+        inv = (real(1) / np.sqrt(m)).astype(real)
+        ybar = g * inv.astype(cplx)
+        inv_bar = np.sum((np.conj(g) * y).real, axis=1, keepdims=True).astype(real)
+        ss_bar = np.where(ss > eps, inv_bar * (real(-0.5) * inv / m), real(0)).astype(real)
+        ybar = ybar + (real(2) * ss_bar).astype(cplx) * y
+        # y = p + p Q^T + c v
+        pbar = ybar + ybar @ np.conj(Q)
+        Qbar = Qbar + (np.conj(p.T) @ ybar).T
+        vbar = ybar * c[:, None].astype(cplx)
+        # loss term: (x - e)^2 / 2, e = 2 Re(conj(p) . v)
+        e_bar = (lbar * (e - x)).astype(real)
+        pbar = pbar + (real(2) * e_bar)[:, None].astype(cplx) * v          # d/dconj(p) side
+        vbar = vbar + (real(2) * e_bar)[:, None].astype(cplx) * p
+        # v = p Rc^T
+        pbar = pbar + vbar @ np.conj(Rc)
+        Rcbar = Rcbar + (np.conj(p.T) @ vbar).T
+        g = pbar.astype(cplx)
+    # Q = dt (-i Hs - R^T R / 2)
+    Hs_bar = (-dtr * Qbar.imag).astype(real)
+    M_bar = (-(dtr / real(2)) * Qbar.real).astype(real)
+    gR = (Rcbar.real + R @ (M_bar + M_bar.T)).astype(real)
+    gH = np.tril(Hs_bar + Hs_bar.T).astype(real)
+    return {"loss": real(np.mean(loss, dtype=real)), "per_clip": loss, "gH": gH, "gR": gR, "Qbar": Qbar, "Rcbar": Rcbar}

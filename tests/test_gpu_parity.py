@@ -331,3 +331,22 @@ def test_more_clips_than_simds():
     g, gr = unpack_grad(m.grad_sums()[0].cpu().numpy(), 32), C.unpack_grad(ref["grad"], 32)
     for k in ("Rbar", "fbar", "psi0bar", "Abar"):
         assert rel_inf(g[k], gr[k]) <= GRAD_RTOL, k
+
+
+# ---------------------------------------------------------------------------------------------------
+# next row: the legacy AudioMPS arithmetic
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("D,T,B,dt", [(5, 200, 8, 0.01), (10, 300, 4, 0.001), (32, 150, 3, 0.01), (40, 60, 2, 0.01)])
+def test_legacy_audiomps_matches_oracle(D, T, B, dt):
+    from audio_mps_amd import AudioMPS, LegacyAudioMPS
+    audio = make_audio(B, T, dt, D, noise=0.05)
+    m = AudioMPS(D, dt, B, data_iterator=audio, arithmetic="legacy", seed=D)
+    assert isinstance(m, LegacyAudioMPS)
+    ref = O.legacy_loss_and_grads(m.variables["H"], m.variables["R"], dt, audio, "f32")
+    per = m.loss_per_clip()
+    assert np.max(np.abs(per - ref["per_clip"]) / np.maximum(np.abs(ref["per_clip"]), 1.0)) <= LOSS_RTOL
+    loss, grads = m.loss_and_grads()
+    assert abs(float(loss) - float(ref["loss"])) <= LOSS_RTOL * max(1.0, abs(float(ref["loss"])))
+    assert rel_inf(grads["R"], ref["gR"]) <= GRAD_RTOL
+    assert rel_inf(grads["H"], ref["gH"]) <= GRAD_RTOL
+    assert np.allclose(np.triu(grads["H"], 1), 0)                  # only the lower triangle of H is used

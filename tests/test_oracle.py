@@ -138,3 +138,21 @@ def test_sampling_shape_and_twin():
     np.testing.assert_allclose(np.linalg.norm(states, axis=-1), 1.0, rtol=1e-5)
     w64 = O.psi_sample(hp, var.astype(np.float64), noise, "f64")
     assert np.max(np.abs(w - w64)) < 1e-5
+
+
+def test_legacy_audiomps_gradients_match_finite_differences():
+    D, dt = 3, 0.01
+    H, R = O.legacy_init(D, 1)
+    data = (O.damped_sine(2, 25, dt, seed=2) + 0.05 * np.random.default_rng(3).standard_normal((2, 25))).astype(np.float32)
+    H64, R64 = H.astype(np.float64), R.astype(np.float64)
+    out = O.legacy_loss_and_grads(H64, R64, dt, data, "f64")
+    for name in ("H", "R"):
+        for idx in np.ndindex(D, D):
+            hp_, hm_ = H64.copy(), H64.copy()
+            rp_, rm_ = R64.copy(), R64.copy()
+            (hp_ if name == "H" else rp_)[idx] += 1e-6
+            (hm_ if name == "H" else rm_)[idx] -= 1e-6
+            fd = (float(O.legacy_loss_and_grads(hp_, rp_, dt, data, "f64")["loss"])
+                  - float(O.legacy_loss_and_grads(hm_, rm_, dt, data, "f64")["loss"])) / 2e-6
+            an = out["gH" if name == "H" else "gR"][idx]
+            assert abs(fd - an) <= 1e-6 * max(1.0, abs(fd)), (name, idx, fd, an)
