@@ -28,6 +28,8 @@ SYMBOLS = (
     "cmps_get_variant", "cmps_workspace_bytes", "cmps_set_params", "cmps_psi_loss_fwd",
     "cmps_psi_loss_bwd", "cmps_psi_update_ancilla", "cmps_psi_states", "cmps_psi_sample",
     "cmps_legacy_set_params", "cmps_legacy_loss_fwd", "cmps_legacy_loss_bwd",
+    "cmps_rho_workspace_bytes", "cmps_rho_set_state", "cmps_rho_loss_fwd", "cmps_rho_loss_bwd",
+    "cmps_rho_update_ancilla", "cmps_rho_sample", "cmps_rho_states",
 )
 
 
@@ -73,6 +75,20 @@ def _declare(lib):
     lib.cmps_legacy_loss_fwd.restype = c_int
     lib.cmps_legacy_loss_bwd.argtypes = [vp, vp, c_int, c_int, vp, vp]
     lib.cmps_legacy_loss_bwd.restype = c_int
+    lib.cmps_rho_workspace_bytes.argtypes = [c_int, c_int, c_int, c_int, c_int]
+    lib.cmps_rho_workspace_bytes.restype = c_size_t
+    lib.cmps_rho_set_state.argtypes = [vp, vp, vp, c_int, c_int, c_int, c_int, vp, c_size_t, vp]
+    lib.cmps_rho_set_state.restype = c_int
+    lib.cmps_rho_loss_fwd.argtypes = [vp, vp, c_int, c_int, vp, c_int, vp]
+    lib.cmps_rho_loss_fwd.restype = c_int
+    lib.cmps_rho_loss_bwd.argtypes = [vp, vp, c_int, c_int, vp, vp]
+    lib.cmps_rho_loss_bwd.restype = c_int
+    lib.cmps_rho_update_ancilla.argtypes = [vp, vp, vp, c_float, c_int, vp, vp]
+    lib.cmps_rho_update_ancilla.restype = c_int
+    lib.cmps_rho_sample.argtypes = [vp, vp, c_int, c_int, vp, c_int, vp]
+    lib.cmps_rho_sample.restype = c_int
+    lib.cmps_rho_states.argtypes = [vp, c_int, c_int, vp, vp, vp]
+    lib.cmps_rho_states.restype = c_int
 
 
 _lib = None

@@ -26,6 +26,13 @@ struct cmps_handle_s {
     char* tt_ws = nullptr;
     int tt_N = -1;
     float tt_dt = 0.f;
+    // RhoCMPS state (cmps_rho_set_state)
+    bool rho_set = false;
+    bool rho_saved = false;       // the rho stash holds the columns of rho_saved_B x rho_saved_steps steps
+    bool rho_bwd_ok = false;      // ... written by cmps_rho_loss_fwd (not by the sampler)
+    int rho_B = 0, rho_T = 0, rho_flags = 0, rho_saved_B = 0, rho_saved_steps = 0;
+    RhoLayout RL{};
+    RhoDev W{};
     std::string err;
 };
 
@@ -144,6 +151,8 @@ int cmps_set_params(cmps_handle_t h, const float* R_re_dev, const float* R_im_de
     h->params_set = true;
     h->legacy = false;
     h->fwd_saved = false;
+    h->rho_set = false;               // the columns of rho_0 are handed over again after every parameter change
+    h->rho_saved = false;
     return CMPS_OK;
 }
 
@@ -261,6 +270,7 @@ int cmps_legacy_set_params(cmps_handle_t h, const float* R_dev, const float* Q_r
     h->params_set = true;
     h->legacy = true;
     h->fwd_saved = false;
+    h->rho_set = false;
     return CMPS_OK;
 }
 
@@ -296,6 +306,130 @@ int cmps_legacy_loss_bwd(cmps_handle_t h, const float* audio_dev, int B, int T, 
     e = launch_reduce_only(P, s);
     if (e == hipSuccess) e = launch_finalize_legacy(P, h->saved_loss, grad_dev, s);
     if (e != hipSuccess) return fail_hip(h, e, "cmps_legacy_loss_bwd (reduce)");
+    return CMPS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// RhoCMPS (model.py:55-203)
+// ---------------------------------------------------------------------------------------------------
+size_t cmps_rho_workspace_bytes(int D, int rank, int B, int T, int flags) {
+    if (D < 1 || D > 128 || rank < 1 || B < 1 || T < 2) return 0;
+    return make_rho_layout(D, rank, B, T, flags).total;
+}
+
+int cmps_rho_set_state(cmps_handle_t h, const float* phi_re_dev, const float* phi_im_dev, int rank, int T, int B_max,
+                       int flags, void* rho_workspace_dev, size_t rho_workspace_bytes, void* stream) {
+    if (!h) return CMPS_ERR_BAD_ARG;
+    if (!h->params_set || h->legacy) return fail(h, CMPS_ERR_STATE, "cmps_rho_set_state: call cmps_set_params first");
+    if (!phi_re_dev || !phi_im_dev || rank < 1 || B_max < 1 || T < 2)
+        return fail(h, CMPS_ERR_BAD_ARG, "cmps_rho_set_state: bad argument");
+    if (T > h->L.T) return fail(h, CMPS_ERR_BAD_ARG, "cmps_rho_set_state: T exceeds T of cmps_set_params (the per-step tables)");
+    const size_t rD = (size_t)rank * h->D;
+    if (rD > ((flags & CMPS_WS_TRAIN) ? 5000u : 6500u))
+        return fail(h, CMPS_ERR_UNSUPPORTED_D, "cmps_rho_set_state: rank * D too large for the LDS-resident columns");
+    if (!rho_workspace_dev) return fail(h, CMPS_ERR_WORKSPACE, "cmps_rho_set_state: null workspace");
+    if (((uintptr_t)rho_workspace_dev & 255) != 0)
+        return fail(h, CMPS_ERR_WORKSPACE, "cmps_rho_set_state: workspace must be 256-byte aligned");
+    RhoLayout RL = make_rho_layout(h->D, rank, B_max, T, flags);
+    if (rho_workspace_bytes < RL.total) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "cmps_rho_set_state: workspace has %zu bytes, needs %zu", rho_workspace_bytes, RL.total);
+        return fail(h, CMPS_ERR_WORKSPACE, buf);
+    }
+    char* ws = static_cast<char*>(rho_workspace_dev);
+    RhoDev W{};
+    W.rank = rank;
+    W.phi0 = reinterpret_cast<float2*>(ws + RL.off_phi0);
+    const bool train = (flags & CMPS_WS_TRAIN) != 0;
+    W.stash = train ? reinterpret_cast<float2*>(ws + RL.off_stash) : nullptr;
+    W.slabs = train ? reinterpret_cast<float*>(ws + RL.off_slabs) : nullptr;
+    W.sums = train ? reinterpret_cast<float*>(ws + RL.off_sums) : nullptr;
+    W.slab_floats = RL.slab_floats;
+    hipError_t e = launch_pack_phi(h->P, W, phi_re_dev, phi_im_dev, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail_hip(h, e, "cmps_rho_set_state");
+    h->RL = RL; h->W = W;
+    h->rho_B = B_max; h->rho_T = T; h->rho_flags = flags;
+    h->rho_set = true;
+    h->rho_saved = false;
+    h->rho_bwd_ok = false;
+    return CMPS_OK;
+}
+
+int cmps_rho_loss_fwd(cmps_handle_t h, const float* audio_dev, int B, int T, float* loss_dev, int save_for_bwd,
+                      void* stream) {
+    if (!h) return CMPS_ERR_BAD_ARG;
+    if (!h->params_set || h->legacy || !h->rho_set)
+        return fail(h, CMPS_ERR_STATE, "cmps_rho_loss_fwd: call cmps_set_params and cmps_rho_set_state first");
+    if (!audio_dev || !loss_dev) return fail(h, CMPS_ERR_BAD_ARG, "cmps_rho_loss_fwd: null pointer");
+    if (T != h->rho_T) return fail(h, CMPS_ERR_BAD_ARG, "cmps_rho_loss_fwd: T differs from cmps_rho_set_state");
+    if (B < 1 || B > h->rho_B) return fail(h, CMPS_ERR_BAD_ARG, "cmps_rho_loss_fwd: B outside [1, B_max]");
+    if (save_for_bwd && !(h->rho_flags & CMPS_WS_TRAIN))
+        return fail(h, CMPS_ERR_WORKSPACE, "cmps_rho_loss_fwd: save_for_bwd needs a CMPS_WS_TRAIN rho workspace");
+    Dev P = h->P;
+    P.B = B; P.T = T; P.N = T - 1;
+    hipError_t e = launch_fwd_rho(P, h->W, audio_dev, loss_dev, save_for_bwd != 0, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail_hip(h, e, "cmps_rho_loss_fwd");
+    h->rho_saved = h->rho_bwd_ok = save_for_bwd != 0;
+    h->rho_saved_B = B; h->rho_saved_steps = T - 1;
+    h->saved_audio = audio_dev; h->saved_loss = loss_dev;
+    return CMPS_OK;
+}
+
+int cmps_rho_loss_bwd(cmps_handle_t h, const float* audio_dev, int B, int T, float* grad_dev, void* stream) {
+    if (!h) return CMPS_ERR_BAD_ARG;
+    if (!h->params_set || !h->rho_set || !h->rho_saved || !h->rho_bwd_ok)
+        return fail(h, CMPS_ERR_STATE, "cmps_rho_loss_bwd: needs cmps_rho_loss_fwd(save_for_bwd=1) first");
+    if (!audio_dev || !grad_dev) return fail(h, CMPS_ERR_BAD_ARG, "cmps_rho_loss_bwd: null pointer");
+    if (B != h->rho_saved_B || T - 1 != h->rho_saved_steps || audio_dev != h->saved_audio)
+        return fail(h, CMPS_ERR_STATE, "cmps_rho_loss_bwd: audio / B / T differ from the forward call");
+    Dev P = h->P;
+    P.B = B; P.T = T; P.N = T - 1;
+    P.slabs = h->W.slabs; P.sums = h->W.sums; P.slab_floats = h->W.slab_floats;   // the reduction runs on the rho slabs
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = launch_bwd_rho(P, h->W, audio_dev, s);
+    if (e != hipSuccess) return fail_hip(h, e, "cmps_rho_loss_bwd (scan)");
+    e = launch_reduce_finalize(P, h->saved_loss, grad_dev, s);
+    if (e == hipSuccess) e = launch_finalize_rho(P, h->W, grad_dev, s);
+    if (e != hipSuccess) return fail_hip(h, e, "cmps_rho_loss_bwd (reduce)");
+    return CMPS_OK;
+}
+
+int cmps_rho_update_ancilla(cmps_handle_t h, const float* rho_in_dev, const float* signal_dev, float t, int B,
+                            float* rho_out_dev, void* stream) {
+    if (!h) return CMPS_ERR_BAD_ARG;
+    if (!h->params_set || h->legacy) return fail(h, CMPS_ERR_STATE, "cmps_rho_update_ancilla: call cmps_set_params first");
+    if (!rho_in_dev || !signal_dev || !rho_out_dev || B < 1 || rho_in_dev == rho_out_dev)
+        return fail(h, CMPS_ERR_BAD_ARG, "cmps_rho_update_ancilla: bad argument");
+    hipError_t e = launch_update_ancilla_rho(h->P, rho_in_dev, signal_dev, t, B, rho_out_dev, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail_hip(h, e, "cmps_rho_update_ancilla");
+    return CMPS_OK;
+}
+
+int cmps_rho_sample(cmps_handle_t h, const float* noise_dev, int n, int length, float* out_dev, int save_states,
+                    void* stream) {
+    if (!h) return CMPS_ERR_BAD_ARG;
+    if (!h->params_set || h->legacy || !h->rho_set)
+        return fail(h, CMPS_ERR_STATE, "cmps_rho_sample: call cmps_set_params and cmps_rho_set_state first");
+    if (!noise_dev || !out_dev || n < 1 || length < 1) return fail(h, CMPS_ERR_BAD_ARG, "cmps_rho_sample: bad argument");
+    if (length > h->L.N) return fail(h, CMPS_ERR_BAD_ARG, "cmps_rho_sample: length exceeds T - 1 of cmps_set_params");
+    if (save_states && (!(h->rho_flags & CMPS_WS_TRAIN) || (size_t)n * length > (size_t)h->rho_B * (h->rho_T - 1)))
+        return fail(h, CMPS_ERR_WORKSPACE, "cmps_rho_sample: save_states needs a CMPS_WS_TRAIN rho workspace with B_max*(T-1) >= n*length");
+    hipError_t e = launch_sample_rho(h->P, h->W, noise_dev, n, length, out_dev, save_states != 0, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail_hip(h, e, "cmps_rho_sample");
+    h->rho_saved = save_states != 0;
+    h->rho_bwd_ok = false;
+    h->rho_saved_B = n; h->rho_saved_steps = length;
+    return CMPS_OK;
+}
+
+int cmps_rho_states(cmps_handle_t h, int B, int steps, float* rho_out_dev, float* purity_out_dev, void* stream) {
+    if (!h) return CMPS_ERR_BAD_ARG;
+    if (!h->params_set || !h->rho_set || !h->rho_saved)
+        return fail(h, CMPS_ERR_STATE, "cmps_rho_states: needs cmps_rho_loss_fwd(save_for_bwd=1) or cmps_rho_sample(save_states=1) first");
+    if (B != h->rho_saved_B || steps != h->rho_saved_steps || (!rho_out_dev && !purity_out_dev))
+        return fail(h, CMPS_ERR_BAD_ARG, "cmps_rho_states: bad argument");
+    hipError_t e = launch_states_rho(h->P, h->W, B, steps, rho_out_dev, purity_out_dev, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail_hip(h, e, "cmps_rho_states");
     return CMPS_OK;
 }
 

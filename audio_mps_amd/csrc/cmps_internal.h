@@ -95,7 +95,55 @@ struct Dev {
     float c_half;        // (float)(-delta_t * sigma^2) / 2   (model.py:312)
 };
 
+// ---------------------------------------------------------------------------------------------
+// RhoCMPS (cmps_rho.hip): its own caller-provided workspace next to the main one.
+//   phi0  : [rank][DP] float2         columns of rho_0 = sum_a phi_a phi_a^dagger (trace 1)
+//   stash : [B][N][rank][DP] float2   un-normalised rotating-frame columns y_a of every step (TRAIN / sampling states)
+//   slabs : [B][slab] float           pure-state slab followed by the 2 rank DP cotangents of the initial columns
+//   sums  : [slab] float + [32][slab] double first-pass partials
+// ---------------------------------------------------------------------------------------------
+struct RhoLayout {
+    int rank;
+    size_t off_phi0, off_stash, off_slabs, off_sums, total, slab_floats;
+};
+
+inline RhoLayout make_rho_layout(int D, int rank, int B, int T, int flags) {
+    RhoLayout L{};
+    const size_t DP = (size_t)padded_D(D), N = (size_t)(T - 1), r = (size_t)rank;
+    L.rank = rank;
+    L.slab_floats = 4 * DP * DP + 3 * DP + 2 + 2 * r * DP;
+    size_t o = 0;
+    L.off_phi0 = o; o = align256(o + r * DP * sizeof(float2));
+    L.off_stash = L.off_slabs = L.off_sums = o;
+    if (flags & 1) {
+        L.off_stash = o; o = align256(o + (size_t)B * N * r * DP * sizeof(float2));
+        L.off_slabs = o; o = align256(o + (size_t)B * L.slab_floats * sizeof(float));
+        L.off_sums = o;  o = align256(o + (L.slab_floats + 64) * sizeof(float) + 32 * L.slab_floats * sizeof(double));
+    }
+    L.total = o;
+    return L;
+}
+
+struct RhoDev {
+    int rank;
+    const float2* phi0;  // [rank][DP]
+    float2* stash;       // [B][N][rank][DP]
+    float* slabs;        // [B][slab]
+    float* sums;         // [slab]
+    size_t slab_floats;
+};
+
 // ---- launchers (each returns the hipError_t of its launches) ----
+hipError_t launch_pack_phi(const Dev& P, const RhoDev& W, const float* re, const float* im, hipStream_t s);
+hipError_t launch_fwd_rho(const Dev& P, const RhoDev& W, const float* audio, float* loss, bool save, hipStream_t s);
+hipError_t launch_bwd_rho(const Dev& P, const RhoDev& W, const float* audio, hipStream_t s);
+hipError_t launch_finalize_rho(const Dev& P, const RhoDev& W, float* grad_out, hipStream_t s);
+hipError_t launch_states_rho(const Dev& P, const RhoDev& W, int B, int steps, float* rho_out, float* purity_out,
+                             hipStream_t s);
+hipError_t launch_update_ancilla_rho(const Dev& P, const float* rho_in, const float* signal, float t, int B,
+                                     float* rho_out, hipStream_t s);
+hipError_t launch_sample_rho(const Dev& P, const RhoDev& W, const float* noise, int n, int length, float* out,
+                             bool save, hipStream_t s);
 hipError_t launch_prep(const Dev& P, const float* R_re, const float* R_im, const float* freqs,
                        const float* psi0_re, const float* psi0_im, float dt, bool rebuild_ttab,
                        float* ttab, float* dtk, float2* R, float2* RT, float2* Q, float2* psi0,

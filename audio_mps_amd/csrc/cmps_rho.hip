@@ -1,0 +1,541 @@
+// RhoCMPS, the density-matrix scan (model.py:55-203), general D, correctness-first.
+//
+// The reference carries rho [B, D, D] and applies  rho' = U rho U^dagger,  U = 1 - (dt sigma^2/2) Rt^dagger Rt + s Rt
+// (model.py:172-187), loss += -log(1 + Re tr((Rt + Rt^dagger) rho') x / A) (:166, 189-196), rho = rho' / max(tr rho', eps)
+// (:198-203).  rho_0 = W^dagger W / tr (:127-132) has rank r = initial_rank (default D), and U rho U^dagger keeps the rank,
+// so this file never forms the D x D matrix in the scan: it carries the r columns phi_a of rho = sum_a phi_a phi_a^dagger
+// (phi_a(0) = conj(W[a, :]) / sqrt(tr W^dagger W)) through the SAME rotating-frame step as the pure-state kernels,
+//
+//     y_a = u_a + Q u_a + s R u_a,     e = sum_a y_a^dagger (R + R^dagger) y_a,     n = sum_a |y_a|^2  (= tr rho'),
+//     u_a <- rho_k * y_a / sqrt(max(n, 1e-12)),
+//
+// coupled only through the two scalars e and n: 3 r D^2 complex MACs per step instead of the 4 D^3 of the matrix form.
+// One workgroup owns one clip; thread t owns component t of every column; the columns live in LDS.
+// Reverse sweep (cotangents g_a of u_a, convention zbar = dL/dRe z + i dL/dIm z), cf. cmps_block.hip:
+//     yhb_a = conj(rho_k) g_a;  dot = sum_a Re(yhat_a^dagger yhb_a);  ybar_a = (yhb_a - yhat_a dot)/sqrt(n) + 2 ebar H y_a
+//     Rbar += 2 ebar sum_a y_a y_a^dagger + s sum_a ybar_a u_a^dagger;   Qbar += sum_a ybar_a u_a^dagger
+//     g_a  = ybar_a + Q ybar_a + s R^dagger ybar_a;   fbar += dt_k sum_a Im(g_a conj(u_a(k+1)))
+#include "cmps_internal.h"
+
+namespace cmps {
+
+template <int NT>
+__device__ __forceinline__ float rblock_sum(float v, float* red) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    constexpr int NW = NT / 64;
+    if constexpr (NW == 1) return v;
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += red[w];
+    __syncthreads();
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward: RhoCMPS._build_loss_rho (model.py:133-144)
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(NT) void k_fwd_rho(Dev P, RhoDev W, const float* __restrict__ audio,
+                                                float* __restrict__ loss_out, int save) {
+    extern __shared__ float2 sh[];
+    const int D = P.D, DP = P.DP, N = P.N, r = W.rank, rD = r * D;
+    float2* cur = sh;
+    float2* nxt = sh + rD;
+    float* red = reinterpret_cast<float*>(sh + 2 * rD);
+    const int b = blockIdx.x, t = threadIdx.x;
+    const bool act = t < D;
+    const float* xrow = audio + (size_t)b * P.T;
+    float2* st = save ? W.stash + (size_t)b * N * r * DP : nullptr;
+    if (act)
+        for (int a = 0; a < r; ++a) cur[a * D + t] = W.phi0[a * DP + t];
+    float loss = 0.f;
+    for (int k = 0; k < N; ++k) {
+        const float x = xrow[k + 1] - xrow[k];     // model.py:138
+        const float s = x / P.A;                   // :175
+        __syncthreads();
+        if (act) {
+            for (int a = 0; a < r; ++a) {
+                const float2* ua = cur + a * D;
+                float2 v = make_float2(0.f, 0.f), q = make_float2(0.f, 0.f);
+                for (int j = 0; j < D; ++j) {
+                    const float2 uj = ua[j];
+                    v = cfma(P.RT[j * DP + t], uj, v);            // (R u_a)_t
+                    q = cfma_conj_a(P.Q[j * DP + t], uj, q);      // (Q u_a)_t, Q Hermitian
+                }
+                const float2 u = ua[t];
+                const float2 y = make_float2(u.x + q.x + s * v.x, u.y + q.y + s * v.y);   // column of U rho U^dagger, :186
+                nxt[a * D + t] = y;
+                if (save) st[((size_t)k * r + a) * DP + t] = y;
+            }
+        }
+        __syncthreads();
+        float pe = 0.f, pn = 0.f;
+        if (act) {
+            for (int a = 0; a < r; ++a) {
+                const float2* ya = nxt + a * D;
+                float2 hy = make_float2(0.f, 0.f);
+                for (int j = 0; j < D; ++j) {
+                    const float2 yj = ya[j];
+                    hy = cfma(P.RT[j * DP + t], yj, hy);
+                    hy = cfma_conj_a(P.R[j * DP + t], yj, hy);   // ((R + R^dagger) y_a)_t, :193-194
+                }
+                const float2 y = ya[t];
+                pe += y.x * hy.x + y.y * hy.y;
+                pn += y.x * y.x + y.y * y.y;
+            }
+        }
+        const float e = rblock_sum<NT>(pe, red);                  // Re tr(x rho'), :195-196
+        const float n = rblock_sum<NT>(pn, red);                  // tr rho', :200
+        loss += -logf(1.0f + (e * x) / P.A);                      // :166, 155
+        const float sc = sqrtf(1.0f / fmaxf(n, 1e-12f));          // :201 (columns scale with the square root)
+        if (act) {
+            const float2 rho = P.rho[(size_t)k * DP + t];
+            for (int a = 0; a < r; ++a) nxt[a * D + t] = cmul(rho, cscale(sc, nxt[a * D + t]));
+        }
+        float2* tmp = cur; cur = nxt; nxt = tmp;
+    }
+    if (t == 0) loss_out[b] = loss;
+}
+
+// ------------------------------------------------------------------------------------------------
+// reverse sweep
+// ------------------------------------------------------------------------------------------------
+template <int NT, int EPT>
+__global__ __launch_bounds__(NT) void k_bwd_rho(Dev P, RhoDev W, const float* __restrict__ audio) {
+    extern __shared__ float2 sh[];
+    const int D = P.D, DP = P.DP, N = P.N, r = W.rank, rD = r * D;
+    float2* Y = sh;             // y_a of step k
+    float2* YB = sh + rD;       // yhb_a, then ybar_a
+    float2* U = sh + 2 * rD;    // H y_a, then u_a(k)
+    float2* G = sh + 3 * rD;    // cotangent of u_a(k+1)
+    float* red = reinterpret_cast<float*>(sh + 4 * rD);
+    const int b = blockIdx.x, t = threadIdx.x;
+    const bool act = t < D;
+    const float* xrow = audio + (size_t)b * P.T;
+    const float2* st = W.stash + (size_t)b * N * r * DP;
+    const float2 zero = make_float2(0.f, 0.f);
+    float2 Rb[EPT], Qb[EPT];
+#pragma unroll
+    for (int m = 0; m < EPT; ++m) Rb[m] = Qb[m] = zero;
+    float facc = 0.f, Abar = 0.f;
+    if (act)
+        for (int a = 0; a < r; ++a) G[a * D + t] = zero;
+
+    for (int k = N - 1; k >= 0; --k) {
+        const float x = xrow[k + 1] - xrow[k];
+        const float s = x / P.A;
+        const float2 rho = act ? P.rho[(size_t)k * DP + t] : make_float2(1.f, 0.f);
+        float pn = 0.f;
+        if (act) {
+            for (int a = 0; a < r; ++a) {
+                const float2 y = st[((size_t)k * r + a) * DP + t];
+                Y[a * D + t] = y;
+                pn += y.x * y.x + y.y * y.y;
+            }
+        }
+        const float nraw = rblock_sum<NT>(pn, red);
+        const float inv = sqrtf(1.0f / fmaxf(nraw, 1e-12f));
+        float pd = 0.f;
+        if (act) {
+            const float dk = P.dtk[k];
+            for (int a = 0; a < r; ++a) {
+                const float2 yh = cscale(inv, Y[a * D + t]);
+                const float2 un = cmul(rho, yh);
+                const float2 g = G[a * D + t];
+                facc += dk * (g.y * un.x - g.x * un.y);
+                const float2 yhb = cmul_conj_a(rho, g);
+                pd += yh.x * yhb.x + yh.y * yhb.y;
+                YB[a * D + t] = yhb;
+            }
+        }
+        const float dot = rblock_sum<NT>(pd, red);
+        __syncthreads();
+        float pe = 0.f;
+        if (act) {
+            for (int a = 0; a < r; ++a) {
+                const float2* ya = Y + a * D;
+                float2 hy = zero;
+                for (int j = 0; j < D; ++j) {
+                    const float2 yj = ya[j];
+                    hy = cfma(P.RT[j * DP + t], yj, hy);
+                    hy = cfma_conj_a(P.R[j * DP + t], yj, hy);
+                }
+                const float2 y = ya[t];
+                pe += y.x * hy.x + y.y * hy.y;
+                U[a * D + t] = hy;
+            }
+        }
+        const float e = rblock_sum<NT>(pe, red);
+        const float ex = e * x;
+        const float z = ex / P.A;
+        const float zbar = -1.0f / (1.0f + z);
+        const float ebar = zbar * x / P.A;
+        Abar += zbar * (-ex / (P.A * P.A));
+        const float te = 2.0f * ebar;
+        float pnp = 0.f;
+        if (act) {
+            for (int a = 0; a < r; ++a) {
+                const float2 yhb = YB[a * D + t], hy = U[a * D + t];
+                const float2 yh = cscale(inv, Y[a * D + t]);
+                float2 yb;
+                if (nraw > 1e-12f)
+                    yb = make_float2((yhb.x - yh.x * dot) * inv, (yhb.y - yh.y * dot) * inv);
+                else
+                    yb = cscale(inv, yhb);
+                yb.x += te * hy.x;
+                yb.y += te * hy.y;
+                YB[a * D + t] = yb;
+                float2 up;
+                if (k > 0) {
+                    up = st[((size_t)(k - 1) * r + a) * DP + t];
+                    pnp += up.x * up.x + up.y * up.y;
+                } else {
+                    up = W.phi0[a * DP + t];
+                }
+                U[a * D + t] = up;
+            }
+        }
+        if (k > 0) {
+            const float nprev = rblock_sum<NT>(pnp, red);
+            const float invp = sqrtf(1.0f / fmaxf(nprev, 1e-12f));
+            if (act) {
+                const float2 rhop = P.rho[(size_t)(k - 1) * DP + t];
+                for (int a = 0; a < r; ++a) U[a * D + t] = cmul(rhop, cscale(invp, U[a * D + t]));
+            }
+        }
+        __syncthreads();
+        float ps = 0.f;
+        if (act) {
+            for (int a = 0; a < r; ++a) {
+                const float2* yb = YB + a * D;
+                float2 bq = zero, d = zero;
+                for (int j = 0; j < D; ++j) {
+                    const float2 yj = yb[j];
+                    bq = cfma_conj_a(P.Q[j * DP + t], yj, bq);   // (Q ybar_a)_t
+                    d = cfma_conj_a(P.R[j * DP + t], yj, d);     // (R^dagger ybar_a)_t
+                }
+                const float2 uk = U[a * D + t], ybt = yb[t];
+                ps += d.x * uk.x + d.y * uk.y;
+                G[a * D + t] = make_float2(ybt.x + bq.x + s * d.x, ybt.y + bq.y + s * d.y);
+            }
+        }
+        const float sbar = rblock_sum<NT>(ps, red);
+        Abar += sbar * (-x / (P.A * P.A));
+#pragma unroll
+        for (int m = 0; m < EPT; ++m) {
+            const int idx = t + m * NT;
+            if (idx < D * D) {
+                const int i = idx / D, j = idx % D;
+                float2 o1 = zero, o2 = zero;
+                for (int a = 0; a < r; ++a) {
+                    const float2 yi = Y[a * D + i], yj = Y[a * D + j], ybi = YB[a * D + i], uj = U[a * D + j];
+                    o1.x += yi.x * yj.x + yi.y * yj.y;
+                    o1.y += yi.y * yj.x - yi.x * yj.y;
+                    o2.x += ybi.x * uj.x + ybi.y * uj.y;
+                    o2.y += ybi.y * uj.x - ybi.x * uj.y;
+                }
+                Rb[m].x += te * o1.x + s * o2.x;
+                Rb[m].y += te * o1.y + s * o2.y;
+                Qb[m].x += o2.x;
+                Qb[m].y += o2.y;
+            }
+        }
+        __syncthreads();
+    }
+    // slab: the pure-state layout (psi_0 slots zero) followed by the cotangents of the r initial columns
+    float* slab = W.slabs + (size_t)b * W.slab_floats;
+    const int DD = DP * DP;
+    for (int idx = t; idx < (int)W.slab_floats; idx += NT) slab[idx] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < EPT; ++m) {
+        const int idx = t + m * NT;
+        if (idx < D * D) {
+            const int i = idx / D, j = idx % D, o = i * DP + j;
+            slab[o] = Rb[m].x;
+            slab[DD + o] = Rb[m].y;
+            slab[2 * DD + o] = Qb[m].x;
+            slab[3 * DD + o] = Qb[m].y;
+        }
+    }
+    if (act) {
+        slab[4 * DD + t] = facc;
+        float* tail = slab + 4 * DD + 3 * DP + 2;
+        for (int a = 0; a < r; ++a) {
+            const float2 g = G[a * D + t];
+            tail[a * DP + t] = g.x;
+            tail[(r + a) * DP + t] = g.y;
+        }
+    }
+    if (t == 0) slab[4 * DD + 3 * DP] = Abar;
+}
+
+// tail of the gradient buffer: d phi_re [r][D] | d phi_im [r][D]
+__global__ void k_finalize_rho(Dev P, RhoDev W, float* __restrict__ grad_out) {
+    const int D = P.D, DP = P.DP, r = W.rank;
+    const float* tail = W.sums + 4 * DP * DP + 3 * DP + 2;
+    float* out = grad_out + 2 * D * D + 3 * D + 2;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+    for (int idx = tid; idx < 2 * r * D; idx += nth) {
+        const int a = idx / D, d = idx % D;      // a in [0, 2r): re rows then im rows
+        out[idx] = tail[a * DP + d];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// rho_evolve_with_data / rho_evolve_with_sampling / purity (model.py:76-107): lab-frame rho after every
+// step from the stashed columns,  rho_k = phases_k (sum_a y_a y_a^dagger) phases_k^dagger / max(n, eps)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_states_rho(Dev P, RhoDev W, int steps, float* __restrict__ rho_out,
+                                                    float* __restrict__ purity_out) {
+    extern __shared__ float2 sh[];
+    const int D = P.D, DP = P.DP, r = W.rank;
+    float2* Y = sh;                                         // [r][D]
+    float2* ph = sh + r * D;                                // [D]
+    float* red = reinterpret_cast<float*>(sh + r * D + D);
+    const size_t row = blockIdx.x;                          // b * steps + k
+    const int k = (int)(row % steps), t = threadIdx.x;
+    const float2* st = W.stash + row * r * DP;
+    float pn = 0.f;
+    for (int idx = t; idx < r * D; idx += 256) {
+        const float2 y = st[(idx / D) * DP + idx % D];
+        Y[idx] = y;
+        pn += y.x * y.x + y.y * y.y;
+    }
+    if (t < D) {
+        const float th = __fmul_rn(P.freqs[t], P.ttab[k]);
+        float sn, cs;
+        sincosf(th, &sn, &cs);
+        ph[t] = make_float2(cs, sn);
+    }
+    const float n = rblock_sum<256>(pn, red);
+    const float inv = 1.0f / fmaxf(n, 1e-12f);
+    __syncthreads();
+    float pp = 0.f;
+    for (int idx = t; idx < D * D; idx += 256) {
+        const int i = idx / D, j = idx % D;
+        float2 o = make_float2(0.f, 0.f);
+        for (int a = 0; a < r; ++a) {
+            const float2 yi = Y[a * D + i], yj = Y[a * D + j];
+            o.x += yi.x * yj.x + yi.y * yj.y;
+            o.y += yi.y * yj.x - yi.x * yj.y;
+        }
+        o = cscale(inv, o);
+        pp += o.x * o.x + o.y * o.y;                        // tr rho^2 = sum |rho_ij|^2 (Hermitian), model.py:96
+        if (rho_out) {
+            const float2 w = cmul(cmul(ph[i], o), make_float2(ph[j].x, -ph[j].y));
+            rho_out[(row * D * D + idx) * 2] = w.x;
+            rho_out[(row * D * D + idx) * 2 + 1] = w.y;
+        }
+    }
+    const float pur = rblock_sum<256>(pp, red);
+    if (purity_out && t == 0) purity_out[row] = pur;
+}
+
+// ------------------------------------------------------------------------------------------------
+// RhoCMPS._update_ancilla_rho (model.py:172-187) for a general rho [B][D][D]: one workgroup per (clip, row i)
+//   U[i][j] = delta_ij + phases_i (Q[i][j] + s R[i][j]) conj(phases_j);   out = (U rho) U^dagger
+// ------------------------------------------------------------------------------------------------
+__global__ void k_update_ancilla_rho(Dev P, const float* __restrict__ rho_in, const float* __restrict__ signal,
+                                     float tt, float* __restrict__ rho_out) {
+    extern __shared__ float2 sh[];
+    const int D = P.D, DP = P.DP;
+    float2* ph = sh;            // [D]
+    float2* Ui = sh + D;        // row i of U
+    float2* Ti = sh + 2 * D;    // row i of U rho
+    const int b = blockIdx.x / D, i = blockIdx.x % D, t = threadIdx.x;
+    const bool act = t < D;
+    const float s = signal[b] / P.A;
+    if (act) {
+        const float th = __fmul_rn(P.freqs[t], tt);
+        float sn, cs;
+        sincosf(th, &sn, &cs);
+        ph[t] = make_float2(cs, sn);
+    }
+    __syncthreads();
+    auto Uel = [&](int a, int c) {
+        const float2 q = P.Q[c * DP + a];           // Q[a][c] = conj(Q[c][a])
+        const float2 rr = P.RT[c * DP + a];         // R[a][c]
+        const float2 m = make_float2(q.x + s * rr.x, -q.y + s * rr.y);
+        float2 u = cmul(cmul(ph[a], m), make_float2(ph[c].x, -ph[c].y));
+        if (a == c) u.x += 1.0f;
+        return u;
+    };
+    if (act) Ui[t] = Uel(i, t);
+    __syncthreads();
+    const float* rin = rho_in + (size_t)b * D * D * 2;
+    if (act) {
+        float2 acc = make_float2(0.f, 0.f);
+        for (int j = 0; j < D; ++j)
+            acc = cfma(Ui[j], make_float2(rin[(j * D + t) * 2], rin[(j * D + t) * 2 + 1]), acc);
+        Ti[t] = acc;
+    }
+    __syncthreads();
+    if (act) {
+        float2 acc = make_float2(0.f, 0.f);        // out[i][l=t] = sum_k T[i][k] conj(U[l][k])
+        for (int k = 0; k < D; ++k) {
+            const float2 u = Uel(t, k);
+            acc = cfma(Ti[k], make_float2(u.x, -u.y), acc);
+        }
+        float* o = rho_out + ((size_t)b * D * D + (size_t)i * D + t) * 2;
+        o[0] = acc.x;
+        o[1] = acc.y;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// RhoCMPS.sample / rho_evolve_with_sampling / purity (model.py:86-116, 160-167)
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(NT) void k_sample_rho(Dev P, RhoDev W, const float* __restrict__ noise, int length,
+                                                   float* __restrict__ out, int save) {
+    extern __shared__ float2 sh[];
+    const int D = P.D, DP = P.DP, r = W.rank, rD = r * D;
+    float2* S = sh;             // u_a
+    float2* Vb = sh + rD;       // R u_a
+    float2* Wb = sh + 2 * rD;   // u_a + Q u_a
+    float* red = reinterpret_cast<float*>(sh + 3 * rD);
+    const int b = blockIdx.x, t = threadIdx.x;
+    const bool act = t < D;
+    float2* st = save ? W.stash + (size_t)b * length * r * DP : nullptr;
+    if (act)
+        for (int a = 0; a < r; ++a) S[a * D + t] = W.phi0[a * DP + t];
+    float samp = 0.f;
+    for (int k = 0; k < length; ++k) {
+        __syncthreads();
+        float pe = 0.f;
+        if (act) {
+            for (int a = 0; a < r; ++a) {
+                const float2* ua = S + a * D;
+                float2 v = make_float2(0.f, 0.f), q = make_float2(0.f, 0.f);
+                for (int j = 0; j < D; ++j) {
+                    const float2 uj = ua[j];
+                    v = cfma(P.RT[j * DP + t], uj, v);
+                    q = cfma_conj_a(P.Q[j * DP + t], uj, q);
+                }
+                const float2 u = ua[t];
+                pe += u.x * v.x + u.y * v.y;
+                Vb[a * D + t] = v;
+                Wb[a * D + t] = cadd(u, q);
+            }
+        }
+        const float e = 2.0f * rblock_sum<NT>(pe, red);                            // Re tr((Rt + Rt^dagger) rho), :189-196
+        const float inc = e * P.dt + noise[(size_t)b * length + k];                // :162
+        samp += inc;                                                               // :163
+        const float s = inc / P.A;                                                 // :164, 175
+        float pn = 0.f;
+        if (act) {
+            for (int a = 0; a < r; ++a) {
+                const float2 w = Wb[a * D + t], v = Vb[a * D + t];
+                const float2 y = make_float2(w.x + s * v.x, w.y + s * v.y);
+                Wb[a * D + t] = y;
+                pn += y.x * y.x + y.y * y.y;
+                if (save) st[((size_t)k * r + a) * DP + t] = y;
+            }
+        }
+        const float n = rblock_sum<NT>(pn, red);
+        const float sc = sqrtf(1.0f / fmaxf(n, 1e-12f));                           // :165
+        __syncthreads();
+        if (act) {
+            const float2 rho = P.rho[(size_t)k * DP + t];
+            for (int a = 0; a < r; ++a) S[a * D + t] = cmul(rho, cscale(sc, Wb[a * D + t]));
+        }
+        if (t == 0) out[(size_t)b * length + k] = P.A * samp;                      // :116
+    }
+}
+
+// pack the r initial columns into the DP-strided table
+__global__ void k_pack_phi(int D, int DP, int r, const float* __restrict__ re, const float* __restrict__ im,
+                           float2* __restrict__ phi0) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= r * DP) return;
+    const int a = idx / DP, d = idx % DP;
+    phi0[idx] = d < D ? make_float2(re[a * D + d], im[a * D + d]) : make_float2(0.f, 0.f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+template <typename K>
+static hipError_t want_lds(K kernel, size_t shm) {
+    if (shm <= 64 * 1024) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+}
+
+hipError_t launch_pack_phi(const Dev& P, const RhoDev& W, const float* re, const float* im, hipStream_t s) {
+    const int n = W.rank * P.DP;
+    hipLaunchKernelGGL(k_pack_phi, dim3((n + 255) / 256), dim3(256), 0, s, P.D, P.DP, W.rank, re, im,
+                       const_cast<float2*>(W.phi0));
+    return hipGetLastError();
+}
+
+hipError_t launch_fwd_rho(const Dev& P, const RhoDev& W, const float* audio, float* loss, bool save, hipStream_t s) {
+    const size_t shm = (size_t)2 * W.rank * P.D * sizeof(float2) + 128;
+    hipError_t e;
+    if (P.D <= 64) {
+        if ((e = want_lds(k_fwd_rho<64>, shm)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_fwd_rho<64>, dim3(P.B), dim3(64), shm, s, P, W, audio, loss, save ? 1 : 0);
+    } else {
+        if ((e = want_lds(k_fwd_rho<128>, shm)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_fwd_rho<128>, dim3(P.B), dim3(128), shm, s, P, W, audio, loss, save ? 1 : 0);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_bwd_rho(const Dev& P, const RhoDev& W, const float* audio, hipStream_t s) {
+    const size_t shm = (size_t)4 * W.rank * P.D * sizeof(float2) + 128;
+    hipError_t e;
+    if (P.D <= 32) {
+        if ((e = want_lds(k_bwd_rho<64, 16>, shm)) != hipSuccess) return e;
+        hipLaunchKernelGGL((k_bwd_rho<64, 16>), dim3(P.B), dim3(64), shm, s, P, W, audio);
+    } else if (P.D <= 64) {
+        if ((e = want_lds(k_bwd_rho<256, 16>, shm)) != hipSuccess) return e;
+        hipLaunchKernelGGL((k_bwd_rho<256, 16>), dim3(P.B), dim3(256), shm, s, P, W, audio);
+    } else {
+        if ((e = want_lds(k_bwd_rho<1024, 16>, shm)) != hipSuccess) return e;
+        hipLaunchKernelGGL((k_bwd_rho<1024, 16>), dim3(P.B), dim3(1024), shm, s, P, W, audio);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_finalize_rho(const Dev& P, const RhoDev& W, float* grad_out, hipStream_t s) {
+    hipLaunchKernelGGL(k_finalize_rho, dim3(8), dim3(256), 0, s, P, W, grad_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_states_rho(const Dev& P, const RhoDev& W, int B, int steps, float* rho_out, float* purity_out,
+                             hipStream_t s) {
+    const size_t shm = ((size_t)W.rank * P.D + P.D) * sizeof(float2) + 128;
+    hipError_t e = want_lds(k_states_rho, shm);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_states_rho, dim3((unsigned)((size_t)B * steps)), dim3(256), shm, s, P, W, steps, rho_out,
+                       purity_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_update_ancilla_rho(const Dev& P, const float* rho_in, const float* signal, float t, int B,
+                                     float* rho_out, hipStream_t s) {
+    const size_t shm = (size_t)3 * P.D * sizeof(float2);
+    const int nt = (P.D + 63) / 64 * 64;
+    hipLaunchKernelGGL(k_update_ancilla_rho, dim3((unsigned)(B * P.D)), dim3(nt), shm, s, P, rho_in, signal, t, rho_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_sample_rho(const Dev& P, const RhoDev& W, const float* noise, int n, int length, float* out,
+                             bool save, hipStream_t s) {
+    const size_t shm = (size_t)3 * W.rank * P.D * sizeof(float2) + 128;
+    hipError_t e;
+    if (P.D <= 64) {
+        if ((e = want_lds(k_sample_rho<64>, shm)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_sample_rho<64>, dim3(n), dim3(64), shm, s, P, W, noise, length, out, save ? 1 : 0);
+    } else {
+        if ((e = want_lds(k_sample_rho<128>, shm)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_sample_rho<128>, dim3(n), dim3(128), shm, s, P, W, noise, length, out, save ? 1 : 0);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace cmps

@@ -8,8 +8,7 @@ training_estimators.py:43-45 / follow_vae.py:45-51 call.  The reference builds a
 the forward + reverse kernels and applies the tiny host-side chain rule from the kernels' outputs
 (gradients w.r.t. the effective R, freqs, psi_0, A) to the raw variables (Rx, Ry, freqs, psi_x, psi_y, A).
 
-Out of scope on this surface ("next" rows): RhoCMPS / ``mixed=True``.
-They raise NotImplementedError rather than silently doing something else.
+RhoCMPS (model.py:55-203, ``mixed=True``) is mirrored the same way on top of the cmps_rho_* entry points.
 """
 from __future__ import annotations
 
@@ -144,6 +143,51 @@ class CMPS:
     def freqsc(self) -> np.ndarray:
         return self.freqs.astype(np.complex64)                    # model.py:52
 
+    # ---- backend plumbing (shared by PsiCMPS and RhoCMPS) ----
+    _backend = None
+
+    def _get_backend(self):
+        if self._backend is None:
+            from .scan import HipScan   # raises if libcmps.so or the GPU is missing: no fallback
+            self._backend = HipScan(self.bond_d)
+        return self._backend
+
+    def _batch(self, data=None):
+        data = self.data_iterator if data is None else data
+        if callable(data):
+            data = data()
+        return data
+
+    def _to_device(self, data):
+        import torch
+        be = self._get_backend()
+        dev = getattr(be, "device", None)
+        if isinstance(data, torch.Tensor):
+            t = data.to(dtype=torch.float32)
+            if dev is not None:
+                t = t.to(dev)
+            return t.contiguous()
+        t = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32))
+        return t.to(dev) if dev is not None else t
+
+    def _chain_common(self, Rbar, fbar, Abar, loss, with_reg: bool):
+        """Adjoint of model.py:36-42 (scaling + the row-broadcast diagonal removal) and :49 for batch-mean cotangents of
+        the effective R, freqs, A; optionally the regularisers of train.py:55-60."""
+        if with_reg:
+            R = self.R.astype(np.complex128)
+            f = self.freqs.astype(np.float64)
+            loss = loss + self.h_reg * np.sum(f * f) + self.r_reg * np.sum((np.conj(R) * R).real)
+            fbar = fbar + 2.0 * self.h_reg * f
+            Rbar = Rbar + 2.0 * self.r_reg * R
+        Zbar = Rbar - np.diag(np.sum(Rbar, axis=0))               # adjoint of model.py:42
+        c_r, c_h = float(self._c_r), float(self._c_h)
+        return loss, {
+            "A": np.asarray(np.float32(Abar)),
+            "Rx": (c_r * Zbar.real).astype(np.float32),
+            "Ry": (c_r * Zbar.imag).astype(np.float32),
+            "freqs": (c_h * fbar).astype(np.float32),
+        }
+
 
 # --------------------------------------------------------------------------------------------------
 class PsiCMPS(CMPS):
@@ -189,34 +233,10 @@ class PsiCMPS(CMPS):
         return np.float32(np.mean(per_clip, dtype=np.float32))
 
     # ---- backend plumbing ----
-    def _get_backend(self):
-        if self._backend is None:
-            from .scan import HipScan   # raises if libcmps.so or the GPU is missing: no fallback
-            self._backend = HipScan(self.bond_d)
-        return self._backend
-
     def effective_params(self):
         from .scan import EffectiveParams
         return EffectiveParams(R=self.R, freqs=self.freqs, psi0=self.psi_0, A=float(self.A),
                                sigma=float(self.sigma), delta_t=float(self.delta_t))
-
-    def _batch(self, data=None):
-        data = self.data_iterator if data is None else data
-        if callable(data):
-            data = data()
-        return data
-
-    def _to_device(self, data):
-        import torch
-        be = self._get_backend()
-        dev = getattr(be, "device", None)
-        if isinstance(data, torch.Tensor):
-            t = data.to(dtype=torch.float32)
-            if dev is not None:
-                t = t.to(dev)
-            return t.contiguous()
-        t = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32))
-        return t.to(dev) if dev is not None else t
 
     # ---- the hot path ----
     def loss_per_clip(self, data=None) -> np.ndarray:
@@ -251,14 +271,7 @@ class PsiCMPS(CMPS):
         p0bar = g["psi0bar"] * invB
         Abar = g["Abar"] * invB
         loss = g["loss_sum"] * invB
-        if with_reg:
-            R = self.R.astype(np.complex128)
-            f = self.freqs.astype(np.float64)
-            loss = loss + self.h_reg * np.sum(f * f) + self.r_reg * np.sum((np.conj(R) * R).real)
-            fbar = fbar + 2.0 * self.h_reg * f
-            Rbar = Rbar + 2.0 * self.r_reg * R
-        Zbar = Rbar - np.diag(np.sum(Rbar, axis=0))               # adjoint of model.py:42
-        c_r, c_h = float(self._c_r), float(self._c_h)
+        loss, grads = self._chain_common(Rbar, fbar, Abar, loss, with_reg)
         p = (self.variables["psi_x"].astype(np.float64) + 1j * self.variables["psi_y"].astype(np.float64))
         ss = float(np.sum(np.abs(p) ** 2))
         m = max(ss, 1e-12)
@@ -267,14 +280,8 @@ class PsiCMPS(CMPS):
         if ss > 1e-12:
             inv_bar = float(np.sum((np.conj(p0bar) * p).real))
             pbar = pbar + 2.0 * (inv_bar * (-0.5 * inv / m)) * p
-        grads = {
-            "A": np.asarray(np.float32(Abar)),
-            "Rx": (c_r * Zbar.real).astype(np.float32),
-            "Ry": (c_r * Zbar.imag).astype(np.float32),
-            "freqs": (c_h * fbar).astype(np.float32),
-            "psi_x": pbar.real.astype(np.float32),
-            "psi_y": pbar.imag.astype(np.float32),
-        }
+        grads["psi_x"] = pbar.real.astype(np.float32)
+        grads["psi_y"] = pbar.imag.astype(np.float32)
         return np.float32(loss), grads
 
     def loss_and_grads(self, data=None, with_reg: bool = False):
@@ -320,8 +327,156 @@ class PsiCMPS(CMPS):
 
 # --------------------------------------------------------------------------------------------------
 class RhoCMPS(CMPS):
-    def __init__(self, *args, **kwargs):
-        raise NotImplementedError("RhoCMPS (model.py:55-203) is a 'next' row (SURVEY.md 8f), not built yet")
+    """Evolves the density matrix (model.py:55-203).
+
+    Variables Wx, Wy [rank, D] (rank = hparams.initial_rank or bond_dim, :62-65), rho_0 = W^dagger W / trace (:127-132).
+    The HIP scan carries rho as its ``rank`` columns phi_a = conj(W[a, :]) / sqrt(trace) (cmps_rho_* in include/cmps.h);
+    everything the reference exposes on this class is mirrored: ``loss``, ``rho_0``, ``rho_evolve_with_data``,
+    ``rho_evolve_with_sampling``, ``purity``, ``sample``, ``_update_ancilla_rho``."""
+
+    VARIABLE_NAMES = ("A", "Rx", "Ry", "freqs", "Wx", "Wy")
+
+    def __init__(self, hparams, W_in=None, *args, backend=None, **kwargs):
+        super().__init__(hparams, *args, **kwargs)
+        D = self.bond_d
+        self.rank_rho_0 = int(hparams.initial_rank) if hparams.initial_rank is not None else D     # :62-65
+        if W_in is not None:
+            W_in = np.asarray(W_in)
+            if W_in.ndim != 2 or W_in.shape[1] != D:
+                raise ValueError(f"W_in must be [rank, {D}]")
+            self.rank_rho_0 = W_in.shape[0]
+            self.variables["Wx"] = W_in.real.astype(np.float32)                                    # :121-124
+            self.variables["Wy"] = W_in.imag.astype(np.float32)
+        else:
+            # initializer=None -> glorot_uniform on [rank, D]: limit sqrt(6 / (rank + D))           (:126-127)
+            lim = math.sqrt(6.0 / (self.rank_rho_0 + D))
+            self.variables["Wx"] = self._rng.uniform(-lim, lim, (self.rank_rho_0, D)).astype(np.float32)
+            self.variables["Wy"] = self._rng.uniform(-lim, lim, (self.rank_rho_0, D)).astype(np.float32)
+        self._backend = backend
+        self._last = None
+
+    # ---- attributes of the reference object ----
+    @property
+    def W(self) -> np.ndarray:
+        return (self.variables["Wx"] + 1j * self.variables["Wy"]).astype(np.complex64)            # :128
+
+    @property
+    def rho_0(self) -> np.ndarray:
+        W = self.W
+        r0 = (np.conj(W.T) @ W).astype(np.complex64)                                               # :129
+        return (r0 / np.trace(r0)).astype(np.complex64)                                            # :130
+
+    def columns(self) -> np.ndarray:
+        """phi [rank, D] with rho_0 = sum_a phi_a phi_a^dagger: phi_a = conj(W[a, :]) / sqrt(tr W^dagger W)."""
+        W = self.W.astype(np.complex128)
+        t0 = float(np.sum(np.abs(W) ** 2))
+        return (np.conj(W) / math.sqrt(t0)).astype(np.complex64)
+
+    @property
+    def loss(self) -> np.float32:
+        """RhoCMPS.loss (model.py:69-70, 144): mean over the batch of the per-clip loss."""
+        if self.data_iterator is None:
+            raise AttributeError("loss: the model was built without a data_iterator (model.py:69)")
+        return np.float32(np.mean(self.loss_per_clip(), dtype=np.float32))
+
+    def effective_params(self):
+        from .scan import EffectiveParams
+        e0 = np.zeros(self.bond_d, dtype=np.complex64)
+        e0[0] = 1                                                  # the pure-state psi_0 slot is unused on this path
+        return EffectiveParams(R=self.R, freqs=self.freqs, psi0=e0, A=float(self.A),
+                               sigma=float(self.sigma), delta_t=float(self.delta_t))
+
+    def _prepare(self, B, T, train):
+        be = self._get_backend()
+        be.set_params(self.effective_params(), B, T, train=False)
+        be.rho_set_state(self.columns(), B, T, train=train)
+        return be
+
+    # ---- the scan ----
+    def loss_per_clip(self, data=None) -> np.ndarray:
+        audio = self._to_device(self._batch(data))
+        B, T = audio.shape
+        be = self._prepare(B, T, train=False)
+        return be.rho_forward(audio, save_for_bwd=False).detach().cpu().numpy()
+
+    def grad_sums(self, data=None):
+        """(flat buffer of SUMS over this process's clips as laid out by cmps_rho_loss_bwd, number of clips)."""
+        audio = self._to_device(self._batch(data))
+        B, T = audio.shape
+        be = self._prepare(B, T, train=True)
+        _, grad = be.rho_loss_and_grad_sums(audio)
+        return grad, B
+
+    def chain_rule(self, flat_sums: np.ndarray, global_batch: int, with_reg: bool = False):
+        """Effective-parameter gradient sums -> (mean loss, gradients w.r.t. A, Rx, Ry, freqs, Wx, Wy)."""
+        from .scan import unpack_grad, grad_size
+        D, r = self.bond_d, self.rank_rho_0
+        flat = np.asarray(flat_sums, dtype=np.float64)
+        g = unpack_grad(flat, D)
+        invB = 1.0 / float(global_batch)
+        loss, grads = self._chain_common(g["Rbar"] * invB, g["fbar"] * invB, g["Abar"] * invB, g["loss_sum"] * invB,
+                                         with_reg)
+        tail = flat[grad_size(D):grad_size(D) + 2 * r * D]
+        phibar = (tail[:r * D] + 1j * tail[r * D:]).reshape(r, D) * invB
+        # phi = p / |p|, p = conj(W) (all rank * D entries as one vector), then W = conj(p)        adjoint of :128-130
+        W = self.W.astype(np.complex128)
+        nrm = math.sqrt(float(np.sum(np.abs(W) ** 2)))
+        phi = np.conj(W) / nrm
+        pbar = (phibar - phi * float(np.sum((np.conj(phi) * phibar).real))) / nrm
+        grads["Wx"] = pbar.real.astype(np.float32)
+        grads["Wy"] = (-pbar.imag).astype(np.float32)
+        return np.float32(loss), grads
+
+    def loss_and_grads(self, data=None, with_reg: bool = False):
+        flat, B = self.grad_sums(data)
+        host = flat.detach().cpu().numpy() if hasattr(flat, "detach") else np.asarray(flat)
+        self._last = host
+        return self.chain_rule(host, B, with_reg=with_reg)
+
+    # ---- other reference methods on this class ----
+    def _update_ancilla_rho(self, rho, signal, t):
+        """model.py:172-187 for a batch of density matrices [B, D, D]."""
+        be = self._get_backend()
+        rho = np.asarray(rho, dtype=np.complex64)
+        be.set_params(self.effective_params(), rho.shape[0], 2, train=False)
+        return be.rho_update_ancilla(rho, np.asarray(signal, dtype=np.float32), float(t))
+
+    def rho_evolve_with_data(self, data=None) -> np.ndarray:
+        """model.py:76-84: the normalised rho after every step, [B, T-1, D, D]."""
+        audio = self._to_device(self._batch(data))
+        B, T = audio.shape
+        be = self._prepare(B, T, train=True)
+        be.rho_forward(audio, save_for_bwd=True)
+        return be.rho_states(B, T - 1, want_rho=True)
+
+    def _noise(self, num_samples, length, temp, seed, noise):
+        if noise is None:
+            rng = np.random.default_rng(seed)
+            std = float(self.sigma) * math.sqrt(temp * float(self.delta_t))                        # :88, 96, 106
+            noise = (std * rng.standard_normal((length, num_samples))).astype(np.float32)
+        noise = np.asarray(noise, dtype=np.float32)
+        if noise.shape != (length, num_samples):
+            raise ValueError(f"noise must be [{length}, {num_samples}]")
+        return noise
+
+    def _sample_scan(self, num_samples, length, temp, seed, noise, save_states):
+        noise = self._noise(num_samples, length, temp, seed, noise)
+        be = self._prepare(num_samples, length + 1, train=save_states)
+        return be, be.rho_sample(noise, save_states=save_states)
+
+    def sample(self, num_samples, length, temp=1, seed=None, noise=None):
+        """model.py:103-116: waveforms [num_samples, length] = A * running sum of the sampled increments."""
+        return self._sample_scan(num_samples, length, temp, seed, noise, False)[1]
+
+    def rho_evolve_with_sampling(self, num_samples, length, temp=1, seed=None, noise=None) -> np.ndarray:
+        """model.py:86-92: rho after every sampled step, [num_samples, length, D, D]."""
+        be, _ = self._sample_scan(num_samples, length, temp, seed, noise, True)
+        return be.rho_states(num_samples, length, want_rho=True)
+
+    def purity(self, num_samples, length, temp=1, seed=None, noise=None) -> np.ndarray:
+        """model.py:94-101: tr rho^2 along sampled paths, [num_samples, length]."""
+        be, _ = self._sample_scan(num_samples, length, temp, seed, noise, True)
+        return be.rho_states(num_samples, length, want_rho=False, want_purity=True)
 
 
 class LegacyAudioMPS:
@@ -425,17 +580,28 @@ class AudioMPS(PsiCMPS):
                 kwargs["dt"] = dt
             kwargs.pop("hparams", None)
             return LegacyAudioMPS(*args, **kwargs)
+        # mixed=True: the density-matrix model (RhoCMPS); a non-instance return skips AudioMPS.__init__
+        names = ("bond_d", "dt", "batch_size", "data_iterator", "mixed")
+        bound = dict(zip(names, args))
+        bound.update(kwargs)
+        if bound.get("mixed", False):
+            hp = cls._hparams(bound["bond_d"], bound.get("dt"), bound.get("batch_size", 8), bound.get("delta_t"),
+                              bound.get("hparams"))
+            extra = {k: v for k, v in bound.items() if k not in names + ("delta_t", "hparams")}
+            return RhoCMPS(hp, data_iterator=bound.get("data_iterator"), **extra)
         return super().__new__(cls)
 
-    def __init__(self, bond_d, dt=None, batch_size=8, data_iterator=None, mixed=False, delta_t=None,
-                 hparams: Optional[HParams] = None, arithmetic: str = "psi", **kwargs):
-        if mixed:
-            raise NotImplementedError("AudioMPS(mixed=True) maps to RhoCMPS, a 'next' row (SURVEY.md 8f)")
+    @staticmethod
+    def _hparams(bond_d, dt, batch_size, delta_t, hparams):
         if dt is None:
             dt = delta_t
         if dt is None:
             raise TypeError("AudioMPS needs dt (or delta_t)")
         hp = hparams if hparams is not None else HParams()
-        hp = HParams(**{**hp.values(), "bond_dim": int(bond_d), "delta_t": float(dt),
-                        "minibatch_size": int(batch_size)})
+        return HParams(**{**hp.values(), "bond_dim": int(bond_d), "delta_t": float(dt),
+                          "minibatch_size": int(batch_size)})
+
+    def __init__(self, bond_d, dt=None, batch_size=8, data_iterator=None, mixed=False, delta_t=None,
+                 hparams: Optional[HParams] = None, arithmetic: str = "psi", **kwargs):
+        hp = self._hparams(bond_d, dt, batch_size, delta_t, hparams)
         super().__init__(hp, data_iterator=data_iterator, **kwargs)

@@ -236,3 +236,98 @@ class HipScan:
         _capi.check(self._h, self._lib.cmps_legacy_loss_bwd(
             self._h, audio.data_ptr(), B, T, self._legacy_grad.data_ptr(), self._stream()))
         return self._legacy_grad
+
+    # ------------------------------------------------------------------
+    # RhoCMPS: the density matrix carried as its `rank` columns
+    # ------------------------------------------------------------------
+    def rho_grad_size(self, rank: int) -> int:
+        return grad_size(self.D) + 2 * rank * self.D
+
+    def rho_set_state(self, phi: np.ndarray, B: int, T: int, train: bool = True):
+        """cmps_rho_set_state: phi [rank, D] complex, rho_0 = sum_a phi_a phi_a^dagger.  After set_params."""
+        phi = np.asarray(phi)
+        r, D = phi.shape
+        if D != self.D:
+            raise ValueError("phi has the wrong bond dimension")
+        flags = _capi.CMPS_WS_TRAIN if train else _capi.CMPS_WS_FWD_ONLY
+        nbytes = int(self._lib.cmps_rho_workspace_bytes(D, r, B, T, flags))
+        if nbytes == 0:
+            raise ValueError(f"invalid shape for the rho scan: D={D}, rank={r}, B={B}, T={T}")
+        key = (r, B, T, train)
+        if getattr(self, "_rho_ws_key", None) != key:
+            self._rho_ws = None
+            self._rho_ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+            self._rho_ws_key = key
+        base = (self._rho_ws.data_ptr() + 255) // 256 * 256
+        host = np.concatenate([phi.real.astype(np.float32).ravel(), phi.imag.astype(np.float32).ravel()])
+        self._phi_buf = torch.from_numpy(host).to(self.device)
+        pb = self._phi_buf.data_ptr()
+        _capi.check(self._h, self._lib.cmps_rho_set_state(
+            self._h, pb, pb + r * D * 4, r, int(T), int(B), flags, base, self._rho_ws.numel() - 256, self._stream()))
+        self._rho_rank, self._rho_B, self._rho_T = r, B, T
+
+    def rho_forward(self, audio: torch.Tensor, save_for_bwd: bool = False) -> torch.Tensor:
+        B, T = self._check_audio(audio)
+        if self._loss is None or self._loss.numel() != B:
+            self._loss = torch.empty(B, dtype=torch.float32, device=self.device)
+        _capi.check(self._h, self._lib.cmps_rho_loss_fwd(
+            self._h, audio.data_ptr(), B, T, self._loss.data_ptr(), 1 if save_for_bwd else 0, self._stream()))
+        self._audio = audio
+        return self._loss
+
+    def rho_backward(self) -> torch.Tensor:
+        audio = self._audio
+        if audio is None:
+            raise RuntimeError("rho_backward() needs rho_forward(save_for_bwd=True) first")
+        B, T = audio.shape
+        n = self.rho_grad_size(self._rho_rank)
+        if getattr(self, "_rho_grad", None) is None or self._rho_grad.numel() != n:
+            self._rho_grad = torch.empty(n, dtype=torch.float32, device=self.device)
+        _capi.check(self._h, self._lib.cmps_rho_loss_bwd(
+            self._h, audio.data_ptr(), B, T, self._rho_grad.data_ptr(), self._stream()))
+        return self._rho_grad
+
+    def rho_loss_and_grad_sums(self, audio: torch.Tensor):
+        loss = self.rho_forward(audio, save_for_bwd=True)
+        return loss, self.rho_backward()
+
+    def rho_update_ancilla(self, rho: np.ndarray, signal: np.ndarray, t: float) -> np.ndarray:
+        """RhoCMPS._update_ancilla_rho for a batch of matrices [B, D, D] (host in, host out)."""
+        rho = np.asarray(rho, dtype=np.complex64)
+        B, D, D2 = rho.shape
+        if D != self.D or D2 != self.D:
+            raise ValueError("rho has the wrong bond dimension")
+        inter = np.stack([rho.real, rho.imag], axis=-1).astype(np.float32)
+        d_in = torch.from_numpy(np.ascontiguousarray(inter)).to(self.device)
+        d_sig = torch.from_numpy(np.ascontiguousarray(signal, dtype=np.float32)).to(self.device)
+        d_out = torch.empty_like(d_in)
+        _capi.check(self._h, self._lib.cmps_rho_update_ancilla(
+            self._h, d_in.data_ptr(), d_sig.data_ptr(), float(t), B, d_out.data_ptr(), self._stream()))
+        o = d_out.cpu().numpy()
+        return (o[..., 0] + 1j * o[..., 1]).astype(np.complex64)
+
+    def rho_sample(self, noise: np.ndarray, save_states: bool = False) -> np.ndarray:
+        """RhoCMPS.sample for pre-drawn noise [length, n] -> waveforms [n, length]."""
+        noise = np.asarray(noise, dtype=np.float32)
+        length, n = noise.shape
+        d_noise = torch.from_numpy(np.ascontiguousarray(noise.T)).to(self.device)
+        d_out = torch.empty((n, length), dtype=torch.float32, device=self.device)
+        _capi.check(self._h, self._lib.cmps_rho_sample(self._h, d_noise.data_ptr(), n, length, d_out.data_ptr(),
+                                                       1 if save_states else 0, self._stream()))
+        return d_out.cpu().numpy()
+
+    def rho_states(self, B: int, steps: int, want_rho: bool = True, want_purity: bool = False):
+        """Lab-frame rho [B, steps, D, D] and/or purity [B, steps] of the last saved scan."""
+        D = self.D
+        d_rho = torch.empty((B, steps, D, D, 2), dtype=torch.float32, device=self.device) if want_rho else None
+        d_pur = torch.empty((B, steps), dtype=torch.float32, device=self.device) if want_purity else None
+        _capi.check(self._h, self._lib.cmps_rho_states(
+            self._h, B, steps, d_rho.data_ptr() if want_rho else None, d_pur.data_ptr() if want_purity else None,
+            self._stream()))
+        out = []
+        if want_rho:
+            o = d_rho.cpu().numpy()
+            out.append((o[..., 0] + 1j * o[..., 1]).astype(np.complex64))
+        if want_purity:
+            out.append(d_pur.cpu().numpy())
+        return out[0] if len(out) == 1 else tuple(out)

@@ -22,7 +22,7 @@ from typing import Dict, Optional
 
 import numpy as np
 
-from .model import HParams, PsiCMPS, VARIABLE_NAMES
+from .model import HParams, PsiCMPS, RhoCMPS
 from .parallel import DataParallel
 
 
@@ -40,7 +40,7 @@ class AdamOptimizer:
     def apply_gradients(self, variables: Dict[str, np.ndarray], grads: Dict[str, np.ndarray]):
         self.t += 1
         lr_t = self.lr * math.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
-        for name in VARIABLE_NAMES:
+        for name in sorted(grads):
             g = np.asarray(grads[name], dtype=np.float32)
             if name not in self.m:
                 self.m[name] = np.zeros_like(g)
@@ -93,7 +93,7 @@ class Trainer:
         if not os.path.exists(path):
             return False
         with np.load(path) as z:
-            for k in VARIABLE_NAMES:
+            for k in list(self.model.variables):
                 self.model.variables[k] = np.asarray(z[f"model/{k}"], dtype=np.float32)
             self.opt.load_state_dict({k[5:]: z[k] for k in z.files if k.startswith("adam/")})
             self.global_step = int(z["global_step"])
@@ -120,8 +120,6 @@ def main(argv=None):
     import torch
     from .data import get_audio
     args = build_parser().parse_args(argv)
-    if args.mps_model == "rho_mps":
-        raise NotImplementedError("rho_mps (RhoCMPS) is a 'next' row (SURVEY.md 8f)")
     hp = HParams(delta_t=1.0 / args.sample_rate, h_reg=200.0 / (math.pi * args.sample_rate) ** 2)  # train.py:41-43
     hp.parse(args.hparams)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -129,7 +127,7 @@ def main(argv=None):
     dev = torch.device("cuda", local_rank)
     dp = DataParallel(device=dev)
     start, count = dp.shard(hp.minibatch_size)
-    model = PsiCMPS(hp, seed=args.seed)
+    model = RhoCMPS(hp, seed=args.seed) if args.mps_model == "rho_mps" else PsiCMPS(hp, seed=args.seed)   # train.py:50-53
     trainer = Trainer(model, hp, dp)
     logdir = f"{args.logdir}/{args.dataset}/{hp.bond_dim}_{hp.delta_t}_{hp.minibatch_size}"    # train.py:94
     ckpt = os.path.join(logdir, "model.ckpt.npz")

@@ -140,6 +140,46 @@ int cmps_legacy_loss_fwd(cmps_handle_t h, const float* audio_dev, int B, int T, 
                          void* stream);
 int cmps_legacy_loss_bwd(cmps_handle_t h, const float* audio_dev, int B, int T, float* grad_dev, void* stream);
 
+/*
+ * RhoCMPS: the density-matrix scan (model.py:55-203).  All entries need cmps_set_params first (R, freqs, A, sigma,
+ * delta_t and the per-step tables are shared with the pure-state path; its psi_0 arguments are ignored here).
+ *
+ * The reference's rho_0 = W^dagger W / trace (model.py:127-132) has rank `rank` = hparams.initial_rank (default D), and
+ * rho -> U rho U^dagger / trace keeps it, so the state is handed over and carried as its `rank` columns:
+ *   phi_re_dev, phi_im_dev [rank*D] row-major [a][d],  rho_0 = sum_a phi_a phi_a^dagger,  phi_a = conj(W[a, :]) / sqrt(tr).
+ *
+ * cmps_rho_workspace_bytes / cmps_rho_set_state: a second caller-owned, 256-B aligned workspace for the columns, their
+ *   per-step stash (CMPS_WS_TRAIN: B_max * (T-1) * rank * D' * 8 bytes) and the reduction buffers.  Replaces `_rho_init`
+ *   (model.py:119-132) + `tf.stack(batch_size * [self.rho_0])` (:136).  Returns CMPS_ERR_UNSUPPORTED_D when rank * D is too
+ *   large for the LDS-resident columns (rank * D <= 5000 for training, 6500 forward-only).
+ * cmps_rho_loss_fwd: RhoCMPS._build_loss_rho (model.py:133-144) = tf.foldl of _rho_and_loss_update (:152-158):
+ *   _update_ancilla_rho (:172-187), _inc_loss_rho (:166), _expectation (:189-196), _normalize_rho (:198-203).
+ *   loss_dev [B] per-clip loss; the caller takes the mean (:144).
+ * cmps_rho_loss_bwd: the reverse while-loop TF autodiff builds for that fold.  grad_dev [2*D*D + 3*D + 2 + 2*rank*D]
+ *   receives sums over clips:  the cmps_psi_loss_bwd layout (dR_re, dR_im, dfreqs, 2*D unused zeros, dA, sum_b loss_b)
+ *   followed by dphi_re [rank*D], dphi_im [rank*D] (cotangents of the columns phi_a).
+ * cmps_rho_update_ancilla: RhoCMPS._update_ancilla_rho (model.py:172-187) for arbitrary rho_in_dev [B*D*D*2]
+ *   (row-major, interleaved re/im), signal_dev [B], time t; rho_out_dev like rho_in_dev.  Needs no cmps_rho_set_state.
+ * cmps_rho_sample: RhoCMPS.sample / rho_evolve_with_sampling / purity (model.py:86-116): tf.scan of
+ *   _rho_and_sample_update (:160-167) for pre-drawn noise_dev [n*length] ([path][step]); out_dev [n*length] = A * running
+ *   sum.  save_states != 0 keeps the columns of every step (needs a CMPS_WS_TRAIN rho workspace sized for B_max >= n,
+ *   T >= length + 1) for cmps_rho_states.
+ * cmps_rho_states: lab-frame normalised rho after every step of the last cmps_rho_loss_fwd(save_for_bwd=1) or
+ *   cmps_rho_sample(save_states=1): rho_out_dev [B*steps*D*D*2] (rho_evolve_with_data, model.py:76-84 /
+ *   rho_evolve_with_sampling, :86-92) and/or purity_out_dev [B*steps] = tr rho^2 (:94-101); either may be NULL.
+ */
+size_t cmps_rho_workspace_bytes(int D, int rank, int B, int T, int flags);
+int cmps_rho_set_state(cmps_handle_t h, const float* phi_re_dev, const float* phi_im_dev, int rank, int T, int B_max,
+                       int flags, void* rho_workspace_dev, size_t rho_workspace_bytes, void* stream);
+int cmps_rho_loss_fwd(cmps_handle_t h, const float* audio_dev, int B, int T, float* loss_dev, int save_for_bwd,
+                      void* stream);
+int cmps_rho_loss_bwd(cmps_handle_t h, const float* audio_dev, int B, int T, float* grad_dev, void* stream);
+int cmps_rho_update_ancilla(cmps_handle_t h, const float* rho_in_dev, const float* signal_dev, float t, int B,
+                            float* rho_out_dev, void* stream);
+int cmps_rho_sample(cmps_handle_t h, const float* noise_dev, int n, int length, float* out_dev, int save_states,
+                    void* stream);
+int cmps_rho_states(cmps_handle_t h, int B, int steps, float* rho_out_dev, float* purity_out_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -570,3 +570,177 @@ def legacy_loss_and_grads(H, R, dt, data, dtype="f32"):
     gR = (Rcbar.real + R @ (M_bar + M_bar.T)).astype(real)
     gH = np.tril(Hs_bar + Hs_bar.T).astype(real)
     return {"loss": real(np.mean(loss, dtype=real)), "per_clip": loss, "gH": gH, "gR": gR, "Qbar": Qbar, "Rcbar": Rcbar}
+
+
+# --------------------------------------------------------------------------------------------
+# next row: RhoCMPS, the density-matrix scan  (model.py:55-203)
+# --------------------------------------------------------------------------------------------
+def rho_init_W(hp: HParams, seed=0):
+    """Wx, Wy [rank, D]: initializer=None -> glorot-uniform, limit sqrt(6 / (rank + D))   (model.py:127-128)."""
+    D = hp.bond_dim
+    r = hp.initial_rank if hp.initial_rank is not None else D
+    rng = np.random.default_rng(seed + 777)
+    lim = math.sqrt(6.0 / (r + D))
+    return (rng.uniform(-lim, lim, (r, D)).astype(np.float32), rng.uniform(-lim, lim, (r, D)).astype(np.float32))
+
+
+def rho_0(Wx, Wy, dtype="f32"):
+    """model.py:129-132: rho_0 = W^dagger W / trace(W^dagger W)."""
+    real, cplx = _dt(dtype)
+    W = (np.asarray(Wx, dtype=real) + 1j * np.asarray(Wy, dtype=real)).astype(cplx)
+    r0 = (np.conj(W.T) @ W).astype(cplx)
+    return (r0 / np.trace(r0)).astype(cplx)
+
+
+def _rho_step(rho, x, t, R, freqs, A, hp, dtype):
+    """One _rho_and_loss_update (model.py:152-158) in the reference's lab-frame matrix form; returns the pieces the
+    adjoint needs."""
+    real, cplx = _dt(dtype)
+    s = (x.astype(real) / real(A)).astype(cplx)                                    # :175
+    ph = _phases(freqs, real(t), dtype)                                            # :178
+    Rt = (ph[:, None] * R * np.conj(ph)[None, :]).astype(cplx)                     # :179 einsum('a,ab,b->ab')
+    RRd = (np.conj(Rt.T) @ Rt).astype(cplx)                                        # :180
+    # :184  `- 0.5 * RR_dag * self.delta_t * self.sigma**2`: three successive complex64 products, left to right
+    damp = (((cplx(-0.5) * RRd).astype(cplx) * cplx(hp.delta_t)).astype(cplx) * cplx(hp.sigma ** 2)).astype(cplx)
+    c = cplx(cplx(-0.5) * cplx(hp.delta_t) * cplx(hp.sigma ** 2))                  # the same factor, for the adjoint
+    U = (np.eye(R.shape[0], dtype=cplx)[None] + (damp[None] + s[:, None, None] * Rt[None])).astype(cplx)
+    new_rho = np.matmul(np.matmul(U, rho).astype(cplx), np.conj(np.transpose(U, (0, 2, 1)))).astype(cplx)   # :186 U rho U^dagger
+    X = (Rt + np.conj(Rt.T)).astype(cplx)                                          # :193-194
+    e = np.einsum('ab,cba->c', X, new_rho).real.astype(real)                       # :195 trace(X rho)
+    z = (e * x.astype(real)) / real(A)                                             # :166
+    tr = np.trace(new_rho, axis1=1, axis2=2).real.astype(real)                     # :200
+    m = np.maximum(tr, real(1e-12))
+    return dict(s=s, ph=ph, Rt=Rt, RRd=RRd, c=c, U=U, new_rho=new_rho, X=X, e=e, z=z, tr=tr, m=m)
+
+
+def rho_loss_per_clip(hp: HParams, var: Variables, Wx, Wy, data, dtype="f32", return_states=False):
+    real, cplx = _dt(dtype)
+    data = np.asarray(data, dtype=real)
+    B, T = data.shape
+    R, freqs, _, _ = effective_params(hp, var, dtype)
+    A = real(var.A)
+    rho = np.tile(rho_0(Wx, Wy, dtype)[None], (B, 1, 1))
+    incs = (data[:, 1:] - data[:, :-1]).astype(real)
+    loss = np.zeros(B, dtype=real)
+    t = real(0)
+    states = []
+    for k in range(T - 1):
+        st = _rho_step(rho, incs[:, k], t, R, freqs, A, hp, dtype)
+        loss = (loss + (-np.log(real(1) + st["z"]))).astype(real)
+        rho = (st["new_rho"] * (real(1) / st["m"]).astype(cplx)[:, None, None]).astype(cplx)    # :201-203
+        t = real(t + real(hp.delta_t))
+        if return_states:
+            states.append(rho)
+    return (loss, np.stack(states, axis=1)) if return_states else loss
+
+
+def rho_loss_and_grads(hp: HParams, var: Variables, Wx, Wy, data, dtype="f32"):
+    """mean_b loss_b of RhoCMPS and its gradients w.r.t. A, Rx, Ry, freqs, Wx, Wy (reverse-mode adjoint of the
+    matrix recursion above; cotangent convention Mbar = dL/dRe M + i dL/dIm M, dL = Re tr(Mbar^dagger dM))."""
+    real, cplx = _dt(dtype)
+    data = np.asarray(data, dtype=real)
+    B, T = data.shape
+    N = T - 1
+    D = hp.bond_dim
+    R, freqs, c_r, c_h = effective_params(hp, var, dtype)
+    A = real(var.A)
+    W = (np.asarray(Wx, dtype=real) + 1j * np.asarray(Wy, dtype=real)).astype(cplx)
+    r0 = (np.conj(W.T) @ W).astype(cplx)
+    tr0 = np.trace(r0)
+    rho = np.tile((r0 / tr0)[None], (B, 1, 1)).astype(cplx)
+    incs = (data[:, 1:] - data[:, :-1]).astype(real)
+    loss = np.zeros(B, dtype=real)
+    t = real(0)
+    tape = []
+    for k in range(N):
+        tape.append((rho, t))
+        st = _rho_step(rho, incs[:, k], t, R, freqs, A, hp, dtype)
+        loss = (loss + (-np.log(real(1) + st["z"]))).astype(real)
+        rho = (st["new_rho"] * (real(1) / st["m"]).astype(cplx)[:, None, None]).astype(cplx)
+        t = real(t + real(hp.delta_t))
+    G = np.zeros((B, D, D), dtype=cplx)          # cotangent of the carried rho
+    Rbar = np.zeros((D, D), dtype=cplx)
+    fbar = np.zeros(D, dtype=real)
+    Abar = real(0)
+    lbar = real(1) / real(B)
+    for k in range(N - 1, -1, -1):
+        rho_k, tk = tape[k]
+        x = incs[:, k]
+        st = _rho_step(rho_k, x, tk, R, freqs, A, hp, dtype)
+        U, nr, Rt, X, ph, s = st["U"], st["new_rho"], st["Rt"], st["X"], st["ph"], st["s"]
+        # normalise: rho_next = nr / m
+        inv = (real(1) / st["m"]).astype(real)
+        nr_bar = G * inv.astype(cplx)[:, None, None]
+        inv_bar = np.einsum('abc,abc->a', np.conj(G), nr).real.astype(real)
+        tr_bar = np.where(st["tr"] > real(1e-12), inv_bar * (-inv * inv), real(0)).astype(real)
+        nr_bar = nr_bar + tr_bar.astype(cplx)[:, None, None] * np.eye(D, dtype=cplx)[None]
+        # loss: l = -log(1 + z), z = (e x)/A, e = Re tr(X nr)
+        z_bar = (-lbar / (real(1) + st["z"])).astype(real)
+        Abar = real(Abar + np.sum(z_bar * (-(st["e"] * x) / (A * A)), dtype=real))
+        e_bar = (z_bar * x / A).astype(real)
+        nr_bar = nr_bar + e_bar.astype(cplx)[:, None, None] * np.conj(X.T)[None]      # d tr(X nr)/d nr -> X^dagger
+        X_bar = np.einsum('a,abc->bc', e_bar.astype(cplx), np.conj(np.transpose(nr, (0, 2, 1))))
+        # nr = U rho U^dagger
+        UR = np.matmul(U, rho_k)
+        Ud = np.conj(np.transpose(U, (0, 2, 1)))
+        U_bar = np.matmul(nr_bar + np.conj(np.transpose(nr_bar, (0, 2, 1))), UR)
+        G = np.matmul(np.matmul(Ud, nr_bar), U).astype(cplx)                          # U^dagger nr_bar U
+        # U = I + c RRd + s Rt
+        RRd_bar = np.conj(st["c"]) * np.sum(U_bar, axis=0)
+        Rt_bar = np.einsum('a,abc->bc', np.conj(s), U_bar)
+        s_bar = np.einsum('abc,bc->a', U_bar, np.conj(Rt)).real.astype(real)
+        Abar = real(Abar + np.sum(s_bar * (-x / (A * A)), dtype=real))
+        # RRd = Rt^dagger Rt ;  X = Rt + Rt^dagger
+        Rt_bar = Rt_bar + Rt @ (RRd_bar + np.conj(RRd_bar.T)) + X_bar + np.conj(X_bar.T)
+        # Rt = ph R conj(ph)
+        Rbar = Rbar + np.conj(ph)[:, None] * Rt_bar * ph[None, :]
+        M = Rt_bar * np.conj(R)
+        ph_bar = np.sum(M * ph[None, :], axis=1) + np.conj(np.sum(M * np.conj(ph)[:, None], axis=0))
+        w_bar = ph_bar * np.conj(ph)
+        fbar = (fbar + tk * w_bar.imag).astype(real)
+    rho0_bar = np.sum(G, axis=0)
+    # rho_0 = r0 / tr(r0), r0 = W^dagger W
+    r0_bar = rho0_bar / np.conj(tr0) + np.eye(D, dtype=cplx) * (-(np.sum(np.conj(rho0_bar) * r0) / (tr0 * tr0))).conjugate()
+    W_bar = W @ (r0_bar + np.conj(r0_bar.T))
+    Zbar = Rbar - np.diag(np.sum(Rbar, axis=0))
+    return {"loss": real(np.mean(loss, dtype=real)), "per_clip": loss,
+            "A": real(Abar), "Rx": (c_r * Zbar.real).astype(real), "Ry": (c_r * Zbar.imag).astype(real),
+            "freqs": (c_h * fbar).astype(real), "Wx": W_bar.real.astype(real), "Wy": W_bar.imag.astype(real),
+            "eff": {"Rbar": Rbar, "fbar": fbar, "Abar": real(Abar), "rho0bar": rho0_bar}}
+
+
+def rho_update_ancilla(hp: HParams, var: Variables, rho, signal, t, dtype="f32"):
+    """RhoCMPS._update_ancilla_rho (model.py:172-187) for a batch rho [B, D, D]."""
+    real, cplx = _dt(dtype)
+    R, freqs, _, _ = effective_params(hp, var, dtype)
+    st = _rho_step(np.asarray(rho, dtype=cplx), np.asarray(signal, dtype=real), real(t), R, freqs, real(var.A), hp, dtype)
+    return st["new_rho"]
+
+
+def rho_sample(hp: HParams, var: Variables, Wx, Wy, noise, dtype="f32"):
+    """RhoCMPS.sample / rho_evolve_with_sampling / purity (model.py:86-116) for pre-drawn noise [length, n]:
+    tf.scan of _rho_and_sample_update (:160-167).  Returns (waveforms [n, length], rho [n, length, D, D], purity [n, length])."""
+    real, cplx = _dt(dtype)
+    noise = np.asarray(noise, dtype=real)
+    length, n = noise.shape
+    R, freqs, _, _ = effective_params(hp, var, dtype)
+    A = real(var.A)
+    rho = np.tile(rho_0(Wx, Wy, dtype)[None], (n, 1, 1))
+    sample = np.zeros(n, dtype=real)
+    t = real(0)
+    outs, rhos = [], []
+    for k in range(length):
+        ph = _phases(freqs, t, dtype)
+        Rt = (ph[:, None] * R * np.conj(ph)[None, :]).astype(cplx)
+        X = (Rt + np.conj(Rt.T)).astype(cplx)
+        e = np.einsum('ab,cba->c', X, rho).real.astype(real)                      # :189-196 on the current rho
+        inc = (e * real(hp.delta_t) + noise[k]).astype(real)                      # :162
+        sample = (sample + inc).astype(real)                                      # :163
+        st = _rho_step(rho, inc, t, R, freqs, A, hp, dtype)                       # :164
+        rho = (st["new_rho"] * (real(1) / st["m"]).astype(cplx)[:, None, None]).astype(cplx)   # :165
+        t = real(t + real(hp.delta_t))
+        outs.append(sample)
+        rhos.append(rho)
+    rhos = np.stack(rhos, axis=1)
+    purity = np.einsum('abcd,abdc->ab', rhos, rhos).real.astype(real)             # :101
+    return (A * np.stack(outs, axis=1)).astype(real), rhos, purity

@@ -124,3 +124,42 @@ class OracleBackend:
         out = self._run(audio, True)
         return (torch.from_numpy(out["loss_per_clip"].astype(np.float32)),
                 torch.from_numpy(out["grad"].astype(np.float32)))
+
+
+    # ---- RhoCMPS stand-in: the numpy oracle's effective-parameter adjoint, repacked like cmps_rho_loss_bwd ----
+    def rho_set_state(self, phi, B, T, train=True):
+        self.phi = np.asarray(phi, dtype=np.complex128)
+
+    def _rho_model(self, audio):
+        import torch
+        a = audio.numpy() if isinstance(audio, torch.Tensor) else np.asarray(audio)
+        D = self.D
+        hp = O.HParams(minibatch_size=a.shape[0], bond_dim=D, delta_t=self.p.delta_t, sigma=self.p.sigma, A=self.p.A,
+                       initial_rank=self.phi.shape[0])
+        R = np.asarray(self.p.R)
+        # effective parameters go in untouched: R_in / freqs_in style variables (no scaling, R has a zero diagonal)
+        var = O.Variables(np.float32(self.p.A), R.real.astype(np.float32), R.imag.astype(np.float32),
+                          np.asarray(self.p.freqs, dtype=np.float32), np.zeros(D, np.float32), np.zeros(D, np.float32),
+                          scaled_R=False, scaled_freqs=False)
+        W = np.conj(self.phi)          # rho_0 = W^dagger W / tr with tr = 1
+        return hp, var, W.real.astype(np.float32), W.imag.astype(np.float32), a
+
+    def rho_forward(self, audio, save_for_bwd=False):
+        import torch
+        hp, var, Wx, Wy, a = self._rho_model(audio)
+        return torch.from_numpy(O.rho_loss_per_clip(hp, var, Wx, Wy, a, self.dtype).astype(np.float32))
+
+    def rho_loss_and_grad_sums(self, audio):
+        import torch
+        hp, var, Wx, Wy, a = self._rho_model(audio)
+        dt = self.dtype
+        g = O.rho_loss_and_grads(hp, var if dt == "f32" else var.astype(np.float64), Wx.astype(np.float64 if dt == "f64" else np.float32),
+                                 Wy.astype(np.float64 if dt == "f64" else np.float32), a, dt)
+        B, D, r = a.shape[0], self.D, self.phi.shape[0]
+        eff = g["eff"]
+        Rbar = eff["Rbar"] * B
+        r0b = eff["rho0bar"] * B
+        phibar = (self.phi @ (r0b + np.conj(r0b.T)).T)           # phibar_a = (rho0bar + rho0bar^dagger) phi_a
+        flat = np.concatenate([Rbar.real.ravel(), Rbar.imag.ravel(), eff["fbar"] * B, np.zeros(2 * D),
+                               [eff["Abar"] * B, float(np.sum(g["per_clip"]))], phibar.real.ravel(), phibar.imag.ravel()])
+        return torch.from_numpy(g["per_clip"].astype(np.float32)), torch.from_numpy(flat.astype(np.float32))

@@ -1,0 +1,231 @@
+"""RhoCMPS on the MI355X (cmps_rho_* entry points) against the oracle's matrix-form restatement of model.py:55-203,
+plus the reference's own TestRhoCMPS cases (tests/test_model.py:31-103).
+
+The two sides use different formulations on purpose: the oracle carries the D x D matrix in the lab frame exactly as
+the reference does; the kernels carry the `rank` columns of rho in the rotating frame.  Tolerances as in
+test_gpu_parity.py: per-clip loss 1e-5 * max(|loss|, 1), gradients 1e-4 of each tensor's max.
+"""
+import numpy as np
+import pytest
+
+from oracle import cmps_oracle as O
+from _util import make_audio, rel_inf
+
+pytestmark = pytest.mark.gpu
+
+LOSS_RTOL = 1e-5
+GRAD_RTOL = 1e-4
+
+
+def _rho_model(D, T, B, rank=None, sigma=1e-4, seed=0, rscale=None, A=100.0, data=True, **kw):
+    from audio_mps_amd import HParams, RhoCMPS
+    hp = HParams(minibatch_size=B, bond_dim=D, sigma=sigma, initial_rank=rank, A=A)
+    audio = make_audio(B, T, hp.delta_t, seed) if data else None
+    m = RhoCMPS(hp, data_iterator=audio, seed=seed, **kw)
+    if rscale is not None:
+        m.variables["Rx"] *= np.float32(rscale)
+        m.variables["Ry"] *= np.float32(rscale)
+    return m, audio
+
+
+def _oracle_side(m):
+    ohp = O.HParams(**m.hparams.values())
+    D = m.bond_d
+    ov = O.Variables(np.asarray(m.variables["A"], dtype=np.float32), m.variables["Rx"].copy(), m.variables["Ry"].copy(),
+                     m.variables["freqs"].copy(), np.zeros(D, np.float32), np.zeros(D, np.float32),
+                     scaled_R=float(m._c_r) != 1.0, scaled_freqs=float(m._c_h) != 1.0)
+    return ohp, ov, m.variables["Wx"], m.variables["Wy"]
+
+
+# ---------------------------------------------------------------------------------------------------
+# the reference's TestRhoCMPS (tests/test_model.py:31-103), hparams of :13-14
+# ---------------------------------------------------------------------------------------------------
+def _ref_hparams(**over):
+    from audio_mps_amd import HParams
+    sr = 16000
+    kw = dict(minibatch_size=8, bond_dim=7, delta_t=1 / sr, sigma=0.0001, initial_rank=None, A=100.,
+              h_reg=2 / (np.pi * sr) ** 2, r_reg=2 / (np.pi * sr))
+    kw.update(over)
+    return HParams(**kw)
+
+
+def test_loss_not_nan():
+    from audio_mps_amd import RhoCMPS
+    from audio_mps_amd.data import get_audio
+    hp = _ref_hparams()
+    data = get_audio(None, "damped_sine", hp, 2 ** 8)
+    model = RhoCMPS(hp, data_iterator=data)
+    assert not np.isnan(model.loss)
+
+
+def test_rho_evolved_with_data_remains_normalized():
+    from audio_mps_amd import RhoCMPS
+    from audio_mps_amd.data import get_audio
+    hp = _ref_hparams()
+    data = get_audio(None, "damped_sine", hp, 2 ** 8)
+    model = RhoCMPS(hp, data_iterator=data)
+    rho_out = model.rho_evolve_with_data()
+    assert rho_out.shape == (8, 255, 7, 7)
+    np.testing.assert_allclose(np.trace(rho_out, axis1=2, axis2=3), np.ones((8, 255)), rtol=1e-5)
+
+
+def test_rho_evolved_sampling_remains_normalized():
+    from audio_mps_amd import RhoCMPS
+    model = RhoCMPS(_ref_hparams())
+    rho_out = model.rho_evolve_with_sampling(num_samples=5, length=256, seed=1)
+    assert rho_out.shape == (5, 256, 7, 7)
+    np.testing.assert_allclose(np.trace(rho_out, axis1=2, axis2=3), np.ones((5, 256)), rtol=1e-4)
+
+
+def test_trivial_update_of_ancilla():
+    """Update with H = R = 0 leaves rho alone."""
+    from audio_mps_amd import RhoCMPS
+    hp = _ref_hparams()
+    D = hp.bond_dim
+    signal = np.random.default_rng(0).random(hp.minibatch_size).astype(np.float32)
+    model = RhoCMPS(hp, freqs_in=np.zeros(D, np.float32), R_in=np.zeros((D, D), np.complex64))
+    stack = np.stack(hp.minibatch_size * [model.rho_0])
+    np.testing.assert_allclose(model._update_ancilla_rho(stack, signal, 0.), stack, rtol=1e-6, atol=1e-7)
+
+
+def test_sampling_two_level_system():
+    from audio_mps_amd import RhoCMPS
+    hp = _ref_hparams(bond_dim=2, sigma=1, A=1.)
+    w = 10
+    qubit = RhoCMPS(hp, R_in=np.array([[0, 1], [0, 0]], dtype=np.complex64), freqs_in=np.array([w, -w], dtype=np.float32))
+    waveform = qubit.sample(num_samples=2, length=512, seed=3)
+    assert waveform.shape == (2, 512) and np.all(np.isfinite(waveform))
+
+
+# ---------------------------------------------------------------------------------------------------
+# parity with the oracle
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("D,T,B,rank,sigma,rscale", [
+    (4, 256, 8, None, 1e-4, None),       # BASELINE C1 shape
+    (7, 256, 8, None, 1e-4, None),       # the reference tests' shape
+    (7, 100, 3, 2, 0.5, 0.3),            # low rank, visible damping
+    (16, 130, 4, 5, 1e-4, None),
+    (32, 96, 3, 32, 1e-4, None),         # full rank at the wave kernels' D
+    (40, 40, 2, 6, 1e-4, None),          # D > 32
+    (72, 24, 2, 3, 1e-4, None),          # D > 64 (two-wave workgroups)
+    (64, 12, 2, 40, 1e-4, None),         # more than 64 KB of LDS-resident columns in the reverse sweep
+])
+def test_rho_loss_and_gradients_match_oracle(D, T, B, rank, sigma, rscale):
+    m, audio = _rho_model(D, T, B, rank=rank, sigma=sigma, seed=D + T, rscale=rscale)
+    ohp, ov, Wx, Wy = _oracle_side(m)
+    ref = O.rho_loss_and_grads(ohp, ov, Wx, Wy, audio, "f32")
+    ref64 = O.rho_loss_and_grads(ohp, ov.astype(np.float64), Wx.astype(np.float64), Wy.astype(np.float64), audio, "f64")
+    per = m.loss_per_clip()
+    err = np.max(np.abs(per - ref["per_clip"]) / np.maximum(np.abs(ref["per_clip"]), 1.0))
+    assert err <= LOSS_RTOL, f"loss rel err {err}"
+    loss, grads = m.loss_and_grads()
+    assert abs(float(loss) - float(ref["loss"])) <= LOSS_RTOL * max(abs(float(ref["loss"])), 1.0)
+    for k in ("A", "Rx", "Ry", "freqs", "Wx", "Wy"):
+        # the float32 oracle's own gradient error (vs float64) bounds what can be asked of the kernels
+        own = rel_inf(ref[k], ref64[k])
+        e = rel_inf(grads[k], ref64[k])
+        assert e <= max(GRAD_RTOL, 3 * own), f"{k}: rel err {e} (oracle f32 vs f64: {own})"
+
+
+def test_rank_one_rho_reproduces_the_pure_state_path():
+    """rho_0 = |psi_0><psi_0| evolves exactly like PsiCMPS: the two HIP paths must agree on the loss."""
+    from audio_mps_amd import HParams, PsiCMPS, RhoCMPS
+    hp = HParams(minibatch_size=6, bond_dim=32, initial_rank=1)
+    audio = make_audio(6, 500, hp.delta_t, 11)
+    psi = PsiCMPS(hp, data_iterator=audio, seed=5)
+    rho = RhoCMPS(hp, data_iterator=audio, seed=5, W_in=np.conj(psi.psi_0)[None, :])
+    for k in ("A", "Rx", "Ry", "freqs"):
+        rho.variables[k] = psi.variables[k].copy()
+    a, b = psi.loss_per_clip(), rho.loss_per_clip()
+    assert np.max(np.abs(a - b) / np.maximum(np.abs(a), 1.0)) <= LOSS_RTOL
+
+
+def test_rho_gradient_is_directional_derivative():
+    """Central difference of the HIP loss along a random direction in (A, Rx, Ry, freqs, Wx, Wy) vs the HIP gradient."""
+    m, audio = _rho_model(8, 64, 4, rank=3, sigma=0.3, seed=21, rscale=0.2, A=5.0)
+    _, grads = m.loss_and_grads()
+    rng = np.random.default_rng(0)
+    names = ("A", "Rx", "Ry", "freqs", "Wx", "Wy")
+    dirs = {k: rng.standard_normal(np.shape(m.variables[k])).astype(np.float32) for k in names}
+    dd = sum(float(np.sum(grads[k].astype(np.float64) * dirs[k])) for k in names)
+    base = {k: np.array(m.variables[k], copy=True) for k in names}
+    eps = 2e-3
+    vals = []
+    for sgn in (+1, -1):
+        for k in names:
+            m.variables[k] = (base[k] + sgn * eps * dirs[k]).astype(np.float32)
+        vals.append(float(np.mean(m.loss_per_clip().astype(np.float64))))
+    fd = (vals[0] - vals[1]) / (2 * eps)
+    assert fd == pytest.approx(dd, rel=2e-2, abs=1e-4)
+
+
+def test_rho_update_ancilla_matches_oracle():
+    m, _ = _rho_model(7, 16, 5, rank=3, sigma=0.8, seed=2, rscale=0.3, data=False)
+    ohp, ov, Wx, Wy = _oracle_side(m)
+    rng = np.random.default_rng(1)
+    Z = rng.standard_normal((5, 7, 7)) + 1j * rng.standard_normal((5, 7, 7))
+    rho = np.einsum("bij,bkj->bik", Z, np.conj(Z)).astype(np.complex64)          # general Hermitian PSD input
+    rho /= np.trace(rho, axis1=1, axis2=2)[:, None, None]
+    signal = rng.standard_normal(5).astype(np.float32)
+    t = 0.0123
+    out = m._update_ancilla_rho(rho, signal, t)
+    ref = O.rho_update_ancilla(ohp, ov, rho, signal, t)
+    assert rel_inf(out, ref) <= 1e-5
+
+
+@pytest.mark.parametrize("D,rank,length,n", [(7, None, 256, 5), (2, None, 512, 2), (32, 4, 200, 3), (40, 3, 64, 2)])
+def test_rho_sampling_matches_oracle(D, rank, length, n):
+    sigma = 1.0 if D == 2 else 0.05
+    m, _ = _rho_model(D, 8, 2, rank=rank, sigma=sigma, seed=D, rscale=0.2, A=1.0 if D == 2 else 10.0, data=False)
+    ohp, ov, Wx, Wy = _oracle_side(m)
+    rng = np.random.default_rng(4)
+    noise = (sigma * np.sqrt(ohp.delta_t) * rng.standard_normal((length, n))).astype(np.float32)
+    wav = m.sample(n, length, noise=noise)
+    rhos = m.rho_evolve_with_sampling(n, length, noise=noise)
+    pur = m.purity(n, length, noise=noise)
+    rw, rr, rp = O.rho_sample(ohp, ov, Wx, Wy, noise)
+    scale = max(float(np.max(np.abs(rw))), 1e-6)
+    assert np.max(np.abs(wav - rw)) <= 2e-4 * scale
+    assert rel_inf(rhos, rr) <= 2e-4
+    np.testing.assert_allclose(pur, rp, rtol=2e-4, atol=1e-6)
+    assert np.all(pur <= 1 + 1e-4) and np.all(pur >= 1.0 / D - 1e-4)
+
+
+def test_rho_trainer_step_decreases_loss():
+    """train.py's loop with --mps_model rho_mps: Adam on the total loss through the HIP RhoCMPS scan."""
+    from audio_mps_amd import HParams, RhoCMPS
+    from audio_mps_amd.train import Trainer
+    hp = HParams(minibatch_size=8, bond_dim=8, initial_rank=3, learning_rate=1e-2)
+    audio = make_audio(8, 256, hp.delta_t, 3)
+    m = RhoCMPS(hp, data_iterator=audio, seed=1)
+    tr = Trainer(m, hp)
+    losses = [tr.step()["total_loss"] for _ in range(25)]
+    assert np.all(np.isfinite(losses)) and losses[-1] < losses[0]
+
+
+def test_rho_error_codes():
+    from audio_mps_amd import _capi
+    m, audio = _rho_model(4, 32, 2, rank=2)
+    be = m._get_backend()
+    import torch
+    d_audio = torch.from_numpy(audio).to(be.device)
+    be.set_params(m.effective_params(), 2, 32, train=False)
+    with pytest.raises(_capi.CmpsError) as ei:               # no cmps_rho_set_state yet
+        be.rho_forward(d_audio)
+    assert ei.value.code == _capi.CMPS_ERR_STATE
+    be.rho_set_state(m.columns(), 2, 32, train=False)
+    with pytest.raises(_capi.CmpsError) as ei:               # forward-only workspace cannot save
+        be.rho_forward(d_audio, save_for_bwd=True)
+    assert ei.value.code == _capi.CMPS_ERR_WORKSPACE
+    be.rho_forward(d_audio)
+    with pytest.raises(_capi.CmpsError) as ei:               # backward without a saved forward
+        be.rho_backward()
+    assert ei.value.code == _capi.CMPS_ERR_STATE
+    from audio_mps_amd.scan import HipScan
+    be64 = HipScan(64)
+    from audio_mps_amd.scan import EffectiveParams
+    be64.set_params(EffectiveParams(R=np.zeros((64, 64), np.complex64), freqs=np.zeros(64, np.float32),
+                                    psi0=np.eye(64, dtype=np.complex64)[0], A=1.0, sigma=1.0, delta_t=1e-3), 1, 8, train=False)
+    with pytest.raises(_capi.CmpsError) as ei:               # rank * D beyond the LDS-resident limit
+        be64.rho_set_state(np.zeros((128, 64), np.complex64), 1, 8, train=True)
+    assert ei.value.code == _capi.CMPS_ERR_UNSUPPORTED_D

@@ -110,10 +110,37 @@ def test_audiomps_surface():
     data = make_audio(4, 64, 0.001, 1)
     a = AudioMPS(4, 0.001, 4, data_iterator=data, mixed=False, backend=OracleBackend(4))
     assert a.bond_d == 4 and a.delta_t == 0.001 and np.isfinite(a.loss)
-    with pytest.raises(NotImplementedError):
-        AudioMPS(4, 0.001, 4, data_iterator=data, mixed=True)
-    with pytest.raises(NotImplementedError):
-        RhoCMPS(HParams())
+    r = AudioMPS(4, 0.001, 4, data_iterator=data, mixed=True, backend=OracleBackend(4))
+    assert isinstance(r, RhoCMPS) and r.bond_d == 4 and r.rank_rho_0 == 4 and np.isfinite(r.loss)
+
+
+def test_rho0_is_a_density_matrix():
+    """tests/test_model.py:41-48 (testRho0IsADensityMatrix) plus the column form handed to the scan."""
+    m = RhoCMPS(HParams(bond_dim=7, initial_rank=3), seed=2)
+    r0 = m.rho_0
+    np.testing.assert_allclose(r0, r0 / np.trace(r0), rtol=1e-6)
+    np.testing.assert_allclose(r0, np.conj(r0.T), atol=1e-7)
+    phi = m.columns()
+    assert phi.shape == (3, 7)
+    np.testing.assert_allclose(np.einsum("ai,aj->ij", phi, np.conj(phi)), r0, atol=1e-6)
+
+
+@pytest.mark.parametrize("rank", [None, 2])
+def test_rho_chain_rule_matches_oracle(rank):
+    """RhoCMPS.loss_and_grads (host chain rule over the cmps_rho_loss_bwd layout) against the oracle's direct
+    variable gradients, with the oracle standing in for the kernels."""
+    hp = HParams(minibatch_size=3, bond_dim=4, sigma=0.5, A=2.0, initial_rank=rank, r_reg=0.3, h_reg=1e-4)
+    data = make_audio(3, 24, hp.delta_t, 5, noise=0.05)
+    m = RhoCMPS(hp, data_iterator=data, seed=4, backend=OracleBackend(4, "f64"))
+    loss, grads = m.loss_and_grads()
+    ov = O.Variables(np.asarray(m.variables["A"]), m.variables["Rx"], m.variables["Ry"], m.variables["freqs"],
+                     np.zeros(4, np.float32), np.zeros(4, np.float32), scaled_R=True, scaled_freqs=True)
+    ohp = O.HParams(**hp.values())
+    ref = O.rho_loss_and_grads(ohp, ov.astype(np.float64), m.variables["Wx"].astype(np.float64),
+                               m.variables["Wy"].astype(np.float64), data, "f64")
+    assert float(loss) == pytest.approx(float(ref["loss"]), rel=1e-5)
+    for k in ("A", "Rx", "Ry", "freqs", "Wx", "Wy"):
+        assert rel_inf(grads[k], ref[k]) < 2e-5, k
 
 
 def test_get_audio():
