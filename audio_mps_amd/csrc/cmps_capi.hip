@@ -2,6 +2,7 @@
 #include "../../include/cmps.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -169,8 +170,11 @@ int cmps_psi_loss_fwd(cmps_handle_t h, const float* audio_dev, int B, int T, flo
     P.B = B;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int variant = resolve_variant(h);
+    // the two-waves-per-clip forward (cmps_wave2.hip) is the default; CMPS_FWD1=1 selects the one-wave kernel for A/B runs
+    static const bool fwd2 = [] { const char* v = getenv("CMPS_FWD1"); return !(v && v[0] == '1'); }();
     hipError_t e = (variant == CMPS_VARIANT_WAVE)
-                       ? launch_fwd_wave(P, audio_dev, loss_dev, save_for_bwd != 0, s)
+                       ? (fwd2 ? launch_fwd_wave2(P, audio_dev, loss_dev, save_for_bwd != 0, s)
+                               : launch_fwd_wave(P, audio_dev, loss_dev, save_for_bwd != 0, s))
                        : launch_fwd_block(P, audio_dev, loss_dev, save_for_bwd != 0, s);
     if (e != hipSuccess) return fail_hip(h, e, "cmps_psi_loss_fwd");
     h->fwd_saved = save_for_bwd != 0;

@@ -153,6 +153,7 @@ hipError_t launch_fwd_block(const Dev& P, const float* audio, float* loss, bool 
 hipError_t launch_bwd_block(const Dev& P, const float* audio, hipStream_t s);
 hipError_t launch_fwd_wave(const Dev& P, const float* audio, float* loss, bool save, hipStream_t s);
 hipError_t launch_bwd_wave(const Dev& P, const float* audio, hipStream_t s);
+hipError_t launch_fwd_wave2(const Dev& P, const float* audio, float* loss, bool save, hipStream_t s);
 hipError_t launch_reduce_finalize(const Dev& P, const float* loss, float* grad_out, hipStream_t s);
 hipError_t launch_update_ancilla(const Dev& P, const float* psi_in, const float* signal, float t,
                                  int B, float* psi_out, hipStream_t s);

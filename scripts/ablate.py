@@ -4,7 +4,8 @@ import os, sys, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from audio_mps_amd import build
-variants = {"base": [], "no_wait": ["-DABL_NO_WAIT"], "no_wait_no_mv1_no_reduce": ["-DABL_NO_WAIT", "-DABL_NO_REDUCE", "-DABL_NO_MV1"]}
+variants = {"base": [], "no_loss": ["-DABL2_NO_LOSS"], "no_chain": ["-DABL2_NO_CHAIN"], "no_prio": ["-DABL2_NO_PRIO"],
+            "chain_nowait": ["-DABL2_CHAIN_NOWAIT"], "no_loss_chain_nowait": ["-DABL2_NO_LOSS", "-DABL2_CHAIN_NOWAIT"]}
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 for name, flags in variants.items():
     lib = os.path.join(ROOT, "gpurun_out", f"libcmps_{name}.so")

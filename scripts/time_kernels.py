@@ -11,7 +11,7 @@ from audio_mps_amd.data import damped_sine
 D = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 16000
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
-rounds = 5
+rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 5
 hp = HParams(minibatch_size=B, bond_dim=D)
 rng = np.random.default_rng(15345)
 x = damped_sine(B, T, hp.delta_t, seed=3000)
