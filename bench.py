@@ -171,7 +171,8 @@ def main():
         flops_fwd = 24.0 * D * D * B * N
         bytes_alg = 8.0 * B * T                                  # 4 B read forward + 4 B read in the reverse sweep
         wave = backend.variant == 2
-        kern = {"fwd": {"name": "k_fwd_wave (forward scan)" if wave else "k_fwd_block", "t": t_fwd, "flops": flops_fwd,
+        fwd_name = "k_fwd_wave (forward scan)" if os.environ.get("CMPS_FWD1") == "1" else "k_fwd_wave2 (forward scan, two waves per clip)"
+        kern = {"fwd": {"name": fwd_name if wave else "k_fwd_block", "t": t_fwd, "flops": flops_fwd,
                         "pmc": "k_fwd_wave" if wave else "k_fwd_block"},
                 "bwd": {"name": "k_bwd_wave (reverse scan)" if wave else "k_bwd_block", "t": t_bwd, "flops": flops_bwd,
                         "pmc": "k_bwd_wave" if wave else "k_bwd_block"}}
