@@ -21,6 +21,7 @@ CMPS_WS_TRAIN = 1
 CMPS_VARIANT_AUTO = 0
 CMPS_VARIANT_BLOCK = 1
 CMPS_VARIANT_WAVE = 2
+CMPS_VARIANT_PAIR = 3
 
 # every symbol include/cmps.h declares
 SYMBOLS = (

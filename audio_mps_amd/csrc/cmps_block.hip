@@ -432,6 +432,11 @@ hipError_t launch_reduce_finalize(const Dev& P, const float* loss, float* grad_o
     return hipGetLastError();
 }
 
+hipError_t launch_finalize_only(const Dev& P, const float* loss, float* grad_out, hipStream_t s) {
+    hipLaunchKernelGGL(k_finalize, dim3(8), dim3(256), 0, s, P, (const float*)P.sums, loss, grad_out);
+    return hipGetLastError();
+}
+
 hipError_t launch_update_ancilla(const Dev& P, const float* psi_in, const float* signal, float t,
                                  int B, float* psi_out, hipStream_t s) {
     const size_t shm = (size_t)2 * P.D * sizeof(float2);

@@ -54,6 +54,8 @@ int fail_hip(cmps_handle_t h, hipError_t e, const char* where) {
 int resolve_variant(const cmps_handle_s* h) {
     if (h->variant_req == CMPS_VARIANT_BLOCK) return CMPS_VARIANT_BLOCK;
     if (h->variant_req == CMPS_VARIANT_WAVE) return h->D <= 32 ? CMPS_VARIANT_WAVE : CMPS_VARIANT_BLOCK;
+    if (h->variant_req == CMPS_VARIANT_PAIR) return h->D == 128 ? CMPS_VARIANT_PAIR : CMPS_VARIANT_BLOCK;
+    // AUTO: float32 everywhere; the bf16-operand MFMA kernels of D = 128 are opt-in (they change the arithmetic)
     return h->D <= 32 ? CMPS_VARIANT_WAVE : CMPS_VARIANT_BLOCK;
 }
 
@@ -83,8 +85,10 @@ const char* cmps_last_error(cmps_handle_t h) { return h ? h->err.c_str() : "null
 
 int cmps_set_variant(cmps_handle_t h, int variant) {
     if (!h) return CMPS_ERR_BAD_ARG;
-    if (variant < CMPS_VARIANT_AUTO || variant > CMPS_VARIANT_WAVE)
+    if (variant < CMPS_VARIANT_AUTO || variant > CMPS_VARIANT_PAIR)
         return fail(h, CMPS_ERR_BAD_ARG, "cmps_set_variant: unknown variant");
+    if (variant == CMPS_VARIANT_PAIR && h->D != 128)
+        return fail(h, CMPS_ERR_UNSUPPORTED_D, "cmps_set_variant: the pair (MFMA) variant needs D = 128");
     if (variant == CMPS_VARIANT_WAVE && h->D > 32)
         return fail(h, CMPS_ERR_UNSUPPORTED_D, "cmps_set_variant: the wave variant needs D <= 32");
     h->variant_req = variant;
@@ -172,15 +176,19 @@ int cmps_psi_loss_fwd(cmps_handle_t h, const float* audio_dev, int B, int T, flo
     const int variant = resolve_variant(h);
     // the two-waves-per-clip forward (cmps_wave2.hip) is the default; CMPS_FWD1=1 selects the one-wave kernel for A/B runs
     static const bool fwd2 = [] { const char* v = getenv("CMPS_FWD1"); return !(v && v[0] == '1'); }();
-    hipError_t e = (variant == CMPS_VARIANT_WAVE)
-                       ? (fwd2 ? launch_fwd_wave2(P, audio_dev, loss_dev, save_for_bwd != 0, s)
-                               : launch_fwd_wave(P, audio_dev, loss_dev, save_for_bwd != 0, s))
-                       : launch_fwd_block(P, audio_dev, loss_dev, save_for_bwd != 0, s);
+    hipError_t e;
+    if (variant == CMPS_VARIANT_WAVE)
+        e = fwd2 ? launch_fwd_wave2(P, audio_dev, loss_dev, save_for_bwd != 0, s)
+                 : launch_fwd_wave(P, audio_dev, loss_dev, save_for_bwd != 0, s);
+    else if (variant == CMPS_VARIANT_PAIR)
+        e = launch_fwd_pair(P, audio_dev, loss_dev, save_for_bwd != 0, s);
+    else
+        e = launch_fwd_block(P, audio_dev, loss_dev, save_for_bwd != 0, s);
     if (e != hipSuccess) return fail_hip(h, e, "cmps_psi_loss_fwd");
     h->fwd_saved = save_for_bwd != 0;
     h->saved_B = B; h->saved_T = T; h->saved_audio = audio_dev; h->saved_loss = loss_dev;
     h->saved_variant = variant;
-    h->P.stash_layout = (variant == CMPS_VARIANT_WAVE) ? 1 : 0;
+    h->P.stash_layout = (variant == CMPS_VARIANT_WAVE) ? 1 : (variant == CMPS_VARIANT_PAIR ? 2 : 0);
     return CMPS_OK;
 }
 
@@ -195,6 +203,18 @@ int cmps_psi_loss_bwd(cmps_handle_t h, const float* audio_dev, int B, int T, flo
     P.B = B;
     hipStream_t s = static_cast<hipStream_t>(stream);
     // the stash layout belongs to the variant that wrote it
+    if (h->saved_variant == CMPS_VARIANT_PAIR) {
+        // reverse scan, then the gradient GEMM over the rows both scans left behind; one slab per PAIR of clips
+        hipError_t e = launch_bwd_pair(P, audio_dev, s);
+        if (e == hipSuccess) e = launch_grad_pair(P, audio_dev, s);
+        if (e != hipSuccess) return fail_hip(h, e, "cmps_psi_loss_bwd (pair scan)");
+        Dev Pp = P;
+        Pp.B = (B + 1) / 2;
+        e = launch_reduce_only(Pp, s);
+        if (e == hipSuccess) e = launch_finalize_only(P, h->saved_loss, grad_dev, s);
+        if (e != hipSuccess) return fail_hip(h, e, "cmps_psi_loss_bwd (pair reduce)");
+        return CMPS_OK;
+    }
     hipError_t e = (h->saved_variant == CMPS_VARIANT_WAVE) ? launch_bwd_wave(P, audio_dev, s)
                                                            : launch_bwd_block(P, audio_dev, s);
     if (e != hipSuccess) return fail_hip(h, e, "cmps_psi_loss_bwd (scan)");
@@ -221,6 +241,7 @@ int cmps_psi_states(cmps_handle_t h, int B, int T, float* psi_out_dev, void* str
         return fail(h, CMPS_ERR_STATE, "cmps_psi_states: needs cmps_psi_loss_fwd(save_for_bwd=1) first");
     if (!psi_out_dev || B != h->saved_B || T != h->saved_T)
         return fail(h, CMPS_ERR_BAD_ARG, "cmps_psi_states: bad argument");
+    if (h->saved_variant == CMPS_VARIANT_PAIR) return fail(h, CMPS_ERR_STATE, "cmps_psi_states: not available for the pair variant");
     hipError_t e = launch_states(h->P, B, psi_out_dev, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail_hip(h, e, "cmps_psi_states");
     return CMPS_OK;

@@ -59,7 +59,9 @@ inline Layout make_layout(int D, int B, int T, int flags) {
     L.off_sums = o;
     if (flags & 1) {
         // the two variants never run on the same stash: their layouts share one region
-        size_t stash_bytes = (size_t)B * N * DP * sizeof(float2);
+        // D > 32: the pair kernels (D = 128) keep (y, H y) per step, 16 B per component; the block kernels use half of it
+        size_t stash_bytes = D > 32 ? (size_t)((B + 1) / 2 * 2) * N * DP * sizeof(float2) * 2   // whole pairs
+                                    : (size_t)B * N * DP * sizeof(float2);
         if (D <= 32 && stash_bytes < (size_t)B * N * 128 * sizeof(float)) stash_bytes = (size_t)B * N * 128 * sizeof(float);
         L.off_hst = L.off_stash;
         o = align256(o + stash_bytes);
@@ -85,7 +87,7 @@ struct Dev {
     const float2* rho;   // [N][DP]
     float2* stash;       // [B][N][DP]
     float* hst;          // [B][N][64][2] (wave variant)
-    int stash_layout;    // 0: stash [B][N][DP] float2 (block variant)  1: hst rows (wave variant)
+    int stash_layout;    // 0: stash [B][N][DP] float2 (block variant)  1: hst rows (wave variant)  2: pair rows (cmps_pair.hip)
     float* scal;         // [B][NC][2][64]
     float* slabs;        // [B][slab]
     float* sums;         // [slab]
@@ -154,6 +156,10 @@ hipError_t launch_bwd_block(const Dev& P, const float* audio, hipStream_t s);
 hipError_t launch_fwd_wave(const Dev& P, const float* audio, float* loss, bool save, hipStream_t s);
 hipError_t launch_bwd_wave(const Dev& P, const float* audio, hipStream_t s);
 hipError_t launch_fwd_wave2(const Dev& P, const float* audio, float* loss, bool save, hipStream_t s);
+hipError_t launch_fwd_pair(const Dev& P, const float* audio, float* loss, bool save, hipStream_t s);
+hipError_t launch_bwd_pair(const Dev& P, const float* audio, hipStream_t s);
+hipError_t launch_grad_pair(const Dev& P, const float* audio, hipStream_t s);
+hipError_t launch_finalize_only(const Dev& P, const float* loss, float* grad_out, hipStream_t s);
 hipError_t launch_reduce_finalize(const Dev& P, const float* loss, float* grad_out, hipStream_t s);
 hipError_t launch_update_ancilla(const Dev& P, const float* psi_in, const float* signal, float t,
                                  int B, float* psi_out, hipStream_t s);

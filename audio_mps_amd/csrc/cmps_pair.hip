@@ -1,0 +1,777 @@
+// D = 128 ("bf16 with fp32 accumulate", BASELINE configs[4]): MFMA kernels, one workgroup per PAIR of clips.
+//
+// At D = 128 and B = 512 there are two clips per CU and a matrix is 128 KB in complex64: nothing like the wave-per-clip
+// layout fits.  What does fit is the batched 4x4x4 bf16 MFMA (v_mfma_f32_4x4x4_16b_bf16: 16 independent 4x4 blocks per
+// instruction, D_b += A_b B_b).  A complex mat-vec y = M u is the real product  [M_re | M_im] (128 x 256)  times a
+// 256-vector, once with  c0 = [u_re; -u_im]  (-> Re y) and once with  c1 = [u_im; u_re]  (-> Im y).  With TWO clips the
+// four B columns of every block are {clip0 c0, clip0 c1, clip1 c0, clip1 c1}: all of the MFMA is useful work and the
+// matrix is stored once, in registers, as bf16 A fragments (64 VGPRs per matrix and wave).
+//
+//   workgroup = 4 waves; wave w owns rows 32w..32w+31 of every matrix.
+//   lane l: block b = l >> 2 = (rg = b & 7, kh = b >> 3), position p = l & 3.
+//     A operand of instruction t (0..31): rows 32w + 4rg + p, columns 4t..4t+3 of M_re (kh = 0) or M_im (kh = 1).
+//     B operand: column c = p, entries 4t..4t+3 of  [u_re | u_im] (kh = 0)  or  [-u_im | u_re] (kh = 1)  of clip c >> 1,
+//       read from LDS (every lane reads 256 contiguous bytes per vector: 16 ds_read_b128, shared by all matrices).
+//     D: 4 registers = rows 4rg..4rg+3, column c, partial over this lane half's K range; one v_permlane32_swap + add per
+//       register pair sums the halves: lane (rg, kh, c) ends up owning rows 32w + 4rg + kh and +2 of component
+//       (c & 1 ? Im : Re) of clip c >> 1 -- every (row, component, clip) lives in exactly one lane.
+//   Per step: 64 MFMAs on the chain (R ut, Q ut), 32 off it (H y of the previous step), ONE workgroup barrier.
+//   The identity part of y = ut + Q ut + s R ut stays float32; only the small correction goes through bf16.
+// Arithmetic restated (with the same rounding points) by oracle/cmps_oracle.py::psi_bf16_scan.
+#include "cmps_internal.h"
+
+namespace cmps {
+
+namespace {
+
+constexpr int PD = 128;      // bond dimension of this variant
+constexpr int PWV = 4;       // waves per workgroup
+constexpr int PCH = 64;      // steps per chunk of per-step scalars
+
+typedef short bf4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned short bf16_rne(float f) {
+    unsigned u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+// (lo, hi) -> packed bf16x2, round to nearest even
+__device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ float rdl(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+// workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. waits every step for the
+// stash row's store to reach L2 (~1.5 us; measured: it was 80 % of the step)
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+// sum over the two lane halves: lower lanes get a0 + a0', upper lanes get a1 + a1'  (see cmps_wave_util.h::swapadd)
+__device__ __forceinline__ float half_add(float a0, float a1) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a0), __float_as_uint(a1), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+// sum over the 32 lanes that carry the same clip (c >> 1); every lane receives its clip's total
+__device__ __forceinline__ float clip_sum(float x) {
+#ifdef PABL_NO_REDUCE
+    return x;
+#endif
+    x += dpp_mov<0xB1>(x);        // quad_perm [1,0,3,2]: re + im partner
+    x += dpp_mov<0x124>(x);       // row_ror:4
+    x += dpp_mov<0x128>(x);       // row_ror:8   -> total of this 16-lane row for this clip
+    {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+        x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+        x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    return x;
+}
+
+// LDS image of one broadcast vector for both clips: arrays re | im | -im, each [2 clips][128] bf16, + a dummy row
+// Rows are padded by 16 B: the eight lane groups (kh, c) of a wave read eight DIFFERENT rows at the same offset in the same
+// instruction, and unpadded 256-byte rows would all start in the same LDS bank (measured: 73 % of the LDS cycles were bank
+// conflicts before the padding).
+constexpr int VROW = PD * 2 + 16;                           // bytes per (array, clip) row
+constexpr int VEC_BYTES = 8 * VROW;                         // re, im, -im (x 2 clips) + 2 dummy rows (the even lanes' second write)
+
+struct PairLds {
+    __attribute__((aligned(16))) unsigned char vec[2][2][VEC_BYTES];   // [parity][0: ut, 1: y]
+    __attribute__((aligned(16))) float nrm[2][2][PWV];                 // [parity][clip][wave]
+    __attribute__((aligned(16))) float ee[2][2][PWV];
+};
+
+typedef unsigned u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf4 frag_of(unsigned lo, unsigned hi) {
+    const u2 t = {lo, hi};
+    return __builtin_bit_cast(bf4, t);
+}
+
+// eight consecutive 16-byte reads issued back to back (the compiler's own schedule waits for each read right before its
+// first use, one read ahead: ~70 exposed cycles per read); completion is awaited with counted lgkmcnt waits
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+__device__ __forceinline__ void rd8(unsigned addr, u4 (&o)[8]) {
+    asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\t"
+                 "ds_read_b128 %2, %8 offset:32\n\tds_read_b128 %3, %8 offset:48\n\t"
+                 "ds_read_b128 %4, %8 offset:64\n\tds_read_b128 %5, %8 offset:80\n\t"
+                 "ds_read_b128 %6, %8 offset:96\n\tds_read_b128 %7, %8 offset:112"
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
+                 : "v"(addr) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void rd_wait(u4 (&o)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(%8)"
+                 : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(o[4]), "+v"(o[5]), "+v"(o[6]), "+v"(o[7])
+                 : "n"(N) : "memory");
+}
+#ifdef PABL_NO_MFMA
+#define MFMA4(A, B, C) (C)
+#else
+#define MFMA4(A, B, C) __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(A, B, C, 0, 0, 0)
+#endif
+// two matrices against eight 16-byte pieces of one vector (instructions t = 2 * (T0 + i), 2 * (T0 + i) + 1); two
+// accumulators per matrix keep dependent MFMAs four instructions apart (no wait states)
+struct Acc2 { f4 a, b; };
+template <int T0>
+__device__ __forceinline__ void mm2(const bf4 (&FA)[32], const bf4 (&FB)[32], const u4 (&v)[8], Acc2& x, Acc2& y) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const bf4 lo = frag_of(v[i].x, v[i].y), hi = frag_of(v[i].z, v[i].w);
+        x.a = MFMA4(FA[2 * (T0 + i)], lo, x.a);
+        y.a = MFMA4(FB[2 * (T0 + i)], lo, y.a);
+        x.b = MFMA4(FA[2 * (T0 + i) + 1], hi, x.b);
+        y.b = MFMA4(FB[2 * (T0 + i) + 1], hi, y.b);
+    }
+}
+// one matrix, four accumulators
+struct Acc4 { f4 a, b, c, d; };
+template <int T0>
+__device__ __forceinline__ void mm1(const bf4 (&FA)[32], const u4 (&v)[8], Acc4& x) {
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+        x.a = MFMA4(FA[2 * (T0 + i)], frag_of(v[i].x, v[i].y), x.a);
+        x.b = MFMA4(FA[2 * (T0 + i) + 1], frag_of(v[i].z, v[i].w), x.b);
+        x.c = MFMA4(FA[2 * (T0 + i) + 2], frag_of(v[i + 1].x, v[i + 1].y), x.c);
+        x.d = MFMA4(FA[2 * (T0 + i) + 3], frag_of(v[i + 1].z, v[i + 1].w), x.d);
+    }
+}
+// the two rows a lane owns after the K halves are summed: registers (0, 2) -> row 2 kh, registers (1, 3) -> row 2 kh + 1
+__device__ __forceinline__ void rows_of(const f4& t, float& ra, float& rb) {
+    ra = half_add(t[0], t[2]);
+    rb = half_add(t[1], t[3]);
+}
+
+// rho rows are staged through LDS one 32-step chunk at a time (a row per step straight from L2 / HBM costs its full
+// latency every step: the table is 16 MB at D = 128); the next chunk is loaded into registers at the start of a chunk and
+// committed to the other buffer in the middle of it
+constexpr int RCH = 32;
+struct RhoStage {
+    __attribute__((aligned(16))) float2 row[2][RCH][PD];
+};
+__device__ __forceinline__ void rho_load(const Dev& P, int chunk, int tid, float4 (&r)[8]) {
+    const float4* src = reinterpret_cast<const float4*>(P.rho);       // [N + 1][PD] float2 = 64 float4 per row
+    const int maxrow = P.N;                                            // the table has N + 1 rows
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int e = tid + 256 * i;
+        int rowi = chunk * RCH + (e >> 6);
+        rowi = rowi < 0 ? 0 : (rowi > maxrow ? maxrow : rowi);
+        r[i] = src[(size_t)rowi * 64 + (e & 63)];
+    }
+}
+__device__ __forceinline__ void rho_commit(RhoStage& S, int buf, int tid, const float4 (&r)[8]) {
+    float4* dst = reinterpret_cast<float4*>(&S.row[buf][0][0]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dst[tid + 256 * i] = r[i];
+}
+
+// A fragments of one matrix for this lane: frag[t] = 4 bf16 = M_part[row][4t..4t+3]
+template <typename F>
+__device__ __forceinline__ void load_frags(bf4 (&frag)[32], F&& elem) {
+#pragma unroll
+    for (int t = 0; t < 32; ++t) {
+        bf4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (short)bf16_rne(elem(4 * t + j));
+        frag[t] = v;
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <bool SAVE>
+__global__ __launch_bounds__(64 * PWV, 1) void k_fwd_pair(Dev P, const float* __restrict__ audio,
+                                                          float* __restrict__ loss_out) {
+    __shared__ PairLds L;
+    __shared__ RhoStage RS;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int c = lane & 3, q = c >> 1, rg = (lane >> 2) & 7, kh = lane >> 5;
+    const bool odd = (c & 1) != 0;
+    const int N = P.N, T = P.T, NC = (N + PCH - 1) / PCH;
+    const int b0 = 2 * blockIdx.x, b1 = (b0 + 1 < P.B) ? b0 + 1 : b0;   // an odd batch repeats its last clip (not stored)
+    const bool two = b1 != b0;
+    const int ia = 32 * w + 4 * rg + 2 * kh, ib = ia + 1;              // the two (adjacent) rows this lane owns after rows_of
+    const int arow = 32 * w + 4 * rg + c;                              // the row of this lane's A operand
+
+    // ---- matrices as bf16 A fragments (rounded once per launch) ----
+    bf4 FR[32], FQ[32], FH[32];
+    {
+        const float2* Rrow = P.R + (size_t)arow * PD;
+        const float2* Qrow = P.Q + (size_t)arow * PD;
+        const float2* RTrow = P.RT + (size_t)arow * PD;     // RT[i][j] = R[j][i]
+        if (kh == 0) {
+            load_frags(FR, [&](int j) { return Rrow[j].x; });
+            load_frags(FQ, [&](int j) { return Qrow[j].x; });
+            load_frags(FH, [&](int j) { return Rrow[j].x + RTrow[j].x; });
+        } else {
+            load_frags(FR, [&](int j) { return Rrow[j].y; });
+            load_frags(FQ, [&](int j) { return Qrow[j].y; });
+            load_frags(FH, [&](int j) { return Rrow[j].y - RTrow[j].y; });
+        }
+    }
+    // ---- LDS addressing ----
+    // read: lane (kh, c) streams 256 B of array  kh == 0 ? (odd ? im : re) : (odd ? re : -im)  of clip q
+    const int rd_arr = kh == 0 ? (odd ? 1 : 0) : (odd ? 0 : 2);
+    const int rd_off = (rd_arr * 2 + q) * VROW;
+    // write: even lanes own Re rows -> array re (second write to the dummy row); odd lanes own Im rows -> im and -im
+    const int wr1 = ((odd ? 1 : 0) * 2 + q) * VROW;
+    const int wr2 = (odd ? 2 * 2 + q : 3 * 2 + q) * VROW;
+    auto write_vec = [&](unsigned char* base, float xa, float xb) {
+        const unsigned pk = pk_bf16(xa, xb);                           // rows ia, ia + 1 are adjacent: one 4-byte store each
+        *reinterpret_cast<unsigned*>(base + wr1 + ia * 2) = pk;
+        *reinterpret_cast<unsigned*>(base + wr2 + ia * 2) = pk ^ 0x80008000u;
+    };
+
+    const float* xr0 = audio + (size_t)b0 * T;
+    const float* xr1 = audio + (size_t)b1 * T;
+    const float A = P.A;
+    float4* st = SAVE ? reinterpret_cast<float4*>(P.stash) + ((size_t)blockIdx.x * N * PWV + w) * 64 + lane : nullptr;
+    float* sc0 = SAVE ? P.scal + ((size_t)b0 * NC) * 128 : nullptr;
+    float* sc1 = SAVE ? P.scal + ((size_t)b1 * NC) * 128 : nullptr;
+
+    const float2 pa = P.psi0[ia], pb = P.psi0[ib];
+    float uta = odd ? pa.y : pa.x, utb = odd ? pb.y : pb.x;          // ut_0 = psi_0 (both clips)
+    float inv = 1.f;                                                  // 1/sqrt(max(|y_{k-1}|^2, eps)) of this lane's clip
+    float ya = 0.f, yb = 0.f;                                         // y_{k-1}
+    float loss0 = 0.f, loss1 = 0.f;
+    float nv0 = 1.f, nv1 = 1.f, ev0 = 0.f, ev1 = 0.f;                 // per-chunk |y_k|^2 and e_k rows, lane <-> step
+    float sv0 = 0.f, sv1 = 0.f;                                       // s = x / A of the chain's current chunk
+    write_vec(L.vec[0][0], uta, utb);
+    {
+        float4 rpre[8];
+        rho_load(P, 0, threadIdx.x, rpre);
+        rho_commit(RS, 0, threadIdx.x, rpre);
+    }
+    __syncthreads();
+
+    for (int k = 0; k <= N + 1; ++k) {
+        const int p = k & 1;
+        const bool chain = k < N, hpart = k >= 1 && k <= N;
+        if ((k & (RCH - 1)) == 0) {        // next chunk of rho into the other buffer (no register staging: the kernel
+            float4 rpre[8];                // has none to spare, and a spilled stage serialises the eight loads)
+            rho_load(P, k / RCH + 1, threadIdx.x, rpre);
+            rho_commit(RS, (k / RCH + 1) & 1, threadIdx.x, rpre);
+        }
+        if (chain && (k & (PCH - 1)) == 0) {                          // increments of the next 64 steps, one per lane
+            const int idx = k + lane;
+            const bool in0 = idx < T, in1 = idx + 1 < T;
+            sv0 = ((in1 ? xr0[idx + 1] : 0.f) - (in0 ? xr0[idx] : 0.f)) / A;     // model.py:263, 303
+            sv1 = ((in1 ? xr1[idx + 1] : 0.f) - (in0 ? xr1[idx] : 0.f)) / A;
+        }
+        const float2 rha = RS.row[(k / RCH) & 1][k & (RCH - 1)][ia];   // rho_k of this lane's rows
+        const float2 rhb = RS.row[(k / RCH) & 1][k & (RCH - 1)][ib];
+        // ---- totals published by the previous iteration ----
+        if (hpart) {                                                   // |y_{k-1}|^2
+            const f4 t4 = *reinterpret_cast<const f4*>(&L.nrm[p][q][0]);
+            const float n = (t4.x + t4.y) + (t4.z + t4.w);
+            inv = __builtin_amdgcn_rsqf(fmaxf(n, 1e-12f));             // model.py:332 (v_rsq_f32: 1 ulp)
+            const int j = k - 1, jl = j & (PCH - 1);
+            const float n0 = rdl(n, 0), n1 = rdl(n, 2);
+            nv0 = lane == jl ? n0 : nv0;
+            nv1 = lane == jl ? n1 : nv1;
+            if (SAVE && w == 0 && (jl == PCH - 1 || j == N - 1)) {
+                sc0[(size_t)(j / PCH) * 128 + lane] = nv0;
+                if (two) sc1[(size_t)(j / PCH) * 128 + lane] = nv1;
+            }
+        }
+        if (k >= 2) {                                                  // e_{k-2}
+            const f4 t4 = *reinterpret_cast<const f4*>(&L.ee[p][q][0]);
+            const float e = (t4.x + t4.y) + (t4.z + t4.w);
+            const int j = k - 2, jl = j & (PCH - 1);
+            const float e0 = rdl(e, 0), e1 = rdl(e, 2);
+            ev0 = lane == jl ? e0 : ev0;
+            ev1 = lane == jl ? e1 : ev1;
+            if (jl == PCH - 1 || j == N - 1) {                         // a chunk of the loss is complete
+                const int base = j - jl, cnt = jl + 1, idx = base + lane;
+                const bool in0 = idx < T, in1 = idx + 1 < T;
+                const float inc0 = (in1 ? xr0[idx + 1] : 0.f) - (in0 ? xr0[idx] : 0.f);
+                const float inc1 = (in1 ? xr1[idx + 1] : 0.f) - (in0 ? xr1[idx] : 0.f);
+                const float lv0 = -logf(1.0f + (ev0 * inc0) / A);      // model.py:294 operation order
+                const float lv1 = -logf(1.0f + (ev1 * inc1) / A);
+                for (int jj = 0; jj < cnt; ++jj) {                     // model.py:279: sequential in time
+                    loss0 += rdl(lv0, jj);
+                    loss1 += rdl(lv1, jj);
+                }
+                if (SAVE && w == 0) {
+                    sc0[(size_t)(j / PCH) * 128 + 64 + lane] = ev0;
+                    if (two) sc1[(size_t)(j / PCH) * 128 + 64 + lane] = ev1;
+                }
+            }
+        }
+        // ---- the mat-vecs: B fragments in two batches of eight reads each, double buffered ----
+        const f4 z4 = {0.f, 0.f, 0.f, 0.f};
+        Acc2 cR = {z4, z4}, cQ = {z4, z4};
+        Acc4 cH = {z4, z4, z4, z4};
+        {
+            const unsigned aU = lds_addr_of(L.vec[p][0]) + rd_off, aY = lds_addr_of(L.vec[p][1]) + rd_off;
+            u4 B0[8], B1[8];
+            if (chain && hpart) {
+                rd8(aU, B0);
+                rd8(aU + 128, B1);
+                rd_wait<8>(B0);
+                mm2<0>(FR, FQ, B0, cR, cQ);
+                rd8(aY, B0);
+                rd_wait<8>(B1);
+                mm2<8>(FR, FQ, B1, cR, cQ);
+                rd8(aY + 128, B1);
+                rd_wait<8>(B0);
+                mm1<0>(FH, B0, cH);
+                rd_wait<0>(B1);
+                mm1<8>(FH, B1, cH);
+            } else if (chain) {
+                rd8(aU, B0);
+                rd8(aU + 128, B1);
+                rd_wait<8>(B0);
+                mm2<0>(FR, FQ, B0, cR, cQ);
+                rd_wait<0>(B1);
+                mm2<8>(FR, FQ, B1, cR, cQ);
+            } else if (hpart) {
+                rd8(aY, B0);
+                rd8(aY + 128, B1);
+                rd_wait<8>(B0);
+                mm1<0>(FH, B0, cH);
+                rd_wait<0>(B1);
+                mm1<8>(FH, B1, cH);
+            }
+        }
+        const f4 aR = cR.a + cR.b, aQ = cQ.a + cQ.b, aH = (cH.a + cH.b) + (cH.c + cH.d);
+        float yna = 0.f, ynb = 0.f;
+        if (chain) {
+            const int kl = k & (PCH - 1);
+            const float s0 = rdl(sv0, kl), s1 = rdl(sv1, kl);
+            const float s = q ? s1 : s0;
+            float ra, rb, qa, qb;
+            rows_of(aR, ra, rb);
+            rows_of(aQ, qa, qb);
+            yna = inv * (uta + (qa + s * ra));                         // y_k, rows ia / ib
+            ynb = inv * (utb + (qb + s * rb));
+            const float nn = clip_sum(yna * yna + ynb * ynb);
+            if (lane == 0 || lane == 2) L.nrm[p ^ 1][q][w] = nn;
+            // ut_{k+1} = rho_k y_k (un-normalised): own component with the partner's (re <-> im) through DPP
+            const float pya = dpp_mov<0xB1>(yna), pyb = dpp_mov<0xB1>(ynb);
+            uta = rha.x * yna + (odd ? rha.y : -rha.y) * pya;
+            utb = rhb.x * ynb + (odd ? rhb.y : -rhb.y) * pyb;
+            write_vec(L.vec[p ^ 1][0], uta, utb);
+            write_vec(L.vec[p ^ 1][1], yna, ynb);
+        }
+        if (hpart) {
+            float ha, hb;                                              // ((R + R^dagger) y_{k-1}) rows ia / ib
+            rows_of(aH, ha, hb);
+            if (SAVE) st[(size_t)(k - 1) * PWV * 64] = make_float4(ya, yb, ha, hb);
+            const float ep = clip_sum(ya * ha + yb * hb);
+            if (lane == 0 || lane == 2) L.ee[p ^ 1][q][w] = ep;
+        }
+        ya = yna;
+        yb = ynb;
+        lds_barrier();
+    }
+    if (w == 0 && lane == 0) {
+        loss_out[b0] = loss0;
+        if (two) loss_out[b1] = loss1;
+    }
+}
+
+hipError_t launch_fwd_pair(const Dev& P, const float* audio, float* loss, bool save, hipStream_t s) {
+    const unsigned nb = (unsigned)((P.B + 1) / 2);
+    if (save)
+        hipLaunchKernelGGL(k_fwd_pair<true>, dim3(nb), dim3(64 * PWV), 0, s, P, audio, loss);
+    else
+        hipLaunchKernelGGL(k_fwd_pair<false>, dim3(nb), dim3(64 * PWV), 0, s, P, audio, loss);
+    return hipGetLastError();
+}
+
+}  // namespace cmps
+
+namespace cmps {
+
+// ------------------------------------------------------------------------------------------------
+// reverse scan: the cotangent recursion only; the rank-1 gradient contractions over (clip, step) are a GEMM and run in
+// k_grad_pair from the rows this kernel leaves behind (stash row k becomes (y_k, ybar_k)).
+//   yhat = y_k inv_k;  yhb = conj(rho_k) g;  ybar = (yhb - yhat rad_{k+1}) inv_k + te_k H y_k
+//   g    = ybar + Q ybar + s_k R^dagger ybar            (64 MFMAs, bf16 operands)
+//   fbar += dt_k Im(g conj(rho_k yhat));   Abar += zbar_k (-e_k x_k / A^2) + Re(d^dagger u_k) (-x_k / A^2)
+// rad_{k+1} = Re(u_{k+1}^dagger g_{k+1}) = 2 ebar_{k+1} e_{k+1} (Euler's theorem: everything downstream of u_{k+1} is
+// scale invariant except the loss term of step k+1, which is homogeneous of degree 2), 0 behind the last step.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+// per-step scalars of one clip: (s, inv, ok, te | rad, xa = -x/A^2, dt, -)
+struct StepTab {
+    __attribute__((aligned(16))) f4 row[PWV][2][PCH][2][2];            // [wave][chunk parity][step][clip][half]
+};
+
+}  // namespace
+
+__global__ __launch_bounds__(64 * PWV, 1) void k_bwd_pair(Dev P, const float* __restrict__ audio) {
+    __shared__ PairLds L;
+    __shared__ StepTab TB;
+    __shared__ float redA[PWV];
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int c = lane & 3, q = c >> 1, rg = (lane >> 2) & 7, kh = lane >> 5;
+    const bool odd = (c & 1) != 0;
+    const int N = P.N, T = P.T, NC = (N + PCH - 1) / PCH;
+    const int b0 = 2 * blockIdx.x, b1 = (b0 + 1 < P.B) ? b0 + 1 : b0;
+    const bool two = b1 != b0;
+    const float wq = (q == 0 || two) ? 1.f : 0.f;                      // weight of this lane's clip (0: the repeated clip)
+    const int ia = 32 * w + 4 * rg + 2 * kh, ib = ia + 1;
+    const int arow = 32 * w + 4 * rg + c;
+
+    bf4 FQ[32], FD[32];                                                // Q (Hermitian) and R^dagger
+    {
+        const float2* Qrow = P.Q + (size_t)arow * PD;
+        const float2* RTrow = P.RT + (size_t)arow * PD;                // R^dagger[i][j] = conj(R[j][i]) = conj(RT[i][j])
+        if (kh == 0) {
+            load_frags(FQ, [&](int j) { return Qrow[j].x; });
+            load_frags(FD, [&](int j) { return RTrow[j].x; });
+        } else {
+            load_frags(FQ, [&](int j) { return Qrow[j].y; });
+            load_frags(FD, [&](int j) { return -RTrow[j].y; });
+        }
+    }
+    const int rd_arr = kh == 0 ? (odd ? 1 : 0) : (odd ? 0 : 2);
+    const int rd_off = (rd_arr * 2 + q) * VROW;
+    const int wr1 = ((odd ? 1 : 0) * 2 + q) * VROW;
+    const int wr2 = (odd ? 2 * 2 + q : 3 * 2 + q) * VROW;
+    auto write_vec = [&](unsigned char* base, float xa, float xb) {
+        const unsigned pk = pk_bf16(xa, xb);                           // rows ia, ia + 1 are adjacent: one 4-byte store each
+        *reinterpret_cast<unsigned*>(base + wr1 + ia * 2) = pk;
+        *reinterpret_cast<unsigned*>(base + wr2 + ia * 2) = pk ^ 0x80008000u;
+    };
+    const float* xr0 = audio + (size_t)b0 * T;
+    const float* xr1 = audio + (size_t)b1 * T;
+    const float* sc0 = P.scal + ((size_t)b0 * NC) * 128;
+    const float* sc1 = P.scal + ((size_t)b1 * NC) * 128;
+    float4* st = reinterpret_cast<float4*>(P.stash) + ((size_t)blockIdx.x * N * PWV + w) * 64 + lane;
+    const float A = P.A;
+    const float sgn = odd ? 1.f : -1.f;                                // (rho x)_own = rho_re x_own + sgn rho_im x_partner
+
+    // every wave builds its own copy of the chunk's scalar rows (no cross-wave hand-over): lane <-> step
+    float accA = 0.f;
+    auto chunk_rows = [&](int cj) {
+        const int idx = cj * PCH + lane;
+        const bool in = idx < N;
+        const float dtv = in ? P.dtk[idx] : 0.f;
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+            const float* xr = qq ? xr1 : xr0;
+            const float* sc = qq ? sc1 : sc0;
+            const float x0 = idx < T ? xr[idx] : 0.f, x1 = idx + 1 < T ? xr[idx + 1] : 0.f;
+            const float inc = x1 - x0;
+            const float nv = in ? sc[(size_t)cj * 128 + lane] : 1.f;
+            const float ev = in ? sc[(size_t)cj * 128 + 64 + lane] : 0.f;
+            const float ex = ev * inc;                                 // model.py:294 operation order
+            const float z = ex / A;
+            const float zbar = -1.0f / (1.0f + z);
+            const float te = 2.0f * (zbar * inc / A);
+            f4 r0, r1;
+            r0.x = inc / A;
+            r0.y = 1.0f / sqrtf(fmaxf(nv, 1e-12f));
+            r0.z = nv > 1e-12f ? 1.f : 0.f;
+            r0.w = te;
+            r1.x = te * ev;
+            r1.y = -inc / (A * A);
+            r1.z = dtv;
+            r1.w = 0.f;
+            TB.row[w][cj & 1][lane][qq][0] = r0;
+            TB.row[w][cj & 1][lane][qq][1] = r1;
+            if (in && w == 0 && (qq == 0 || two)) accA += zbar * (-ex / (A * A));
+        }
+    };
+
+    float ga = 0.f, gb = 0.f, facca = 0.f, faccb = 0.f, accS = 0.f, rad_next = 0.f;
+    float4 cur = st[(size_t)(N - 1) * PWV * 64];
+    chunk_rows((N - 1) / PCH);
+    int p = 0;
+    for (int k = N - 1; k >= 0; --k, p ^= 1) {
+        const int jl = k & (PCH - 1), cp = (k / PCH) & 1;
+        if (jl == 0 && k > 0) chunk_rows(k / PCH - 1);                 // u_k needs inv_{k-1}: the chunk below, other buffer
+        const float4 nxt = k > 0 ? st[(size_t)(k - 1) * PWV * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float2 rha = P.rho[(size_t)k * PD + ia], rhb = P.rho[(size_t)k * PD + ib];
+        float2 rpa = make_float2(1.f, 0.f), rpb = rpa;
+        if (k > 0) {
+            rpa = P.rho[(size_t)(k - 1) * PD + ia];
+            rpb = P.rho[(size_t)(k - 1) * PD + ib];
+        }
+        const f4 S0 = TB.row[w][cp][jl][q][0], S1 = TB.row[w][cp][jl][q][1];
+        const float s = S0.x, inv = S0.y, ok = S0.z, te = S0.w, rad = S1.x, xa = S1.y, dt = S1.z;
+        const float ya = cur.x, yb = cur.y, ha = cur.z, hb = cur.w;
+        const float yha = ya * inv, yhb = yb * inv;
+        const float pga = dpp_mov<0xB1>(ga), pgb = dpp_mov<0xB1>(gb);
+        {   // u_{k+1} = rho_k yhat and the frequency gradient (meaningful in the Re lanes)
+            const float una = rha.x * yha + sgn * rha.y * dpp_mov<0xB1>(yha);
+            const float unb = rhb.x * yhb + sgn * rhb.y * dpp_mov<0xB1>(yhb);
+            facca += dt * (pga * una - ga * dpp_mov<0xB1>(una));
+            faccb += dt * (pgb * unb - gb * dpp_mov<0xB1>(unb));
+        }
+        const float hba = rha.x * ga - sgn * rha.y * pga;              // conj(rho_k) g
+        const float hbb = rhb.x * gb - sgn * rhb.y * pgb;
+        const float yba = (hba - ok * yha * rad_next) * inv + te * ha;
+        const float ybb = (hbb - ok * yhb * rad_next) * inv + te * hb;
+        write_vec(L.vec[p][0], yba, ybb);
+        st[(size_t)k * PWV * 64] = make_float4(ya, yb, yba, ybb);      // the row the gradient GEMM reads
+        lds_barrier();
+        const f4 z4 = {0.f, 0.f, 0.f, 0.f};
+        Acc2 cQ = {z4, z4}, cD = {z4, z4};
+        {
+            const unsigned aV = lds_addr_of(L.vec[p][0]) + rd_off;
+            u4 B0[8], B1[8];
+            rd8(aV, B0);
+            rd8(aV + 128, B1);
+            rd_wait<8>(B0);
+            mm2<0>(FQ, FD, B0, cQ, cD);
+            rd_wait<0>(B1);
+            mm2<8>(FQ, FD, B1, cQ, cD);
+        }
+        float qa, qb, da, db;
+        rows_of(cQ.a + cQ.b, qa, qb);
+        rows_of(cD.a + cD.b, da, db);
+        // u_k = rho_{k-1} y_{k-1} inv_{k-1}  (psi_0 at k = 0)
+        float uka, ukb;
+        if (k > 0) {
+            const int jp = (k - 1) & (PCH - 1), cpp = ((k - 1) / PCH) & 1;
+            const float invp = TB.row[w][cpp][jp][q][0].y;
+            const float ypa = nxt.x * invp, ypb = nxt.y * invp;
+            uka = rpa.x * ypa + sgn * rpa.y * dpp_mov<0xB1>(ypa);
+            ukb = rpb.x * ypb + sgn * rpb.y * dpp_mov<0xB1>(ypb);
+        } else {
+            const float2 pa = P.psi0[ia], pb = P.psi0[ib];
+            uka = odd ? pa.y : pa.x;
+            ukb = odd ? pb.y : pb.x;
+        }
+        accS += (da * uka + db * ukb) * xa;
+        ga = yba + qa + s * da;
+        gb = ybb + qb + s * db;
+        rad_next = rad;
+        cur = nxt;
+    }
+    // ---- the pair's slab: f | psi0bar_re | psi0bar_im | A (the R / Q sections are written by k_grad_pair) ----
+    float* slab = P.slabs + (size_t)blockIdx.x * P.slab_floats;
+    const int DD = PD * PD;
+    {
+        const float fa = facca * wq, fb = faccb * wq;
+        const float fta = fa + dpp_mov<0x4E>(fa), ftb = fb + dpp_mov<0x4E>(fb);      // quad_perm [2,3,0,1]: the other clip
+        const float g0a = ga * wq, g0b = gb * wq;
+        const float gta = g0a + dpp_mov<0x4E>(g0a), gtb = g0b + dpp_mov<0x4E>(g0b);
+        if (c == 0) {
+            slab[4 * DD + ia] = fta;
+            slab[4 * DD + ib] = ftb;
+            slab[4 * DD + PD + ia] = gta;
+            slab[4 * DD + PD + ib] = gtb;
+        } else if (c == 1) {
+            slab[4 * DD + 2 * PD + ia] = gta;
+            slab[4 * DD + 2 * PD + ib] = gtb;
+        }
+    }
+    // Abar: sum of accS over all lanes (both clips, weighted) + sum of accA over wave 0's lanes
+    {
+        float t = accS * wq + (w == 0 ? accA : 0.f);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+        if (lane == 0) redA[w] = t;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            slab[4 * DD + 3 * PD] = (redA[0] + redA[1]) + (redA[2] + redA[3]);
+            slab[4 * DD + 3 * PD + 1] = 0.f;
+        }
+    }
+}
+
+hipError_t launch_bwd_pair(const Dev& P, const float* audio, hipStream_t s) {
+    const unsigned nb = (unsigned)((P.B + 1) / 2);
+    hipLaunchKernelGGL(k_bwd_pair, dim3(nb), dim3(64 * PWV), 0, s, P, audio);
+    return hipGetLastError();
+}
+
+}  // namespace cmps
+
+namespace cmps {
+
+// ------------------------------------------------------------------------------------------------
+// gradient contraction: Rbar = sum_{clip,k} (te_k y_k) y_k^dagger + (s_k ybar_k) u_k^dagger,  Qbar = sum ybar_k u_k^dagger
+// as bf16 MFMA GEMMs (v_mfma_f32_32x32x16_bf16, fp32 accumulators resident for the whole pair) over the rows the two
+// scans left in the stash.  A complex outer product  C += a b^dagger  is two real GEMMs over K = (step, clip, {re, im}):
+//   Re C = [a_re | a_im] [b_re | b_im]^T,   Im C = [a_im | -a_re] [b_re | b_im]^T.
+// One MFMA covers K = 16 = 4 steps x 2 clips x {re, im}; wave w owns the row block 32w..32w+31 of all four outputs.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+typedef short bf8 __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+constexpr int GS = 4;                                   // steps per MFMA group
+struct GradLds {
+    // [buffer][operand: te y, ybar, s ybar, y, u][re / im][row][(clip, step in group)] bf16
+    __attribute__((aligned(16))) unsigned short op[2][5][2][PD][2 * GS];
+    __attribute__((aligned(16))) f4 tab[PWV][2][PCH][2];            // per wave: (s, te, inv, -) per step and clip
+};
+
+__device__ __forceinline__ bf8 neg_if(bf8 v, unsigned mask) {
+    u4 t = __builtin_bit_cast(u4, v);
+    t.x ^= mask; t.y ^= mask; t.z ^= mask; t.w ^= mask;
+    return __builtin_bit_cast(bf8, t);
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(64 * PWV, 1) void k_grad_pair(Dev P, const float* __restrict__ audio) {
+    __shared__ GradLds G;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    // producer view of a lane (the scans' layout): rows ia / ib, component (c & 1), clip q
+    const int c = lane & 3, q = c >> 1, rg = (lane >> 2) & 7, kh = lane >> 5;
+    const bool odd = (c & 1) != 0;
+    const int ia = 32 * w + 4 * rg + 2 * kh, ib = ia + 1;
+    // consumer view (32x32x16 MFMA): row / column = lane & 31, K half = lane >> 5
+    const int mr = lane & 31, mh = lane >> 5;
+    const int N = P.N, T = P.T, NC = (N + PCH - 1) / PCH;
+    const int b0 = 2 * blockIdx.x, b1 = (b0 + 1 < P.B) ? b0 + 1 : b0;
+    const bool two = b1 != b0;
+    const float wq = (q == 0 || two) ? 1.f : 0.f;
+    const float* xr0 = audio + (size_t)b0 * T;
+    const float* xr1 = audio + (size_t)b1 * T;
+    const float* sc0 = P.scal + ((size_t)b0 * NC) * 128;
+    const float* sc1 = P.scal + ((size_t)b1 * NC) * 128;
+    const float4* st = reinterpret_cast<const float4*>(P.stash) + ((size_t)blockIdx.x * N * PWV + w) * 64 + lane;
+    const float A = P.A;
+    const float sgn = odd ? 1.f : -1.f;
+
+    auto chunk_rows = [&](int cj) {
+        const int idx = cj * PCH + lane;
+        const bool in = idx < N;
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+            const float* xr = qq ? xr1 : xr0;
+            const float* sc = qq ? sc1 : sc0;
+            const float x0 = idx < T ? xr[idx] : 0.f, x1 = idx + 1 < T ? xr[idx + 1] : 0.f;
+            const float inc = x1 - x0;
+            const float nv = in ? sc[(size_t)cj * 128 + lane] : 1.f;
+            const float ev = in ? sc[(size_t)cj * 128 + 64 + lane] : 0.f;
+            const float z = (ev * inc) / A;
+            const float zbar = -1.0f / (1.0f + z);
+            f4 r;
+            r.x = inc / A;
+            r.y = in ? 2.0f * (zbar * inc / A) : 0.f;
+            r.z = 1.0f / sqrtf(fmaxf(nv, 1e-12f));
+            r.w = 0.f;
+            G.tab[w][cj & 1][lane][qq] = r;
+        }
+    };
+
+    f16v Rre[4], Rim[4], Qre[4], Qim[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Rre[cb][r] = Rim[cb][r] = Qre[cb][r] = Qim[cb][r] = 0.f;
+
+    // producer: fill one group's operand rows (this lane's two rows, component and clip; 4 steps -> one 8-byte store each)
+    float ypa = 0.f, ypb = 0.f, invp = 1.f;                           // y_{k-1} and inv_{k-1} carried across groups
+    float2 rpa = make_float2(1.f, 0.f), rpb = rpa;                     // rho_{k-1}
+    auto fill = [&](int g, int buf) {
+        unsigned short v[5][2][GS];
+#pragma unroll
+        for (int s4 = 0; s4 < GS; ++s4) {
+            const int k = g * GS + s4;
+            const bool in = k < N;
+            if (in && (k & (PCH - 1)) == 0) chunk_rows(k / PCH);
+            float4 row = make_float4(0.f, 0.f, 0.f, 0.f);
+            f4 sr = {0.f, 0.f, 1.f, 0.f};
+            if (in) {
+                row = st[(size_t)k * PWV * 64];
+                sr = G.tab[w][(k / PCH) & 1][k & (PCH - 1)][q];
+            }
+            const float s = sr.x, te = sr.y * wq;
+            float uka, ukb;
+            if (k == 0) {
+                const float2 pa = P.psi0[ia], pb = P.psi0[ib];
+                uka = odd ? pa.y : pa.x;
+                ukb = odd ? pb.y : pb.x;
+            } else {
+                const float ta = ypa * invp, tb = ypb * invp;
+                uka = rpa.x * ta + sgn * rpa.y * dpp_mov<0xB1>(ta);
+                ukb = rpb.x * tb + sgn * rpb.y * dpp_mov<0xB1>(tb);
+            }
+            const float yba = row.z * wq, ybb = row.w * wq;
+            v[0][0][s4] = bf16_rne(te * row.x); v[0][1][s4] = bf16_rne(te * row.y);
+            v[1][0][s4] = bf16_rne(yba);        v[1][1][s4] = bf16_rne(ybb);
+            v[2][0][s4] = bf16_rne(s * yba);    v[2][1][s4] = bf16_rne(s * ybb);
+            v[3][0][s4] = bf16_rne(row.x);      v[3][1][s4] = bf16_rne(row.y);
+            v[4][0][s4] = bf16_rne(in ? uka : 0.f); v[4][1][s4] = bf16_rne(in ? ukb : 0.f);
+            if (in) {
+                ypa = row.x; ypb = row.y; invp = sr.z;
+                rpa = P.rho[(size_t)k * PD + ia];
+                rpb = P.rho[(size_t)k * PD + ib];
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < 5; ++o) {
+            unsigned short* da = &G.op[buf][o][odd ? 1 : 0][ia][q * GS];
+            unsigned short* db = &G.op[buf][o][odd ? 1 : 0][ib][q * GS];
+            *reinterpret_cast<uint2*>(da) = make_uint2(v[o][0][0] | (unsigned)v[o][0][1] << 16, v[o][0][2] | (unsigned)v[o][0][3] << 16);
+            *reinterpret_cast<uint2*>(db) = make_uint2(v[o][1][0] | (unsigned)v[o][1][1] << 16, v[o][1][2] | (unsigned)v[o][1][3] << 16);
+        }
+    };
+
+    const int NG = (N + GS - 1) / GS;
+    fill(0, 0);
+    __syncthreads();
+    const unsigned nmask = mh ? 0x80008000u : 0u;
+    for (int g = 0; g < NG; ++g) {
+        const int buf = g & 1;
+        if (g + 1 < NG) fill(g + 1, buf ^ 1);
+        // A fragments of this wave's row block: Re form (h ? X_im : X_re), Im form (h ? -X_re : X_im)
+        bf8 aRe[3], aIm[3];
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            aRe[o] = *reinterpret_cast<const bf8*>(&G.op[buf][o][mh][32 * w + mr][0]);
+            aIm[o] = neg_if(*reinterpret_cast<const bf8*>(&G.op[buf][o][mh ^ 1][32 * w + mr][0]), nmask);
+        }
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            const bf8 by = *reinterpret_cast<const bf8*>(&G.op[buf][3][mh][32 * cb + mr][0]);
+            const bf8 bu = *reinterpret_cast<const bf8*>(&G.op[buf][4][mh][32 * cb + mr][0]);
+            Rre[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aRe[0], by, Rre[cb], 0, 0, 0);
+            Rim[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aIm[0], by, Rim[cb], 0, 0, 0);
+            Qre[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aRe[1], bu, Qre[cb], 0, 0, 0);
+            Qim[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aIm[1], bu, Qim[cb], 0, 0, 0);
+            Rre[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aRe[2], bu, Rre[cb], 0, 0, 0);
+            Rim[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aIm[2], bu, Rim[cb], 0, 0, 0);
+        }
+        lds_barrier();
+    }
+    float* slab = P.slabs + (size_t)blockIdx.x * P.slab_floats;
+    constexpr int DD = PD * PD;
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 * w + (r & 3) + 8 * (r >> 2) + 4 * mh;   // C/D layout of the 32x32 MFMA: column = lane & 31
+            const int o = row * PD + 32 * cb + mr;
+            slab[o] = Rre[cb][r];
+            slab[DD + o] = Rim[cb][r];
+            slab[2 * DD + o] = Qre[cb][r];
+            slab[3 * DD + o] = Qim[cb][r];
+        }
+}
+
+hipError_t launch_grad_pair(const Dev& P, const float* audio, hipStream_t s) {
+    const unsigned nb = (unsigned)((P.B + 1) / 2);
+    hipLaunchKernelGGL(k_grad_pair, dim3(nb), dim3(64 * PWV), 0, s, P, audio);
+    return hipGetLastError();
+}
+
+}  // namespace cmps

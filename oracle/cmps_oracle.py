@@ -744,3 +744,114 @@ def rho_sample(hp: HParams, var: Variables, Wx, Wy, noise, dtype="f32"):
     rhos = np.stack(rhos, axis=1)
     purity = np.einsum('abcd,abdc->ab', rhos, rhos).real.astype(real)             # :101
     return (A * np.stack(outs, axis=1)).astype(real), rhos, purity
+
+
+# --------------------------------------------------------------------------------------------
+# BASELINE configs[4] (D = 128, "bf16 with fp32 accumulate"): emulation of the arithmetic the MFMA pair kernels execute
+# (audio_mps_amd/csrc/cmps_pair.hip).  Same recurrence as above in the rotating frame, but every matrix-vector
+# product takes bfloat16 operands (round-to-nearest-even) with float32 accumulation; everything else stays float32.
+# The float32 restatement above remains the reference; this one pins down WHAT the reduced-precision kernels compute so
+# that their parity test can be tight, and the distance between the two is the documented cost of bf16.
+# --------------------------------------------------------------------------------------------
+def bf16_round(x):
+    """float32 -> nearest bfloat16 (ties to even), returned as float32 (v_cvt_pk_bf16_f32)."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    r = ((u >> np.uint32(16)) & np.uint32(1)) + np.uint32(0x7FFF)
+    return ((u + r) & np.uint32(0xFFFF0000)).view(np.float32)
+
+
+def _cbf(z):
+    return (bf16_round(z.real) + 1j * bf16_round(z.imag)).astype(np.complex64)
+
+
+def _cmatvec32(Mb, vb):
+    """rows of vb [B, D] times Mb^T with float32 real arithmetic: (M v)_i = sum_j M_ij v_j."""
+    Mr, Mi = Mb.real.astype(np.float32), Mb.imag.astype(np.float32)
+    vr, vi = vb.real.astype(np.float32), vb.imag.astype(np.float32)
+    return ((vr @ Mr.T - vi @ Mi.T) + 1j * (vi @ Mr.T + vr @ Mi.T)).astype(np.complex64)
+
+
+def psi_bf16_scan(hp: HParams, var: Variables, data, want_grad=True):
+    """Per-clip loss and effective-parameter gradient SUMS (layout of cmps_psi_loss_bwd / c_oracle.unpack_grad) with
+    bfloat16 mat-vec operands.  Rotating frame: ut_k = rho_{k-1} y_{k-1} (un-normalised), y_k = inv_{k-1} (ut + Q ut + s R ut)."""
+    f32, c64 = np.float32, np.complex64
+    data = np.asarray(data, dtype=f32)
+    B, T = data.shape
+    N = T - 1
+    D = hp.bond_dim
+    R, freqs, _, _ = effective_params(hp, var, "f32")
+    A = f32(var.A)
+    p0 = psi_0(var, "f32")
+    c_half = f32(f32(-hp.delta_t * hp.sigma ** 2) / f32(2))
+    Q = (np.float64(c_half) * (np.conj(R.T).astype(np.complex128) @ R.astype(np.complex128))).astype(c64)
+    H = (R + np.conj(R.T)).astype(c64)
+    Rb, Qb, Hb = _cbf(R), _cbf(Q), _cbf(H)
+    tt = time_table(hp.delta_t, N, "f32")
+    th = (freqs[None, :].astype(f32) * tt[:, None].astype(f32)).astype(f32)              # fl32(f * t_k)
+    dth = th[:-1].astype(np.float64) - th[1:].astype(np.float64)
+    rho = (np.cos(dth) + 1j * np.sin(dth)).astype(c64)                                     # rho_k = phases_k conj(phases_{k+1})
+    incs = (data[:, 1:] - data[:, :-1]).astype(f32)
+    ut = np.tile(p0[None, :], (B, 1)).astype(c64)
+    inv_prev = np.ones(B, dtype=f32)
+    loss = np.zeros(B, dtype=f32)
+    ys, hys, ns, es = [], [], [], []
+    for k in range(N):
+        x = incs[:, k]
+        s = (x / A).astype(f32)
+        ub = _cbf(ut)
+        av, aq = _cmatvec32(Rb, ub), _cmatvec32(Qb, ub)
+        y = (inv_prev[:, None] * (ut + (aq + s[:, None] * av))).astype(c64)
+        hy = _cmatvec32(Hb, _cbf(y))
+        e = np.sum(y.real * hy.real + y.imag * hy.imag, axis=1, dtype=f32)
+        n = np.sum(y.real ** 2 + y.imag ** 2, axis=1, dtype=f32)
+        loss = (loss + (-np.log(f32(1) + (e * x) / A))).astype(f32)
+        ys.append(y); hys.append(hy); ns.append(n); es.append(e)
+        inv_prev = (f32(1) / np.sqrt(np.maximum(n, f32(1e-12)))).astype(f32)
+        ut = (rho[k][None, :] * y).astype(c64)
+    out = {"loss_per_clip": loss}
+    if not want_grad:
+        return out
+    g = np.zeros((B, D), dtype=c64)
+    Rbar = np.zeros((D, D), dtype=np.complex128)
+    Qbar = np.zeros((D, D), dtype=np.complex128)
+    fbar = np.zeros(D, dtype=np.float64)
+    Abar = 0.0
+    dtk = (tt[:-1].astype(f32) - tt[1:].astype(f32)).astype(f32)
+    for k in range(N - 1, -1, -1):
+        x = incs[:, k]
+        s = (x / A).astype(f32)
+        y, hy, n, e = ys[k], hys[k], ns[k], es[k]
+        inv = (f32(1) / np.sqrt(np.maximum(n, f32(1e-12)))).astype(f32)
+        yhat = (inv[:, None] * y).astype(c64)
+        un = (rho[k][None, :] * yhat).astype(c64)
+        fbar += np.sum(dtk[k] * (g.imag * un.real - g.real * un.imag), axis=0, dtype=np.float64)
+        yhb = (np.conj(rho[k])[None, :] * g).astype(c64)
+        dot = np.sum(yhat.real * yhb.real + yhat.imag * yhb.imag, axis=1, dtype=f32)
+        ok = n > f32(1e-12)
+        ybar = np.where(ok[:, None], (yhb - yhat * dot[:, None]) * inv[:, None], yhb * inv[:, None]).astype(c64)
+        ex = (e * x).astype(f32)
+        z = (ex / A).astype(f32)
+        zbar = (f32(-1) / (f32(1) + z)).astype(f32)
+        te = (f32(2) * (zbar * x / A)).astype(f32)
+        Abar += float(np.sum(zbar * (-ex / (A * A)), dtype=np.float64))
+        ybar = (ybar + te[:, None] * hy).astype(c64)
+        ybb = _cbf(ybar)
+        bq = _cmatvec32(Qb, ybb)                                                           # Q Hermitian
+        d = _cmatvec32(np.conj(Rb.T), ybb)                                                 # R^dagger ybar
+        if k > 0:
+            invp = (f32(1) / np.sqrt(np.maximum(ns[k - 1], f32(1e-12)))).astype(f32)
+            uk = (rho[k - 1][None, :] * (invp[:, None] * ys[k - 1])).astype(c64)
+        else:
+            uk = np.tile(p0[None, :], (B, 1)).astype(c64)
+        sbar = np.sum(d.real * uk.real + d.imag * uk.imag, axis=1, dtype=f32)
+        Abar += float(np.sum(sbar * (-x / (A * A)), dtype=np.float64))
+        g = (ybar + bq + s[:, None] * d).astype(c64)
+        a1, b1 = _cbf((te[:, None] * y).astype(c64)), _cbf(y)
+        a2, a3, b2 = ybb, _cbf((s[:, None] * ybar).astype(c64)), _cbf(uk)
+        Rbar += np.einsum('bi,bj->ij', a1.astype(np.complex128), np.conj(b1).astype(np.complex128))
+        Rbar += np.einsum('bi,bj->ij', a3.astype(np.complex128), np.conj(b2).astype(np.complex128))
+        Qbar += np.einsum('bi,bj->ij', a2.astype(np.complex128), np.conj(b2).astype(np.complex128))
+    Rbar = Rbar + np.float64(c_half) * (R.astype(np.complex128) @ (Qbar + np.conj(Qbar.T)))
+    out.update({"Rbar": Rbar, "fbar": fbar, "psi0bar": np.sum(g, axis=0).astype(np.complex128), "Abar": Abar,
+                "loss_sum": float(np.sum(loss, dtype=np.float64))})
+    return out

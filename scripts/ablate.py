@@ -4,13 +4,12 @@ import os, sys, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from audio_mps_amd import build
-variants = {"base": [], "no_loss": ["-DABL2_NO_LOSS"], "no_chain": ["-DABL2_NO_CHAIN"], "no_prio": ["-DABL2_NO_PRIO"],
-            "chain_nowait": ["-DABL2_CHAIN_NOWAIT"], "no_loss_chain_nowait": ["-DABL2_NO_LOSS", "-DABL2_CHAIN_NOWAIT"]}
+variants = {"base": [], "no_mfma": ["-DPABL_NO_MFMA"], "no_reduce": ["-DPABL_NO_REDUCE"], "no_mfma_no_reduce": ["-DPABL_NO_MFMA", "-DPABL_NO_REDUCE"]}
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 for name, flags in variants.items():
     lib = os.path.join(ROOT, "gpurun_out", f"libcmps_{name}.so")
     subprocess.run([build._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", lib] + flags
                    + [os.path.join(build.CSRC, s) for s in build.SOURCES], check=True)
     env = dict(os.environ, CMPS_LIB=lib)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "time_kernels.py")], env=env, capture_output=True, text=True).stdout
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "time_kernels.py"), "128", "16000", "512", "2", "3"], env=env, capture_output=True, text=True).stdout
     print("==", name); print("\n".join(l for l in out.splitlines() if "median" in l))

@@ -16,7 +16,8 @@ hp = HParams(minibatch_size=B, bond_dim=D)
 rng = np.random.default_rng(15345)
 x = damped_sine(B, T, hp.delta_t, seed=3000)
 audio = torch.from_numpy((x + 0.02 * rng.standard_normal(x.shape)).astype(np.float32)).cuda()
-be = HipScan(D)
+variant = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+be = HipScan(D, variant=variant)
 m = PsiCMPS(hp, seed=0, backend=be)
 be.set_params(m.effective_params(), B, T, train=True)
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
