@@ -173,6 +173,7 @@ __device__ __forceinline__ void rho_load(const Dev& P, int chunk, int tid, float
     }
 }
 __device__ __forceinline__ void rho_commit(RhoStage& S, int buf, int tid, const float4 (&r)[8]) {
+    asm volatile("" ::: "memory");      // all eight loads are issued before the first store (else: load, wait, store, x 8)
     float4* dst = reinterpret_cast<float4*>(&S.row[buf][0][0]);
 #pragma unroll
     for (int i = 0; i < 8; ++i) dst[tid + 256 * i] = r[i];
@@ -193,14 +194,22 @@ __device__ __forceinline__ void load_frags(bf4 (&frag)[32], F&& elem) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
-// forward
+// forward: 8 waves per workgroup.  Waves 0-3 ("chain") carry the recurrence u -> y -> u' with the R and Q fragments;
+// waves 4-7 ("loss") hold the H = R + R^dagger fragments and do everything nothing waits for: H y_{k-1}, e_{k-1}, the
+// stash row, the per-step scalars and the loss.  Both kinds own the same (row, component, clip) per lane, meet at ONE
+// LDS-only barrier per step, and share each SIMD's issue slots and matrix pipe (a lone wave issues one instruction per
+// ~5.4 cycles; the split also keeps each wave's fragments in arch VGPRs -- the 4-wave version copied 48 of them out of
+// AGPRs every step).
 // ------------------------------------------------------------------------------------------------
 template <bool SAVE>
-__global__ __launch_bounds__(64 * PWV, 1) void k_fwd_pair(Dev P, const float* __restrict__ audio,
-                                                          float* __restrict__ loss_out) {
+__global__ __launch_bounds__(128 * PWV, 1) void k_fwd_pair(Dev P, const float* __restrict__ audio,
+                                                           float* __restrict__ loss_out) {
     __shared__ PairLds L;
     __shared__ RhoStage RS;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    __shared__ __attribute__((aligned(8))) float2 yf[2][PWV][64];       // y_k in float32, [parity][chain wave][lane]
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int w = wv & (PWV - 1);
+    const bool loss_wave = wv >= PWV;
     const int c = lane & 3, q = c >> 1, rg = (lane >> 2) & 7, kh = lane >> 5;
     const bool odd = (c & 1) != 0;
     const int N = P.N, T = P.T, NC = (N + PCH - 1) / PCH;
@@ -208,89 +217,149 @@ __global__ __launch_bounds__(64 * PWV, 1) void k_fwd_pair(Dev P, const float* __
     const bool two = b1 != b0;
     const int ia = 32 * w + 4 * rg + 2 * kh, ib = ia + 1;              // the two (adjacent) rows this lane owns after rows_of
     const int arow = 32 * w + 4 * rg + c;                              // the row of this lane's A operand
-
-    // ---- matrices as bf16 A fragments (rounded once per launch) ----
-    bf4 FR[32], FQ[32], FH[32];
-    {
-        const float2* Rrow = P.R + (size_t)arow * PD;
-        const float2* Qrow = P.Q + (size_t)arow * PD;
-        const float2* RTrow = P.RT + (size_t)arow * PD;     // RT[i][j] = R[j][i]
-        if (kh == 0) {
-            load_frags(FR, [&](int j) { return Rrow[j].x; });
-            load_frags(FQ, [&](int j) { return Qrow[j].x; });
-            load_frags(FH, [&](int j) { return Rrow[j].x + RTrow[j].x; });
-        } else {
-            load_frags(FR, [&](int j) { return Rrow[j].y; });
-            load_frags(FQ, [&](int j) { return Qrow[j].y; });
-            load_frags(FH, [&](int j) { return Rrow[j].y - RTrow[j].y; });
-        }
-    }
-    // ---- LDS addressing ----
-    // read: lane (kh, c) streams 256 B of array  kh == 0 ? (odd ? im : re) : (odd ? re : -im)  of clip q
+    // LDS addressing (see PairLds): read 256 B of array  kh == 0 ? (odd ? im : re) : (odd ? re : -im)  of clip q
     const int rd_arr = kh == 0 ? (odd ? 1 : 0) : (odd ? 0 : 2);
     const int rd_off = (rd_arr * 2 + q) * VROW;
-    // write: even lanes own Re rows -> array re (second write to the dummy row); odd lanes own Im rows -> im and -im
-    const int wr1 = ((odd ? 1 : 0) * 2 + q) * VROW;
-    const int wr2 = (odd ? 2 * 2 + q : 3 * 2 + q) * VROW;
-    auto write_vec = [&](unsigned char* base, float xa, float xb) {
-        const unsigned pk = pk_bf16(xa, xb);                           // rows ia, ia + 1 are adjacent: one 4-byte store each
-        *reinterpret_cast<unsigned*>(base + wr1 + ia * 2) = pk;
-        *reinterpret_cast<unsigned*>(base + wr2 + ia * 2) = pk ^ 0x80008000u;
-    };
-
     const float* xr0 = audio + (size_t)b0 * T;
     const float* xr1 = audio + (size_t)b1 * T;
     const float A = P.A;
+    const f4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const int tid = threadIdx.x;
+
+    if (!loss_wave) {
+        // ================================================================== chain waves
+        bf4 FR[32], FQ[32];
+        {
+            const float2* Rrow = P.R + (size_t)arow * PD;
+            const float2* Qrow = P.Q + (size_t)arow * PD;
+            if (kh == 0) {
+                load_frags(FR, [&](int j) { return Rrow[j].x; });
+                load_frags(FQ, [&](int j) { return Qrow[j].x; });
+            } else {
+                load_frags(FR, [&](int j) { return Rrow[j].y; });
+                load_frags(FQ, [&](int j) { return Qrow[j].y; });
+            }
+        }
+        // write: even lanes own Re rows -> array re (second write to a dummy row); odd lanes own Im rows -> im and -im
+        const int wr1 = ((odd ? 1 : 0) * 2 + q) * VROW;
+        const int wr2 = (odd ? 2 * 2 + q : 3 * 2 + q) * VROW;
+        auto write_vec = [&](unsigned char* base, float xa, float xb) {
+            const unsigned pk = pk_bf16(xa, xb);                       // rows ia, ia + 1 are adjacent: one 4-byte store each
+            *reinterpret_cast<unsigned*>(base + wr1 + ia * 2) = pk;
+            *reinterpret_cast<unsigned*>(base + wr2 + ia * 2) = pk ^ 0x80008000u;
+        };
+        const float2 pa = P.psi0[ia], pb = P.psi0[ib];
+        float uta = odd ? pa.y : pa.x, utb = odd ? pb.y : pb.x;      // ut_0 = psi_0 (both clips)
+        float inv = 1.f;                                              // 1/sqrt(max(|y_{k-1}|^2, eps)) of this lane's clip
+        float sv0 = 0.f, sv1 = 0.f;                                   // s = x / A of the current 64 steps, lane <-> step
+        write_vec(L.vec[0][0], uta, utb);
+        if (tid < 256) {
+            float4 rpre[8];
+            rho_load(P, 0, tid, rpre);
+            rho_commit(RS, 0, tid, rpre);
+        }
+        __syncthreads();
+        for (int k = 0; k <= N + 1; ++k) {
+            const int p = k & 1;
+            if (k < N) {
+                if ((k & (PCH - 1)) == 0) {                            // increments of the next 64 steps, one per lane
+                    const int idx = k + lane;
+                    const bool in0 = idx < T, in1 = idx + 1 < T;
+                    sv0 = ((in1 ? xr0[idx + 1] : 0.f) - (in0 ? xr0[idx] : 0.f)) / A;     // model.py:263, 303
+                    sv1 = ((in1 ? xr1[idx + 1] : 0.f) - (in0 ? xr1[idx] : 0.f)) / A;
+                }
+                if ((k & (RCH - 1)) == 0) {                            // next chunk of rho into the other buffer
+                    float4 rpre[8];
+                    rho_load(P, k / RCH + 1, tid, rpre);
+                    rho_commit(RS, (k / RCH + 1) & 1, tid, rpre);
+                }
+                const float2 rha = RS.row[(k / RCH) & 1][k & (RCH - 1)][ia];   // rho_k of this lane's rows
+                const float2 rhb = RS.row[(k / RCH) & 1][k & (RCH - 1)][ib];
+                if (k >= 1) {                                          // |y_{k-1}|^2, published by the previous iteration
+                    const f4 t4 = *reinterpret_cast<const f4*>(&L.nrm[p][q][0]);
+                    inv = __builtin_amdgcn_rsqf(fmaxf((t4.x + t4.y) + (t4.z + t4.w), 1e-12f));   // model.py:332
+                }
+                const unsigned aU = lds_addr_of(L.vec[p][0]) + rd_off;
+                u4 B0[8], B1[8];
+                rd8(aU, B0);
+                rd8(aU + 128, B1);
+                Acc2 cR = {z4, z4}, cQ = {z4, z4};
+                rd_wait<8>(B0);
+                mm2<0>(FR, FQ, B0, cR, cQ);
+                rd_wait<0>(B1);
+                mm2<8>(FR, FQ, B1, cR, cQ);
+                const int kl = k & (PCH - 1);
+                const float s = q ? rdl(sv1, kl) : rdl(sv0, kl);
+                float ra, rb, qa, qb;
+                rows_of(cR.a + cR.b, ra, rb);
+                rows_of(cQ.a + cQ.b, qa, qb);
+                const float yna = inv * (uta + (qa + s * ra));         // y_k, rows ia / ib
+                const float ynb = inv * (utb + (qb + s * rb));
+                const float nn = clip_sum(yna * yna + ynb * ynb);
+                if (lane == 0 || lane == 2) L.nrm[p ^ 1][q][w] = nn;
+                // ut_{k+1} = rho_k y_k (un-normalised): own component with the partner's (re <-> im) through DPP
+                const float pya = dpp_mov<0xB1>(yna), pyb = dpp_mov<0xB1>(ynb);
+                uta = rha.x * yna + (odd ? rha.y : -rha.y) * pya;
+                utb = rhb.x * ynb + (odd ? rhb.y : -rhb.y) * pyb;
+                write_vec(L.vec[p ^ 1][0], uta, utb);
+                write_vec(L.vec[p ^ 1][1], yna, ynb);
+                yf[p ^ 1][w][lane] = make_float2(yna, ynb);
+            }
+            lds_barrier();
+        }
+        return;
+    }
+
+    // ====================================================================== loss waves
+    bf4 FH[32];
+    {
+        const float2* Rrow = P.R + (size_t)arow * PD;
+        const float2* RTrow = P.RT + (size_t)arow * PD;     // RT[i][j] = R[j][i]
+        if (kh == 0)
+            load_frags(FH, [&](int j) { return Rrow[j].x + RTrow[j].x; });
+        else
+            load_frags(FH, [&](int j) { return Rrow[j].y - RTrow[j].y; });
+    }
     float4* st = SAVE ? reinterpret_cast<float4*>(P.stash) + ((size_t)blockIdx.x * N * PWV + w) * 64 + lane : nullptr;
     float* sc0 = SAVE ? P.scal + ((size_t)b0 * NC) * 128 : nullptr;
     float* sc1 = SAVE ? P.scal + ((size_t)b1 * NC) * 128 : nullptr;
-
-    const float2 pa = P.psi0[ia], pb = P.psi0[ib];
-    float uta = odd ? pa.y : pa.x, utb = odd ? pb.y : pb.x;          // ut_0 = psi_0 (both clips)
-    float inv = 1.f;                                                  // 1/sqrt(max(|y_{k-1}|^2, eps)) of this lane's clip
-    float ya = 0.f, yb = 0.f;                                         // y_{k-1}
     float loss0 = 0.f, loss1 = 0.f;
     float nv0 = 1.f, nv1 = 1.f, ev0 = 0.f, ev1 = 0.f;                 // per-chunk |y_k|^2 and e_k rows, lane <-> step
-    float sv0 = 0.f, sv1 = 0.f;                                       // s = x / A of the chain's current chunk
-    write_vec(L.vec[0][0], uta, utb);
-    {
-        float4 rpre[8];
-        rho_load(P, 0, threadIdx.x, rpre);
-        rho_commit(RS, 0, threadIdx.x, rpre);
-    }
     __syncthreads();
-
     for (int k = 0; k <= N + 1; ++k) {
         const int p = k & 1;
-        const bool chain = k < N, hpart = k >= 1 && k <= N;
-        if ((k & (RCH - 1)) == 0) {        // next chunk of rho into the other buffer (no register staging: the kernel
-            float4 rpre[8];                // has none to spare, and a spilled stage serialises the eight loads)
-            rho_load(P, k / RCH + 1, threadIdx.x, rpre);
-            rho_commit(RS, (k / RCH + 1) & 1, threadIdx.x, rpre);
-        }
-        if (chain && (k & (PCH - 1)) == 0) {                          // increments of the next 64 steps, one per lane
-            const int idx = k + lane;
-            const bool in0 = idx < T, in1 = idx + 1 < T;
-            sv0 = ((in1 ? xr0[idx + 1] : 0.f) - (in0 ? xr0[idx] : 0.f)) / A;     // model.py:263, 303
-            sv1 = ((in1 ? xr1[idx + 1] : 0.f) - (in0 ? xr1[idx] : 0.f)) / A;
-        }
-        const float2 rha = RS.row[(k / RCH) & 1][k & (RCH - 1)][ia];   // rho_k of this lane's rows
-        const float2 rhb = RS.row[(k / RCH) & 1][k & (RCH - 1)][ib];
-        // ---- totals published by the previous iteration ----
-        if (hpart) {                                                   // |y_{k-1}|^2
-            const f4 t4 = *reinterpret_cast<const f4*>(&L.nrm[p][q][0]);
-            const float n = (t4.x + t4.y) + (t4.z + t4.w);
-            inv = __builtin_amdgcn_rsqf(fmaxf(n, 1e-12f));             // model.py:332 (v_rsq_f32: 1 ulp)
-            const int j = k - 1, jl = j & (PCH - 1);
-            const float n0 = rdl(n, 0), n1 = rdl(n, 2);
-            nv0 = lane == jl ? n0 : nv0;
-            nv1 = lane == jl ? n1 : nv1;
-            if (SAVE && w == 0 && (jl == PCH - 1 || j == N - 1)) {
-                sc0[(size_t)(j / PCH) * 128 + lane] = nv0;
-                if (two) sc1[(size_t)(j / PCH) * 128 + lane] = nv1;
+        if (k >= 1 && k <= N) {
+            // ---- |y_{k-1}|^2 for the scalar rows ----
+            {
+                const f4 t4 = *reinterpret_cast<const f4*>(&L.nrm[p][q][0]);
+                const float n = (t4.x + t4.y) + (t4.z + t4.w);
+                const int j = k - 1, jl = j & (PCH - 1);
+                const float n0 = rdl(n, 0), n1 = rdl(n, 2);
+                nv0 = lane == jl ? n0 : nv0;
+                nv1 = lane == jl ? n1 : nv1;
+                if (SAVE && w == 0 && (jl == PCH - 1 || j == N - 1)) {
+                    sc0[(size_t)(j / PCH) * 128 + lane] = nv0;
+                    if (two) sc1[(size_t)(j / PCH) * 128 + lane] = nv1;
+                }
             }
+            // ---- H y_{k-1}, the stash row, the partial of e_{k-1} ----
+            const unsigned aY = lds_addr_of(L.vec[p][1]) + rd_off;
+            u4 B0[8], B1[8];
+            rd8(aY, B0);
+            rd8(aY + 128, B1);
+            const float2 yv = yf[p][w][lane];
+            Acc4 cH = {z4, z4, z4, z4};
+            rd_wait<8>(B0);
+            mm1<0>(FH, B0, cH);
+            rd_wait<0>(B1);
+            mm1<8>(FH, B1, cH);
+            float ha, hb;                                              // ((R + R^dagger) y_{k-1}) rows ia / ib
+            rows_of((cH.a + cH.b) + (cH.c + cH.d), ha, hb);
+            if (SAVE) st[(size_t)(k - 1) * PWV * 64] = make_float4(yv.x, yv.y, ha, hb);
+            const float ep = clip_sum(yv.x * ha + yv.y * hb);
+            if (lane == 0 || lane == 2) L.ee[p ^ 1][q][w] = ep;
         }
-        if (k >= 2) {                                                  // e_{k-2}
+        if (k >= 2) {                                                  // e_{k-2}, published by the previous iteration
             const f4 t4 = *reinterpret_cast<const f4*>(&L.ee[p][q][0]);
             const float e = (t4.x + t4.y) + (t4.z + t4.w);
             const int j = k - 2, jl = j & (PCH - 1);
@@ -314,71 +383,6 @@ __global__ __launch_bounds__(64 * PWV, 1) void k_fwd_pair(Dev P, const float* __
                 }
             }
         }
-        // ---- the mat-vecs: B fragments in two batches of eight reads each, double buffered ----
-        const f4 z4 = {0.f, 0.f, 0.f, 0.f};
-        Acc2 cR = {z4, z4}, cQ = {z4, z4};
-        Acc4 cH = {z4, z4, z4, z4};
-        {
-            const unsigned aU = lds_addr_of(L.vec[p][0]) + rd_off, aY = lds_addr_of(L.vec[p][1]) + rd_off;
-            u4 B0[8], B1[8];
-            if (chain && hpart) {
-                rd8(aU, B0);
-                rd8(aU + 128, B1);
-                rd_wait<8>(B0);
-                mm2<0>(FR, FQ, B0, cR, cQ);
-                rd8(aY, B0);
-                rd_wait<8>(B1);
-                mm2<8>(FR, FQ, B1, cR, cQ);
-                rd8(aY + 128, B1);
-                rd_wait<8>(B0);
-                mm1<0>(FH, B0, cH);
-                rd_wait<0>(B1);
-                mm1<8>(FH, B1, cH);
-            } else if (chain) {
-                rd8(aU, B0);
-                rd8(aU + 128, B1);
-                rd_wait<8>(B0);
-                mm2<0>(FR, FQ, B0, cR, cQ);
-                rd_wait<0>(B1);
-                mm2<8>(FR, FQ, B1, cR, cQ);
-            } else if (hpart) {
-                rd8(aY, B0);
-                rd8(aY + 128, B1);
-                rd_wait<8>(B0);
-                mm1<0>(FH, B0, cH);
-                rd_wait<0>(B1);
-                mm1<8>(FH, B1, cH);
-            }
-        }
-        const f4 aR = cR.a + cR.b, aQ = cQ.a + cQ.b, aH = (cH.a + cH.b) + (cH.c + cH.d);
-        float yna = 0.f, ynb = 0.f;
-        if (chain) {
-            const int kl = k & (PCH - 1);
-            const float s0 = rdl(sv0, kl), s1 = rdl(sv1, kl);
-            const float s = q ? s1 : s0;
-            float ra, rb, qa, qb;
-            rows_of(aR, ra, rb);
-            rows_of(aQ, qa, qb);
-            yna = inv * (uta + (qa + s * ra));                         // y_k, rows ia / ib
-            ynb = inv * (utb + (qb + s * rb));
-            const float nn = clip_sum(yna * yna + ynb * ynb);
-            if (lane == 0 || lane == 2) L.nrm[p ^ 1][q][w] = nn;
-            // ut_{k+1} = rho_k y_k (un-normalised): own component with the partner's (re <-> im) through DPP
-            const float pya = dpp_mov<0xB1>(yna), pyb = dpp_mov<0xB1>(ynb);
-            uta = rha.x * yna + (odd ? rha.y : -rha.y) * pya;
-            utb = rhb.x * ynb + (odd ? rhb.y : -rhb.y) * pyb;
-            write_vec(L.vec[p ^ 1][0], uta, utb);
-            write_vec(L.vec[p ^ 1][1], yna, ynb);
-        }
-        if (hpart) {
-            float ha, hb;                                              // ((R + R^dagger) y_{k-1}) rows ia / ib
-            rows_of(aH, ha, hb);
-            if (SAVE) st[(size_t)(k - 1) * PWV * 64] = make_float4(ya, yb, ha, hb);
-            const float ep = clip_sum(ya * ha + yb * hb);
-            if (lane == 0 || lane == 2) L.ee[p ^ 1][q][w] = ep;
-        }
-        ya = yna;
-        yb = ynb;
         lds_barrier();
     }
     if (w == 0 && lane == 0) {
@@ -390,9 +394,9 @@ __global__ __launch_bounds__(64 * PWV, 1) void k_fwd_pair(Dev P, const float* __
 hipError_t launch_fwd_pair(const Dev& P, const float* audio, float* loss, bool save, hipStream_t s) {
     const unsigned nb = (unsigned)((P.B + 1) / 2);
     if (save)
-        hipLaunchKernelGGL(k_fwd_pair<true>, dim3(nb), dim3(64 * PWV), 0, s, P, audio, loss);
+        hipLaunchKernelGGL(k_fwd_pair<true>, dim3(nb), dim3(128 * PWV), 0, s, P, audio, loss);
     else
-        hipLaunchKernelGGL(k_fwd_pair<false>, dim3(nb), dim3(64 * PWV), 0, s, P, audio, loss);
+        hipLaunchKernelGGL(k_fwd_pair<false>, dim3(nb), dim3(128 * PWV), 0, s, P, audio, loss);
     return hipGetLastError();
 }
 
@@ -421,6 +425,7 @@ struct StepTab {
 __global__ __launch_bounds__(64 * PWV, 1) void k_bwd_pair(Dev P, const float* __restrict__ audio) {
     __shared__ PairLds L;
     __shared__ StepTab TB;
+    __shared__ RhoStage RS;
     __shared__ float redA[PWV];
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int c = lane & 3, q = c >> 1, rg = (lane >> 2) & 7, kh = lane >> 5;
@@ -495,19 +500,33 @@ __global__ __launch_bounds__(64 * PWV, 1) void k_bwd_pair(Dev P, const float* __
     };
 
     float ga = 0.f, gb = 0.f, facca = 0.f, faccb = 0.f, accS = 0.f, rad_next = 0.f;
-    float4 cur = st[(size_t)(N - 1) * PWV * 64];
     chunk_rows((N - 1) / PCH);
+    // rho: 32-step chunks staged in LDS, descending; chunk j lives in buffer j & 1 and is loaded when the sweep enters
+    // chunk j + 1 (rows k and k - 1 of a step can straddle two chunks, so two are always resident)
+    {
+        float4 rpre[8];
+        const int cl = (N - 1) / RCH;
+        rho_load(P, cl, threadIdx.x, rpre);
+        rho_commit(RS, cl & 1, threadIdx.x, rpre);
+        if (cl > 0) {
+            rho_load(P, cl - 1, threadIdx.x, rpre);
+            rho_commit(RS, (cl - 1) & 1, threadIdx.x, rpre);
+        }
+    }
+    __syncthreads();
     int p = 0;
-    for (int k = N - 1; k >= 0; --k, p ^= 1) {
+    // one step; `cur` = stash row k, `prv` = stash row k - 1 (both prefetched four steps ahead into a register ring)
+    auto step = [&](int k, const float4& cur, const float4& prv) {
         const int jl = k & (PCH - 1), cp = (k / PCH) & 1;
         if (jl == 0 && k > 0) chunk_rows(k / PCH - 1);                 // u_k needs inv_{k-1}: the chunk below, other buffer
-        const float4 nxt = k > 0 ? st[(size_t)(k - 1) * PWV * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float2 rha = P.rho[(size_t)k * PD + ia], rhb = P.rho[(size_t)k * PD + ib];
-        float2 rpa = make_float2(1.f, 0.f), rpb = rpa;
-        if (k > 0) {
-            rpa = P.rho[(size_t)(k - 1) * PD + ia];
-            rpb = P.rho[(size_t)(k - 1) * PD + ib];
+        if ((k & (RCH - 1)) == RCH - 1 && k != N - 1 && k >= RCH) {    // entering rho chunk k / RCH: fetch the one below
+            float4 rpre[8];
+            rho_load(P, k / RCH - 1, threadIdx.x, rpre);
+            rho_commit(RS, (k / RCH - 1) & 1, threadIdx.x, rpre);
         }
+        const float2 rha = RS.row[(k / RCH) & 1][k & (RCH - 1)][ia], rhb = RS.row[(k / RCH) & 1][k & (RCH - 1)][ib];
+        const int km = k > 0 ? k - 1 : 0;
+        const float2 rpa = RS.row[(km / RCH) & 1][km & (RCH - 1)][ia], rpb = RS.row[(km / RCH) & 1][km & (RCH - 1)][ib];
         const f4 S0 = TB.row[w][cp][jl][q][0], S1 = TB.row[w][cp][jl][q][1];
         const float s = S0.x, inv = S0.y, ok = S0.z, te = S0.w, rad = S1.x, xa = S1.y, dt = S1.z;
         const float ya = cur.x, yb = cur.y, ha = cur.z, hb = cur.w;
@@ -546,7 +565,7 @@ __global__ __launch_bounds__(64 * PWV, 1) void k_bwd_pair(Dev P, const float* __
         if (k > 0) {
             const int jp = (k - 1) & (PCH - 1), cpp = ((k - 1) / PCH) & 1;
             const float invp = TB.row[w][cpp][jp][q][0].y;
-            const float ypa = nxt.x * invp, ypb = nxt.y * invp;
+            const float ypa = prv.x * invp, ypb = prv.y * invp;
             uka = rpa.x * ypa + sgn * rpa.y * dpp_mov<0xB1>(ypa);
             ukb = rpb.x * ypb + sgn * rpb.y * dpp_mov<0xB1>(ypb);
         } else {
@@ -558,8 +577,25 @@ __global__ __launch_bounds__(64 * PWV, 1) void k_bwd_pair(Dev P, const float* __
         ga = yba + qa + s * da;
         gb = ybb + qb + s * db;
         rad_next = rad;
-        cur = nxt;
+        p ^= 1;
+    };
+    // unconditional (clamped) loads: a select on the loaded value would force the wait right behind the load
+    auto row_at = [&](int k) { return st[(size_t)(k > 0 ? k : 0) * PWV * 64]; };
+    float4 r0 = row_at(N - 1), r1 = row_at(N - 2), r2 = row_at(N - 3), r3 = row_at(N - 4);
+    int k = N - 1;
+    for (; k >= 3; k -= 4) {                                           // ring: r0 = row k, r1 = k - 1, r2 = k - 2, r3 = k - 3
+        step(k, r0, r1);
+        r0 = row_at(k - 4);
+        step(k - 1, r1, r2);
+        r1 = row_at(k - 5);
+        step(k - 2, r2, r3);
+        r2 = row_at(k - 6);
+        step(k - 3, r3, r0);
+        r3 = row_at(k - 7);
     }
+    if (k >= 0) step(k, r0, r1);
+    if (k >= 1) step(k - 1, r1, r2);
+    if (k >= 2) step(k - 2, r2, r3);
     // ---- the pair's slab: f | psi0bar_re | psi0bar_im | A (the R / Q sections are written by k_grad_pair) ----
     float* slab = P.slabs + (size_t)blockIdx.x * P.slab_floats;
     const int DD = PD * PD;
@@ -678,22 +714,35 @@ __global__ __launch_bounds__(64 * PWV, 1) void k_grad_pair(Dev P, const float* _
 #pragma unroll
         for (int r = 0; r < 16; ++r) Rre[cb][r] = Rim[cb][r] = Qre[cb][r] = Qim[cb][r] = 0.f;
 
-    // producer: fill one group's operand rows (this lane's two rows, component and clip; 4 steps -> one 8-byte store each)
+    // producer: fill one group's operand rows (this lane's two rows, component and clip; 4 steps -> one 8-byte store each).
+    // The stash rows and rho rows of a group are fetched one whole group ahead (prefetch), so their latency hides behind
+    // the previous group's MFMAs.
     float ypa = 0.f, ypb = 0.f, invp = 1.f;                           // y_{k-1} and inv_{k-1} carried across groups
     float2 rpa = make_float2(1.f, 0.f), rpb = rpa;                     // rho_{k-1}
+    float4 prow[GS];
+    float2 pra[GS], prb[GS];
+    auto prefetch = [&](int g) {
+#pragma unroll
+        for (int s4 = 0; s4 < GS; ++s4) {
+            const int k = g * GS + s4;
+            const bool in = k < N;
+            const int kc = in ? k : N - 1;                            // clamped, unconditional loads (no select behind them)
+            prow[s4] = st[(size_t)kc * PWV * 64];
+            pra[s4] = P.rho[(size_t)kc * PD + ia];
+            prb[s4] = P.rho[(size_t)kc * PD + ib];
+        }
+    };
     auto fill = [&](int g, int buf) {
-        unsigned short v[5][2][GS];
+        float v[5][2][GS];
 #pragma unroll
         for (int s4 = 0; s4 < GS; ++s4) {
             const int k = g * GS + s4;
             const bool in = k < N;
             if (in && (k & (PCH - 1)) == 0) chunk_rows(k / PCH);
-            float4 row = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 row = prow[s4];
+            if (!in) row = make_float4(0.f, 0.f, 0.f, 0.f);
             f4 sr = {0.f, 0.f, 1.f, 0.f};
-            if (in) {
-                row = st[(size_t)k * PWV * 64];
-                sr = G.tab[w][(k / PCH) & 1][k & (PCH - 1)][q];
-            }
+            if (in) sr = G.tab[w][(k / PCH) & 1][k & (PCH - 1)][q];
             const float s = sr.x, te = sr.y * wq;
             float uka, ukb;
             if (k == 0) {
@@ -706,33 +755,41 @@ __global__ __launch_bounds__(64 * PWV, 1) void k_grad_pair(Dev P, const float* _
                 ukb = rpb.x * tb + sgn * rpb.y * dpp_mov<0xB1>(tb);
             }
             const float yba = row.z * wq, ybb = row.w * wq;
-            v[0][0][s4] = bf16_rne(te * row.x); v[0][1][s4] = bf16_rne(te * row.y);
-            v[1][0][s4] = bf16_rne(yba);        v[1][1][s4] = bf16_rne(ybb);
-            v[2][0][s4] = bf16_rne(s * yba);    v[2][1][s4] = bf16_rne(s * ybb);
-            v[3][0][s4] = bf16_rne(row.x);      v[3][1][s4] = bf16_rne(row.y);
-            v[4][0][s4] = bf16_rne(in ? uka : 0.f); v[4][1][s4] = bf16_rne(in ? ukb : 0.f);
+            v[0][0][s4] = te * row.x; v[0][1][s4] = te * row.y;
+            v[1][0][s4] = yba;        v[1][1][s4] = ybb;
+            v[2][0][s4] = s * yba;    v[2][1][s4] = s * ybb;
+            v[3][0][s4] = row.x;      v[3][1][s4] = row.y;
+            v[4][0][s4] = in ? uka : 0.f; v[4][1][s4] = in ? ukb : 0.f;
             if (in) {
                 ypa = row.x; ypb = row.y; invp = sr.z;
-                rpa = P.rho[(size_t)k * PD + ia];
-                rpb = P.rho[(size_t)k * PD + ib];
+                rpa = pra[s4];
+                rpb = prb[s4];
             }
         }
 #pragma unroll
         for (int o = 0; o < 5; ++o) {
             unsigned short* da = &G.op[buf][o][odd ? 1 : 0][ia][q * GS];
             unsigned short* db = &G.op[buf][o][odd ? 1 : 0][ib][q * GS];
-            *reinterpret_cast<uint2*>(da) = make_uint2(v[o][0][0] | (unsigned)v[o][0][1] << 16, v[o][0][2] | (unsigned)v[o][0][3] << 16);
-            *reinterpret_cast<uint2*>(db) = make_uint2(v[o][1][0] | (unsigned)v[o][1][1] << 16, v[o][1][2] | (unsigned)v[o][1][3] << 16);
+            // (integer rounding: measured 13 % faster here than v_cvt_pk_bf16_f32 through inline asm)
+            *reinterpret_cast<uint2*>(da) = make_uint2(bf16_rne(v[o][0][0]) | (unsigned)bf16_rne(v[o][0][1]) << 16,
+                                                       bf16_rne(v[o][0][2]) | (unsigned)bf16_rne(v[o][0][3]) << 16);
+            *reinterpret_cast<uint2*>(db) = make_uint2(bf16_rne(v[o][1][0]) | (unsigned)bf16_rne(v[o][1][1]) << 16,
+                                                       bf16_rne(v[o][1][2]) | (unsigned)bf16_rne(v[o][1][3]) << 16);
         }
     };
 
     const int NG = (N + GS - 1) / GS;
+    prefetch(0);
     fill(0, 0);
+    prefetch(1);
     __syncthreads();
     const unsigned nmask = mh ? 0x80008000u : 0u;
     for (int g = 0; g < NG; ++g) {
         const int buf = g & 1;
-        if (g + 1 < NG) fill(g + 1, buf ^ 1);
+        if (g + 1 < NG) {
+            fill(g + 1, buf ^ 1);
+            prefetch(g + 2);
+        }
         // A fragments of this wave's row block: Re form (h ? X_im : X_re), Im form (h ? -X_re : X_im)
         bf8 aRe[3], aIm[3];
 #pragma unroll

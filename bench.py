@@ -28,6 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 vector peak == fp32-input MFMA peak (dense)
+BF16_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA peak (never the 2:1-sparsity figure)
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec peak
 
 
@@ -39,7 +40,8 @@ def parse_args():
     p.add_argument("--bond-dim", type=int, default=32)
     p.add_argument("--T", type=int, default=16000)
     p.add_argument("--batch-per-gpu", type=int, default=1024)
-    p.add_argument("--variant", type=int, default=0, help="0 auto, 1 block-per-clip, 2 wave-per-clip")
+    p.add_argument("--variant", type=int, default=0,
+                   help="0 auto, 1 block-per-clip, 2 wave-per-clip, 3 MFMA pair kernels (needs --bond-dim 128; bf16 operands)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-clips", type=int, default=0, help="clips in the CPU sample (0 = 8 per thread)")
     return p.parse_args()
@@ -171,18 +173,23 @@ def main():
         flops_fwd = 24.0 * D * D * B * N
         bytes_alg = 8.0 * B * T                                  # 4 B read forward + 4 B read in the reverse sweep
         wave = backend.variant == 2
+        pair = backend.variant == 3
         fwd_name = "k_fwd_wave (forward scan)" if os.environ.get("CMPS_FWD1") == "1" else "k_fwd_wave2 (forward scan, two waves per clip)"
         kern = {"fwd": {"name": fwd_name if wave else "k_fwd_block", "t": t_fwd, "flops": flops_fwd,
                         "pmc": "k_fwd_wave" if wave else "k_fwd_block"},
                 "bwd": {"name": "k_bwd_wave (reverse scan)" if wave else "k_bwd_block", "t": t_bwd, "flops": flops_bwd,
                         "pmc": "k_bwd_wave" if wave else "k_bwd_block"}}
+        if pair:                                                 # D = 128: MFMA pair kernels (bf16 operands, fp32 accumulate)
+            kern["fwd"].update(name="k_fwd_pair (forward scan, 4x4x4 bf16 MFMA)", pmc="k_fwd_pair")
+            kern["bwd"].update(name="k_bwd_pair + k_grad_pair (reverse scan + gradient GEMM)", pmc="k_bwd_pair")
         dom = "fwd" if t_fwd >= t_bwd else "bwd"                 # the dominant kernel = the longer launch
         oth = "bwd" if dom == "fwd" else "fwd"
         traffic = profiled_traffic(kern[dom]["pmc"]) if (D, T, B) == (32, 16000, 1024) else None
         ach = kern[dom]["flops"] / kern[dom]["t"] / 1e12
+        peak = BF16_PEAK_TFLOPS if pair else FP32_PEAK_TFLOPS
         roofline = {
-            "bound": "mfma", "kernel": kern[dom]["name"], "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": ach / FP32_PEAK_TFLOPS,
+            "bound": "mfma", "kernel": kern[dom]["name"], "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+            "frac": ach / peak,
             "traffic": traffic["bytes"] if traffic else None, "traffic_source": traffic["source"] if traffic else None,
             "algorithmic_bytes": 4.0 * B * T, "launch_ms": kern[dom]["t"] * 1e3,
             "flops_per_launch": kern[dom]["flops"],
@@ -192,16 +199,21 @@ def main():
                     "count includes work the kernel avoids (merged R + R^dagger mat-vec) and its rank-1 updates run "
                     "as bf16 hi/lo-split MFMA, so its fraction is not an executed-fp32-flop fraction",
             "other_kernel": {"kernel": kern[oth]["name"], "achieved": kern[oth]["flops"] / kern[oth]["t"] / 1e12,
-                             "frac": kern[oth]["flops"] / kern[oth]["t"] / 1e12 / FP32_PEAK_TFLOPS,
+                             "frac": kern[oth]["flops"] / kern[oth]["t"] / 1e12 / peak,
                              "launch_ms": kern[oth]["t"] * 1e3},
             "hbm": {"achieved": bytes_alg / (t_fwd + t_bwd) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": bytes_alg / (t_fwd + t_bwd) / 1e9 / HBM_PEAK_GBS}}
+        if pair:
+            roofline["note"] = ("bf16-operand path (BASELINE configs[4]): peak = 2500 TFLOP/s dense bf16 MFMA; the mat-vecs use "
+                                "v_mfma_f32_4x4x4_16b_bf16 (two clips x {re, im} fill its four B columns), whose own ceiling is "
+                                "256 flop/cycle/SIMD = 629 TFLOP/s; the scans are per-step latency / issue bound")
+        cfg_name = "BASELINE configs[4]" if pair else "BASELINE configs[2]"
         out = {
-            "metric": "audio samples/sec (fwd+bwd) at D=32, T=16000",
+            "metric": f"audio samples/sec (fwd+bwd) at D={D}, T={T}",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": ARGS.steps, "warmup": ARGS.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[2]: PsiCMPS fwd+bwd scan, D={D}, T={T}, batch {B} per GPU"
+            "dtype": "bf16" if pair else "f32", "data": "synthetic",
+            "config": {"workload": f"{cfg_name}: PsiCMPS fwd+bwd scan, D={D}, T={T}, batch {B} per GPU"
                                    f" (global {B * world}), damped sine + noise, full optimiser step",
                        "parallelism": f"dp{world}", "kernel_variant": int(backend.variant)},
             "roofline": roofline,

@@ -1,0 +1,85 @@
+"""The D = 128 MFMA pair kernels (CMPS_VARIANT_PAIR: bf16 mat-vec operands, float32 accumulation; BASELINE configs[4]).
+
+Two comparisons, two tolerances (stated here, derived from oracle-vs-oracle distances measured on the CPU):
+  * against oracle.psi_bf16_scan, which restates the SAME reduced-precision arithmetic (same rounding points):
+      per-clip loss 3e-4 * max(|loss|, 1), gradients 2e-3 of each tensor's max.  It is not tighter because a float32
+      difference of 1e-7 occasionally flips a bf16 rounding (2^-9 relative), after which the two trajectories drift.
+  * against the float32 restatement (the reference's arithmetic): per-clip loss 2e-3, gradients 3e-2 -- the cost of
+      bf16 operands, the same distance the bf16 emulation itself has from float32 (tests/test_oracle.py).
+"""
+import numpy as np
+import pytest
+
+from oracle import cmps_oracle as O
+from oracle import c_oracle as C
+from _util import c_oracle_run, make_audio, oracle_hparams, oracle_variables, rel_inf
+
+pytestmark = pytest.mark.gpu
+PAIR = 3
+
+
+def _pair_model(T, B, seed=3, **hpkw):
+    from audio_mps_amd import HParams, PsiCMPS
+    from audio_mps_amd.scan import HipScan
+    hp = HParams(minibatch_size=B, bond_dim=128, **hpkw)
+    audio = make_audio(B, T, hp.delta_t, seed + 4)
+    return PsiCMPS(hp, data_iterator=audio, seed=seed, backend=HipScan(128, variant=PAIR)), audio
+
+
+@pytest.mark.parametrize("T,B", [(2, 2), (40, 2), (65, 1), (200, 4), (300, 5)])
+def test_pair_matches_bf16_oracle_and_float32(T, B):
+    from audio_mps_amd.scan import unpack_grad
+    m, audio = _pair_model(T, B)
+    assert m._get_backend().variant == PAIR
+    per = m.loss_per_clip()
+    flat, _ = m.grad_sums()
+    g = unpack_grad(flat.cpu().numpy(), 128)
+    em = O.psi_bf16_scan(oracle_hparams(m.hparams), oracle_variables(m), audio, want_grad=True)
+    ref = c_oracle_run(m, audio, "f32", want_grad=True)
+    gr = C.unpack_grad(ref["grad"], 128)
+    den = np.maximum(np.abs(ref["loss_per_clip"]), 1.0)
+    assert np.max(np.abs(per - em["loss_per_clip"]) / den) <= 3e-4
+    assert np.max(np.abs(per - ref["loss_per_clip"]) / den) <= 2e-3
+    for k in ("Rbar", "fbar", "psi0bar", "Abar"):
+        assert rel_inf(g[k], em[k]) <= 2e-3, k
+        assert rel_inf(g[k], gr[k]) <= 3e-2, k
+    assert abs(g["loss_sum"] - float(np.sum(per, dtype=np.float64))) <= 1e-4 * max(1.0, abs(g["loss_sum"]))
+
+
+def test_pair_agrees_with_block_variant_at_reduced_c5():
+    """BASELINE configs[4] at reduced length and batch: the MFMA path against the float32 block kernels on the GPU."""
+    from audio_mps_amd import PsiCMPS
+    from audio_mps_amd.scan import HipScan
+    m, audio = _pair_model(1000, 8, seed=5)
+    blk = PsiCMPS(m.hparams, data_iterator=audio, seed=5, backend=HipScan(128, variant=1))
+    for k in m.variables:
+        blk.variables[k] = m.variables[k].copy()
+    a, b = m.loss_per_clip(), blk.loss_per_clip()
+    assert np.max(np.abs(a - b) / np.maximum(np.abs(b), 1.0)) <= 2e-3
+    la, ga = m.loss_and_grads()
+    lb, gb = blk.loss_and_grads()
+    assert abs(float(la) - float(lb)) <= 2e-3 * max(1.0, abs(float(lb)))
+    for k in ga:
+        assert rel_inf(ga[k], gb[k]) <= 5e-2, k
+
+
+def test_pair_training_reduces_the_loss():
+    from audio_mps_amd.train import Trainer
+    m, _ = _pair_model(300, 6, seed=2, learning_rate=1e-2)
+    tr = Trainer(m, m.hparams)
+    losses = [tr.step()["total_loss"] for _ in range(12)]
+    assert np.all(np.isfinite(losses)) and losses[-1] < losses[0]
+
+
+def test_pair_variant_rules():
+    from audio_mps_amd import _capi
+    from audio_mps_amd.scan import HipScan
+    with pytest.raises(_capi.CmpsError) as ei:
+        HipScan(64, variant=PAIR)                      # the MFMA pair kernels exist for D = 128 only
+    assert ei.value.code == _capi.CMPS_ERR_UNSUPPORTED_D
+    assert HipScan(128).variant == 1                   # AUTO stays float32: the bf16-operand path is opt-in
+    m, _ = _pair_model(20, 2)
+    m.psi_evolve_with_data                              # attribute exists; the call is refused for this variant
+    with pytest.raises(_capi.CmpsError) as ei:
+        m.psi_evolve_with_data()
+    assert ei.value.code == _capi.CMPS_ERR_STATE

@@ -8,7 +8,7 @@ import pytest
 
 from oracle import cmps_oracle as O
 from oracle import c_oracle as C
-from _util import golden_names, load_golden, golden_hparams, golden_oracle_variables, rel_inf
+from _util import golden_names, load_golden, golden_hparams, golden_oracle_variables, rel_inf, make_audio
 
 # tests/test_model.py:13-14
 TEST_HP = O.HParams(minibatch_size=8, bond_dim=7, delta_t=1 / 16000, sigma=0.0001, initial_rank=None, A=100.0,
@@ -156,3 +156,24 @@ def test_legacy_audiomps_gradients_match_finite_differences():
                   - float(O.legacy_loss_and_grads(hm_, rm_, dt, data, "f64")["loss"])) / 2e-6
             an = out["gH" if name == "H" else "gR"][idx]
             assert abs(fd - an) <= 1e-6 * max(1.0, abs(fd)), (name, idx, fd, an)
+
+
+def test_bf16_emulation_stays_close_to_float32():
+    """oracle.psi_bf16_scan restates the arithmetic of the D = 128 MFMA kernels (bf16 mat-vec operands, float32
+    accumulation, rotating frame, analytic adjoint).  It must stay within the documented bf16 distance of the float32
+    restatement -- which also validates its hand-written reverse sweep."""
+    from oracle import c_oracle as C
+    hp = O.HParams(minibatch_size=3, bond_dim=24)
+    var = O.init_variables(hp, seed=2)
+    data = make_audio(3, 150, hp.delta_t, 3)
+    em = O.psi_bf16_scan(hp, var, data)
+    R, f, _, _ = O.effective_params(hp, var)
+    ref = C.psi_scan(data, R, f, O.psi_0(var), float(var.A), hp.delta_t, hp.sigma, "f32", want_grad=True)
+    gr = C.unpack_grad(ref["grad"], 24)
+    den = np.maximum(np.abs(ref["loss_per_clip"]), 1.0)
+    assert np.max(np.abs(em["loss_per_clip"] - ref["loss_per_clip"]) / den) <= 2e-3
+    for k in ("Rbar", "fbar", "psi0bar", "Abar"):
+        assert rel_inf(em[k], gr[k]) <= 3e-2, k
+    # and the rounding helper is round-to-nearest-even on the top 16 bits
+    x = np.array([1.0, 1.00390625, 1.01171875, -2.5, 3.0e-39], dtype=np.float32)
+    np.testing.assert_array_equal(O.bf16_round(x), np.array([1.0, 1.0, 1.015625, -2.5, O.bf16_round(x[4:5])[0]], dtype=np.float32))
