@@ -1,4 +1,4 @@
-// D = 128 ("bf16 with fp32 accumulate", BASELINE configs[4]): MFMA kernels, one workgroup per PAIR of clips.
+// D = 128 ("bf16 with fp32 accumulate", BASELINE configs[4]) and D = 64: MFMA kernels, one workgroup per PAIR of clips.
 //
 // At D = 128 and B = 512 there are two clips per CU and a matrix is 128 KB in complex64: nothing like the wave-per-clip
 // layout fits.  What does fit is the batched 4x4x4 bf16 MFMA (v_mfma_f32_4x4x4_16b_bf16: 16 independent 4x4 blocks per
@@ -24,9 +24,9 @@ namespace cmps {
 
 namespace {
 
-constexpr int PD = 128;      // bond dimension of this variant
-constexpr int PWV = 4;       // waves per workgroup
 constexpr int PCH = 64;      // steps per chunk of per-step scalars
+// Everything below is templated on the bond dimension D (64 or 128): D / 32 waves own 32 rows each, a mat-vec is D / 4
+// MFMA instructions per matrix and wave, a broadcast vector is D / 8 16-byte reads per lane.
 
 typedef short bf4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -83,14 +83,24 @@ __device__ __forceinline__ float clip_sum(float x) {
 // Rows are padded by 16 B: the eight lane groups (kh, c) of a wave read eight DIFFERENT rows at the same offset in the same
 // instruction, and unpadded 256-byte rows would all start in the same LDS bank (measured: 73 % of the LDS cycles were bank
 // conflicts before the padding).
-constexpr int VROW = PD * 2 + 16;                           // bytes per (array, clip) row
-constexpr int VEC_BYTES = 8 * VROW;                         // re, im, -im (x 2 clips) + 2 dummy rows (the even lanes' second write)
-
+template <int D>
 struct PairLds {
+    static constexpr int VROW = D * 2 + 16;                           // bytes per (array, clip) row
+    static constexpr int VEC_BYTES = 8 * VROW;    // re, im, -im (x 2 clips) + 2 dummy rows (the even lanes' second write)
     __attribute__((aligned(16))) unsigned char vec[2][2][VEC_BYTES];   // [parity][0: ut, 1: y]
-    __attribute__((aligned(16))) float nrm[2][2][PWV];                 // [parity][clip][wave]
-    __attribute__((aligned(16))) float ee[2][2][PWV];
+    __attribute__((aligned(16))) float nrm[2][2][4];                   // [parity][clip][wave]
+    __attribute__((aligned(16))) float ee[2][2][4];
 };
+template <int W>
+__device__ __forceinline__ float sum_waves(const float* p) {          // p[0..W-1], 16-byte aligned
+    if constexpr (W == 4) {
+        const f4 t = *reinterpret_cast<const f4*>(p);
+        return (t.x + t.y) + (t.z + t.w);
+    } else {
+        const float2 t = *reinterpret_cast<const float2*>(p);
+        return t.x + t.y;
+    }
+}
 
 typedef unsigned u2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ bf4 frag_of(unsigned lo, unsigned hi) {
@@ -125,8 +135,8 @@ __device__ __forceinline__ void rd_wait(u4 (&o)[8]) {
 // two matrices against eight 16-byte pieces of one vector (instructions t = 2 * (T0 + i), 2 * (T0 + i) + 1); two
 // accumulators per matrix keep dependent MFMAs four instructions apart (no wait states)
 struct Acc2 { f4 a, b; };
-template <int T0>
-__device__ __forceinline__ void mm2(const bf4 (&FA)[32], const bf4 (&FB)[32], const u4 (&v)[8], Acc2& x, Acc2& y) {
+template <int T0, int NT>
+__device__ __forceinline__ void mm2(const bf4 (&FA)[NT], const bf4 (&FB)[NT], const u4 (&v)[8], Acc2& x, Acc2& y) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const bf4 lo = frag_of(v[i].x, v[i].y), hi = frag_of(v[i].z, v[i].w);
@@ -138,8 +148,8 @@ __device__ __forceinline__ void mm2(const bf4 (&FA)[32], const bf4 (&FB)[32], co
 }
 // one matrix, four accumulators
 struct Acc4 { f4 a, b, c, d; };
-template <int T0>
-__device__ __forceinline__ void mm1(const bf4 (&FA)[32], const u4 (&v)[8], Acc4& x) {
+template <int T0, int NT>
+__device__ __forceinline__ void mm1(const bf4 (&FA)[NT], const u4 (&v)[8], Acc4& x) {
 #pragma unroll
     for (int i = 0; i < 8; i += 2) {
         x.a = MFMA4(FA[2 * (T0 + i)], frag_of(v[i].x, v[i].y), x.a);
@@ -158,32 +168,36 @@ __device__ __forceinline__ void rows_of(const f4& t, float& ra, float& rb) {
 // latency every step: the table is 16 MB at D = 128); the next chunk is loaded into registers at the start of a chunk and
 // committed to the other buffer in the middle of it
 constexpr int RCH = 32;
+template <int D>
 struct RhoStage {
-    __attribute__((aligned(16))) float2 row[2][RCH][PD];
+    __attribute__((aligned(16))) float2 row[2][RCH][D];
 };
+// D / 32 waves (tid < 2 D) move one chunk: 32 rows x D / 2 float4 = 8 float4 per thread
+template <int D>
 __device__ __forceinline__ void rho_load(const Dev& P, int chunk, int tid, float4 (&r)[8]) {
-    const float4* src = reinterpret_cast<const float4*>(P.rho);       // [N + 1][PD] float2 = 64 float4 per row
+    const float4* src = reinterpret_cast<const float4*>(P.rho);       // [N + 1][D] float2 = D / 2 float4 per row
     const int maxrow = P.N;                                            // the table has N + 1 rows
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int e = tid + 256 * i;
-        int rowi = chunk * RCH + (e >> 6);
+        const int e = tid + 2 * D * i;
+        int rowi = chunk * RCH + e / (D / 2);
         rowi = rowi < 0 ? 0 : (rowi > maxrow ? maxrow : rowi);
-        r[i] = src[(size_t)rowi * 64 + (e & 63)];
+        r[i] = src[(size_t)rowi * (D / 2) + e % (D / 2)];
     }
 }
-__device__ __forceinline__ void rho_commit(RhoStage& S, int buf, int tid, const float4 (&r)[8]) {
+template <int D>
+__device__ __forceinline__ void rho_commit(RhoStage<D>& S, int buf, int tid, const float4 (&r)[8]) {
     asm volatile("" ::: "memory");      // all eight loads are issued before the first store (else: load, wait, store, x 8)
     float4* dst = reinterpret_cast<float4*>(&S.row[buf][0][0]);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) dst[tid + 256 * i] = r[i];
+    for (int i = 0; i < 8; ++i) dst[tid + 2 * D * i] = r[i];
 }
 
 // A fragments of one matrix for this lane: frag[t] = 4 bf16 = M_part[row][4t..4t+3]
-template <typename F>
-__device__ __forceinline__ void load_frags(bf4 (&frag)[32], F&& elem) {
+template <int NT, typename F>
+__device__ __forceinline__ void load_frags(bf4 (&frag)[NT], F&& elem) {
 #pragma unroll
-    for (int t = 0; t < 32; ++t) {
+    for (int t = 0; t < NT; ++t) {
         bf4 v;
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = (short)bf16_rne(elem(4 * t + j));
@@ -201,14 +215,15 @@ __device__ __forceinline__ void load_frags(bf4 (&frag)[32], F&& elem) {
 // ~5.4 cycles; the split also keeps each wave's fragments in arch VGPRs -- the 4-wave version copied 48 of them out of
 // AGPRs every step).
 // ------------------------------------------------------------------------------------------------
-template <bool SAVE>
-__global__ __launch_bounds__(128 * PWV, 1) void k_fwd_pair(Dev P, const float* __restrict__ audio,
-                                                           float* __restrict__ loss_out) {
-    __shared__ PairLds L;
-    __shared__ RhoStage RS;
+template <int PD, bool SAVE>
+__global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __restrict__ audio,
+                                                        float* __restrict__ loss_out) {
+    constexpr int PWV = PD / 32, NT = PD / 4, VROW = PairLds<PD>::VROW;
+    __shared__ PairLds<PD> L;
+    __shared__ RhoStage<PD> RS;
     __shared__ __attribute__((aligned(8))) float2 yf[2][PWV][64];       // y_k in float32, [parity][chain wave][lane]
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int w = wv & (PWV - 1);
+    const int w = wv % PWV;
     const bool loss_wave = wv >= PWV;
     const int c = lane & 3, q = c >> 1, rg = (lane >> 2) & 7, kh = lane >> 5;
     const bool odd = (c & 1) != 0;
@@ -228,7 +243,7 @@ __global__ __launch_bounds__(128 * PWV, 1) void k_fwd_pair(Dev P, const float* _
 
     if (!loss_wave) {
         // ================================================================== chain waves
-        bf4 FR[32], FQ[32];
+        bf4 FR[NT], FQ[NT];
         {
             const float2* Rrow = P.R + (size_t)arow * PD;
             const float2* Qrow = P.Q + (size_t)arow * PD;
@@ -253,10 +268,10 @@ __global__ __launch_bounds__(128 * PWV, 1) void k_fwd_pair(Dev P, const float* _
         float inv = 1.f;                                              // 1/sqrt(max(|y_{k-1}|^2, eps)) of this lane's clip
         float sv0 = 0.f, sv1 = 0.f;                                   // s = x / A of the current 64 steps, lane <-> step
         write_vec(L.vec[0][0], uta, utb);
-        if (tid < 256) {
+        {
             float4 rpre[8];
-            rho_load(P, 0, tid, rpre);
-            rho_commit(RS, 0, tid, rpre);
+            rho_load<PD>(P, 0, tid, rpre);
+            rho_commit<PD>(RS, 0, tid, rpre);
         }
         __syncthreads();
         for (int k = 0; k <= N + 1; ++k) {
@@ -270,24 +285,28 @@ __global__ __launch_bounds__(128 * PWV, 1) void k_fwd_pair(Dev P, const float* _
                 }
                 if ((k & (RCH - 1)) == 0) {                            // next chunk of rho into the other buffer
                     float4 rpre[8];
-                    rho_load(P, k / RCH + 1, tid, rpre);
-                    rho_commit(RS, (k / RCH + 1) & 1, tid, rpre);
+                    rho_load<PD>(P, k / RCH + 1, tid, rpre);
+                    rho_commit<PD>(RS, (k / RCH + 1) & 1, tid, rpre);
                 }
                 const float2 rha = RS.row[(k / RCH) & 1][k & (RCH - 1)][ia];   // rho_k of this lane's rows
                 const float2 rhb = RS.row[(k / RCH) & 1][k & (RCH - 1)][ib];
                 if (k >= 1) {                                          // |y_{k-1}|^2, published by the previous iteration
-                    const f4 t4 = *reinterpret_cast<const f4*>(&L.nrm[p][q][0]);
-                    inv = __builtin_amdgcn_rsqf(fmaxf((t4.x + t4.y) + (t4.z + t4.w), 1e-12f));   // model.py:332
+                    inv = __builtin_amdgcn_rsqf(fmaxf(sum_waves<PWV>(&L.nrm[p][q][0]), 1e-12f));   // model.py:332
                 }
                 const unsigned aU = lds_addr_of(L.vec[p][0]) + rd_off;
                 u4 B0[8], B1[8];
-                rd8(aU, B0);
-                rd8(aU + 128, B1);
                 Acc2 cR = {z4, z4}, cQ = {z4, z4};
-                rd_wait<8>(B0);
-                mm2<0>(FR, FQ, B0, cR, cQ);
-                rd_wait<0>(B1);
-                mm2<8>(FR, FQ, B1, cR, cQ);
+                rd8(aU, B0);
+                if constexpr (PD == 128) {
+                    rd8(aU + 128, B1);
+                    rd_wait<8>(B0);
+                    mm2<0>(FR, FQ, B0, cR, cQ);
+                    rd_wait<0>(B1);
+                    mm2<8>(FR, FQ, B1, cR, cQ);
+                } else {
+                    rd_wait<0>(B0);
+                    mm2<0>(FR, FQ, B0, cR, cQ);
+                }
                 const int kl = k & (PCH - 1);
                 const float s = q ? rdl(sv1, kl) : rdl(sv0, kl);
                 float ra, rb, qa, qb;
@@ -311,7 +330,7 @@ __global__ __launch_bounds__(128 * PWV, 1) void k_fwd_pair(Dev P, const float* _
     }
 
     // ====================================================================== loss waves
-    bf4 FH[32];
+    bf4 FH[NT];
     {
         const float2* Rrow = P.R + (size_t)arow * PD;
         const float2* RTrow = P.RT + (size_t)arow * PD;     // RT[i][j] = R[j][i]
@@ -331,8 +350,7 @@ __global__ __launch_bounds__(128 * PWV, 1) void k_fwd_pair(Dev P, const float* _
         if (k >= 1 && k <= N) {
             // ---- |y_{k-1}|^2 for the scalar rows ----
             {
-                const f4 t4 = *reinterpret_cast<const f4*>(&L.nrm[p][q][0]);
-                const float n = (t4.x + t4.y) + (t4.z + t4.w);
+                const float n = sum_waves<PWV>(&L.nrm[p][q][0]);
                 const int j = k - 1, jl = j & (PCH - 1);
                 const float n0 = rdl(n, 0), n1 = rdl(n, 2);
                 nv0 = lane == jl ? n0 : nv0;
@@ -346,13 +364,18 @@ __global__ __launch_bounds__(128 * PWV, 1) void k_fwd_pair(Dev P, const float* _
             const unsigned aY = lds_addr_of(L.vec[p][1]) + rd_off;
             u4 B0[8], B1[8];
             rd8(aY, B0);
-            rd8(aY + 128, B1);
+            if constexpr (PD == 128) rd8(aY + 128, B1);
             const float2 yv = yf[p][w][lane];
             Acc4 cH = {z4, z4, z4, z4};
-            rd_wait<8>(B0);
-            mm1<0>(FH, B0, cH);
-            rd_wait<0>(B1);
-            mm1<8>(FH, B1, cH);
+            if constexpr (PD == 128) {
+                rd_wait<8>(B0);
+                mm1<0>(FH, B0, cH);
+                rd_wait<0>(B1);
+                mm1<8>(FH, B1, cH);
+            } else {
+                rd_wait<0>(B0);
+                mm1<0>(FH, B0, cH);
+            }
             float ha, hb;                                              // ((R + R^dagger) y_{k-1}) rows ia / ib
             rows_of((cH.a + cH.b) + (cH.c + cH.d), ha, hb);
             if (SAVE) st[(size_t)(k - 1) * PWV * 64] = make_float4(yv.x, yv.y, ha, hb);
@@ -360,8 +383,7 @@ __global__ __launch_bounds__(128 * PWV, 1) void k_fwd_pair(Dev P, const float* _
             if (lane == 0 || lane == 2) L.ee[p ^ 1][q][w] = ep;
         }
         if (k >= 2) {                                                  // e_{k-2}, published by the previous iteration
-            const f4 t4 = *reinterpret_cast<const f4*>(&L.ee[p][q][0]);
-            const float e = (t4.x + t4.y) + (t4.z + t4.w);
+            const float e = sum_waves<PWV>(&L.ee[p][q][0]);
             const int j = k - 2, jl = j & (PCH - 1);
             const float e0 = rdl(e, 0), e1 = rdl(e, 2);
             ev0 = lane == jl ? e0 : ev0;
@@ -393,10 +415,15 @@ __global__ __launch_bounds__(128 * PWV, 1) void k_fwd_pair(Dev P, const float* _
 
 hipError_t launch_fwd_pair(const Dev& P, const float* audio, float* loss, bool save, hipStream_t s) {
     const unsigned nb = (unsigned)((P.B + 1) / 2);
-    if (save)
-        hipLaunchKernelGGL(k_fwd_pair<true>, dim3(nb), dim3(128 * PWV), 0, s, P, audio, loss);
-    else
-        hipLaunchKernelGGL(k_fwd_pair<false>, dim3(nb), dim3(128 * PWV), 0, s, P, audio, loss);
+    if (P.D == 128) {
+        if (save) hipLaunchKernelGGL((k_fwd_pair<128, true>), dim3(nb), dim3(512), 0, s, P, audio, loss);
+        else hipLaunchKernelGGL((k_fwd_pair<128, false>), dim3(nb), dim3(512), 0, s, P, audio, loss);
+    } else if (P.D == 64) {
+        if (save) hipLaunchKernelGGL((k_fwd_pair<64, true>), dim3(nb), dim3(256), 0, s, P, audio, loss);
+        else hipLaunchKernelGGL((k_fwd_pair<64, false>), dim3(nb), dim3(256), 0, s, P, audio, loss);
+    } else {
+        return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 
@@ -416,16 +443,19 @@ namespace cmps {
 namespace {
 
 // per-step scalars of one clip: (s, inv, ok, te | rad, xa = -x/A^2, dt, -)
+template <int W>
 struct StepTab {
-    __attribute__((aligned(16))) f4 row[PWV][2][PCH][2][2];            // [wave][chunk parity][step][clip][half]
+    __attribute__((aligned(16))) f4 row[W][2][PCH][2][2];              // [wave][chunk parity][step][clip][half]
 };
 
 }  // namespace
 
-__global__ __launch_bounds__(64 * PWV, 1) void k_bwd_pair(Dev P, const float* __restrict__ audio) {
-    __shared__ PairLds L;
-    __shared__ StepTab TB;
-    __shared__ RhoStage RS;
+template <int PD>
+__global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __restrict__ audio) {
+    constexpr int PWV = PD / 32, NT = PD / 4, VROW = PairLds<PD>::VROW;
+    __shared__ PairLds<PD> L;
+    __shared__ StepTab<PWV> TB;
+    __shared__ RhoStage<PD> RS;
     __shared__ float redA[PWV];
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int c = lane & 3, q = c >> 1, rg = (lane >> 2) & 7, kh = lane >> 5;
@@ -437,7 +467,7 @@ __global__ __launch_bounds__(64 * PWV, 1) void k_bwd_pair(Dev P, const float* __
     const int ia = 32 * w + 4 * rg + 2 * kh, ib = ia + 1;
     const int arow = 32 * w + 4 * rg + c;
 
-    bf4 FQ[32], FD[32];                                                // Q (Hermitian) and R^dagger
+    bf4 FQ[NT], FD[NT];                                                // Q (Hermitian) and R^dagger
     {
         const float2* Qrow = P.Q + (size_t)arow * PD;
         const float2* RTrow = P.RT + (size_t)arow * PD;                // R^dagger[i][j] = conj(R[j][i]) = conj(RT[i][j])
@@ -506,11 +536,11 @@ __global__ __launch_bounds__(64 * PWV, 1) void k_bwd_pair(Dev P, const float* __
     {
         float4 rpre[8];
         const int cl = (N - 1) / RCH;
-        rho_load(P, cl, threadIdx.x, rpre);
-        rho_commit(RS, cl & 1, threadIdx.x, rpre);
+        rho_load<PD>(P, cl, threadIdx.x, rpre);
+        rho_commit<PD>(RS, cl & 1, threadIdx.x, rpre);
         if (cl > 0) {
-            rho_load(P, cl - 1, threadIdx.x, rpre);
-            rho_commit(RS, (cl - 1) & 1, threadIdx.x, rpre);
+            rho_load<PD>(P, cl - 1, threadIdx.x, rpre);
+            rho_commit<PD>(RS, (cl - 1) & 1, threadIdx.x, rpre);
         }
     }
     __syncthreads();
@@ -521,8 +551,8 @@ __global__ __launch_bounds__(64 * PWV, 1) void k_bwd_pair(Dev P, const float* __
         if (jl == 0 && k > 0) chunk_rows(k / PCH - 1);                 // u_k needs inv_{k-1}: the chunk below, other buffer
         if ((k & (RCH - 1)) == RCH - 1 && k != N - 1 && k >= RCH) {    // entering rho chunk k / RCH: fetch the one below
             float4 rpre[8];
-            rho_load(P, k / RCH - 1, threadIdx.x, rpre);
-            rho_commit(RS, (k / RCH - 1) & 1, threadIdx.x, rpre);
+            rho_load<PD>(P, k / RCH - 1, threadIdx.x, rpre);
+            rho_commit<PD>(RS, (k / RCH - 1) & 1, threadIdx.x, rpre);
         }
         const float2 rha = RS.row[(k / RCH) & 1][k & (RCH - 1)][ia], rhb = RS.row[(k / RCH) & 1][k & (RCH - 1)][ib];
         const int km = k > 0 ? k - 1 : 0;
@@ -551,11 +581,16 @@ __global__ __launch_bounds__(64 * PWV, 1) void k_bwd_pair(Dev P, const float* __
             const unsigned aV = lds_addr_of(L.vec[p][0]) + rd_off;
             u4 B0[8], B1[8];
             rd8(aV, B0);
-            rd8(aV + 128, B1);
-            rd_wait<8>(B0);
-            mm2<0>(FQ, FD, B0, cQ, cD);
-            rd_wait<0>(B1);
-            mm2<8>(FQ, FD, B1, cQ, cD);
+            if constexpr (PD == 128) {
+                rd8(aV + 128, B1);
+                rd_wait<8>(B0);
+                mm2<0>(FQ, FD, B0, cQ, cD);
+                rd_wait<0>(B1);
+                mm2<8>(FQ, FD, B1, cQ, cD);
+            } else {
+                rd_wait<0>(B0);
+                mm2<0>(FQ, FD, B0, cQ, cD);
+            }
         }
         float qa, qb, da, db;
         rows_of(cQ.a + cQ.b, qa, qb);
@@ -622,7 +657,10 @@ __global__ __launch_bounds__(64 * PWV, 1) void k_bwd_pair(Dev P, const float* __
         if (lane == 0) redA[w] = t;
         __syncthreads();
         if (threadIdx.x == 0) {
-            slab[4 * DD + 3 * PD] = (redA[0] + redA[1]) + (redA[2] + redA[3]);
+            float tot = 0.f;
+#pragma unroll
+            for (int i = 0; i < PWV; ++i) tot += redA[i];
+            slab[4 * DD + 3 * PD] = tot;
             slab[4 * DD + 3 * PD + 1] = 0.f;
         }
     }
@@ -630,7 +668,9 @@ __global__ __launch_bounds__(64 * PWV, 1) void k_bwd_pair(Dev P, const float* __
 
 hipError_t launch_bwd_pair(const Dev& P, const float* audio, hipStream_t s) {
     const unsigned nb = (unsigned)((P.B + 1) / 2);
-    hipLaunchKernelGGL(k_bwd_pair, dim3(nb), dim3(64 * PWV), 0, s, P, audio);
+    if (P.D == 128) hipLaunchKernelGGL(k_bwd_pair<128>, dim3(nb), dim3(256), 0, s, P, audio);
+    else if (P.D == 64) hipLaunchKernelGGL(k_bwd_pair<64>, dim3(nb), dim3(128), 0, s, P, audio);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
@@ -651,10 +691,11 @@ typedef short bf8 __attribute__((ext_vector_type(8)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 
 constexpr int GS = 4;                                   // steps per MFMA group
+template <int D>
 struct GradLds {
     // [buffer][operand: te y, ybar, s ybar, y, u][re / im][row][(clip, step in group)] bf16
-    __attribute__((aligned(16))) unsigned short op[2][5][2][PD][2 * GS];
-    __attribute__((aligned(16))) f4 tab[PWV][2][PCH][2];            // per wave: (s, te, inv, -) per step and clip
+    __attribute__((aligned(16))) unsigned short op[2][5][2][D][2 * GS];
+    __attribute__((aligned(16))) f4 tab[D / 32][2][PCH][2];         // per wave: (s, te, inv, -) per step and clip
 };
 
 __device__ __forceinline__ bf8 neg_if(bf8 v, unsigned mask) {
@@ -665,8 +706,10 @@ __device__ __forceinline__ bf8 neg_if(bf8 v, unsigned mask) {
 
 }  // namespace
 
-__global__ __launch_bounds__(64 * PWV, 1) void k_grad_pair(Dev P, const float* __restrict__ audio) {
-    __shared__ GradLds G;
+template <int PD>
+__global__ __launch_bounds__(2 * PD, 1) void k_grad_pair(Dev P, const float* __restrict__ audio) {
+    constexpr int PWV = PD / 32;
+    __shared__ GradLds<PD> G;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     // producer view of a lane (the scans' layout): rows ia / ib, component (c & 1), clip q
     const int c = lane & 3, q = c >> 1, rg = (lane >> 2) & 7, kh = lane >> 5;
@@ -708,9 +751,9 @@ __global__ __launch_bounds__(64 * PWV, 1) void k_grad_pair(Dev P, const float* _
         }
     };
 
-    f16v Rre[4], Rim[4], Qre[4], Qim[4];
+    f16v Rre[PWV], Rim[PWV], Qre[PWV], Qim[PWV];                   // this wave's row block x PWV column blocks
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
+    for (int cb = 0; cb < PWV; ++cb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) Rre[cb][r] = Rim[cb][r] = Qre[cb][r] = Qim[cb][r] = 0.f;
 
@@ -798,7 +841,7 @@ __global__ __launch_bounds__(64 * PWV, 1) void k_grad_pair(Dev P, const float* _
             aIm[o] = neg_if(*reinterpret_cast<const bf8*>(&G.op[buf][o][mh ^ 1][32 * w + mr][0]), nmask);
         }
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) {
+        for (int cb = 0; cb < PWV; ++cb) {
             const bf8 by = *reinterpret_cast<const bf8*>(&G.op[buf][3][mh][32 * cb + mr][0]);
             const bf8 bu = *reinterpret_cast<const bf8*>(&G.op[buf][4][mh][32 * cb + mr][0]);
             Rre[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aRe[0], by, Rre[cb], 0, 0, 0);
@@ -813,7 +856,7 @@ __global__ __launch_bounds__(64 * PWV, 1) void k_grad_pair(Dev P, const float* _
     float* slab = P.slabs + (size_t)blockIdx.x * P.slab_floats;
     constexpr int DD = PD * PD;
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
+    for (int cb = 0; cb < PWV; ++cb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = 32 * w + (r & 3) + 8 * (r >> 2) + 4 * mh;   // C/D layout of the 32x32 MFMA: column = lane & 31
@@ -827,7 +870,9 @@ __global__ __launch_bounds__(64 * PWV, 1) void k_grad_pair(Dev P, const float* _
 
 hipError_t launch_grad_pair(const Dev& P, const float* audio, hipStream_t s) {
     const unsigned nb = (unsigned)((P.B + 1) / 2);
-    hipLaunchKernelGGL(k_grad_pair, dim3(nb), dim3(64 * PWV), 0, s, P, audio);
+    if (P.D == 128) hipLaunchKernelGGL(k_grad_pair<128>, dim3(nb), dim3(256), 0, s, P, audio);
+    else if (P.D == 64) hipLaunchKernelGGL(k_grad_pair<64>, dim3(nb), dim3(128), 0, s, P, audio);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 

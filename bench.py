@@ -41,7 +41,7 @@ def parse_args():
     p.add_argument("--T", type=int, default=16000)
     p.add_argument("--batch-per-gpu", type=int, default=1024)
     p.add_argument("--variant", type=int, default=0,
-                   help="0 auto, 1 block-per-clip, 2 wave-per-clip, 3 MFMA pair kernels (needs --bond-dim 128; bf16 operands)")
+                   help="0 auto, 1 block-per-clip, 2 wave-per-clip, 3 MFMA pair kernels (needs --bond-dim 64 or 128; bf16 operands)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-clips", type=int, default=0, help="clips in the CPU sample (0 = 8 per thread)")
     return p.parse_args()

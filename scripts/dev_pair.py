@@ -9,8 +9,7 @@ from audio_mps_amd.scan import HipScan, unpack_grad
 from oracle import cmps_oracle as O, c_oracle as C
 from _util import make_audio, oracle_hparams, oracle_variables, c_oracle_run
 
-D = 128
-for (T, B) in [(40, 2), (200, 4), (300, 5)]:
+for (D, T, B) in [(64, 40, 2), (64, 300, 5), (128, 40, 2), (128, 200, 4), (128, 300, 5)]:
     hp = HParams(minibatch_size=B, bond_dim=D)
     audio = make_audio(B, T, hp.delta_t, 7)
     m = PsiCMPS(hp, data_iterator=audio, seed=3, backend=HipScan(D, variant=3))
@@ -21,7 +20,7 @@ for (T, B) in [(40, 2), (200, 4), (300, 5)]:
     ref = c_oracle_run(m, audio, "f32", want_grad=True)
     gr = C.unpack_grad(ref["grad"], D)
     den = np.maximum(np.abs(ref["loss_per_clip"]), 1.0)
-    print(f"T={T} B={B}: loss hip vs bf16-emulation {np.max(np.abs(per - em['loss_per_clip']) / den):.3e}   hip vs f32 {np.max(np.abs(per - ref['loss_per_clip']) / den):.3e}")
+    print(f"D={D} T={T} B={B}: loss hip vs bf16-emulation {np.max(np.abs(per - em['loss_per_clip']) / den):.3e}   hip vs f32 {np.max(np.abs(per - ref['loss_per_clip']) / den):.3e}")
     for k in ("Rbar", "fbar", "psi0bar", "Abar"):
         a, e_, r_ = np.asarray(g[k]), np.asarray(em[k]), np.asarray(gr[k])
         print(f"   {k:8s} hip vs emulation {np.max(np.abs(a - e_)) / max(np.max(np.abs(e_)), 1e-30):.3e}   hip vs f32 {np.max(np.abs(a - r_)) / max(np.max(np.abs(r_)), 1e-30):.3e}   emul vs f32 {np.max(np.abs(e_ - r_)) / max(np.max(np.abs(r_)), 1e-30):.3e}")

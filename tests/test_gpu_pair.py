@@ -1,4 +1,4 @@
-"""The D = 128 MFMA pair kernels (CMPS_VARIANT_PAIR: bf16 mat-vec operands, float32 accumulation; BASELINE configs[4]).
+"""The D = 64 / 128 MFMA pair kernels (CMPS_VARIANT_PAIR: bf16 mat-vec operands, float32 accumulation; BASELINE configs[4]).
 
 Two comparisons, two tolerances (stated here, derived from oracle-vs-oracle distances measured on the CPU):
   * against oracle.psi_bf16_scan, which restates the SAME reduced-precision arithmetic (same rounding points):
@@ -18,25 +18,26 @@ pytestmark = pytest.mark.gpu
 PAIR = 3
 
 
-def _pair_model(T, B, seed=3, **hpkw):
+def _pair_model(T, B, seed=3, D=128, **hpkw):
     from audio_mps_amd import HParams, PsiCMPS
     from audio_mps_amd.scan import HipScan
-    hp = HParams(minibatch_size=B, bond_dim=128, **hpkw)
+    hp = HParams(minibatch_size=B, bond_dim=D, **hpkw)
     audio = make_audio(B, T, hp.delta_t, seed + 4)
-    return PsiCMPS(hp, data_iterator=audio, seed=seed, backend=HipScan(128, variant=PAIR)), audio
+    return PsiCMPS(hp, data_iterator=audio, seed=seed, backend=HipScan(D, variant=PAIR)), audio
 
 
-@pytest.mark.parametrize("T,B", [(2, 2), (40, 2), (65, 1), (200, 4), (300, 5)])
-def test_pair_matches_bf16_oracle_and_float32(T, B):
+@pytest.mark.parametrize("D,T,B", [(128, 2, 2), (128, 40, 2), (128, 65, 1), (128, 200, 4), (128, 300, 5),
+                                   (64, 3, 1), (64, 130, 3), (64, 300, 6)])
+def test_pair_matches_bf16_oracle_and_float32(D, T, B):
     from audio_mps_amd.scan import unpack_grad
-    m, audio = _pair_model(T, B)
+    m, audio = _pair_model(T, B, D=D)
     assert m._get_backend().variant == PAIR
     per = m.loss_per_clip()
     flat, _ = m.grad_sums()
-    g = unpack_grad(flat.cpu().numpy(), 128)
+    g = unpack_grad(flat.cpu().numpy(), D)
     em = O.psi_bf16_scan(oracle_hparams(m.hparams), oracle_variables(m), audio, want_grad=True)
     ref = c_oracle_run(m, audio, "f32", want_grad=True)
-    gr = C.unpack_grad(ref["grad"], 128)
+    gr = C.unpack_grad(ref["grad"], D)
     den = np.maximum(np.abs(ref["loss_per_clip"]), 1.0)
     assert np.max(np.abs(per - em["loss_per_clip"]) / den) <= 3e-4
     assert np.max(np.abs(per - ref["loss_per_clip"]) / den) <= 2e-3
@@ -75,9 +76,9 @@ def test_pair_variant_rules():
     from audio_mps_amd import _capi
     from audio_mps_amd.scan import HipScan
     with pytest.raises(_capi.CmpsError) as ei:
-        HipScan(64, variant=PAIR)                      # the MFMA pair kernels exist for D = 128 only
+        HipScan(96, variant=PAIR)                      # the MFMA pair kernels exist for D = 64 and 128 only
     assert ei.value.code == _capi.CMPS_ERR_UNSUPPORTED_D
-    assert HipScan(128).variant == 1                   # AUTO stays float32: the bf16-operand path is opt-in
+    assert HipScan(128).variant == 1 and HipScan(64).variant == 1   # AUTO stays float32: the bf16-operand path is opt-in
     m, _ = _pair_model(20, 2)
     m.psi_evolve_with_data                              # attribute exists; the call is refused for this variant
     with pytest.raises(_capi.CmpsError) as ei:
