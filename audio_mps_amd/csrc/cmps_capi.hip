@@ -54,7 +54,7 @@ int fail_hip(cmps_handle_t h, hipError_t e, const char* where) {
 int resolve_variant(const cmps_handle_s* h) {
     if (h->variant_req == CMPS_VARIANT_BLOCK) return CMPS_VARIANT_BLOCK;
     if (h->variant_req == CMPS_VARIANT_WAVE) return h->D <= 32 ? CMPS_VARIANT_WAVE : CMPS_VARIANT_BLOCK;
-    if (h->variant_req == CMPS_VARIANT_PAIR) return (h->D == 128 || h->D == 64) ? CMPS_VARIANT_PAIR : CMPS_VARIANT_BLOCK;
+    if (h->variant_req == CMPS_VARIANT_PAIR) return h->D > 32 ? CMPS_VARIANT_PAIR : CMPS_VARIANT_BLOCK;
     // AUTO: float32 everywhere; the bf16-operand MFMA kernels of D = 128 are opt-in (they change the arithmetic)
     return h->D <= 32 ? CMPS_VARIANT_WAVE : CMPS_VARIANT_BLOCK;
 }
@@ -87,8 +87,8 @@ int cmps_set_variant(cmps_handle_t h, int variant) {
     if (!h) return CMPS_ERR_BAD_ARG;
     if (variant < CMPS_VARIANT_AUTO || variant > CMPS_VARIANT_PAIR)
         return fail(h, CMPS_ERR_BAD_ARG, "cmps_set_variant: unknown variant");
-    if (variant == CMPS_VARIANT_PAIR && h->D != 128 && h->D != 64)
-        return fail(h, CMPS_ERR_UNSUPPORTED_D, "cmps_set_variant: the pair (MFMA) variant needs D = 64 or 128");
+    if (variant == CMPS_VARIANT_PAIR && h->D <= 32)
+        return fail(h, CMPS_ERR_UNSUPPORTED_D, "cmps_set_variant: the pair (MFMA) variant is for 32 < D <= 128");
     if (variant == CMPS_VARIANT_WAVE && h->D > 32)
         return fail(h, CMPS_ERR_UNSUPPORTED_D, "cmps_set_variant: the wave variant needs D <= 32");
     h->variant_req = variant;

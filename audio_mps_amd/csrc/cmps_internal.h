@@ -21,7 +21,7 @@ namespace cmps {
 //   scal     : [B][NC][2][64] float   per 64-step chunk: |y_k|^2 and e_k, one step per lane (wave variant)
 //   slabs    : [B][slab] float        per-clip gradient partials (TRAIN only)
 //   sums     : [slab] float           reduced partials, followed by [32][slab] double first-pass partial sums
-// DP = D for the block variant; 32 for the wave variant (components >= D are zero padding).
+// DP = D rounded up to a multiple of 32 (components >= D are zero padding and stay exactly zero).
 // ---------------------------------------------------------------------------------------------
 struct Layout {
     int D, DP, B, T, N, flags;
@@ -32,7 +32,7 @@ struct Layout {
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-inline int padded_D(int D) { return D <= 32 ? 32 : D; }
+inline int padded_D(int D) { return (D + 31) / 32 * 32; }   // zero padding to the next multiple of 32 (32, 64, 96, 128)
 
 inline Layout make_layout(int D, int B, int T, int flags) {
     Layout L{};

@@ -1,4 +1,5 @@
-// D = 128 ("bf16 with fp32 accumulate", BASELINE configs[4]) and D = 64: MFMA kernels, one workgroup per PAIR of clips.
+// 32 < D <= 128 ("bf16 with fp32 accumulate", BASELINE configs[4] is D = 128): MFMA kernels, one workgroup per PAIR of
+// clips, instantiated for the padded bond dimensions 64, 96 and 128 (components >= D are zero padding).
 //
 // At D = 128 and B = 512 there are two clips per CU and a matrix is 128 KB in complex64: nothing like the wave-per-clip
 // layout fits.  What does fit is the batched 4x4x4 bf16 MFMA (v_mfma_f32_4x4x4_16b_bf16: 16 independent 4x4 blocks per
@@ -25,7 +26,7 @@ namespace cmps {
 namespace {
 
 constexpr int PCH = 64;      // steps per chunk of per-step scalars
-// Everything below is templated on the bond dimension D (64 or 128): D / 32 waves own 32 rows each, a mat-vec is D / 4
+// Everything below is templated on the padded bond dimension D (64, 96 or 128): D / 32 waves own 32 rows each, a mat-vec is D / 4
 // MFMA instructions per matrix and wave, a broadcast vector is D / 8 16-byte reads per lane.
 
 typedef short bf4 __attribute__((ext_vector_type(4)));
@@ -96,6 +97,9 @@ __device__ __forceinline__ float sum_waves(const float* p) {          // p[0..W-
     if constexpr (W == 4) {
         const f4 t = *reinterpret_cast<const f4*>(p);
         return (t.x + t.y) + (t.z + t.w);
+    } else if constexpr (W == 3) {
+        const float2 t = *reinterpret_cast<const float2*>(p);
+        return (t.x + t.y) + p[2];
     } else {
         const float2 t = *reinterpret_cast<const float2*>(p);
         return t.x + t.y;
@@ -121,6 +125,11 @@ __device__ __forceinline__ void rd8(unsigned addr, u4 (&o)[8]) {
                  : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
                  : "v"(addr) : "memory");
 }
+__device__ __forceinline__ void rd4(unsigned addr, u4 (&o)[8]) {        // first four elements only (D = 96: 8 + 4 reads)
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\t"
+                 "ds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48"
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]) : "v"(addr) : "memory");
+}
 template <int N>
 __device__ __forceinline__ void rd_wait(u4 (&o)[8]) {
     asm volatile("s_waitcnt lgkmcnt(%8)"
@@ -135,10 +144,10 @@ __device__ __forceinline__ void rd_wait(u4 (&o)[8]) {
 // two matrices against eight 16-byte pieces of one vector (instructions t = 2 * (T0 + i), 2 * (T0 + i) + 1); two
 // accumulators per matrix keep dependent MFMAs four instructions apart (no wait states)
 struct Acc2 { f4 a, b; };
-template <int T0, int NT>
+template <int T0, int NT, int NP = 8>
 __device__ __forceinline__ void mm2(const bf4 (&FA)[NT], const bf4 (&FB)[NT], const u4 (&v)[8], Acc2& x, Acc2& y) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NP; ++i) {
         const bf4 lo = frag_of(v[i].x, v[i].y), hi = frag_of(v[i].z, v[i].w);
         x.a = MFMA4(FA[2 * (T0 + i)], lo, x.a);
         y.a = MFMA4(FB[2 * (T0 + i)], lo, y.a);
@@ -148,10 +157,10 @@ __device__ __forceinline__ void mm2(const bf4 (&FA)[NT], const bf4 (&FB)[NT], co
 }
 // one matrix, four accumulators
 struct Acc4 { f4 a, b, c, d; };
-template <int T0, int NT>
+template <int T0, int NT, int NP = 8>
 __device__ __forceinline__ void mm1(const bf4 (&FA)[NT], const u4 (&v)[8], Acc4& x) {
 #pragma unroll
-    for (int i = 0; i < 8; i += 2) {
+    for (int i = 0; i < NP; i += 2) {
         x.a = MFMA4(FA[2 * (T0 + i)], frag_of(v[i].x, v[i].y), x.a);
         x.b = MFMA4(FA[2 * (T0 + i) + 1], frag_of(v[i].z, v[i].w), x.b);
         x.c = MFMA4(FA[2 * (T0 + i) + 2], frag_of(v[i + 1].x, v[i + 1].y), x.c);
@@ -303,6 +312,12 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
                     mm2<0>(FR, FQ, B0, cR, cQ);
                     rd_wait<0>(B1);
                     mm2<8>(FR, FQ, B1, cR, cQ);
+                } else if constexpr (PD == 96) {
+                    rd4(aU + 128, B1);
+                    rd_wait<4>(B0);
+                    mm2<0>(FR, FQ, B0, cR, cQ);
+                    rd_wait<0>(B1);
+                    mm2<8, NT, 4>(FR, FQ, B1, cR, cQ);
                 } else {
                     rd_wait<0>(B0);
                     mm2<0>(FR, FQ, B0, cR, cQ);
@@ -365,6 +380,7 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
             u4 B0[8], B1[8];
             rd8(aY, B0);
             if constexpr (PD == 128) rd8(aY + 128, B1);
+            if constexpr (PD == 96) rd4(aY + 128, B1);
             const float2 yv = yf[p][w][lane];
             Acc4 cH = {z4, z4, z4, z4};
             if constexpr (PD == 128) {
@@ -372,6 +388,11 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
                 mm1<0>(FH, B0, cH);
                 rd_wait<0>(B1);
                 mm1<8>(FH, B1, cH);
+            } else if constexpr (PD == 96) {
+                rd_wait<4>(B0);
+                mm1<0>(FH, B0, cH);
+                rd_wait<0>(B1);
+                mm1<8, NT, 4>(FH, B1, cH);
             } else {
                 rd_wait<0>(B0);
                 mm1<0>(FH, B0, cH);
@@ -415,10 +436,13 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
 
 hipError_t launch_fwd_pair(const Dev& P, const float* audio, float* loss, bool save, hipStream_t s) {
     const unsigned nb = (unsigned)((P.B + 1) / 2);
-    if (P.D == 128) {
+    if (P.DP == 128) {
         if (save) hipLaunchKernelGGL((k_fwd_pair<128, true>), dim3(nb), dim3(512), 0, s, P, audio, loss);
         else hipLaunchKernelGGL((k_fwd_pair<128, false>), dim3(nb), dim3(512), 0, s, P, audio, loss);
-    } else if (P.D == 64) {
+    } else if (P.DP == 96) {
+        if (save) hipLaunchKernelGGL((k_fwd_pair<96, true>), dim3(nb), dim3(384), 0, s, P, audio, loss);
+        else hipLaunchKernelGGL((k_fwd_pair<96, false>), dim3(nb), dim3(384), 0, s, P, audio, loss);
+    } else if (P.DP == 64) {
         if (save) hipLaunchKernelGGL((k_fwd_pair<64, true>), dim3(nb), dim3(256), 0, s, P, audio, loss);
         else hipLaunchKernelGGL((k_fwd_pair<64, false>), dim3(nb), dim3(256), 0, s, P, audio, loss);
     } else {
@@ -587,6 +611,12 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
                 mm2<0>(FQ, FD, B0, cQ, cD);
                 rd_wait<0>(B1);
                 mm2<8>(FQ, FD, B1, cQ, cD);
+            } else if constexpr (PD == 96) {
+                rd4(aV + 128, B1);
+                rd_wait<4>(B0);
+                mm2<0>(FQ, FD, B0, cQ, cD);
+                rd_wait<0>(B1);
+                mm2<8, NT, 4>(FQ, FD, B1, cQ, cD);
             } else {
                 rd_wait<0>(B0);
                 mm2<0>(FQ, FD, B0, cQ, cD);
@@ -668,8 +698,9 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
 
 hipError_t launch_bwd_pair(const Dev& P, const float* audio, hipStream_t s) {
     const unsigned nb = (unsigned)((P.B + 1) / 2);
-    if (P.D == 128) hipLaunchKernelGGL(k_bwd_pair<128>, dim3(nb), dim3(256), 0, s, P, audio);
-    else if (P.D == 64) hipLaunchKernelGGL(k_bwd_pair<64>, dim3(nb), dim3(128), 0, s, P, audio);
+    if (P.DP == 128) hipLaunchKernelGGL(k_bwd_pair<128>, dim3(nb), dim3(256), 0, s, P, audio);
+    else if (P.DP == 96) hipLaunchKernelGGL(k_bwd_pair<96>, dim3(nb), dim3(192), 0, s, P, audio);
+    else if (P.DP == 64) hipLaunchKernelGGL(k_bwd_pair<64>, dim3(nb), dim3(128), 0, s, P, audio);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
@@ -870,8 +901,9 @@ __global__ __launch_bounds__(2 * PD, 1) void k_grad_pair(Dev P, const float* __r
 
 hipError_t launch_grad_pair(const Dev& P, const float* audio, hipStream_t s) {
     const unsigned nb = (unsigned)((P.B + 1) / 2);
-    if (P.D == 128) hipLaunchKernelGGL(k_grad_pair<128>, dim3(nb), dim3(256), 0, s, P, audio);
-    else if (P.D == 64) hipLaunchKernelGGL(k_grad_pair<64>, dim3(nb), dim3(128), 0, s, P, audio);
+    if (P.DP == 128) hipLaunchKernelGGL(k_grad_pair<128>, dim3(nb), dim3(256), 0, s, P, audio);
+    else if (P.DP == 96) hipLaunchKernelGGL(k_grad_pair<96>, dim3(nb), dim3(192), 0, s, P, audio);
+    else if (P.DP == 64) hipLaunchKernelGGL(k_grad_pair<64>, dim3(nb), dim3(128), 0, s, P, audio);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

@@ -45,7 +45,7 @@ enum {
     CMPS_VARIANT_AUTO = 0,
     CMPS_VARIANT_BLOCK = 1, /* one workgroup per clip, any D <= 128 */
     CMPS_VARIANT_WAVE = 2,  /* one wavefront per clip, state and R in registers, D <= 32 */
-    CMPS_VARIANT_PAIR = 3   /* D = 64 or 128: one workgroup per pair of clips, matrices as bf16 MFMA fragments, fp32 accumulate */
+    CMPS_VARIANT_PAIR = 3   /* 32 < D <= 128: one workgroup per pair of clips, matrices as bf16 MFMA fragments, fp32 accumulate */
 };
 
 /* Library version (major * 10000 + minor * 100 + patch). */

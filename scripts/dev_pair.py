@@ -9,7 +9,7 @@ from audio_mps_amd.scan import HipScan, unpack_grad
 from oracle import cmps_oracle as O, c_oracle as C
 from _util import make_audio, oracle_hparams, oracle_variables, c_oracle_run
 
-for (D, T, B) in [(64, 40, 2), (64, 300, 5), (128, 40, 2), (128, 200, 4), (128, 300, 5)]:
+for (D, T, B) in [(40, 60, 3), (64, 300, 5), (80, 100, 2), (96, 150, 4), (100, 70, 3), (128, 300, 5)]:
     hp = HParams(minibatch_size=B, bond_dim=D)
     audio = make_audio(B, T, hp.delta_t, 7)
     m = PsiCMPS(hp, data_iterator=audio, seed=3, backend=HipScan(D, variant=3))

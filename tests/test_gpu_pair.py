@@ -1,4 +1,4 @@
-"""The D = 64 / 128 MFMA pair kernels (CMPS_VARIANT_PAIR: bf16 mat-vec operands, float32 accumulation; BASELINE configs[4]).
+"""The MFMA pair kernels (32 < D <= 128, instantiated for the padded dimensions 64, 96, 128; CMPS_VARIANT_PAIR: bf16 mat-vec operands, float32 accumulation; BASELINE configs[4] is D = 128).
 
 Two comparisons, two tolerances (stated here, derived from oracle-vs-oracle distances measured on the CPU):
   * against oracle.psi_bf16_scan, which restates the SAME reduced-precision arithmetic (same rounding points):
@@ -27,7 +27,8 @@ def _pair_model(T, B, seed=3, D=128, **hpkw):
 
 
 @pytest.mark.parametrize("D,T,B", [(128, 2, 2), (128, 40, 2), (128, 65, 1), (128, 200, 4), (128, 300, 5),
-                                   (64, 3, 1), (64, 130, 3), (64, 300, 6)])
+                                   (64, 3, 1), (64, 130, 3), (64, 300, 6), (96, 150, 4),
+                                   (40, 60, 3), (100, 70, 3)])        # 40 and 100 run zero-padded to 64 and 128
 def test_pair_matches_bf16_oracle_and_float32(D, T, B):
     from audio_mps_amd.scan import unpack_grad
     m, audio = _pair_model(T, B, D=D)
@@ -76,7 +77,7 @@ def test_pair_variant_rules():
     from audio_mps_amd import _capi
     from audio_mps_amd.scan import HipScan
     with pytest.raises(_capi.CmpsError) as ei:
-        HipScan(96, variant=PAIR)                      # the MFMA pair kernels exist for D = 64 and 128 only
+        HipScan(16, variant=PAIR)                      # the MFMA pair kernels are for 32 < D <= 128
     assert ei.value.code == _capi.CMPS_ERR_UNSUPPORTED_D
     assert HipScan(128).variant == 1 and HipScan(64).variant == 1   # AUTO stays float32: the bf16-operand path is opt-in
     m, _ = _pair_model(20, 2)
