@@ -241,7 +241,6 @@ int cmps_psi_states(cmps_handle_t h, int B, int T, float* psi_out_dev, void* str
         return fail(h, CMPS_ERR_STATE, "cmps_psi_states: needs cmps_psi_loss_fwd(save_for_bwd=1) first");
     if (!psi_out_dev || B != h->saved_B || T != h->saved_T)
         return fail(h, CMPS_ERR_BAD_ARG, "cmps_psi_states: bad argument");
-    if (h->saved_variant == CMPS_VARIANT_PAIR) return fail(h, CMPS_ERR_STATE, "cmps_psi_states: not available for the pair variant");
     hipError_t e = launch_states(h->P, B, psi_out_dev, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail_hip(h, e, "cmps_psi_states");
     return CMPS_OK;

@@ -80,8 +80,18 @@ def test_pair_variant_rules():
         HipScan(16, variant=PAIR)                      # the MFMA pair kernels are for 32 < D <= 128
     assert ei.value.code == _capi.CMPS_ERR_UNSUPPORTED_D
     assert HipScan(128).variant == 1 and HipScan(64).variant == 1   # AUTO stays float32: the bf16-operand path is opt-in
-    m, _ = _pair_model(20, 2)
-    m.psi_evolve_with_data                              # attribute exists; the call is refused for this variant
-    with pytest.raises(_capi.CmpsError) as ei:
-        m.psi_evolve_with_data()
-    assert ei.value.code == _capi.CMPS_ERR_STATE
+
+
+@pytest.mark.parametrize("D,B", [(128, 3), (72, 2)])
+def test_pair_states_remain_normalized_and_match_block_variant(D, B):
+    """psi_evolve_with_data (tests/test_model.py:115-122) from the pair kernels' stash layout."""
+    from audio_mps_amd import PsiCMPS
+    from audio_mps_amd.scan import HipScan
+    m, audio = _pair_model(90, B, D=D)
+    psi = m.psi_evolve_with_data()
+    assert psi.shape == (B, 89, D)
+    np.testing.assert_allclose(np.sum(np.abs(psi) ** 2, axis=2), np.ones((B, 89)), rtol=1e-5)
+    blk = PsiCMPS(m.hparams, data_iterator=audio, seed=3, backend=HipScan(D, variant=1))
+    for k in m.variables:
+        blk.variables[k] = m.variables[k].copy()
+    assert rel_inf(psi, blk.psi_evolve_with_data()) <= 5e-3
