@@ -32,6 +32,7 @@ constexpr int PCH = 64;      // steps per chunk of per-step scalars
 typedef short bf4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
+typedef unsigned u2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ unsigned short bf16_rne(float f) {
     unsigned u = __float_as_uint(f);
@@ -106,7 +107,6 @@ __device__ __forceinline__ float sum_waves(const float* p) {          // p[0..W-
     }
 }
 
-typedef unsigned u2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ bf4 frag_of(unsigned lo, unsigned hi) {
     const u2 t = {lo, hi};
     return __builtin_bit_cast(bf4, t);
@@ -139,13 +139,13 @@ __device__ __forceinline__ void rd_wait(u4 (&o)[8]) {
 #ifdef PABL_NO_MFMA
 #define MFMA4(A, B, C) (C)
 #else
-#define MFMA4(A, B, C) __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(A, B, C, 0, 0, 0)
+#define MFMA4(A, B, C) __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(bf4, A), B, C, 0, 0, 0)
 #endif
 // two matrices against eight 16-byte pieces of one vector (instructions t = 2 * (T0 + i), 2 * (T0 + i) + 1); two
 // accumulators per matrix keep dependent MFMAs four instructions apart (no wait states)
 struct Acc2 { f4 a, b; };
 template <int T0, int NT, int NP = 8>
-__device__ __forceinline__ void mm2(const bf4 (&FA)[NT], const bf4 (&FB)[NT], const u4 (&v)[8], Acc2& x, Acc2& y) {
+__device__ __forceinline__ void mm2(const u2 (&FA)[NT], const u2 (&FB)[NT], const u4 (&v)[8], Acc2& x, Acc2& y) {
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
         const bf4 lo = frag_of(v[i].x, v[i].y), hi = frag_of(v[i].z, v[i].w);
@@ -158,7 +158,7 @@ __device__ __forceinline__ void mm2(const bf4 (&FA)[NT], const bf4 (&FB)[NT], co
 // one matrix, four accumulators
 struct Acc4 { f4 a, b, c, d; };
 template <int T0, int NT, int NP = 8>
-__device__ __forceinline__ void mm1(const bf4 (&FA)[NT], const u4 (&v)[8], Acc4& x) {
+__device__ __forceinline__ void mm1(const u2 (&FA)[NT], const u4 (&v)[8], Acc4& x) {
 #pragma unroll
     for (int i = 0; i < NP; i += 2) {
         x.a = MFMA4(FA[2 * (T0 + i)], frag_of(v[i].x, v[i].y), x.a);
@@ -203,13 +203,14 @@ __device__ __forceinline__ void rho_commit(RhoStage<D>& S, int buf, int tid, con
 }
 
 // A fragments of one matrix for this lane: frag[t] = 4 bf16 = M_part[row][4t..4t+3]
+// (kept as two packed dwords: a <4 x i16> array makes hipcc re-assemble every fragment with two v_perm_b32 per MFMA)
 template <int NT, typename F>
-__device__ __forceinline__ void load_frags(bf4 (&frag)[NT], F&& elem) {
+__device__ __forceinline__ void load_frags(u2 (&frag)[NT], F&& elem) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        bf4 v;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (short)bf16_rne(elem(4 * t + j));
+        u2 v;
+        v.x = (unsigned)bf16_rne(elem(4 * t)) | ((unsigned)bf16_rne(elem(4 * t + 1)) << 16);
+        v.y = (unsigned)bf16_rne(elem(4 * t + 2)) | ((unsigned)bf16_rne(elem(4 * t + 3)) << 16);
         frag[t] = v;
     }
 }
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
 
     if (!loss_wave) {
         // ================================================================== chain waves
-        bf4 FR[NT], FQ[NT];
+        u2 FR[NT], FQ[NT];
         {
             const float2* Rrow = P.R + (size_t)arow * PD;
             const float2* Qrow = P.Q + (size_t)arow * PD;
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
     }
 
     // ====================================================================== loss waves
-    bf4 FH[NT];
+    u2 FH[NT];
     {
         const float2* Rrow = P.R + (size_t)arow * PD;
         const float2* RTrow = P.RT + (size_t)arow * PD;     // RT[i][j] = R[j][i]
@@ -491,7 +492,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
     const int ia = 32 * w + 4 * rg + 2 * kh, ib = ia + 1;
     const int arow = 32 * w + 4 * rg + c;
 
-    bf4 FQ[NT], FD[NT];                                                // Q (Hermitian) and R^dagger
+    u2 FQ[NT], FD[NT];                                                // Q (Hermitian) and R^dagger
     {
         const float2* Qrow = P.Q + (size_t)arow * PD;
         const float2* RTrow = P.RT + (size_t)arow * PD;                // R^dagger[i][j] = conj(R[j][i]) = conj(RT[i][j])
