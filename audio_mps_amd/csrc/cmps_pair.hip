@@ -723,6 +723,9 @@ typedef short bf8 __attribute__((ext_vector_type(8)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 
 constexpr int GS = 4;                                   // steps per MFMA group
+#ifndef GRAD_VALU_PER_MFMA
+#define GRAD_VALU_PER_MFMA 12                           // VALU instructions of the fill scheduled behind every MFMA
+#endif
 template <int D>
 struct GradLds {
     // [buffer][operand: te y, ybar, s ybar, y, u][re / im][row][(clip, step in group)] bf16
@@ -813,7 +816,6 @@ __global__ __launch_bounds__(2 * PD, 1) void k_grad_pair(Dev P, const float* __r
         for (int s4 = 0; s4 < GS; ++s4) {
             const int k = g * GS + s4;
             const bool in = k < N;
-            if (in && (k & (PCH - 1)) == 0) chunk_rows(k / PCH);
             float4 row = prow[s4];
             if (!in) row = make_float4(0.f, 0.f, 0.f, 0.f);
             f4 sr = {0.f, 0.f, 1.f, 0.f};
@@ -854,6 +856,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_grad_pair(Dev P, const float* __r
     };
 
     const int NG = (N + GS - 1) / GS;
+    chunk_rows(0);
     prefetch(0);
     fill(0, 0);
     prefetch(1);
@@ -861,10 +864,13 @@ __global__ __launch_bounds__(2 * PD, 1) void k_grad_pair(Dev P, const float* __r
     const unsigned nmask = mh ? 0x80008000u : 0u;
     for (int g = 0; g < NG; ++g) {
         const int buf = g & 1;
-        if (g + 1 < NG) {
-            fill(g + 1, buf ^ 1);
-            prefetch(g + 2);
-        }
+        // per-step scalars of the chunk group g + 1 starts (the rare branch stays outside the interleaved block below)
+        if (((g + 1) * GS & (PCH - 1)) == 0 && (g + 1) * GS < N) chunk_rows((g + 1) * GS / PCH);
+        // Unconditional (rows past the end are zeros): fill, prefetch and the MFMAs of group g form one basic block, and the
+        // schedule barriers at its end interleave them -- one MFMA (32+ cycles on the matrix pipe), a dozen VALU
+        // instructions of the fill, and so on -- instead of fill-then-MFMA.
+        fill(g + 1, buf ^ 1);
+        prefetch(g + 2);
         // A fragments of this wave's row block: Re form (h ? X_im : X_re), Im form (h ? -X_re : X_im)
         bf8 aRe[3], aIm[3];
 #pragma unroll
@@ -882,6 +888,11 @@ __global__ __launch_bounds__(2 * PD, 1) void k_grad_pair(Dev P, const float* __r
             Qim[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aIm[1], bu, Qim[cb], 0, 0, 0);
             Rre[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aRe[2], bu, Rre[cb], 0, 0, 0);
             Rim[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aIm[2], bu, Rim[cb], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 6 * PWV; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, GRAD_VALU_PER_MFMA, 0);
         }
         lds_barrier();
     }

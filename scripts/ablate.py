@@ -4,7 +4,7 @@ import os, sys, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from audio_mps_amd import build
-variants = {"base": [], "no_mfma": ["-DPABL_NO_MFMA"], "no_reduce": ["-DPABL_NO_REDUCE"], "no_mfma_no_reduce": ["-DPABL_NO_MFMA", "-DPABL_NO_REDUCE"]}
+variants = {"v8": ["-DGRAD_VALU_PER_MFMA=8"], "v12": [], "v16": ["-DGRAD_VALU_PER_MFMA=16"], "v20": ["-DGRAD_VALU_PER_MFMA=20"]}
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 for name, flags in variants.items():
     lib = os.path.join(ROOT, "gpurun_out", f"libcmps_{name}.so")
