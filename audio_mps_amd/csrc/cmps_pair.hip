@@ -587,12 +587,6 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
         const float ya = cur.x, yb = cur.y, ha = cur.z, hb = cur.w;
         const float yha = ya * inv, yhb = yb * inv;
         const float pga = dpp_mov<0xB1>(ga), pgb = dpp_mov<0xB1>(gb);
-        {   // u_{k+1} = rho_k yhat and the frequency gradient (meaningful in the Re lanes)
-            const float una = rha.x * yha + sgn * rha.y * dpp_mov<0xB1>(yha);
-            const float unb = rhb.x * yhb + sgn * rhb.y * dpp_mov<0xB1>(yhb);
-            facca += dt * (pga * una - ga * dpp_mov<0xB1>(una));
-            faccb += dt * (pgb * unb - gb * dpp_mov<0xB1>(unb));
-        }
         const float hba = rha.x * ga - sgn * rha.y * pga;              // conj(rho_k) g
         const float hbb = rhb.x * gb - sgn * rhb.y * pgb;
         const float yba = (hba - ok * yha * rad_next) * inv + te * ha;
@@ -606,14 +600,21 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
             const unsigned aV = lds_addr_of(L.vec[p][0]) + rd_off;
             u4 B0[8], B1[8];
             rd8(aV, B0);
+            if constexpr (PD == 128) rd8(aV + 128, B1);
+            if constexpr (PD == 96) rd4(aV + 128, B1);
+            {   // off the chain, in the shadow of the reads and the MFMAs: u_{k+1} = rho_k yhat and the frequency gradient
+                // (meaningful in the Re lanes)
+                const float una = rha.x * yha + sgn * rha.y * dpp_mov<0xB1>(yha);
+                const float unb = rhb.x * yhb + sgn * rhb.y * dpp_mov<0xB1>(yhb);
+                facca += dt * (pga * una - ga * dpp_mov<0xB1>(una));
+                faccb += dt * (pgb * unb - gb * dpp_mov<0xB1>(unb));
+            }
             if constexpr (PD == 128) {
-                rd8(aV + 128, B1);
                 rd_wait<8>(B0);
                 mm2<0>(FQ, FD, B0, cQ, cD);
                 rd_wait<0>(B1);
                 mm2<8>(FQ, FD, B1, cQ, cD);
             } else if constexpr (PD == 96) {
-                rd4(aV + 128, B1);
                 rd_wait<4>(B0);
                 mm2<0>(FQ, FD, B0, cQ, cD);
                 rd_wait<0>(B1);
