@@ -95,3 +95,41 @@ def test_pair_states_remain_normalized_and_match_block_variant(D, B):
     for k in m.variables:
         blk.variables[k] = m.variables[k].copy()
     assert rel_inf(psi, blk.psi_evolve_with_data()) <= 5e-3
+
+
+def test_config5_full_length_reduced_batch():
+    """BASELINE configs[4] (D=128, T=16000) at 4 clips against the float32 restatement.  Over 16 000 steps the bf16 operand
+    rounding accumulates to ~2e-3 of the per-clip loss (the bf16 emulation itself is 1.8e-3 away from float32 here), so the
+    bar is 5e-3 for the loss and 6e-2 of each gradient tensor's max."""
+    from audio_mps_amd.scan import unpack_grad
+    m, audio = _pair_model(16000, 4, seed=2)
+    per = m.loss_per_clip()
+    flat, _ = m.grad_sums()
+    g = unpack_grad(flat.cpu().numpy(), 128)
+    ref = c_oracle_run(m, audio, "f32", want_grad=True, nthreads=4)
+    gr = C.unpack_grad(ref["grad"], 128)
+    den = np.maximum(np.abs(ref["loss_per_clip"]), 1.0)
+    assert np.max(np.abs(per - ref["loss_per_clip"]) / den) <= 5e-3
+    for k in ("Rbar", "fbar", "psi0bar", "Abar"):
+        assert rel_inf(g[k], gr[k]) <= 6e-2, k
+
+
+def test_config5_full_size_properties():
+    """BASELINE configs[4] at full size (D=128, T=16000, 512 clips; 16.8 GB of stash): finite results, the loss sum the
+    reverse path reports equals the sum of the forward's per-clip losses, and the clip order does not matter (clips are
+    processed in pairs: permuting the batch must permute the per-clip losses and leave the gradient sums unchanged)."""
+    import torch
+    from audio_mps_amd.scan import unpack_grad
+    m, audio = _pair_model(16000, 512, seed=4)
+    per = m.loss_per_clip()
+    flat, _ = m.grad_sums()
+    g = unpack_grad(flat.cpu().numpy(), 128)
+    assert np.all(np.isfinite(per)) and np.all(np.isfinite(flat.cpu().numpy()))
+    assert abs(g["loss_sum"] - float(np.sum(per, dtype=np.float64))) <= 1e-4 * abs(g["loss_sum"])
+    perm = np.random.default_rng(0).permutation(512)
+    per2 = m.loss_per_clip(audio[perm])
+    np.testing.assert_allclose(per2, per[perm], rtol=1e-6, atol=1e-6)
+    flat2, _ = m.grad_sums(audio[perm])
+    g2 = unpack_grad(flat2.cpu().numpy(), 128)
+    for k in ("Rbar", "fbar", "psi0bar", "Abar"):
+        assert rel_inf(g2[k], g[k]) <= 1e-4, k
