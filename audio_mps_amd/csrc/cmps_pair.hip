@@ -253,6 +253,7 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
 
     if (!loss_wave) {
         // ================================================================== chain waves
+        __builtin_amdgcn_s_setprio(3);      // both kinds share a SIMD's matrix pipe: the serial chain goes first
         u2 FR[NT], FQ[NT];
         {
             const float2* Rrow = P.R + (size_t)arow * PD;
