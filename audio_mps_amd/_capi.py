@@ -30,7 +30,7 @@ SYMBOLS = (
     "cmps_psi_loss_bwd", "cmps_psi_update_ancilla", "cmps_psi_states", "cmps_psi_sample",
     "cmps_legacy_set_params", "cmps_legacy_loss_fwd", "cmps_legacy_loss_bwd",
     "cmps_rho_workspace_bytes", "cmps_rho_set_state", "cmps_rho_loss_fwd", "cmps_rho_loss_bwd",
-    "cmps_rho_update_ancilla", "cmps_rho_sample", "cmps_rho_states",
+    "cmps_rho_update_ancilla", "cmps_rho_sample", "cmps_rho_states", "cmps_crc32c",
 )
 
 
@@ -90,6 +90,8 @@ def _declare(lib):
     lib.cmps_rho_sample.restype = c_int
     lib.cmps_rho_states.argtypes = [vp, c_int, c_int, vp, vp, vp]
     lib.cmps_rho_states.restype = c_int
+    lib.cmps_crc32c.argtypes = [ctypes.c_char_p, c_size_t, ctypes.c_uint]
+    lib.cmps_crc32c.restype = ctypes.c_uint
 
 
 _lib = None

@@ -34,7 +34,7 @@ def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
     if not force and not needs_build():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Xarch_host", "-msse4.2",
            "-Wall", "-Wno-unused-function",
            "-o", LIB_PATH] + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:

@@ -457,4 +457,34 @@ int cmps_rho_states(cmps_handle_t h, int B, int steps, float* rho_out_dev, float
     return CMPS_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// host utility of the data-format row: CRC-32C (Castagnoli) of TFRecord framing
+// ---------------------------------------------------------------------------------------------------
+unsigned cmps_crc32c(const void* data, size_t n, unsigned crc_in) {
+    const unsigned char* p = static_cast<const unsigned char*>(data);
+    unsigned long long crc = crc_in ^ 0xFFFFFFFFu;
+#if defined(__SSE4_2__)
+    while (n && ((uintptr_t)p & 7)) { crc = __builtin_ia32_crc32qi((unsigned)crc, *p++); --n; }
+    for (; n >= 8; n -= 8, p += 8) {
+        unsigned long long v;
+        memcpy(&v, p, 8);
+        crc = __builtin_ia32_crc32di(crc, v);
+    }
+    while (n--) crc = __builtin_ia32_crc32qi((unsigned)crc, *p++);
+#else
+    static unsigned table[256];
+    static bool init = false;
+    if (!init) {
+        for (unsigned i = 0; i < 256; ++i) {
+            unsigned c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+            table[i] = c;
+        }
+        init = true;
+    }
+    while (n--) crc = table[(crc ^ *p++) & 0xFF] ^ (crc >> 8);
+#endif
+    return (unsigned)crc ^ 0xFFFFFFFFu;
+}
+
 }  // extern "C"

@@ -140,7 +140,9 @@ __global__ __launch_bounds__(128 * WAVES, 1) void k_fwd_wave2(Dev P, const float
 #ifndef ABL2_NO_PRIO
         __builtin_amdgcn_s_setprio(3);
 #endif
+#ifndef FWD2_NO_STAGGER
         stagger(w);
+#endif
         v2f MR[16], MQ[16];
 #pragma unroll
         for (int m = 0; m < 16; ++m) {
@@ -230,7 +232,14 @@ __global__ __launch_bounds__(128 * WAVES, 1) void k_fwd_wave2(Dev P, const float
 #ifdef ABL2_NO_LOSS
     return;
 #endif
+#ifdef FWD2_LOSS_PRIO
+    __builtin_amdgcn_s_setprio(FWD2_LOSS_PRIO);
+#else
     __builtin_amdgcn_s_setprio(0);
+#endif
+#ifdef FWD2_LOSS_STAGGER
+    stagger(w ^ 2);
+#endif
     v2f MH[16];
 #pragma unroll
     for (int m = 0; m < 16; ++m) {

@@ -181,6 +181,14 @@ int cmps_rho_sample(cmps_handle_t h, const float* noise_dev, int n, int length, 
                     void* stream);
 int cmps_rho_states(cmps_handle_t h, int B, int steps, float* rho_out_dev, float* purity_out_dev, void* stream);
 
+/*
+ * Host utility (no GPU involved): CRC-32C (Castagnoli, reflected polynomial 0x82F63B78) of `n` bytes, continuing from
+ * `crc_in` (0 to start).  TFRecord framing stores it masked (((crc >> 15) | (crc << 17)) + 0xa282ead8) behind the length
+ * and behind the payload of every record; the reference reads those files with tf.data.TFRecordDataset (data.py:29,
+ * training_estimators.py:79), which verifies them.  audio_mps_amd/tfrecord.py calls this when verify=True.
+ */
+unsigned cmps_crc32c(const void* data, size_t n, unsigned crc_in);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""Measurement of the SURVEY 8(f) "next" rows on one MI355X (not the headline metric: bench.py stays on the PsiCMPS scan).
+
+For every row: device time of one call at a stated shape (HIP events around the launches, median of a few rounds, inputs
+resident in HBM), the throughput in audio samples/s, and the same arithmetic on the host CPU (the numpy oracle, one
+process, a bounded sample) for scale.  Prints one JSON object; scripts/.. -> profiles/r1_next_rows.json.
+"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+
+from audio_mps_amd import HParams, PsiCMPS, RhoCMPS, LegacyAudioMPS
+from audio_mps_amd import tfrecord
+from oracle import cmps_oracle as O
+from _util import make_audio
+
+
+def dev_ms(fn, rounds=3):
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fn()
+    torch.cuda.synchronize()
+    out = []
+    for _ in range(rounds):
+        ev0.record()
+        fn()
+        ev1.record()
+        torch.cuda.synchronize()
+        out.append(ev0.elapsed_time(ev1))
+    return float(np.median(out))
+
+
+res = {}
+
+# ---- rank 1: PsiCMPS.sample (model.py:242-251): 1024 paths x 16000 steps, D = 32 (wave-per-path kernel)
+hp = HParams(minibatch_size=1024, bond_dim=32, sigma=0.05)
+m = PsiCMPS(hp, seed=0)
+n, length = 1024, 16000
+noise = (0.05 * np.sqrt(hp.delta_t) * np.random.default_rng(0).standard_normal((length, n))).astype(np.float32)
+be = m._get_backend()
+be.set_params(m.effective_params(), n, length + 1, train=False)
+d_noise = torch.from_numpy(np.ascontiguousarray(noise.T)).to(be.device)
+d_out = torch.empty((n, length), dtype=torch.float32, device=be.device)
+from audio_mps_amd import _capi
+ms = dev_ms(lambda: _capi.check(be._h, be._lib.cmps_psi_sample(be._h, d_noise.data_ptr(), n, length, d_out.data_ptr(), be._stream())))
+t0 = time.perf_counter()
+O.psi_sample(O.HParams(**hp.values()), O.Variables(np.asarray(m.variables["A"]), m.variables["Rx"], m.variables["Ry"], m.variables["freqs"],
+                                                m.variables["psi_x"], m.variables["psi_y"], scaled_R=True, scaled_freqs=True), noise[:2000, :16])
+cpu = 16 * 2000 / (time.perf_counter() - t0)
+res["sample_psi"] = {"shape": "D=32, 1024 paths x 16000 steps", "kernel": "k_sample_wave", "ms": ms, "samples_per_s": n * length / ms * 1e3,
+                     "cpu_numpy_samples_per_s": cpu, "bound": "serial chain: two wave reductions per step (latency)"}
+
+# ---- rank 2: legacy AudioMPS forward + backward (block kernels), D = 32, T = 4000, 1024 clips
+T, B = 4000, 1024
+audio = torch.from_numpy(make_audio(B, T, 1e-3, 1)).cuda()
+lm = LegacyAudioMPS(32, 1e-3, B, seed=1)
+lb = lm._get_backend()
+lb.legacy_set_params(lm.variables["R"], lm.Q, lm.delta_t, B, T, train=True)
+ms = dev_ms(lambda: (lb.legacy_forward(audio, save_for_bwd=True), lb.legacy_backward()))
+t0 = time.perf_counter()
+O.legacy_loss_and_grads(lm.variables["H"], lm.variables["R"], lm.delta_t, audio[:8, :1000].cpu().numpy())
+cpu = 8 * 1000 / (time.perf_counter() - t0)
+res["legacy_audiomps"] = {"shape": f"D=32, T={T}, B={B}, fwd+bwd", "kernel": "k_fwd_legacy + k_bwd_legacy (block per clip)", "ms": ms,
+                          "samples_per_s": B * T / ms * 1e3, "cpu_numpy_samples_per_s": cpu, "bound": "correctness-first block kernels (issue / latency)"}
+
+# ---- rank 3: RhoCMPS forward + backward (rank-r column kernels), D = 32, rank 4 and 32, T = 1000, 256 clips
+for rank in (4, 32):
+    T, B = 1000, 256
+    hp = HParams(minibatch_size=B, bond_dim=32, initial_rank=rank)
+    a = make_audio(B, T, hp.delta_t, 2)
+    rm = RhoCMPS(hp, data_iterator=a, seed=2)
+    d_a = rm._to_device(a)
+    rb = rm._prepare(B, T, train=True)
+    ms = dev_ms(lambda: rb.rho_loss_and_grad_sums(d_a), rounds=2)
+    t0 = time.perf_counter()
+    O.rho_loss_and_grads(O.HParams(**hp.values()), O.Variables(np.asarray(rm.variables["A"]), rm.variables["Rx"], rm.variables["Ry"],
+                                                              rm.variables["freqs"], np.zeros(32, np.float32), np.zeros(32, np.float32),
+                                                              scaled_R=True, scaled_freqs=True), rm.variables["Wx"], rm.variables["Wy"], a[:4, :200])
+    cpu = 4 * 200 / (time.perf_counter() - t0)
+    res[f"rho_cmps_rank{rank}"] = {"shape": f"D=32, rank={rank}, T={T}, B={B}, fwd+bwd", "kernel": "k_fwd_rho + k_bwd_rho (block per clip)", "ms": ms,
+                                   "samples_per_s": B * T / ms * 1e3, "cpu_numpy_samples_per_s": cpu,
+                                   "bound": "correctness-first block kernels; 3 r D^2 complex MACs per step"}
+
+# ---- rank 4: TFRecord reader (host, pure Python): records of 65536 float32 samples
+import tempfile
+with tempfile.TemporaryDirectory() as td:
+    path = os.path.join(td, "x.tfrecords")
+    rng = np.random.default_rng(0)
+    recs = [rng.standard_normal(65536).astype(np.float32) for _ in range(32)]
+    tfrecord.write_audio_tfrecord(path, recs)
+    for verify in (False, True):
+        t0 = time.perf_counter()
+        cnt = sum(1 for _ in tfrecord._audio_records(path, 65536, verify))
+        dt = time.perf_counter() - t0
+        res["tfrecord_reader" + ("_verify" if verify else "")] = {
+            "shape": "32 records x 65536 float32", "records": cnt, "ms": dt * 1e3, "samples_per_s": cnt * 65536 / dt,
+            "MB_per_s": cnt * 65536 * 4 / dt / 1e6,
+            "bound": "host: Python framing + protobuf wire decode (numpy frombuffer)" + (" + CRC-32C via cmps_crc32c (SSE4.2)" if verify else "")}
+print(json.dumps(res, indent=1))
