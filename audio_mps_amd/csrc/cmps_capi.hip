@@ -366,6 +366,8 @@ int cmps_rho_set_state(cmps_handle_t h, const float* phi_re_dev, const float* ph
     W.phi0 = reinterpret_cast<float2*>(ws + RL.off_phi0);
     const bool train = (flags & CMPS_WS_TRAIN) != 0;
     W.stash = train ? reinterpret_cast<float2*>(ws + RL.off_stash) : nullptr;
+    W.scal = train ? reinterpret_cast<float*>(ws + RL.off_scal) : nullptr;
+    W.stash_layout = 0;
     W.slabs = train ? reinterpret_cast<float*>(ws + RL.off_slabs) : nullptr;
     W.sums = train ? reinterpret_cast<float*>(ws + RL.off_sums) : nullptr;
     W.slab_floats = RL.slab_floats;
@@ -391,8 +393,12 @@ int cmps_rho_loss_fwd(cmps_handle_t h, const float* audio_dev, int B, int T, flo
         return fail(h, CMPS_ERR_WORKSPACE, "cmps_rho_loss_fwd: save_for_bwd needs a CMPS_WS_TRAIN rho workspace");
     Dev P = h->P;
     P.B = B; P.T = T; P.N = T - 1;
-    hipError_t e = launch_fwd_rho(P, h->W, audio_dev, loss_dev, save_for_bwd != 0, static_cast<hipStream_t>(stream));
+    // D <= 32 (and rank <= 32): the wave-per-clip kernels, unless the block variant was asked for
+    const bool wave = h->D <= 32 && h->W.rank <= 32 && h->variant_req != CMPS_VARIANT_BLOCK;
+    hipError_t e = wave ? launch_fwd_rho_wave(P, h->W, audio_dev, loss_dev, save_for_bwd != 0, static_cast<hipStream_t>(stream))
+                        : launch_fwd_rho(P, h->W, audio_dev, loss_dev, save_for_bwd != 0, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail_hip(h, e, "cmps_rho_loss_fwd");
+    h->W.stash_layout = wave ? 1 : 0;
     h->rho_saved = h->rho_bwd_ok = save_for_bwd != 0;
     h->rho_saved_B = B; h->rho_saved_steps = T - 1;
     h->saved_audio = audio_dev; h->saved_loss = loss_dev;
@@ -410,7 +416,7 @@ int cmps_rho_loss_bwd(cmps_handle_t h, const float* audio_dev, int B, int T, flo
     P.B = B; P.T = T; P.N = T - 1;
     P.slabs = h->W.slabs; P.sums = h->W.sums; P.slab_floats = h->W.slab_floats;   // the reduction runs on the rho slabs
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipError_t e = launch_bwd_rho(P, h->W, audio_dev, s);
+    hipError_t e = h->W.stash_layout == 1 ? launch_bwd_rho_wave(P, h->W, audio_dev, s) : launch_bwd_rho(P, h->W, audio_dev, s);
     if (e != hipSuccess) return fail_hip(h, e, "cmps_rho_loss_bwd (scan)");
     e = launch_reduce_finalize(P, h->saved_loss, grad_dev, s);
     if (e == hipSuccess) e = launch_finalize_rho(P, h->W, grad_dev, s);
@@ -441,6 +447,7 @@ int cmps_rho_sample(cmps_handle_t h, const float* noise_dev, int n, int length, 
     hipError_t e = launch_sample_rho(h->P, h->W, noise_dev, n, length, out_dev, save_states != 0, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail_hip(h, e, "cmps_rho_sample");
     h->rho_saved = save_states != 0;
+    h->W.stash_layout = 0;
     h->rho_bwd_ok = false;
     h->rho_saved_B = n; h->rho_saved_steps = length;
     return CMPS_OK;

@@ -106,7 +106,7 @@ struct Dev {
 // ---------------------------------------------------------------------------------------------
 struct RhoLayout {
     int rank;
-    size_t off_phi0, off_stash, off_slabs, off_sums, total, slab_floats;
+    size_t off_phi0, off_stash, off_scal, off_slabs, off_sums, total, slab_floats;
 };
 
 inline RhoLayout make_rho_layout(int D, int rank, int B, int T, int flags) {
@@ -116,9 +116,11 @@ inline RhoLayout make_rho_layout(int D, int rank, int B, int T, int flags) {
     L.slab_floats = 4 * DP * DP + 3 * DP + 2 + 2 * r * DP;
     size_t o = 0;
     L.off_phi0 = o; o = align256(o + r * DP * sizeof(float2));
-    L.off_stash = L.off_slabs = L.off_sums = o;
+    L.off_stash = L.off_scal = L.off_slabs = L.off_sums = o;
     if (flags & 1) {
-        L.off_stash = o; o = align256(o + (size_t)B * N * r * DP * sizeof(float2));
+        // D <= 32: the wave kernels keep (y_a own, (H y_a) own) per lane, 512 B per column and step
+        L.off_stash = o; o = align256(o + (size_t)B * N * r * DP * sizeof(float2) * (D <= 32 ? 2 : 1));
+        L.off_scal = o;  o = align256(o + (size_t)B * ((N + 63) / 64) * 128 * sizeof(float));
         L.off_slabs = o; o = align256(o + (size_t)B * L.slab_floats * sizeof(float));
         L.off_sums = o;  o = align256(o + (L.slab_floats + 64) * sizeof(float) + 32 * L.slab_floats * sizeof(double));
     }
@@ -128,6 +130,8 @@ inline RhoLayout make_rho_layout(int D, int rank, int B, int T, int flags) {
 
 struct RhoDev {
     int rank;
+    int stash_layout;    // 0: [B][N][rank][DP] float2 (cmps_rho.hip)  1: [B][N][rank][64] (y own, H y own) (cmps_rho_wave.hip)
+    float* scal;         // [B][NC][2][64]: tr rho'_k and e_k, one step per lane (wave kernels)
     const float2* phi0;  // [rank][DP]
     float2* stash;       // [B][N][rank][DP]
     float* slabs;        // [B][slab]
@@ -146,6 +150,8 @@ hipError_t launch_update_ancilla_rho(const Dev& P, const float* rho_in, const fl
                                      float* rho_out, hipStream_t s);
 hipError_t launch_sample_rho(const Dev& P, const RhoDev& W, const float* noise, int n, int length, float* out,
                              bool save, hipStream_t s);
+hipError_t launch_fwd_rho_wave(const Dev& P, const RhoDev& W, const float* audio, float* loss, bool save, hipStream_t s);
+hipError_t launch_bwd_rho_wave(const Dev& P, const RhoDev& W, const float* audio, hipStream_t s);
 hipError_t launch_prep(const Dev& P, const float* R_re, const float* R_im, const float* freqs,
                        const float* psi0_re, const float* psi0_im, float dt, bool rebuild_ttab,
                        float* ttab, float* dtk, float2* R, float2* RT, float2* Q, float2* psi0,

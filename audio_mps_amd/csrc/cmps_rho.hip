@@ -299,9 +299,11 @@ __global__ __launch_bounds__(256) void k_states_rho(Dev P, RhoDev W, int steps, 
     const size_t row = blockIdx.x;                          // b * steps + k
     const int k = (int)(row % steps), t = threadIdx.x;
     const float2* st = W.stash + row * r * DP;
+    const float* stw = reinterpret_cast<const float*>(W.stash) + row * r * 128;   // wave layout: [rank][64] (y own, H y own)
     float pn = 0.f;
     for (int idx = t; idx < r * D; idx += 256) {
-        const float2 y = st[(idx / D) * DP + idx % D];
+        const int a = idx / D, d = idx % D;
+        const float2 y = W.stash_layout == 1 ? make_float2(stw[(a * 64 + d) * 2], stw[(a * 64 + d + 32) * 2]) : st[a * DP + d];
         Y[idx] = y;
         pn += y.x * y.x + y.y * y.y;
     }

@@ -83,9 +83,9 @@ for rank in (4, 32):
                                                               rm.variables["freqs"], np.zeros(32, np.float32), np.zeros(32, np.float32),
                                                               scaled_R=True, scaled_freqs=True), rm.variables["Wx"], rm.variables["Wy"], a[:4, :200])
     cpu = 4 * 200 / (time.perf_counter() - t0)
-    res[f"rho_cmps_rank{rank}"] = {"shape": f"D=32, rank={rank}, T={T}, B={B}, fwd+bwd", "kernel": "k_fwd_rho + k_bwd_rho (block per clip)", "ms": ms,
+    res[f"rho_cmps_rank{rank}"] = {"shape": f"D=32, rank={rank}, T={T}, B={B}, fwd+bwd", "kernel": "k_fwd_rho_wave + k_bwd_rho_wave (wave per clip)", "ms": ms,
                                    "samples_per_s": B * T / ms * 1e3, "cpu_numpy_samples_per_s": cpu,
-                                   "bound": "correctness-first block kernels; 3 r D^2 complex MACs per step"}
+                                   "bound": "straight-line wave-per-clip kernels, 3 r D^2 complex MACs + 6 r exact fp32 MFMAs per step (issue / LDS latency)"}
 
 # ---- rank 4: TFRecord reader (host, pure Python): records of 65536 float32 samples
 import tempfile

@@ -229,3 +229,23 @@ def test_rho_error_codes():
     with pytest.raises(_capi.CmpsError) as ei:               # rank * D beyond the LDS-resident limit
         be64.rho_set_state(np.zeros((128, 64), np.complex64), 1, 8, train=True)
     assert ei.value.code == _capi.CMPS_ERR_UNSUPPORTED_D
+
+
+@pytest.mark.parametrize("D,rank", [(32, 5), (12, 12)])
+def test_rho_wave_and_block_kernels_agree(D, rank):
+    """D <= 32 runs the wave-per-clip RhoCMPS kernels (cmps_rho_wave.hip); CMPS_VARIANT_BLOCK forces the general block
+    kernels (cmps_rho.hip).  Two independent implementations of the same column recurrence must agree."""
+    from audio_mps_amd import RhoCMPS
+    from audio_mps_amd.scan import HipScan
+    m, audio = _rho_model(D, 200, 5, rank=rank, sigma=0.2, seed=9, rscale=0.5)
+    blk = RhoCMPS(m.hparams, data_iterator=audio, seed=9, backend=HipScan(D, variant=1))
+    for k in m.variables:
+        blk.variables[k] = m.variables[k].copy()
+    a, b = m.loss_per_clip(), blk.loss_per_clip()
+    assert np.max(np.abs(a - b) / np.maximum(np.abs(b), 1.0)) <= LOSS_RTOL
+    la, ga = m.loss_and_grads()
+    lb, gb = blk.loss_and_grads()
+    for k in ga:
+        assert rel_inf(ga[k], gb[k]) <= GRAD_RTOL, k
+    ra, rb = m.rho_evolve_with_data(), blk.rho_evolve_with_data()
+    assert rel_inf(ra, rb) <= 1e-5
