@@ -282,6 +282,8 @@ int cmps_legacy_set_params(cmps_handle_t h, const float* R_dev, const float* Q_r
     P.Q = reinterpret_cast<float2*>(ws + L.off_Q);
     P.QT = reinterpret_cast<float2*>(ws + L.off_QT);
     P.stash = (flags & CMPS_WS_TRAIN) ? reinterpret_cast<float2*>(ws + L.off_stash) : nullptr;
+    P.hst = (flags & CMPS_WS_TRAIN) ? reinterpret_cast<float*>(ws + L.off_hst) : nullptr;
+    P.scal = (flags & CMPS_WS_TRAIN) ? reinterpret_cast<float*>(ws + L.off_scal) : nullptr;
     P.slabs = (flags & CMPS_WS_TRAIN) ? reinterpret_cast<float*>(ws + L.off_slabs) : nullptr;
     P.sums = (flags & CMPS_WS_TRAIN) ? reinterpret_cast<float*>(ws + L.off_sums) : nullptr;
     P.slab_floats = L.slab_floats;
@@ -308,8 +310,11 @@ int cmps_legacy_loss_fwd(cmps_handle_t h, const float* audio_dev, int B, int T, 
         return fail(h, CMPS_ERR_WORKSPACE, "cmps_legacy_loss_fwd: save_for_bwd needs a CMPS_WS_TRAIN workspace");
     Dev P = h->P;
     P.B = B;
-    hipError_t e = launch_fwd_legacy(P, audio_dev, loss_dev, save_for_bwd != 0, static_cast<hipStream_t>(stream));
+    const bool wave = h->D <= 32 && h->variant_req != CMPS_VARIANT_BLOCK;     // wave-per-clip kernels (cmps_legacy_wave.hip)
+    hipError_t e = wave ? launch_fwd_legacy_wave(P, audio_dev, loss_dev, save_for_bwd != 0, static_cast<hipStream_t>(stream))
+                        : launch_fwd_legacy(P, audio_dev, loss_dev, save_for_bwd != 0, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail_hip(h, e, "cmps_legacy_loss_fwd");
+    h->saved_variant = wave ? CMPS_VARIANT_WAVE : CMPS_VARIANT_BLOCK;
     h->fwd_saved = save_for_bwd != 0;
     h->saved_B = B; h->saved_T = T; h->saved_audio = audio_dev; h->saved_loss = loss_dev;
     return CMPS_OK;
@@ -325,7 +330,7 @@ int cmps_legacy_loss_bwd(cmps_handle_t h, const float* audio_dev, int B, int T, 
     Dev P = h->P;
     P.B = B;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipError_t e = launch_bwd_legacy(P, audio_dev, s);
+    hipError_t e = h->saved_variant == CMPS_VARIANT_WAVE ? launch_bwd_legacy_wave(P, audio_dev, s) : launch_bwd_legacy(P, audio_dev, s);
     if (e != hipSuccess) return fail_hip(h, e, "cmps_legacy_loss_bwd (scan)");
     e = launch_reduce_only(P, s);
     if (e == hipSuccess) e = launch_finalize_legacy(P, h->saved_loss, grad_dev, s);

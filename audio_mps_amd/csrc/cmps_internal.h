@@ -150,6 +150,8 @@ hipError_t launch_update_ancilla_rho(const Dev& P, const float* rho_in, const fl
                                      float* rho_out, hipStream_t s);
 hipError_t launch_sample_rho(const Dev& P, const RhoDev& W, const float* noise, int n, int length, float* out,
                              bool save, hipStream_t s);
+hipError_t launch_fwd_legacy_wave(const Dev& P, const float* audio, float* loss, bool save, hipStream_t s);
+hipError_t launch_bwd_legacy_wave(const Dev& P, const float* audio, hipStream_t s);
 hipError_t launch_fwd_rho_wave(const Dev& P, const RhoDev& W, const float* audio, float* loss, bool save, hipStream_t s);
 hipError_t launch_bwd_rho_wave(const Dev& P, const RhoDev& W, const float* audio, hipStream_t s);
 hipError_t launch_prep(const Dev& P, const float* R_re, const float* R_im, const float* freqs,

@@ -350,3 +350,19 @@ def test_legacy_audiomps_matches_oracle(D, T, B, dt):
     assert rel_inf(grads["R"], ref["gR"]) <= GRAD_RTOL
     assert rel_inf(grads["H"], ref["gH"]) <= GRAD_RTOL
     assert np.allclose(np.triu(grads["H"], 1), 0)                  # only the lower triangle of H is used
+
+
+@pytest.mark.parametrize("T", [65, 130, 400])
+def test_legacy_wave_and_block_kernels_agree(T):
+    """D <= 32 runs the wave-per-clip legacy kernels (cmps_legacy_wave.hip); CMPS_VARIANT_BLOCK forces the block kernels."""
+    from audio_mps_amd import LegacyAudioMPS
+    from audio_mps_amd.scan import HipScan
+    audio = make_audio(6, T, 0.004, 3, noise=0.05)
+    a = LegacyAudioMPS(24, 0.004, 6, data_iterator=audio, seed=4)
+    b = LegacyAudioMPS(24, 0.004, 6, data_iterator=audio, seed=4, backend=HipScan(24, variant=BLOCK))
+    pa, pb = a.loss_per_clip(), b.loss_per_clip()
+    assert np.max(np.abs(pa - pb) / np.maximum(np.abs(pb), 1.0)) <= LOSS_RTOL
+    la, ga = a.loss_and_grads()
+    lb, gb = b.loss_and_grads()
+    for k in ga:
+        assert rel_inf(ga[k], gb[k]) <= GRAD_RTOL, k
