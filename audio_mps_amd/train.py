@@ -113,6 +113,9 @@ def build_parser():
     p.add_argument("--max_steps", type=int, default=100)
     p.add_argument("--save_checkpoint_secs", type=float, default=60.0)                          # train.py:93
     p.add_argument("--seed", type=int, default=0)                                               # train.py:13
+    p.add_argument("--kernel_variant", type=int, default=0,
+                   help="0 auto (float32: wave-per-clip kernels for D <= 32, block kernels above), 1 block, 2 wave, "
+                        "3 MFMA pair kernels (32 < D <= 128, bf16 mat-vec operands)")
     return p
 
 
@@ -127,7 +130,10 @@ def main(argv=None):
     dev = torch.device("cuda", local_rank)
     dp = DataParallel(device=dev)
     start, count = dp.shard(hp.minibatch_size)
-    model = RhoCMPS(hp, seed=args.seed) if args.mps_model == "rho_mps" else PsiCMPS(hp, seed=args.seed)   # train.py:50-53
+    from .scan import HipScan
+    backend = HipScan(hp.bond_dim, device=dev, variant=args.kernel_variant)
+    cls = RhoCMPS if args.mps_model == "rho_mps" else PsiCMPS                                   # train.py:50-53
+    model = cls(hp, seed=args.seed, backend=backend)
     trainer = Trainer(model, hp, dp)
     logdir = f"{args.logdir}/{args.dataset}/{hp.bond_dim}_{hp.delta_t}_{hp.minibatch_size}"    # train.py:94
     ckpt = os.path.join(logdir, "model.ckpt.npz")
