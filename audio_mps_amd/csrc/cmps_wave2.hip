@@ -95,6 +95,13 @@ template <int N>
 __device__ __forceinline__ void lds_wait_hi_t_after(v4f (&o)[8], v2f& t, v2f& dep) {
     asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(o[4]), "+v"(o[5]), "+v"(o[6]), "+v"(o[7]), "+v"(t), "+v"(dep) : "n"(N) : "memory");
 }
+// vec[lane sel] = val (both wave-uniform): v_writelane_b32 takes its lane select from M0 when the value already occupies the
+// one SGPR operand slot; M0 is reserved by the compiler, so it is saved and restored around the instruction
+__device__ __forceinline__ void write_lane(float& vec, float val, int sel) {
+    unsigned keep;
+    asm("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
+        : "+v"(vec), "=&s"(keep) : "s"(val), "s"(sel));
+}
 __device__ __forceinline__ float vmax_s(float s, float c) {     // one v_max_f32 (fmaxf adds a canonicalising second one)
     float r;
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "s"(s), "v"(c));
@@ -205,8 +212,7 @@ __global__ __launch_bounds__(128 * WAVES, 1) void k_fwd_wave2(Dev P, const float
                 const int kn = kk_ + 1 < CH2 ? kk_ + 1 : 0;               /* chunk end: a dummy, retired below */ \
                 bcast_issue_tab(aUw, aUr, u, aRho + kn * 256, qu, rho);                                       \
                 xsq = y * y;                                                                                  \
-                asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0"                                          \
-                    : "+v"(nvec) : "s"(nprev), "s"((kk_ - 1) & (CH2 - 1)) : "m0");                            \
+                write_lane(nvec, nprev, (kk_ - 1) & (CH2 - 1));                                               \
             }
             CHAIN_STEP(0)
             if (SAVE && c > 0 && lane < CH2) sc[(size_t)((c - 1) >> 1) * 128 + ((c - 1) & 1) * CH2 + lane] = nvec;
@@ -222,7 +228,7 @@ __global__ __launch_bounds__(128 * WAVES, 1) void k_fwd_wave2(Dev P, const float
         if (SAVE) {                                                    // |y_{N-1}|^2 closes the last row
             const float nlast = sum64(xsq);
             const int cl = NC2 - 1;
-            asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(nvec) : "s"(nlast), "s"((N - 1) & (CH2 - 1)) : "m0");
+            write_lane(nvec, nlast, (N - 1) & (CH2 - 1));
             if (lane < CH2) sc[(size_t)(cl >> 1) * 128 + (cl & 1) * CH2 + lane] = nvec;
         }
         return;
