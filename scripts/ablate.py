@@ -1,15 +1,37 @@
 #!/usr/bin/env python3
-"""Diagnostic: build libcmps variants with ablation flags (results wrong, timing informative) and time the scans."""
-import os, sys, subprocess
+"""Diagnostic: build libcmps variants with extra -D flags (results may be wrong, timing is informative) and time the scans.
+
+usage: ablate.py [--shape D T B ROUNDS VARIANT] name=-DFLAG[,-DFLAG...] ...
+  e.g. ablate.py base= no_mfma=-DPABL_NO_MFMA --shape 128 16000 512 2 3
+Known switches: ABL_NO_REDUCE / ABL_NO_MV1 / ABL_NO_WAIT (cmps_wave.hip), ABL2_NO_LOSS / ABL2_NO_CHAIN / ABL2_NO_PRIO /
+ABL2_CHAIN_NOWAIT / FWD2_NO_STAGGER / FWD2_LOSS_PRIO=n (cmps_wave2.hip), PABL_NO_MFMA / PABL_NO_REDUCE /
+GRAD_VALU_PER_MFMA=n (cmps_pair.hip).  Runs on the GPU box (hipcc is available there); libraries go to gpurun_out/.
+"""
+import os
+import subprocess
+import sys
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from audio_mps_amd import build
-variants = {"base": [], "no_stagger": ["-DFWD2_NO_STAGGER"], "loss_prio1": ["-DFWD2_LOSS_PRIO=1"], "loss_prio3": ["-DFWD2_LOSS_PRIO=3"], "loss_stagger": ["-DFWD2_LOSS_STAGGER"]}
+
+args = sys.argv[1:]
+shape = ["32", "16000", "1024", "4"]
+if "--shape" in args:
+    i = args.index("--shape")
+    shape = args[i + 1:i + 6]
+    args = args[:i]
+variants = {}
+for a in args or ["base="]:
+    name, _, flags = a.partition("=")
+    variants[name] = [f for f in flags.split(",") if f]
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 for name, flags in variants.items():
     lib = os.path.join(ROOT, "gpurun_out", f"libcmps_{name}.so")
-    subprocess.run([build._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", lib] + flags
-                   + [os.path.join(build.CSRC, s) for s in build.SOURCES], check=True)
+    subprocess.run([build._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Xarch_host", "-msse4.2",
+                    "-o", lib] + flags + [os.path.join(build.CSRC, s) for s in build.SOURCES], check=True)
     env = dict(os.environ, CMPS_LIB=lib)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "time_kernels.py"), "32", "16000", "1024", "4"], env=env, capture_output=True, text=True).stdout
-    print("==", name); print("\n".join(l for l in out.splitlines() if "median" in l))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "time_kernels.py")] + shape, env=env,
+                         capture_output=True, text=True).stdout
+    print("==", name, " ".join(flags))
+    print("\n".join(l for l in out.splitlines() if "median" in l))
