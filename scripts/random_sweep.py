@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""One-off robustness sweep on the GPU: random shapes and parameter scales through every kernel family against the oracles."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from audio_mps_amd import HParams, PsiCMPS, RhoCMPS, LegacyAudioMPS
+from audio_mps_amd.scan import HipScan, unpack_grad
+from oracle import cmps_oracle as O, c_oracle as C
+from _util import make_audio, c_oracle_run, rel_inf, oracle_hparams, oracle_variables
+
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+worst = {}
+def note(kind, val, cfg):
+    if val > worst.get(kind, (0, None))[0]:
+        worst[kind] = (val, cfg)
+
+for it in range(40):                                   # pure-state wave / block kernels vs the C restatement
+    D = int(rng.integers(1, 33)); T = int(rng.integers(2, 700)); B = int(rng.integers(1, 14))
+    sigma = float(10 ** rng.uniform(-4, 0)); rs = float(10 ** rng.uniform(-1.5, 0)); variant = int(rng.choice([1, 2]))
+    hp = HParams(minibatch_size=B, bond_dim=D, sigma=sigma, A=float(10 ** rng.uniform(0, 2)))
+    audio = make_audio(B, T, hp.delta_t, it)
+    m = PsiCMPS(hp, data_iterator=audio, seed=it, backend=HipScan(D, variant=variant))
+    m.variables["Rx"] *= np.float32(rs); m.variables["Ry"] *= np.float32(rs)
+    per = m.loss_per_clip(); flat, _ = m.grad_sums(); g = unpack_grad(flat.cpu().numpy(), D)
+    ref = c_oracle_run(m, audio, "f32"); gr = C.unpack_grad(ref["grad"], D)
+    cfg = (D, T, B, round(sigma, 5), round(rs, 3), variant)
+    note("psi loss", float(np.max(np.abs(per - ref["loss_per_clip"]) / np.maximum(np.abs(ref["loss_per_clip"]), 1))), cfg)
+    note("psi grad", max(rel_inf(g[k], gr[k]) for k in ("Rbar", "fbar", "psi0bar", "Abar")), cfg)
+for it in range(8):                                    # pair kernels vs the bf16 emulation
+    D = int(rng.integers(33, 129)); T = int(rng.integers(2, 200)); B = int(rng.integers(1, 7))
+    hp = HParams(minibatch_size=B, bond_dim=D)
+    audio = make_audio(B, T, hp.delta_t, 100 + it)
+    m = PsiCMPS(hp, data_iterator=audio, seed=it, backend=HipScan(D, variant=3))
+    per = m.loss_per_clip(); flat, _ = m.grad_sums(); g = unpack_grad(flat.cpu().numpy(), D)
+    em = O.psi_bf16_scan(oracle_hparams(hp), oracle_variables(m), audio)
+    note("pair loss", float(np.max(np.abs(per - em["loss_per_clip"]) / np.maximum(np.abs(em["loss_per_clip"]), 1))), (D, T, B))
+    note("pair grad", max(rel_inf(g[k], em[k]) for k in ("Rbar", "fbar", "psi0bar", "Abar")), (D, T, B))
+for it in range(10):                                   # RhoCMPS (wave for D <= 32, block above)
+    D = int(rng.integers(2, 41)); r = int(rng.integers(1, min(D, 12) + 1)); T = int(rng.integers(2, 150)); B = int(rng.integers(1, 6))
+    hp = HParams(minibatch_size=B, bond_dim=D, initial_rank=r, sigma=float(10 ** rng.uniform(-4, -0.3)))
+    audio = make_audio(B, T, hp.delta_t, 200 + it)
+    m = RhoCMPS(hp, data_iterator=audio, seed=it)
+    m.variables["Rx"] *= np.float32(0.4); m.variables["Ry"] *= np.float32(0.4)
+    ov = O.Variables(np.asarray(m.variables["A"], np.float32), m.variables["Rx"], m.variables["Ry"], m.variables["freqs"],
+                     np.zeros(D, np.float32), np.zeros(D, np.float32), scaled_R=True, scaled_freqs=True)
+    ref = O.rho_loss_and_grads(O.HParams(**hp.values()), ov.astype(np.float64), m.variables["Wx"].astype(np.float64),
+                               m.variables["Wy"].astype(np.float64), audio, "f64")
+    per = m.loss_per_clip(); loss, grads = m.loss_and_grads()
+    note("rho loss", float(np.max(np.abs(per - ref["per_clip"]) / np.maximum(np.abs(ref["per_clip"]), 1))), (D, r, T, B))
+    note("rho grad", max(rel_inf(grads[k], ref[k]) for k in ("A", "Rx", "Ry", "freqs", "Wx", "Wy")), (D, r, T, B))
+for it in range(10):                                   # legacy AudioMPS
+    D = int(rng.integers(2, 41)); T = int(rng.integers(2, 300)); B = int(rng.integers(1, 7)); dt = float(10 ** rng.uniform(-3, -2))
+    audio = make_audio(B, T, dt, 300 + it, noise=0.05)
+    m = LegacyAudioMPS(D, dt, B, data_iterator=audio, seed=it)
+    ref = O.legacy_loss_and_grads(m.variables["H"], m.variables["R"], dt, audio, "f32")
+    per = m.loss_per_clip(); loss, grads = m.loss_and_grads()
+    note("legacy loss", float(np.max(np.abs(per - ref["per_clip"]) / np.maximum(np.abs(ref["per_clip"]), 1))), (D, T, B))
+    note("legacy grad", max(rel_inf(grads["R"], ref["gR"]), rel_inf(grads["H"], ref["gH"])), (D, T, B))
+for k, (v, cfg) in worst.items():
+    print(f"{k:12s} worst {v:.2e} at {cfg}")
