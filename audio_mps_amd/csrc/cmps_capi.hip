@@ -14,6 +14,7 @@ using namespace cmps;
 struct cmps_handle_s {
     int D = 0;
     int variant_req = CMPS_VARIANT_AUTO;
+    int rank1_mode = CMPS_RANK1_BF16X3;
     bool params_set = false;
     bool legacy = false;       // the tables currently hold the legacy AudioMPS arithmetic (cmps_legacy_set_params)
     bool fwd_saved = false;
@@ -63,7 +64,7 @@ int resolve_variant(const cmps_handle_s* h) {
 
 extern "C" {
 
-int cmps_version(void) { return 100; }
+int cmps_version(void) { return 200; }
 
 int cmps_create(int D, cmps_handle_t* out) {
     if (!out) return CMPS_ERR_BAD_ARG;
@@ -96,6 +97,23 @@ int cmps_set_variant(cmps_handle_t h, int variant) {
 }
 
 int cmps_get_variant(cmps_handle_t h) { return h ? resolve_variant(h) : 0; }
+
+int cmps_set_option(cmps_handle_t h, int option, int value) {
+    if (!h) return CMPS_ERR_BAD_ARG;
+    if (option == CMPS_OPT_RANK1) {
+        if (value < CMPS_RANK1_EXACT_F32 || value > CMPS_RANK1_BF16X3)
+            return fail(h, CMPS_ERR_BAD_ARG, "cmps_set_option: unknown value for CMPS_OPT_RANK1");
+        h->rank1_mode = value;
+        return CMPS_OK;
+    }
+    return fail(h, CMPS_ERR_BAD_ARG, "cmps_set_option: unknown option");
+}
+
+int cmps_get_option(cmps_handle_t h, int option) {
+    if (!h) return -1;
+    if (option == CMPS_OPT_RANK1) return h->rank1_mode;
+    return -1;
+}
 
 size_t cmps_workspace_bytes(int D, int B, int T, int flags) {
     if (D < 1 || D > 128 || B < 1 || T < 2) return 0;
@@ -215,7 +233,7 @@ int cmps_psi_loss_bwd(cmps_handle_t h, const float* audio_dev, int B, int T, flo
         if (e != hipSuccess) return fail_hip(h, e, "cmps_psi_loss_bwd (pair reduce)");
         return CMPS_OK;
     }
-    hipError_t e = (h->saved_variant == CMPS_VARIANT_WAVE) ? launch_bwd_wave(P, audio_dev, s)
+    hipError_t e = (h->saved_variant == CMPS_VARIANT_WAVE) ? launch_bwd_wave(P, audio_dev, h->rank1_mode, s)
                                                            : launch_bwd_block(P, audio_dev, s);
     if (e != hipSuccess) return fail_hip(h, e, "cmps_psi_loss_bwd (scan)");
     e = launch_reduce_finalize(P, h->saved_loss, grad_dev, s);

@@ -212,6 +212,9 @@ struct Pre {
 
 }  // namespace
 
+// RANK1: how the three rank-1 gradient updates of a step are applied (cmps_set_option(CMPS_OPT_RANK1)):
+//   0 exact fp32 MFMA every step; 1 bf16 hi/lo split, 3 products; 2 bf16 hi/mid/lo split, 6 products (see below)
+template <int RANK1>
 __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* __restrict__ audio) {
     __shared__ __attribute__((aligned(16))) float4 stY[WAVES][CHB * 32];   // stashed (y, H y) rows of the staged chunk
     __shared__ __attribute__((aligned(16))) float4 stR[WAVES][CHB * 16];   // rho rows
@@ -335,13 +338,20 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
     // it keeps the 144-cycle wave reduction off the serial chain; `exact` (once per staged chunk) does the real
     // projection so that rounding in the radial direction cannot accumulate over the clip.
     float rad_next = 0.f;                         // no step N: g_N = 0
-    // Rank-1 updates, two forms.  Immediate: six exact-fp32 v_mfma_f32_32x32x2_f32 (the fp32 MFMA shares the fp32
-    // ALUs with the VALU, so each blocks the wave for 64 cycles).  Recorded: the seven operand values of the
-    // step are split into bf16 hi (truncation) + bf16 lo (rounded remainder) and packed into slot P of per-lane
-    // K-fragments; after eight steps 18 v_mfma_f32_32x32x16_bf16 (hi*hi + hi*lo + lo*hi per product; K = 8 steps x
-    // {re, im}; error ~2^-17 per product) accumulate them into the same fp32 tiles.  The bf16 MFMA runs on the
-    // matrix pipe beside the VALU and is issued once per eight steps.
+    // Rank-1 updates, three forms (template parameter RANK1, chosen at run time by cmps_set_option):
+    //   0  EXACT_F32: six exact-fp32 v_mfma_f32_32x32x2_f32 per step (the fp32 MFMA shares the fp32 ALUs with the
+    //      VALU, so each holds the wave for 64 cycles).
+    //   1  BF16X2: the seven operand values of a step are split into bf16 hi (truncation) + bf16 lo (rounded
+    //      remainder) and packed into slot P of per-lane K-fragments; after eight steps 18 v_mfma_f32_32x32x16_bf16
+    //      (hi*hi + hi*lo + lo*hi per product; K = 8 steps x {re, im}) accumulate them into the same fp32 tiles:
+    //      16 operand bits, error <= ~2^-16 |a||b| per product.
+    //   2  BF16X3: exact three-way split x = hi + mid + lo (8 + 8 + 8 significand bits, all by truncation, so the
+    //      decomposition is exact) and SIX products per pair (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid): 24 operand
+    //      bits; the dropped terms (mid*lo, lo*mid, lo*lo) are <= 2^-23 |a||b|, i.e. the product is fp32-faithful.  36 MFMAs
+    //      per octet, applied during the next two steps.
+    // The bf16 MFMA runs on the matrix pipe beside the VALU; accumulation is fp32 in all three forms.
     unsigned fH[7][4], fL[7][4];      // K-fragments: value v, register r holds slots 2r (low half) and 2r+1 (high half)
+    unsigned fM[RANK1 == 2 ? 7 : 1][4];
     float fsave[7];
     auto record = [&](auto slot, const float (&val)[7]) {
         constexpr int PSLOT = decltype(slot)::value;
@@ -356,7 +366,17 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
                 v2f lo;
                 lo.x = val[v] - __uint_as_float(xe & 0xFFFF0000u);
                 lo.y = fsave[v] - __uint_as_float(xo & 0xFFFF0000u);
-                fL[v][PSLOT >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf2));
+                if constexpr (RANK1 == 2) {
+                    const unsigned me = __float_as_uint(lo.x), mo = __float_as_uint(lo.y);
+                    fM[v][PSLOT >> 1] = __builtin_amdgcn_perm(mo, me, 0x07060302u);
+                    v2f l3;
+                    l3.x = lo.x - __uint_as_float(me & 0xFFFF0000u);
+                    l3.y = lo.y - __uint_as_float(mo & 0xFFFF0000u);
+                    // at most 8 significand bits are left: the truncation to bf16 is exact
+                    fL[v][PSLOT >> 1] = __builtin_amdgcn_perm(__float_as_uint(l3.y), __float_as_uint(l3.x), 0x07060302u);
+                } else {
+                    fL[v][PSLOT >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf2));
+                }
             }
         }
     };
@@ -366,29 +386,48 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
     // would hold the in-order wave for 18 x 32 cycles.
     bool pend = false;                // a finished octet's fragments are waiting to be applied
     auto mf_group = [&](auto gsel) {
-        constexpr int G = decltype(gsel)::value;
+        constexpr int G = decltype(gsel)::value;       // 0..5: first three products of pair G; 6..11 (BF16X3): the other three
         auto frag = [&](const unsigned (&f)[4]) { return __builtin_bit_cast(bf8, v4u{f[0], f[1], f[2], f[3]}); };
         auto mf = [&](v16f& acc, int ia, int ib) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(fH[ia]), frag(fH[ib]), acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(fH[ia]), frag(fL[ib]), acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(fL[ia]), frag(fH[ib]), acc, 0, 0, 0);
+            if constexpr (RANK1 == 2 && G >= 6) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(fH[ia]), frag(fL[ib]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(fL[ia]), frag(fH[ib]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(fM[ia]), frag(fM[ib]), acc, 0, 0, 0);
+            } else {
+                auto second = [&](int idx) -> const unsigned (&)[4] {      // the next-lower 8 bits
+                    if constexpr (RANK1 == 2) return fM[idx]; else return fL[idx];
+                };
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(fH[ia]), frag(fH[ib]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(fH[ia]), frag(second(ib)), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(second(ia)), frag(fH[ib]), acc, 0, 0, 0);
+            }
         };
+        constexpr int GP = G % 6;
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (G == 0) mf(Rre, 0, 3);
-        if constexpr (G == 1) mf(Rim, 0, 4);
-        if constexpr (G == 2) mf(Qre, 1, 5);
-        if constexpr (G == 3) mf(Qim, 1, 6);
-        if constexpr (G == 4) mf(Rre, 2, 5);
-        if constexpr (G == 5) mf(Rim, 2, 6);
+        if constexpr (GP == 0) mf(Rre, 0, 3);
+        if constexpr (GP == 1) mf(Rim, 0, 4);
+        if constexpr (GP == 2) mf(Qre, 1, 5);
+        if constexpr (GP == 3) mf(Qim, 1, 6);
+        if constexpr (GP == 4) mf(Rre, 2, 5);
+        if constexpr (GP == 5) mf(Rim, 2, 6);
         __builtin_amdgcn_sched_barrier(0);
     };
     auto flush_octet = [&]() {
         mf_group(std::integral_constant<int, 0>{}); mf_group(std::integral_constant<int, 1>{});
         mf_group(std::integral_constant<int, 2>{}); mf_group(std::integral_constant<int, 3>{});
         mf_group(std::integral_constant<int, 4>{}); mf_group(std::integral_constant<int, 5>{});
+        if constexpr (RANK1 == 2) {
+            mf_group(std::integral_constant<int, 6>{}); mf_group(std::integral_constant<int, 7>{});
+            mf_group(std::integral_constant<int, 8>{}); mf_group(std::integral_constant<int, 9>{});
+            mf_group(std::integral_constant<int, 10>{}); mf_group(std::integral_constant<int, 11>{});
+        }
         pend = false;
     };
-#define MF_HOOK(G) if constexpr (decltype(slot)::value == 7) { if (pend) mf_group(std::integral_constant<int, (G)>{}); }
+    // a finished octet is applied at six points of the next step (slot 7); BF16X3 applies its second half at the same six
+    // points of the step after that (slot 6), before that step's record() overwrites fragment register 3
+#define MF_HOOK(G)                                                                                         \
+    if constexpr (decltype(slot)::value == 7) { if (pend) mf_group(std::integral_constant<int, (G)>{}); }  \
+    else if constexpr (RANK1 == 2 && decltype(slot)::value == 6) { if (pend) mf_group(std::integral_constant<int, (G) + 6>{}); }
     auto chain_step = [&](const Pre& S, float uk, float uko, auto have_pre, int jn, bool exact, auto slot) -> Pre {
         // ---- chain, scalar part ----
         MF_HOOK(0)
@@ -422,7 +461,11 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
         accS += sd * uk;
         g = ybar + swapadd(aq.x, aq.y) + sd;
         go = osig_of(g, hb);
-        if constexpr (decltype(slot)::value == 7) { if (pend) { mf_group(std::integral_constant<int, 5>{}); pend = false; } }
+        if constexpr (decltype(slot)::value == 7) {
+            if (pend) { mf_group(std::integral_constant<int, 5>{}); if constexpr (RANK1 != 2) pend = false; }
+        } else if constexpr (RANK1 == 2 && decltype(slot)::value == 6) {
+            if (pend) { mf_group(std::integral_constant<int, 11>{}); pend = false; }
+        }
         // ---- rank-1 gradient updates (A: rows i, B: columns j; K = {re, im}) ----
         //   Rbar += 2 ebar y y^dagger + s ybar u^dagger ;  Qbar += ybar u^dagger
         //   Re(a b^dagger): A = a (split), B = b (split);  Im(a b^dagger): A = a (split), B = -b_osig
@@ -452,8 +495,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
         const bool new_scal = (hh & 1) == 0 && hh > 0;
         if (new_scal) scal_load((hh >> 1) - 1);
         int j = jhi;
-        // steps above the first aligned octet (top chunk only): immediate fp32 updates
-        for (; j >= jlo && (j & 7) != 7; --j) {
+        // steps above the first aligned octet (top chunk only; EXACT_F32: every step): immediate fp32 updates
+        for (; j >= jlo && (RANK1 == 0 || (j & 7) != 7); --j) {
             const int jr = j & (CHB - 1), jc = j & (CH - 1);
             own_issue(aYown + jr * 512, aRho + jr * 256, aScl + jc * 32, yh_j, rho_j, c0_j, c1_j);
             S = chain_step(S, 0.f, 0.f, std::true_type{}, j, j == jhi, std::integral_constant<int, -1>{});
@@ -583,9 +626,14 @@ hipError_t launch_sample_wave(const Dev& P, const float* noise, int n, int lengt
     return hipGetLastError();
 }
 
-hipError_t launch_bwd_wave(const Dev& P, const float* audio, hipStream_t s) {
+hipError_t launch_bwd_wave(const Dev& P, const float* audio, int rank1_mode, hipStream_t s) {
     const unsigned nb = (unsigned)((P.B + WAVES - 1) / WAVES);
-    hipLaunchKernelGGL(k_bwd_wave, dim3(nb), dim3(64 * WAVES), 0, s, P, audio);
+    if (rank1_mode == 0)
+        hipLaunchKernelGGL(k_bwd_wave<0>, dim3(nb), dim3(64 * WAVES), 0, s, P, audio);
+    else if (rank1_mode == 1)
+        hipLaunchKernelGGL(k_bwd_wave<1>, dim3(nb), dim3(64 * WAVES), 0, s, P, audio);
+    else
+        hipLaunchKernelGGL(k_bwd_wave<2>, dim3(nb), dim3(64 * WAVES), 0, s, P, audio);
     return hipGetLastError();
 }
 

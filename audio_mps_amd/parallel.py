@@ -25,6 +25,8 @@ class DataParallel:
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.device = device
         self._own_group = False
+        self.time_collective = False      # bench.py: HIP events around the all-reduce ("print the all-reduce us")
+        self.collective_ms = []
         if self.world_size > 1:
             if backend is None:
                 backend = "nccl" if (device is not None and torch.device(device).type == "cuda") else "gloo"
@@ -58,9 +60,45 @@ class DataParallel:
         buf = torch.empty(flat.numel() + 1, dtype=torch.float32, device=flat.device)
         buf[:-1] = flat
         buf[-1] = float(local_clips)
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
-        host = buf.detach().cpu().numpy().astype(np.float64)
+        if self.time_collective and buf.is_cuda:
+            # the collective is enqueued behind the current stream and the current stream waits for it, so two events
+            # on the current stream bracket exactly the collective (plus its stream hand-over)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            e1.record()
+            host = buf.detach().cpu().numpy().astype(np.float64)     # synchronises the stream
+            self.collective_ms.append(e0.elapsed_time(e1))
+        else:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            host = buf.detach().cpu().numpy().astype(np.float64)
         return host[:-1], int(round(host[-1]))
+
+    def collective_us(self) -> Optional[float]:
+        """Mean HIP-event time of the timed all-reduces in microseconds (None when nothing was timed)."""
+        return 1e3 * float(np.mean(self.collective_ms)) if self.collective_ms else None
+
+    def gather_floats(self, value: float) -> np.ndarray:
+        """One float from every rank -> array [world_size] (same on all ranks)."""
+        if self.world_size == 1:
+            return np.array([float(value)])
+        dev = self.device if self.backend == "nccl" else "cpu"
+        mine = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+        parts = [torch.zeros_like(mine) for _ in range(self.world_size)]
+        dist.all_gather(parts, mine)
+        return np.array([float(p.item()) for p in parts])
+
+    def measured_world_size(self) -> int:
+        """The number of ranks an actual all-reduce of ones adds up to, checked against dist.get_world_size()."""
+        if self.world_size == 1:
+            return 1
+        dev = self.device if self.backend == "nccl" else "cpu"
+        one = torch.ones(1, dtype=torch.float32, device=dev)
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        n = int(round(float(one.item())))
+        if n != dist.get_world_size():
+            raise RuntimeError(f"all-reduce of ones gave {n}, process group says {dist.get_world_size()}")
+        return n
 
     def barrier(self):
         if self.world_size > 1:

@@ -49,7 +49,8 @@ class HipScan:
 
     name = "hip"
 
-    def __init__(self, D: int, device: Optional[torch.device] = None, variant: int = _capi.CMPS_VARIANT_AUTO):
+    def __init__(self, D: int, device: Optional[torch.device] = None, variant: int = _capi.CMPS_VARIANT_AUTO,
+                 rank1: Optional[int] = None):
         self._lib = _capi.load()
         if not torch.cuda.is_available():
             raise RuntimeError("HipScan needs a GPU (torch.cuda.is_available() is False); there is no CPU fallback")
@@ -61,6 +62,8 @@ class HipScan:
             raise _capi.CmpsError(code, f"cmps_create(D={D}) failed")
         self._h = h
         _capi.check(self._h, self._lib.cmps_set_variant(self._h, int(variant)))
+        if rank1 is not None:
+            self.set_rank1(rank1)
         self._ws = None
         self._ws_key = None
         self._param_buf = torch.empty(2 * D * D + 3 * D, dtype=torch.float32, device=self.device)
@@ -83,6 +86,14 @@ class HipScan:
     @property
     def variant(self) -> int:
         return int(self._lib.cmps_get_variant(self._h))
+
+    def set_rank1(self, mode: int):
+        """cmps_set_option(CMPS_OPT_RANK1): arithmetic of the rank-1 gradient updates (wave kernels, D <= 32)."""
+        _capi.check(self._h, self._lib.cmps_set_option(self._h, _capi.CMPS_OPT_RANK1, int(mode)))
+
+    @property
+    def rank1(self) -> int:
+        return int(self._lib.cmps_get_option(self._h, _capi.CMPS_OPT_RANK1))
 
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

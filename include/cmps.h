@@ -48,6 +48,22 @@ enum {
     CMPS_VARIANT_PAIR = 3   /* 32 < D <= 128: one workgroup per pair of clips, matrices as bf16 MFMA fragments, fp32 accumulate */
 };
 
+/* options (cmps_set_option / cmps_get_option) */
+enum {
+    CMPS_OPT_RANK1 = 1 /* arithmetic of the rank-1 gradient updates in the wave-per-clip reverse scan (D <= 32) */
+};
+/* values of CMPS_OPT_RANK1.  All three accumulate in fp32; they differ in how the two factors of every product
+ * dR += a b^dagger enter the matrix cores:
+ *   EXACT_F32  v_mfma_f32_32x32x2_f32, bit-for-bit an fp32 fma chain (slowest: it holds the fp32 ALUs)
+ *   BF16X2     each factor split into two bf16 pieces, 3 products: 16 operand bits, error <= ~2^-16 |a||b|
+ *   BF16X3     each factor split EXACTLY into three bf16 pieces (8+8+8 bits), 6 products: 24 operand bits,
+ *              error <= 2^-23 |a||b| (what is dropped is below the fp32 rounding of the product); the default */
+enum {
+    CMPS_RANK1_EXACT_F32 = 0,
+    CMPS_RANK1_BF16X2 = 1,
+    CMPS_RANK1_BF16X3 = 2
+};
+
 /* Library version (major * 10000 + minor * 100 + patch). */
 int cmps_version(void);
 
@@ -59,6 +75,11 @@ const char* cmps_last_error(cmps_handle_t h);
 int cmps_set_variant(cmps_handle_t h, int variant);
 /* The variant the next launch will use (after AUTO resolution), CMPS_VARIANT_BLOCK or _WAVE. */
 int cmps_get_variant(cmps_handle_t h);
+/* Numerical options of the gradient path; the reference has one arithmetic (TensorFlow float32 kernels behind
+ * train.py:89), so every value of every option must stay within the stated float32 tolerance of it.
+ * cmps_get_option returns the value, or -1 for an unknown option / null handle. */
+int cmps_set_option(cmps_handle_t h, int option, int value);
+int cmps_get_option(cmps_handle_t h, int option);
 
 /* Bytes of device workspace the caller must provide for bond dimension D, B clips of T samples.
  * Returns 0 for invalid arguments. */

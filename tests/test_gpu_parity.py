@@ -124,6 +124,39 @@ def test_config3_reduced_batch():
     _check_against_oracle(m, audio, nthreads=16)
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_rank1_modes(mode):
+    """cmps_set_option(CMPS_OPT_RANK1): exact fp32 MFMA, bf16x2 split and bf16x3 split of the rank-1 gradient updates
+    (k_bwd_wave<0|1|2>) all stay inside the gradient bar; the default is BF16X3 (24 operand bits, fp32-faithful products).
+    T = 3000 spans many aligned octets plus an unaligned top (2999 steps) and a chunk boundary."""
+    from audio_mps_amd import _capi
+    m, audio = _model(32, 3000, 10, WAVE, seed=17)
+    be = m._get_backend()
+    assert be.rank1 == _capi.CMPS_RANK1_BF16X3
+    be.set_rank1(mode)
+    assert be.rank1 == mode
+    _check_against_oracle(m, audio, nthreads=10)
+    with pytest.raises(_capi.CmpsError):
+        be.set_rank1(7)
+
+
+def test_rank1_modes_order_of_accuracy():
+    """Distance of the three modes from each other on the rank-1 sums: x3 must sit closer to the exact-fp32 MFMA than x2
+    does (all three share every other instruction, so the difference isolates the product arithmetic)."""
+    m, audio = _model(32, 2000, 8, WAVE, seed=23)
+    be = m._get_backend()
+    flats = {}
+    for mode in (0, 1, 2):
+        be.set_rank1(mode)
+        flats[mode] = m.grad_sums()[0].cpu().numpy().astype(np.float64)[:2 * 32 * 32]
+    e2 = rel_inf(flats[1], flats[0])
+    e3 = rel_inf(flats[2], flats[0])
+    print(f"rank-1 sums vs exact fp32 MFMA: bf16x2 {e2:.2e}, bf16x3 {e3:.2e}")
+    assert e3 <= 1e-5, e3          # fp32 summation-order noise only (the MFMA adds 16 products per instruction)
+    assert e2 <= 5e-5, e2
+    assert e3 <= e2
+
+
 def test_variants_agree():
     m1, audio = _model(32, 1500, 9, WAVE, seed=5)
     m2, _ = _model(32, 1500, 9, BLOCK, seed=5)
