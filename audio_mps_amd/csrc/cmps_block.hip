@@ -271,7 +271,20 @@ __global__ void k_finalize(Dev P, const float* __restrict__ sums, const float* _
         grad_out[2 * D * D + D + d] = sums[4 * DD + DP + d];
         grad_out[2 * D * D + 2 * D + d] = sums[4 * DD + 2 * DP + d];
     }
-    if (tid == 0) grad_out[2 * D * D + 3 * D] = sums[4 * DD + 3 * DP];
+    if (!P.abar_fix) {
+        if (tid == 0) grad_out[2 * D * D + 3 * D] = sums[4 * DD + 3 * DP];
+    } else if (blockIdx.x == 1 && threadIdx.x < 64) {
+        // sum_k Re(u_k^dagger Q ybar_k) = Re sum_ij Q_ij Qbar_ji with Qbar = sum_k ybar_k u_k^dagger (sums[2 DD ...], [3 DD ...])
+        double p = 0.0;
+        for (int idx = threadIdx.x; idx < D * D; idx += 64) {
+            const int a = idx / D, b = idx % D;
+            const float2 q = P.Q[a * DP + b];
+            p += (double)q.x * (double)sums[2 * DD + b * DP + a] - (double)q.y * (double)sums[3 * DD + b * DP + a];
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) p += __shfl_xor(p, off, 64);
+        if (threadIdx.x == 0) grad_out[2 * D * D + 3 * D] = (float)((double)sums[4 * DD + 3 * DP] + p / (double)P.A);
+    }
     if (blockIdx.x == 0 && threadIdx.x < 64) {      // sum_b loss_b: one wave, strided partials then a fixed-order tree
         double ls = 0.0;
         for (int b = threadIdx.x; b < P.B; b += 64) ls += (double)loss[b];
@@ -436,7 +449,8 @@ hipError_t launch_reduce_only(const Dev& P, hipStream_t s) {
 }
 
 hipError_t launch_reduce_finalize(const Dev& P, const float* loss, float* grad_out, hipStream_t s) {
-    (void)launch_reduce_only(P, s);
+    const hipError_t e = launch_reduce_only(P, s);     // its hipGetLastError() has consumed the launch status
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_finalize, dim3(8), dim3(256), 0, s, P, (const float*)P.sums, loss, grad_out);
     return hipGetLastError();
 }

@@ -117,7 +117,7 @@ int cmps_get_option(cmps_handle_t h, int option) {
 
 size_t cmps_workspace_bytes(int D, int B, int T, int flags) {
     if (D < 1 || D > 128 || B < 1 || T < 2) return 0;
-    return make_layout(D, B, T, flags).total;
+    return make_layout(D, B, T, flags & ~CMPS_WS_FRESH).total;
 }
 
 int cmps_set_params(cmps_handle_t h, const float* R_re_dev, const float* R_im_dev,
@@ -129,6 +129,8 @@ int cmps_set_params(cmps_handle_t h, const float* R_re_dev, const float* R_im_de
         return fail(h, CMPS_ERR_BAD_ARG, "cmps_set_params: null parameter pointer");
     if (T < 2 || B_max < 1) return fail(h, CMPS_ERR_BAD_ARG, "cmps_set_params: need T >= 2 and B_max >= 1");
     if (!workspace_dev) return fail(h, CMPS_ERR_WORKSPACE, "cmps_set_params: null workspace");
+    const bool fresh = (flags & CMPS_WS_FRESH) != 0;
+    flags &= ~CMPS_WS_FRESH;
     Layout L = make_layout(h->D, B_max, T, flags);
     if (workspace_bytes < L.total) {
         char buf[160];
@@ -161,7 +163,7 @@ int cmps_set_params(cmps_handle_t h, const float* R_re_dev, const float* R_im_de
     P.c_half = (float)(-delta_t * sigma * sigma) / 2.0f;
     const float dt = (float)delta_t;  // model.py:16
     P.dt = dt;
-    const bool rebuild = !(h->tt_ws == ws && h->tt_N == L.N && h->tt_dt == dt);
+    const bool rebuild = fresh || !(h->tt_ws == ws && h->tt_N == L.N && h->tt_dt == dt);
     hipError_t e = launch_prep(P, R_re_dev, R_im_dev, freqs_dev, psi0_re_dev, psi0_im_dev, dt, rebuild,
                                const_cast<float*>(P.ttab), const_cast<float*>(P.dtk),
                                const_cast<float2*>(P.R), const_cast<float2*>(P.RT),
@@ -192,12 +194,9 @@ int cmps_psi_loss_fwd(cmps_handle_t h, const float* audio_dev, int B, int T, flo
     P.B = B;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int variant = resolve_variant(h);
-    // the two-waves-per-clip forward (cmps_wave2.hip) is the default; CMPS_FWD1=1 selects the one-wave kernel for A/B runs
-    static const bool fwd2 = [] { const char* v = getenv("CMPS_FWD1"); return !(v && v[0] == '1'); }();
     hipError_t e;
     if (variant == CMPS_VARIANT_WAVE)
-        e = fwd2 ? launch_fwd_wave2(P, audio_dev, loss_dev, save_for_bwd != 0, s)
-                 : launch_fwd_wave(P, audio_dev, loss_dev, save_for_bwd != 0, s);
+        e = launch_fwd_wave2(P, audio_dev, loss_dev, save_for_bwd != 0, s);
     else if (variant == CMPS_VARIANT_PAIR)
         e = launch_fwd_pair(P, audio_dev, loss_dev, save_for_bwd != 0, s);
     else
@@ -236,6 +235,7 @@ int cmps_psi_loss_bwd(cmps_handle_t h, const float* audio_dev, int B, int T, flo
     hipError_t e = (h->saved_variant == CMPS_VARIANT_WAVE) ? launch_bwd_wave(P, audio_dev, h->rank1_mode, s)
                                                            : launch_bwd_block(P, audio_dev, s);
     if (e != hipSuccess) return fail_hip(h, e, "cmps_psi_loss_bwd (scan)");
+    P.abar_fix = h->saved_variant == CMPS_VARIANT_WAVE ? 1 : 0;
     e = launch_reduce_finalize(P, h->saved_loss, grad_dev, s);
     if (e != hipSuccess) return fail_hip(h, e, "cmps_psi_loss_bwd (reduce)");
     return CMPS_OK;

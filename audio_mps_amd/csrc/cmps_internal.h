@@ -95,6 +95,8 @@ struct Dev {
     float A;
     float dt;            // (float)delta_t (model.py:16; also the python-float factor of model.py:286)
     float c_half;        // (float)(-delta_t * sigma^2) / 2   (model.py:312)
+    int abar_fix;        // 1: the slabs' Abar holds -(sum_k Re(u^dagger (Q + s R^dagger) ybar)) / A (k_bwd_wave's merged mat-vec);
+                         //    k_finalize adds Re sum_ij Q_ij Qbar_ji / A from the reduced Qbar
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -161,7 +163,6 @@ hipError_t launch_prep(const Dev& P, const float* R_re, const float* R_im, const
 
 hipError_t launch_fwd_block(const Dev& P, const float* audio, float* loss, bool save, hipStream_t s);
 hipError_t launch_bwd_block(const Dev& P, const float* audio, hipStream_t s);
-hipError_t launch_fwd_wave(const Dev& P, const float* audio, float* loss, bool save, hipStream_t s);
 hipError_t launch_bwd_wave(const Dev& P, const float* audio, int rank1_mode, hipStream_t s);
 hipError_t launch_fwd_wave2(const Dev& P, const float* audio, float* loss, bool save, hipStream_t s);
 hipError_t launch_fwd_pair(const Dev& P, const float* audio, float* loss, bool save, hipStream_t s);

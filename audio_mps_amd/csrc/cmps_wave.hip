@@ -1,5 +1,5 @@
 // Wave-per-clip kernels (the hot path for D <= 32): one 64-lane wavefront owns one clip for the whole
-// scan.  Measured on MI355X (scripts/ubench/issue_rate.hip): a lone wave issues one VALU instruction per
+// scan.  This file holds the reverse scan and the sampler; the forward scan (two waves per clip) is cmps_wave2.hip.  Measured on MI355X (scripts/ubench/issue_rate.hip): a lone wave issues one VALU instruction per
 // ~5.3 cycles whether it is v_fma_f32 or v_pk_fma_f32, dependent accumulation chains cost nothing extra,
 // and the fp32 MFMA shares the fp32 ALUs with the VALU (no overlap).  The kernels are therefore
 // instruction-issue bound; the design minimises instruction count and keeps every memory latency off the
@@ -37,161 +37,6 @@
 
 namespace cmps {
 
-#ifdef ABL_NO_WAIT
-#define ABL_WAIT(a)
-#else
-#define ABL_WAIT(a) a
-#endif
-#ifdef ABL_NO_MV1
-#define ABL_MV1(a, b) b
-#else
-#define ABL_MV1(a, b) a
-#endif
-
-
-// ------------------------------------------------------------------------------------------------
-// forward
-// ------------------------------------------------------------------------------------------------
-template <bool SAVE>
-__global__ __launch_bounds__(64 * WAVES, 1) void k_fwd_wave(Dev P, const float* __restrict__ audio,
-                                                            float* __restrict__ loss_out) {
-    __shared__ __attribute__((aligned(16))) float4 stR[WAVES][CH * 16];   // rho rows of the current chunk
-    __shared__ __attribute__((aligned(16))) float2 bcU[WAVES][DPW], bcY[WAVES][2][DPW];
-    __shared__ float pe[WAVES][64 * PE_LD];   // per-lane products y_own * (H y)_own, row = lane, column = step
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int i = lane & 31, h = lane >> 5;
-    const bool hb = h != 0;
-    const int b = blockIdx.x * WAVES + w;      // wave-uniform (SGPR): the per-clip base addresses stay scalar
-    if (b >= P.B) return;  // whole wave exits together; no workgroup barriers are used below
-    const int N = P.N, T = P.T, NC = (N + CH - 1) / CH;
-    stagger(w);
-
-    v2f MR[16], MQ[16], MH[16];
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-        MR[m] = ld2(&P.R[i * DPW + 16 * h + m]);
-        const v2f rt = ld2(&P.RT[i * DPW + 16 * h + m]);   // R[16h+m][i]
-        MH[m] = mk2(MR[m].x + rt.x, MR[m].y - rt.y);        // (R + R^dagger)[i][16h+m]
-        MQ[m] = ld2(&P.Q[i * DPW + 16 * h + m]);
-    }
-    const unsigned aUw = lds_addr(&bcU[w][0]) + i * 8 + h * 4, aUr = lds_addr(&bcU[w][0]) + h * 128;
-    const unsigned aYw = lds_addr(&bcY[w][0][0]) + i * 8 + h * 4, aYr = lds_addr(&bcY[w][0][0]) + h * 128;
-    const unsigned aRho = lds_addr(&stR[w][0]) + i * 8;
-    const unsigned aPEw = lds_addr(&pe[w][0]) + lane * (PE_LD * 4);   // + 4 * step
-    const unsigned aPEr = lds_addr(&pe[w][0]) + lane * 4;             // + row * PE_LD * 4 (immediate offsets)
-    const float4* rho4 = reinterpret_cast<const float4*>(P.rho);
-    const float* xrow = audio + (size_t)b * T;
-    // stash row of step k: 64 lanes x (y_k own, (H y_k) own) = 512 B, written by ONE 8-byte-per-lane store
-    float2* st = SAVE ? reinterpret_cast<float2*>(P.hst + (size_t)b * N * 128) : nullptr;   // uniform base
-    float* sc = SAVE ? P.scal + scal_off(b, NC, 0) : nullptr;
-    const float A = P.A;
-
-    // chunk 0: tables and increments
-    v4f sr[16];
-    stage_load<16>(rho4, 0, N, lane, sr);
-    float xa0 = lane < T ? xrow[lane] : 0.f;
-    float xa1 = lane + 1 < T ? xrow[lane + 1] : 0.f;
-    stage_commit<16>(stR[w], lane, sr);
-
-    const float2 p0 = P.psi0[i];
-    float u = hb ? p0.y : p0.x;
-    float loss = 0.f;
-    v4f qu[8], qy[8];
-    v2f rho;
-    float evec = 0.f, nvec = 1.f, yprev = 0.f;
-    int kbeg = 0;
-
-    bcast_issue_tab(aUw, aUr, u, aRho, qu, rho);                 // broadcast of u_0 and rho_0 in flight
-    for (int c = 0; c < NC; ++c) {
-        kbeg = c * CH;
-        const int cnt = (N - kbeg) < CH ? (N - kbeg) : CH;
-        const float incv = xa1 - xa0;                            // model.py:263, one step per lane
-        const float sv = incv / A;                               // model.py:303
-        {   // prefetch the next chunk (clamped at the end: a harmless reload)
-            const int cn = c + 1 < NC ? c + 1 : NC - 1;
-            stage_load<16>(rho4, cn * CH, N, lane, sr);
-            const int idx = cn * CH + lane;
-            xa0 = idx < T ? xrow[idx] : 0.f;
-            xa1 = idx + 1 < T ? xrow[idx + 1] : 0.f;
-        }
-        nvec = 1.f;
-#define FWD_STEP(KK, PENDING)                                                                                  \
-        {                                                                                                      \
-            const int kk_ = (KK);                                                                              \
-            const float s = rdlane(sv, kk_);                                                                   \
-            if (PENDING) rows_issue(aYr + ((kk_ - 1) & 1) * 256, qy);   /* y_{k-1} back from LDS (8 ops) */     \
-            /* ---- serial chain: y = u + Q u + s R u ---- */                                                  \
-            ABL_WAIT(lds_wait_lo<(PENDING) ? 13 : 5>(qu);)                                                     \
-            v2f av, aq;                                                                                        \
-            mv2_lo(MR, MQ, qu, av, aq);                                                                        \
-            ABL_WAIT(lds_wait_hi_t<(PENDING) ? 8 : 0>(qu, rho);)                                               \
-            mv2_hi(MR, MQ, qu, av, aq);                                                                        \
-            const v2f wp = aq + s * av;                                                                        \
-            const float y = u + swapadd(wp.x, wp.y);                                                           \
-            lds_write32(aYw + (kk_ & 1) * 256, y);                       /* 1 op */                             \
-            const float n = sum64(y * y);                                                                      \
-            const float inv = __builtin_amdgcn_rsqf(fmaxf(n, 1e-12f));   /* model.py:332 (v_rsq_f32: 1 ulp) */  \
-            const float yo = osig_of(y, hb);                                                                   \
-            const v2f un = cmul2(inv * mk2(y, yo), rho);                 /* u_{k+1} = rho_k y / sqrt(n) */      \
-            u = un.x;                                                                                          \
-            /* next step's broadcast (after the last step of a chunk it is a dummy, retired by the flush) */   \
-            const int kn = kk_ + 1 < CH ? kk_ + 1 : 0;                                                         \
-            bcast_issue_tab(aUw, aUr, u, aRho + kn * 256, qu, rho);      /* 10 ops */                           \
-            if (PENDING) {                                                                                     \
-                /* ---- off the chain, one step late: e_{k-1} = y^dagger H y (model.py:325) ---- */             \
-                lds_wait<11>(qy);                                                                              \
-                ABL_MV1(const v2f ah = mv1(MH, qy);, const v2f ah = lo2(qy[0]) + hi2(qy[7]);)                                                                    \
-                const float hs = swapadd(ah.x, ah.y);                                                          \
-                lds_write32(aPEw + (kk_ - 1) * 4, yprev * hs);           /* summed over lanes at chunk end */    \
-                if (SAVE) st[(size_t)(kbeg + kk_ - 1) * 64 + lane] = make_float2(yprev, hs);                   \
-            }                                                                                                  \
-            nvec = (lane == kk_) ? n : nvec;                                                                   \
-            yprev = y;                                                                                         \
-        }
-        FWD_STEP(0, false)
-        for (int kk = 1; kk < cnt; ++kk) FWD_STEP(kk, true)
-#undef FWD_STEP
-        {   // flush: the loss mat-vec of the chunk's last step; also retires the dummy broadcast
-            const int kl = cnt - 1;
-            rows_issue(aYr + (kl & 1) * 256, qy);
-            lds_wait_all<0>(qy, qu, rho);
-            const v2f ah = mv1(MH, qy);
-            const float hs = swapadd(ah.x, ah.y);
-            lds_write32(aPEw + kl * 4, yprev * hs);
-            if (SAVE) st[(size_t)(kbeg + kl) * 64 + lane] = make_float2(yprev, hs);
-        }
-        // e_k = y^dagger H y = sum over the 64 lanes of the stored products: lane k sums column k
-        {
-            const float* col = &pe[w][lane];
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int l = 0; l < 64; l += 4) {
-                a0 += col[(l + 0) * PE_LD];
-                a1 += col[(l + 1) * PE_LD];
-                a2 += col[(l + 2) * PE_LD];
-                a3 += col[(l + 3) * PE_LD];
-            }
-            evec = (a0 + a1) + (a2 + a3);
-            (void)aPEr;
-        }
-        // loss increments of this chunk in the reference's operation order (model.py:294), then the
-        // sequential float32 accumulation of model.py:279 in time order
-        const float z = (evec * incv) / A;
-        const float lv = -logf(1.0f + z);
-        for (int j = 0; j < cnt; ++j) loss += rdlane(lv, j);
-        if (SAVE) {
-            sc[(size_t)c * 128 + lane] = nvec;
-            sc[(size_t)c * 128 + 64 + lane] = evec;
-        }
-        if (c + 1 < NC) {
-            stage_commit<16>(stR[w], lane, sr);
-            bcast_issue_tab(aUw, aUr, u, aRho, qu, rho);         // first step of the next chunk
-        }
-    }
-    if (lane == 0) loss_out[b] = loss;
-}
-
 // ------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------
@@ -228,7 +73,9 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
     const int N = P.N, T = P.T, NC = (N + CH - 1) / CH;
     stagger(w);
 
-    v2f MRd[16], MQ[16];
+    // One mat-vec on the chain: g = ybar + Q ybar + s_k R^dagger ybar = ybar + M_k ybar, M_k = Q + s_k R^dagger formed with
+    // one packed FMA per complex entry in the shadow of the step's LDS broadcast (see cmps_wave2.hip).
+    v2f MRd[16], MQ[16], MM[16];
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
         const v2f rt = ld2(&P.RT[i * DPW + 16 * h + m]);   // R[16h+m][i]
@@ -248,7 +95,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
     const float A = P.A;
 
     float facc = 0.f;   // per lane: sum_k dtk * g_osig * u_own   (the two halves are added at the end)
-    float accS = 0.f;   // per lane: sum_k s_k d_own u_own
+    float accS = 0.f;   // per lane: sum_k (M_k ybar_k)_own u_own = sum_k Re(u^dagger Q ybar) + s_k Re(u^dagger R^dagger ybar); the Q part
+                        // equals Re tr(Q Qbar^T...) and is removed by k_finalize from the reduced Qbar (Dev::abar_fix)
     float accA = 0.f;   // per lane (one step per lane): sum_k zbar_k (e_k x_k)
 
     // per-step scalars of the 64-step chunk the "pre" stage is working in: computed one step per lane, then
@@ -439,6 +287,11 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
         rad_next = S.rad;
         const float ybar = (yhb - dot * S.yhp) * S.inv + S.pre;
         bcast_issue(aBw, aBr, ybar, qc);                               // 9 ops
+        {   // M_k = Q + s_k R^dagger, in the shadow of the broadcast
+            const v2f s2 = mk2(S.s, S.s);
+#pragma unroll
+            for (int m = 0; m < 16; ++m) MM[m] = __builtin_elementwise_fma(MRd[m], s2, MQ[m]);
+        }
         MF_HOOK(1)
         // ---- off-chain: pre of step k-1 (gives u_k) ----
         Pre Sn = S;
@@ -448,18 +301,18 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
             uk = Sn.un;
             uko = Sn.uno;
         }
-        // ---- chain, mat-vec part: g_k = ybar + Q ybar + s R^dagger ybar ----
+        // ---- chain, mat-vec part: g_k = ybar + M_k ybar ----
         MF_HOOK(2)
         lds_wait_lo<4>(qc);
-        v2f aq, ad;
-        mv2_lo(MQ, MRd, qc, aq, ad);
+        v2f am;
+        mv1_lo(MM, qc, am);
         MF_HOOK(3)
         lds_wait_hi<0>(qc);
-        mv2_hi(MQ, MRd, qc, aq, ad);
+        mv1_hi(MM, qc, am);
         MF_HOOK(4)
-        const float sd = S.s * swapadd(ad.x, ad.y);
-        accS += sd * uk;
-        g = ybar + swapadd(aq.x, aq.y) + sd;
+        const float md = swapadd(am.x, am.y);
+        accS += md * uk;
+        g = ybar + md;
         go = osig_of(g, hb);
         if constexpr (decltype(slot)::value == 7) {
             if (pend) { mf_group(std::integral_constant<int, 5>{}); if constexpr (RANK1 != 2) pend = false; }
@@ -540,7 +393,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
     slab[4 * DD + (hb ? 2 * DPW : DPW) + i] = g;          // cotangent of psi_0: re in [DPW, 2DPW), im in [2DPW, 3DPW)
     if (!hb) slab[4 * DD + i] = ftot;
     if (lane == 0) {
-        // Abar = sum_k zbar_k (-(e x)_k / A^2) + sum_k sbar_k (-x_k / A^2),  s_k = x_k / A
+        // Abar = sum_k zbar_k (-(e x)_k / A^2) + sum_k sbar_k (-x_k / A^2),  s_k = x_k / A;  sumS still contains
+        // sum_k Re(u_k^dagger Q ybar_k), which k_finalize removes (Dev::abar_fix)
         slab[4 * DD + 3 * DPW] = -(sumA / (A * A)) - sumS / A;
         slab[4 * DD + 3 * DPW + 1] = 0.f;
     }
@@ -609,15 +463,6 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_sample_wave(Dev P, const floa
         }
         if (lane < cnt) orow[kbeg + lane] = A * svec;                // model.py:251
     }
-}
-
-hipError_t launch_fwd_wave(const Dev& P, const float* audio, float* loss, bool save, hipStream_t s) {
-    const unsigned nb = (unsigned)((P.B + WAVES - 1) / WAVES);
-    if (save)
-        hipLaunchKernelGGL(k_fwd_wave<true>, dim3(nb), dim3(64 * WAVES), 0, s, P, audio, loss);
-    else
-        hipLaunchKernelGGL(k_fwd_wave<false>, dim3(nb), dim3(64 * WAVES), 0, s, P, audio, loss);
-    return hipGetLastError();
 }
 
 hipError_t launch_sample_wave(const Dev& P, const float* noise, int n, int length, float* out, hipStream_t s) {

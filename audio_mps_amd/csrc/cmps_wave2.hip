@@ -13,6 +13,10 @@
 //     e_k, the stash row (y_k, H y_k); per 32-step chunk the column sums, log(1 + e x / A) in the reference's operation
 //     order and the sequential float32 loss accumulation (model.py:279, 294); publishes `cons` = chunks consumed.
 //
+// One mat-vec on the chain, not two: y = ut + Q ut + s_k R ut = ut + M_k ut with M_k = Q + s_k R.  Forming M_k costs one
+// packed FMA per complex entry (16 per lane) against the two a second mat-vec costs, and it does not depend on the state:
+// M_{k+1} is formed in the shadow of step k's LDS broadcast, where the in-order wave would otherwise wait.
+//
 // Synchronisation is two LDS counters per clip and NO barrier: the ring holds two chunks; the loss wave starts chunk
 // c when prod >= c + 1, the chain wave starts chunk c (c >= 2) when cons >= c - 1.  LDS operations of one wave
 // complete in order, so a counter write issued after the chunk's data is visible after it.
@@ -56,35 +60,30 @@ __device__ __forceinline__ void lds_wait_own9(v4f (&o)[8], float& mine) {
                  : "n"(N) : "memory");
 }
 
-// Two interleaved mat-vec chains (as mv2_lo / mv2_hi) with the wave reduction of `x` threaded through them: a lone
-// in-order wave pays ~20 cycles per dependent DPP step, but nothing when eight independent packed FMAs sit between
-// two steps.  After mv2r_hi, `tot` (SGPR) holds the sum of x over the 64 lanes.
-#define DPPADD(ctrl) "v_add_f32_dpp %2, %2, %2 " ctrl " row_mask:0xf bank_mask:0xf\n\t"
-__device__ __forceinline__ void mv2r_lo(const v2f (&MA)[16], const v2f (&MB)[16], const v4f (&q)[8], v2f& accA, v2f& accB,
-                                        float& x) {
-    asm(CM_FIRST(0, 3, 19) CM_FIRST(1, 11, 19) DPPADD("quad_perm:[1,0,3,2]")
-        CM(0, 4, 20) CM(1, 12, 20) CM(0, 5, 21) CM(1, 13, 21) DPPADD("quad_perm:[2,3,0,1]")
-        CM(0, 6, 22) CM(1, 14, 22) CM(0, 7, 23) CM(1, 15, 23) DPPADD("row_half_mirror")
-        CM(0, 8, 24) CM(1, 16, 24) CM(0, 9, 25) CM(1, 17, 25) DPPADD("row_mirror")
-        CM(0, 10, 26) CM(1, 18, 26)
-        : "=&v"(accA), "=&v"(accB), "+v"(x)
-        : "v"(MA[0]), "v"(MA[1]), "v"(MA[2]), "v"(MA[3]), "v"(MA[4]), "v"(MA[5]), "v"(MA[6]), "v"(MA[7]),
-          "v"(MB[0]), "v"(MB[1]), "v"(MB[2]), "v"(MB[3]), "v"(MB[4]), "v"(MB[5]), "v"(MB[6]), "v"(MB[7]),
+// One mat-vec chain (this half's 16 columns of M u) with the wave reduction of `x` threaded through it: a lone in-order
+// wave pays ~20 cycles per dependent DPP step, but nothing when four independent packed FMAs sit between two steps.
+// After mv1r_hi, `tot` (SGPR) holds the sum of x over the 64 lanes.
+#define DPPADD(ctrl) "v_add_f32_dpp %1, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf\n\t"
+__device__ __forceinline__ void mv1r_lo(const v2f (&M)[16], const v4f (&q)[8], v2f& acc, float& x) {
+    asm(CM_FIRST(0, 2, 10) CM(0, 3, 11) DPPADD("quad_perm:[1,0,3,2]")
+        CM(0, 4, 12) CM(0, 5, 13) DPPADD("quad_perm:[2,3,0,1]")
+        CM(0, 6, 14) CM(0, 7, 15) DPPADD("row_half_mirror")
+        CM(0, 8, 16) CM(0, 9, 17) DPPADD("row_mirror")
+        : "=&v"(acc), "+v"(x)
+        : "v"(M[0]), "v"(M[1]), "v"(M[2]), "v"(M[3]), "v"(M[4]), "v"(M[5]), "v"(M[6]), "v"(M[7]),
           "v"(lo2(q[0])), "v"(hi2(q[0])), "v"(lo2(q[1])), "v"(hi2(q[1])), "v"(lo2(q[2])), "v"(hi2(q[2])),
           "v"(lo2(q[3])), "v"(hi2(q[3])));
 }
-__device__ __forceinline__ void mv2r_hi(const v2f (&MA)[16], const v2f (&MB)[16], const v4f (&q)[8], v2f& accA, v2f& accB,
-                                        float& x, float& tot) {
-    asm(CM(0, 4, 20) CM(1, 12, 20) CM(0, 5, 21) CM(1, 13, 21)
-        "v_add_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        CM(0, 6, 22) CM(1, 14, 22) CM(0, 7, 23) CM(1, 15, 23)
-        "v_add_f32_dpp %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-        CM(0, 8, 24) CM(1, 16, 24) CM(0, 9, 25) CM(1, 17, 25)
-        "v_readlane_b32 %3, %2, 63\n\t"
-        CM(0, 10, 26) CM(1, 18, 26) CM(0, 11, 27) CM(1, 19, 27)
-        : "+v"(accA), "+v"(accB), "+v"(x), "=s"(tot)
-        : "v"(MA[8]), "v"(MA[9]), "v"(MA[10]), "v"(MA[11]), "v"(MA[12]), "v"(MA[13]), "v"(MA[14]), "v"(MA[15]),
-          "v"(MB[8]), "v"(MB[9]), "v"(MB[10]), "v"(MB[11]), "v"(MB[12]), "v"(MB[13]), "v"(MB[14]), "v"(MB[15]),
+__device__ __forceinline__ void mv1r_hi(const v2f (&M)[16], const v4f (&q)[8], v2f& acc, float& x, float& tot) {
+    asm(CM(0, 3, 11) CM(0, 4, 12) CM(0, 5, 13)
+        "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        CM(0, 6, 14) CM(0, 7, 15)
+        "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        CM(0, 8, 16) CM(0, 9, 17)
+        "v_readlane_b32 %2, %1, 63\n\t"
+        CM(0, 10, 18)
+        : "+v"(acc), "+v"(x), "=s"(tot)
+        : "v"(M[8]), "v"(M[9]), "v"(M[10]), "v"(M[11]), "v"(M[12]), "v"(M[13]), "v"(M[14]), "v"(M[15]),
           "v"(lo2(q[4])), "v"(hi2(q[4])), "v"(lo2(q[5])), "v"(hi2(q[5])), "v"(lo2(q[6])), "v"(hi2(q[6])),
           "v"(lo2(q[7])), "v"(hi2(q[7])));
 }
@@ -110,10 +109,17 @@ __device__ __forceinline__ float vmax_s(float s, float c) {     // one v_max_f32
 
 }  // namespace
 
-#ifdef ABL2_CHAIN_NOWAIT
-#define ABL2_W(a)
+// Diagnostic builds only (scripts/ablate.py passes -DCMPS_DIAG -DCMPS_DIAG_NO_LOSS / -DCMPS_DIAG_NO_CHAIN; results are wrong,
+// the timing tells what each wave costs alone).  tests/test_capi_load.py compiles both so that they cannot rot.
+#if defined(CMPS_DIAG) && defined(CMPS_DIAG_NO_LOSS)
+#define DIAG_NO_LOSS 1
 #else
-#define ABL2_W(a) a
+#define DIAG_NO_LOSS 0
+#endif
+#if defined(CMPS_DIAG) && defined(CMPS_DIAG_NO_CHAIN)
+#define DIAG_NO_CHAIN 1
+#else
+#define DIAG_NO_CHAIN 0
 #endif
 
 template <bool SAVE>
@@ -141,16 +147,10 @@ __global__ __launch_bounds__(128 * WAVES, 1) void k_fwd_wave2(Dev P, const float
 
     if (role == 0) {
         // ------------------------------------------------------------------ chain wave
-#ifdef ABL2_NO_CHAIN
-        return;
-#endif
-#ifndef ABL2_NO_PRIO
+        if (DIAG_NO_CHAIN) return;
         __builtin_amdgcn_s_setprio(3);
-#endif
-#ifndef FWD2_NO_STAGGER
         stagger(w);
-#endif
-        v2f MR[16], MQ[16];
+        v2f MR[16], MQ[16], MM[16];
 #pragma unroll
         for (int m = 0; m < 16; ++m) {
             MR[m] = ld2(&P.R[i * DPW + 16 * h + m]);
@@ -169,16 +169,24 @@ __global__ __launch_bounds__(128 * WAVES, 1) void k_fwd_wave2(Dev P, const float
         float u = hb ? p0.y : p0.x;
         v4f qu[8];
         v2f rho;
-        // The normalisation is linear, so it is applied AFTER the mat-vecs: the wave broadcasts ut = rho_{k-1} y_{k-1}
-        // (un-normalised), y_k = inv_{k-1} (ut + Q ut + s R ut) with inv_{k-1} = rsqrt(max(|y_{k-1}|^2, 1e-12)), and the
+        // The normalisation is linear, so it is applied AFTER the mat-vec: the wave broadcasts ut = rho_{k-1} y_{k-1}
+        // (un-normalised), y_k = inv_{k-1} (ut + M_k ut) with inv_{k-1} = rsqrt(max(|y_{k-1}|^2, 1e-12)), and the
         // reduction of |y_{k-1}|^2 rides inside the FMA blocks of step k instead of sitting on the serial chain.
         float xsq = lane == 0 ? 1.f : 0.f;      // "|y_{-1}|^2" = 1: psi_0 arrives normalised
         float nvec = 1.f;
+        float sv = (xa1 - xa0) / A;             // model.py:263, 303: s_k = x_k / A, one step per lane
+        // M_k = Q + s_k R (model.py:308-313 with the two products merged): one packed FMA per complex entry
+#define FORM_M(S_)                                                                                            \
+        {                                                                                                     \
+            const float s_ = (S_);                                                                            \
+            const v2f s2_ = mk2(s_, s_);                                                                      \
+            _Pragma("unroll") for (int m = 0; m < 16; ++m) MM[m] = __builtin_elementwise_fma(MR[m], s2_, MQ[m]); \
+        }
+        FORM_M(rdlane(sv, 0))
         bcast_issue_tab(aUw, aUr, u, aRho, qu, rho);
         for (int c = 0; c < NC2; ++c) {
             const int kbeg = c * CH2;
             const int cnt = (N - kbeg) < CH2 ? (N - kbeg) : CH2;
-            const float sv = (xa1 - xa0) / A;                          // model.py:263, 303: one step per lane
             {
                 const int cn = c + 1 < NC2 ? c + 1 : NC2 - 1;
                 stage_load<8>(rho4, cn * CH2, N, lane, sr);
@@ -186,24 +194,20 @@ __global__ __launch_bounds__(128 * WAVES, 1) void k_fwd_wave2(Dev P, const float
                 xa0 = idx < T ? xrow[idx] : 0.f;
                 xa1 = idx + 1 < T ? xrow[idx + 1] : 0.f;
             }
-#ifndef ABL2_NO_LOSS
-            if (c >= 2)                                               // the ring half about to be overwritten
+            if (!DIAG_NO_LOSS && c >= 2)                              // the ring half about to be overwritten
                 while (flag_load(aCons) < c - 1) __builtin_amdgcn_s_sleep(1);
-#endif
             unsigned ay = aYw + (c & 1) * (CH2 * 256);
 #define CHAIN_STEP(KK)                                                                                        \
             {                                                                                                 \
                 const int kk_ = (KK);                                                                         \
-                const float s = rdlane(sv, kk_);                                                              \
-                ABL2_W(lds_wait_lo<5>(qu);)                                                                   \
-                v2f av, aq;                                                                                   \
+                lds_wait_lo<5>(qu);                                                                           \
+                v2f am;                                                                                       \
                 float nprev;                                                                                  \
-                mv2r_lo(MR, MQ, qu, av, aq, xsq);                                                             \
-                ABL2_W(lds_wait_hi_t_after<0>(qu, rho, av);)                                                  \
-                mv2r_hi(MR, MQ, qu, av, aq, xsq, nprev);                  /* nprev = |y_{k-1}|^2 */           \
+                mv1r_lo(MM, qu, am, xsq);                                                                     \
+                lds_wait_hi_t_after<0>(qu, rho, am);                                                          \
+                mv1r_hi(MM, qu, am, xsq, nprev);                          /* nprev = |y_{k-1}|^2 */           \
                 const float inv = __builtin_amdgcn_rsqf(vmax_s(nprev, 1e-12f));  /* model.py:332 */           \
-                const v2f wp = aq + s * av;                                                                   \
-                const float y = inv * (u + swapadd(wp.x, wp.y));                                              \
+                const float y = inv * (u + swapadd(am.x, am.y));                                              \
                 lds_write32(ay, y);                                                                           \
                 ay += 256;                                                                                    \
                 const float yo = osig_of(y, hb);                                                              \
@@ -211,6 +215,7 @@ __global__ __launch_bounds__(128 * WAVES, 1) void k_fwd_wave2(Dev P, const float
                 u = un.x;                                                                                     \
                 const int kn = kk_ + 1 < CH2 ? kk_ + 1 : 0;               /* chunk end: a dummy, retired below */ \
                 bcast_issue_tab(aUw, aUr, u, aRho + kn * 256, qu, rho);                                       \
+                FORM_M(rdlane(sv, kn))                                    /* in the shadow of the broadcast */ \
                 xsq = y * y;                                                                                  \
                 write_lane(nvec, nprev, (kk_ - 1) & (CH2 - 1));                                               \
             }
@@ -222,9 +227,12 @@ __global__ __launch_bounds__(128 * WAVES, 1) void k_fwd_wave2(Dev P, const float
             flag_store(aProd, c + 1, lane);                            // publish (ordered behind the chunk's y rows)
             if (c + 1 < NC2) {
                 stage_commit<8>(stR[w], lane, sr);
+                sv = (xa1 - xa0) / A;                                  // the next chunk's s_k
+                FORM_M(rdlane(sv, 0))                                  // the last in-loop FORM_M used the stale lane 0
                 bcast_issue_tab(aUw, aUr, u, aRho, qu, rho);
             }
         }
+#undef FORM_M
         if (SAVE) {                                                    // |y_{N-1}|^2 closes the last row
             const float nlast = sum64(xsq);
             const int cl = NC2 - 1;
@@ -235,17 +243,8 @@ __global__ __launch_bounds__(128 * WAVES, 1) void k_fwd_wave2(Dev P, const float
     }
 
     // ---------------------------------------------------------------------- loss wave
-#ifdef ABL2_NO_LOSS
-    return;
-#endif
-#ifdef FWD2_LOSS_PRIO
-    __builtin_amdgcn_s_setprio(FWD2_LOSS_PRIO);
-#else
+    if (DIAG_NO_LOSS) return;
     __builtin_amdgcn_s_setprio(0);
-#endif
-#ifdef FWD2_LOSS_STAGGER
-    stagger(w ^ 2);
-#endif
     v2f MH[16];
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
@@ -265,9 +264,8 @@ __global__ __launch_bounds__(128 * WAVES, 1) void k_fwd_wave2(Dev P, const float
         const int idx = kbeg + lane;
         const float x0 = idx < T ? xrow[idx] : 0.f;
         const float x1 = idx + 1 < T ? xrow[idx + 1] : 0.f;
-#ifndef ABL2_NO_CHAIN
-        while (flag_load(aProd) < c + 1) __builtin_amdgcn_s_sleep(1);
-#endif
+        if (!DIAG_NO_CHAIN)
+            while (flag_load(aProd) < c + 1) __builtin_amdgcn_s_sleep(1);
         const unsigned off = (c & 1) * (CH2 * 256);
         // Branch-free inner loop (branches around the counted waits make hipcc copy the 64 staging registers): every
         // step issues the reads of the next one, clamped to the chunk's last row; an odd chunk ends with one repeated

@@ -84,6 +84,21 @@ __device__ __forceinline__ v2f mv1(const v2f (&M)[16], const v4f (&q)[8]) {
           "v"(lo2(q[7])), "v"(hi2(q[7])));
     return acc;
 }
+// the same chain in two halves, so that the first can start as soon as the first four broadcast reads have landed
+__device__ __forceinline__ void mv1_lo(const v2f (&M)[16], const v4f (&q)[8], v2f& acc) {
+    asm(CM_FIRST(0, 1, 9) CM(0, 2, 10) CM(0, 3, 11) CM(0, 4, 12) CM(0, 5, 13) CM(0, 6, 14) CM(0, 7, 15) CM(0, 8, 16)
+        : "=&v"(acc)
+        : "v"(M[0]), "v"(M[1]), "v"(M[2]), "v"(M[3]), "v"(M[4]), "v"(M[5]), "v"(M[6]), "v"(M[7]),
+          "v"(lo2(q[0])), "v"(hi2(q[0])), "v"(lo2(q[1])), "v"(hi2(q[1])), "v"(lo2(q[2])), "v"(hi2(q[2])),
+          "v"(lo2(q[3])), "v"(hi2(q[3])));
+}
+__device__ __forceinline__ void mv1_hi(const v2f (&M)[16], const v4f (&q)[8], v2f& acc) {
+    asm(CM(0, 1, 9) CM(0, 2, 10) CM(0, 3, 11) CM(0, 4, 12) CM(0, 5, 13) CM(0, 6, 14) CM(0, 7, 15) CM(0, 8, 16)
+        : "+v"(acc)
+        : "v"(M[8]), "v"(M[9]), "v"(M[10]), "v"(M[11]), "v"(M[12]), "v"(M[13]), "v"(M[14]), "v"(M[15]),
+          "v"(lo2(q[4])), "v"(hi2(q[4])), "v"(lo2(q[5])), "v"(hi2(q[5])), "v"(lo2(q[6])), "v"(hi2(q[6])),
+          "v"(lo2(q[7])), "v"(hi2(q[7])));
+}
 // two matrices applied to the same vector, chains interleaved; in two halves so that the first can start as
 // soon as the first four broadcast reads have landed
 __device__ __forceinline__ void mv2_lo(const v2f (&MA)[16], const v2f (&MB)[16], const v4f (&q)[8], v2f& accA, v2f& accB) {
@@ -126,9 +141,6 @@ __device__ __forceinline__ float dpp_add_row(float x) {
     return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float sum64(float x) {   // sum over all 64 lanes, uniform (SGPR) result
-#ifdef ABL_NO_REDUCE
-    return rdlane(x, 63);
-#endif
     x = dpp_add_row<0xB1>(x);    // quad_perm [1,0,3,2]
     x = dpp_add_row<0x4E>(x);    // quad_perm [2,3,0,1]
     x = dpp_add_row<0x141>(x);   // row_half_mirror

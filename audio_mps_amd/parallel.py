@@ -19,13 +19,15 @@ import torch.distributed as dist
 
 
 class DataParallel:
+    time_collective = False       # bench.py sets it: HIP events around the all-reduce ("print the all-reduce us")
+    collective_ms = None          # list of timed collectives (ms), created on first use
+
     def __init__(self, backend: Optional[str] = None, device: Optional[torch.device] = None):
         self.rank = int(os.environ.get("RANK", "0"))
         self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.device = device
         self._own_group = False
-        self.time_collective = False      # bench.py: HIP events around the all-reduce ("print the all-reduce us")
         self.collective_ms = []
         if self.world_size > 1:
             if backend is None:
@@ -68,6 +70,8 @@ class DataParallel:
             dist.all_reduce(buf, op=dist.ReduceOp.SUM)
             e1.record()
             host = buf.detach().cpu().numpy().astype(np.float64)     # synchronises the stream
+            if self.collective_ms is None:
+                self.collective_ms = []
             self.collective_ms.append(e0.elapsed_time(e1))
         else:
             dist.all_reduce(buf, op=dist.ReduceOp.SUM)

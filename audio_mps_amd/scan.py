@@ -110,6 +110,7 @@ class HipScan:
             self._ws = None
             self._ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
             self._ws_key = key
+            self._ws_fresh = True         # the allocator may hand back the old address: the cached tables are gone
         base = self._ws.data_ptr()
         return (base + 255) // 256 * 256, self._ws.numel() - 256
 
@@ -136,10 +137,14 @@ class HipScan:
         ws_ptr, ws_bytes = self._ensure_ws(B, T, train)
         base = self._param_buf.data_ptr()
         f4 = 4
+        flags = _capi.CMPS_WS_TRAIN if train else _capi.CMPS_WS_FWD_ONLY
+        if getattr(self, "_ws_fresh", False):
+            flags |= _capi.CMPS_WS_FRESH
+            self._ws_fresh = False
         _capi.check(self._h, self._lib.cmps_set_params(
             self._h, base, base + DD * f4, base + 2 * DD * f4, base + (2 * DD + D) * f4,
             base + (2 * DD + 2 * D) * f4, float(p.A), float(p.sigma), float(p.delta_t), int(T), int(B),
-            _capi.CMPS_WS_TRAIN if train else _capi.CMPS_WS_FWD_ONLY, ws_ptr, ws_bytes, self._stream()))
+            flags, ws_ptr, ws_bytes, self._stream()))
         self._B, self._T, self._train = B, T, train
 
     def _check_audio(self, audio: torch.Tensor):

@@ -67,17 +67,23 @@ class Trainer:
         self.dp = dp if dp is not None else DataParallel()
         self.opt = AdamOptimizer(hparams.learning_rate)
         self.global_step = 0
+        self.history = []             # the dict of every step (the scalar summaries of train.py:62-66)
 
     def step(self, data=None) -> dict:
         """``data``: this rank's shard [B_local, T] (or None to use model.data_iterator)."""
         flat, b_local = self.model.grad_sums(data)
         host, b_global = self.dp.allreduce_sums(flat, b_local)
         total, grads = self.model.chain_rule(host, b_global, with_reg=True)       # train.py:55-60
-        model_loss = host[-1] / b_global
+        # sum_b loss_b sits at the end of the pure-state layout (2 D^2 + 3 D + 2 floats); RhoCMPS appends the column
+        # cotangents behind it (include/cmps.h: cmps_rho_loss_bwd)
+        D = self.model.bond_d
+        model_loss = host[2 * D * D + 3 * D + 1] / b_global
         self.opt.apply_gradients(self.model.variables, grads)                     # train.py:89
         self.global_step += 1
-        return {"model_loss": float(model_loss), "total_loss": float(total), "global_step": self.global_step,
-                "global_batch": b_global}
+        out = {"model_loss": float(model_loss), "total_loss": float(total), "global_step": self.global_step,
+               "global_batch": b_global}
+        self.history.append(out)
+        return out
 
     # -- checkpoint / resume (train.py:93: save_checkpoint_secs=60, automatic restore from logdir) --
     def save(self, path: str):
@@ -119,19 +125,29 @@ def build_parser():
     return p
 
 
-def main(argv=None):
-    import torch
+def main(argv=None, backend=None):
+    """``backend``: a scan backend to use instead of HipScan (CPU tests of the host logic inject one; the product
+    always builds a HipScan and fails loudly without a GPU)."""
     from .data import get_audio
     args = build_parser().parse_args(argv)
     hp = HParams(delta_t=1.0 / args.sample_rate, h_reg=200.0 / (math.pi * args.sample_rate) ** 2)  # train.py:41-43
     hp.parse(args.hparams)
+    if args.mps_model == "rho_mps":
+        rank = hp.initial_rank if hp.initial_rank is not None else hp.bond_dim
+        if rank * hp.bond_dim > 5000:
+            raise SystemExit(f"rho_mps: initial_rank * bond_dim = {rank * hp.bond_dim} exceeds 5000 (the columns of rho are "
+                             "LDS-resident in the HIP kernels); lower --hparams=initial_rank=... or bond_dim")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dp = DataParallel(device=dev)
+    if backend is None:
+        import torch
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        dp = DataParallel(device=dev)
+        from .scan import HipScan
+        backend = HipScan(hp.bond_dim, device=dev, variant=args.kernel_variant)
+    else:
+        dp = DataParallel(backend="gloo")
     start, count = dp.shard(hp.minibatch_size)
-    from .scan import HipScan
-    backend = HipScan(hp.bond_dim, device=dev, variant=args.kernel_variant)
     cls = RhoCMPS if args.mps_model == "rho_mps" else PsiCMPS                                   # train.py:50-53
     model = cls(hp, seed=args.seed, backend=backend)
     trainer = Trainer(model, hp, dp)
@@ -140,15 +156,25 @@ def main(argv=None):
     if trainer.restore(ckpt) and dp.rank == 0:
         print(f"Restoring parameters from {ckpt} (global_step {trainer.global_step})")
     last_save = time.time()
+    # train.py:46-47: the input pipeline is built ONCE; for TFRecord datasets get_audio returns the one-shot iterator's
+    # get_next (batch -> shuffle(24) -> repeat, data.py:37-40), for damped_sine every step draws fresh delays (data.py:15)
+    source = get_audio(args.datadir, args.dataset, hp, args.sample_duration, seed=args.seed) \
+        if args.dataset != "damped_sine" else None
     for it in range(args.max_steps):
-        full = get_audio(args.datadir, args.dataset, hp, args.sample_duration, seed=args.seed + trainer.global_step)
-        out = trainer.step(full[start:start + count])
+        if source is not None:
+            full = source()
+        else:
+            full = get_audio(args.datadir, args.dataset, hp, args.sample_duration, seed=args.seed + trainer.global_step)
+        # every rank reads the same global batch and keeps its shard (a short final batch of an epoch is sharded as it is)
+        s0, c0 = dp.shard(full.shape[0]) if full.shape[0] != hp.minibatch_size else (start, count)
+        out = trainer.step(full[s0:s0 + c0])
         if dp.rank == 0:
             print(f"step {out['global_step']}: model_loss {out['model_loss']:.6f} total_loss {out['total_loss']:.6f}")
             if time.time() - last_save > args.save_checkpoint_secs or it == args.max_steps - 1:
                 trainer.save(ckpt)
                 last_save = time.time()
     dp.close()
+    return trainer
 
 
 if __name__ == "__main__":

@@ -36,7 +36,9 @@ enum {
 /* workspace flags */
 enum {
     CMPS_WS_FWD_ONLY = 0, /* loss only */
-    CMPS_WS_TRAIN = 1     /* forward + backward (adds the per-step state stash and gradient slabs) */
+    CMPS_WS_TRAIN = 1,    /* forward + backward (adds the per-step state stash and gradient slabs) */
+    CMPS_WS_FRESH = 2     /* OR-ed into `flags` of cmps_set_params: the workspace memory was (re)allocated, zeroed or used
+                           * for something else since the previous call -- rebuild every cached table (see below) */
 };
 
 /* kernel variants (cmps_set_variant); AUTO picks the register-resident wave-per-clip kernel when the
@@ -96,6 +98,10 @@ size_t cmps_workspace_bytes(int D, int B, int T, int flags);
  * A = model.A (model.py:19), sigma (model.py:21), delta_t (model.py:15), T = samples per clip.
  * Builds, on `stream`, inside `workspace_dev`: R^T, Q = -(delta_t sigma^2 / 2) R^dagger R, the float32
  * time table t_k, and the per-step phase-rotation table.
+ * Caching contract: the time table depends only on (T, delta_t), so it is rebuilt only when the workspace ADDRESS, T or
+ * delta_t differ from the handle's previous call.  The workspace is caller-owned memory: a caller that frees, reuses,
+ * zeroes or re-obtains it (an allocator may hand back the same address) must pass CMPS_WS_FRESH once; everything else
+ * in the workspace is rebuilt by every call.
  */
 int cmps_set_params(cmps_handle_t h, const float* R_re_dev, const float* R_im_dev,
                     const float* freqs_dev, const float* psi0_re_dev, const float* psi0_im_dev,

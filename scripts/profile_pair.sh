@@ -3,6 +3,7 @@
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_pair_pmc
 rm -rf $OUT; mkdir -p $OUT
+export PROF_OUT=$OUT     # read by the summariser below (the working directory changes to /tmp)
 cd /tmp && export TMPDIR=/tmp
 CMD="python3 $ROOT/scripts/time_kernels.py 128 4000 512 1 3"
 for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_MFMA" \
@@ -13,7 +14,7 @@ for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS
 done
 python3 - <<'PY'
 import csv, glob, os, collections
-out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "prof_pair_pmc")
+out = os.environ["PROF_OUT"]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/pmc_*/*/*counter_collection.csv"):
     per = collections.defaultdict(float)

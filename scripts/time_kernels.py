@@ -17,7 +17,8 @@ rng = np.random.default_rng(15345)
 x = damped_sine(B, T, hp.delta_t, seed=3000)
 audio = torch.from_numpy((x + 0.02 * rng.standard_normal(x.shape)).astype(np.float32)).cuda()
 variant = int(sys.argv[5]) if len(sys.argv) > 5 else 0
-be = HipScan(D, variant=variant)
+rank1 = int(sys.argv[6]) if len(sys.argv) > 6 else None      # cmps_set_option(CMPS_OPT_RANK1): 0 exact, 1 bf16x2, 2 bf16x3
+be = HipScan(D, variant=variant, rank1=rank1)
 m = PsiCMPS(hp, seed=0, backend=be)
 be.set_params(m.effective_params(), B, T, train=True)
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]

@@ -35,6 +35,39 @@ def test_trainer_tracks_oracle_trainer(tmp_path):
     assert t2.step()["total_loss"] == pytest.approx(t_hip.step()["total_loss"], rel=1e-6)
 
 
+def test_train_main_on_tfrecords(tmp_path):
+    """train.py on a TFRecord dataset (data.py:25-43: batch -> shuffle(24) -> repeat, built once, get_next per step):
+    `python -m audio_mps_amd.train --dataset guitar` for 3 steps on the HIP scan, against the same main() driven by the
+    oracle stand-in on the same file and seed (same batches in the same order)."""
+    from audio_mps_amd import tfrecord as tfr
+    from audio_mps_amd import train
+    clips = make_audio(12, 300, 1 / 16000, 8)
+    tfr.write_audio_tfrecord(os.path.join(tmp_path, "guitar.tfrecords"), clips)
+    argv = ["--dataset", "guitar", "--datadir", str(tmp_path), "--sample_duration", "300", "--max_steps", "4",
+            "--hparams", "bond_dim=8,minibatch_size=4,learning_rate=0.01", "--seed", "3"]
+    t_hip = train.main(argv + ["--logdir", os.path.join(tmp_path, "hip")])
+    t_ref = train.main(argv + ["--logdir", os.path.join(tmp_path, "ref")], backend=OracleBackend(8))
+    a = np.array([h["model_loss"] for h in t_hip.history])
+    b = np.array([h["model_loss"] for h in t_ref.history])
+    assert len(a) == 4 and np.all(np.isfinite(a))
+    assert len(set(np.round(b, 6))) > 1                                # the batches differ from step to step
+    np.testing.assert_allclose(a, b, rtol=2e-4)
+    assert os.path.exists(os.path.join(tmp_path, "hip", "guitar", f"8_{t_hip.hparams.delta_t}_4", "model.ckpt.npz"))
+
+
+def test_trainer_model_loss_for_rho():
+    """Trainer.step's model_loss is the mean of the per-clip losses for RhoCMPS too (its gradient buffer is longer)."""
+    from audio_mps_amd import HParams, RhoCMPS
+    from audio_mps_amd.scan import HipScan
+    from audio_mps_amd.train import Trainer
+    hp = HParams(minibatch_size=5, bond_dim=6, initial_rank=3)
+    data = make_audio(5, 120, hp.delta_t, 2)
+    m = RhoCMPS(hp, data_iterator=data, seed=1, backend=HipScan(6))
+    per = m.loss_per_clip()
+    out = Trainer(m, hp).step()
+    assert out["model_loss"] == pytest.approx(float(np.mean(per.astype(np.float64))), rel=1e-5)
+
+
 def test_smoke_entry():
     import __graft_entry__ as ge
     ge.smoke()
@@ -62,6 +95,11 @@ def test_nccl_single_rank_collectives(tmp_path):
         flat = torch.arange(10, dtype=torch.float32, device=dev)
         host, nb = dp.allreduce_sums(flat, 7)
         assert nb == 7 and host.tolist() == list(range(10)), (nb, host)
+        dp.time_collective = True  # bench.py's all-reduce timing: HIP events around the collective
+        for _ in range(3):
+            host, nb = dp.allreduce_sums(flat, 7)
+        assert len(dp.collective_ms) == 3 and 0.0 < dp.collective_us() < 1e6, dp.collective_ms
+        assert dp.measured_world_size() == 1           # an all-reduce of ones over the (one-rank) RCCL group
         dp.barrier()
         assert dp.max_over_ranks(1.5) == 1.5
         dist.destroy_process_group()

@@ -181,6 +181,60 @@ def test_tfrecord_pipeline(tmp_path):
         list(tfr.read_records(bad, verify=True))
 
 
+def test_tfrecord_known_answer_bytes(tmp_path):
+    """One framed tf.train.Example assembled BY HAND from the wire specification (not by tfrecord.write_audio_tfrecord):
+    audio = [0.5, -1.25, 3.0] -> FloatList{1: packed} 0A 0C <12 bytes little-endian>; Feature{2: float_list} 12 0E ...;
+    map entry {1: "audio", 2: Feature} 0A 05 'audio' 12 10 ...; Features{1: entry} 0A 19 ...; Example{1: features} 0A 1B ...
+    (data.py:31-32, make-small-dataset.py:24-32); framing uint64 length 0x1D | masked CRC | payload | masked CRC with
+    CRC-32C computed by a bit-at-a-time loop (polynomial 0x82F63B78; crc(length) = 0x224440AE, crc(payload) = 0x21628FEF)
+    and mask ((crc >> 15 | crc << 17) + 0xA282EAD8)."""
+    from audio_mps_amd import tfrecord as tfr
+    rec = bytes.fromhex("1d00000000000000" "602fdf23"
+                        "0a1b0a190a05617564696f1210120e0a0c0000003f0000a0bf00004040" "9d2d61c2")
+    payload = rec[12:-4]
+    assert tfr.crc32c(rec[:8]) == 0x224440AE and tfr.crc32c(payload) == 0x21628FEF
+    assert tfr._crc32c_python(payload) == 0x21628FEF
+    path = os.path.join(tmp_path, "one.tfrecords")
+    open(path, "wb").write(rec + rec)
+    got = [tfr.parse_example(r)["audio"] for r in tfr.read_records(path, verify=True)]
+    assert len(got) == 2
+    np.testing.assert_array_equal(got[0], np.array([0.5, -1.25, 3.0], np.float32))
+    # the writer produces exactly these bytes
+    out = os.path.join(tmp_path, "w.tfrecords")
+    tfr.write_audio_tfrecord(out, [np.array([0.5, -1.25, 3.0], np.float32)])
+    assert open(out, "rb").read() == rec
+    # the reference's pipeline on it: FixedLenFeature([3]) -> batch(2)
+    nxt = get_audio(str(tmp_path), "one", HParams(minibatch_size=2), sample_duration=3)
+    np.testing.assert_array_equal(nxt(), np.tile(np.array([0.5, -1.25, 3.0], np.float32), (2, 1)))
+
+
+def test_train_main_iterates_a_tfrecord_dataset(tmp_path):
+    """train.py:46-47 builds the input ONCE and every session.run pulls the next batch.  main() on a TFRecord dataset (host
+    logic only: the scan is the oracle stand-in) must see different batches in successive steps, cover the epoch, and
+    write its checkpoint (it used to index the batch callable)."""
+    from audio_mps_amd import tfrecord as tfr
+    from audio_mps_amd import train
+    clips = make_audio(8, 64, 1 / 16000, 3)
+    tfr.write_audio_tfrecord(os.path.join(tmp_path, "organ.tfrecords"), clips)
+    seen = []
+
+    class Spy(OracleBackend):
+        def loss_and_grad_sums(self, audio):
+            seen.append(np.asarray(audio).copy())
+            return super().loss_and_grad_sums(audio)
+
+    tr = train.main(["--dataset", "organ", "--datadir", str(tmp_path), "--sample_duration", "64", "--max_steps", "4",
+                     "--hparams", "bond_dim=4,minibatch_size=4", "--logdir", os.path.join(tmp_path, "log")], backend=Spy(4))
+    assert tr.global_step == 4 and len(seen) == 4 and all(s.shape == (4, 64) for s in seen)
+    epoch = np.concatenate(seen[:2])
+    assert sorted(map(tuple, epoch.round(5).tolist())) == sorted(map(tuple, clips.round(5).tolist()))
+    assert all(np.isfinite(h["model_loss"]) for h in tr.history)
+    assert os.path.exists(os.path.join(tmp_path, "log", "organ", f"4_{tr.hparams.delta_t}_4", "model.ckpt.npz"))
+    with pytest.raises(SystemExit):                                # rho: rank * D beyond the LDS-resident limit
+        train.main(["--mps_model", "rho_mps", "--hparams", "bond_dim=80,minibatch_size=2", "--max_steps", "1"],
+                   backend=OracleBackend(80))
+
+
 def test_product_has_no_cpu_fallback():
     """Without a GPU the product must refuse to compute rather than silently use something else."""
     import torch

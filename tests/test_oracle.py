@@ -2,6 +2,7 @@
 of /root/reference) restated on the restatement, the two oracle implementations against each other, the
 float64 twin, finite-difference gradients, and the committed golden fixtures."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -177,3 +178,54 @@ def test_bf16_emulation_stays_close_to_float32():
     # and the rounding helper is round-to-nearest-even on the top 16 bits
     x = np.array([1.0, 1.00390625, 1.01171875, -2.5, 3.0e-39], dtype=np.float32)
     np.testing.assert_array_equal(O.bf16_round(x), np.array([1.0, 1.0, 1.015625, -2.5, O.bf16_round(x[4:5])[0]], dtype=np.float32))
+
+
+# ---------------------------------------------------------------------------------------------------
+# the only reference-held NUMBERS on the path: the constants of logging/graph.pbtxt (legacy AudioMPS graph)
+# ---------------------------------------------------------------------------------------------------
+def _graph_constants():
+    import json
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "legacy_graph_constants.json")
+    with open(path) as fh:
+        return {k: v["value"] for k, v in json.load(fh)["constants"].items()}
+
+
+def test_legacy_oracle_uses_the_graphs_constants():
+    """tests/golden/legacy_graph_constants.json is extracted from /root/reference/logging/graph.pbtxt by
+    scripts/graph_constants.py (committed).  A two-step scan evaluated from those numbers ALONE (float64, written here, none
+    of the oracle's code) must agree with oracle/cmps_oracle.py::legacy_loss_and_grads, whose own constants are literals."""
+    c = _graph_constants()
+    assert c["loop_bound"] == 4095                                   # T - 1 for the notebook's T = 4096
+    assert c["hamiltonian_factor"] == {"re": -0.0, "im": -1.0}
+    dt = c["delta_t_Q"]["re"]
+    assert dt == c["delta_t_signal"]["re"] == float(np.float32(0.01))
+    D, B, T = 5, 8, 3                                                # the graph's D and batch; two steps
+    H, R = O.legacy_init(D, seed=3)
+    data = make_audio(B, T, dt, 1, noise=0.3)
+    ref = O.legacy_loss_and_grads(H, R, dt, data, "f64")
+    H64, R64 = H.astype(np.float64), R.astype(np.float64)
+    Hs = np.tril(H64) + np.tril(H64).T                               # Appendix A: band_part(H,-1,0) + its transpose
+    fac = complex(c["hamiltonian_factor"]["re"], c["hamiltonian_factor"]["im"])
+    Q = dt * (fac * Hs - (R64.T @ R64) / c["dissipator_divisor"]["re"])
+    per = np.zeros(B)
+    for b in range(B):
+        psi = np.zeros(D, complex)
+        psi[0] = 1.0
+        for k in range(T - 1):
+            x = float(data[b, k + 1]) - float(data[b, k])
+            e = c["expectation_factor"] * np.real(np.vdot(psi, R64 @ psi))
+            per[b] += (x - e) ** c["loss_exponent"] / c["loss_divisor"]
+            y = psi + Q @ psi + c["delta_t_signal"]["re"] * x * (R64 @ psi)
+            psi = y / np.sqrt(max(np.sum(np.abs(y) ** 2), c["norm_floor"]))
+    np.testing.assert_allclose(ref["per_clip"], per, rtol=1e-12)
+    # a wrong constant is visible at this tolerance: e.g. factor 2 -> 1 or divisor 2 -> 1 changes the loss by O(1)
+    assert abs(np.mean(per) - float(ref["loss"])) < 1e-12
+
+
+def test_adam_defaults_are_the_graphs():
+    """tf.train.AdamOptimizer as serialized in the legacy graph (learning rate 1e-3, beta1 0.9, beta2 0.999, eps 1e-8)."""
+    from audio_mps_amd.train import AdamOptimizer
+    c = _graph_constants()
+    opt = AdamOptimizer()
+    for mine, key in ((opt.lr, "adam_learning_rate"), (opt.b1, "adam_beta1"), (opt.b2, "adam_beta2"), (opt.eps, "adam_epsilon")):
+        assert np.float32(mine) == np.float32(c[key]), key
