@@ -64,7 +64,7 @@ __device__ __forceinline__ float dpp_mov(float x) {
 }
 // sum over the 32 lanes that carry the same clip (c >> 1); every lane receives its clip's total
 __device__ __forceinline__ float clip_sum(float x) {
-#ifdef PABL_NO_REDUCE
+#if defined(CMPS_DIAG) && defined(PABL_NO_REDUCE)     // diagnostic builds only (scripts/ablate.py)
     return x;
 #endif
     x += dpp_mov<0xB1>(x);        // quad_perm [1,0,3,2]: re + im partner
@@ -136,7 +136,7 @@ __device__ __forceinline__ void rd_wait(u4 (&o)[8]) {
                  : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(o[4]), "+v"(o[5]), "+v"(o[6]), "+v"(o[7])
                  : "n"(N) : "memory");
 }
-#ifdef PABL_NO_MFMA
+#if defined(CMPS_DIAG) && defined(PABL_NO_MFMA)       // diagnostic builds only (scripts/ablate.py)
 #define MFMA4(A, B, C) (C)
 #else
 #define MFMA4(A, B, C) __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(bf4, A), B, C, 0, 0, 0)

@@ -3,9 +3,10 @@
 
 usage: ablate.py [--shape D T B ROUNDS VARIANT] name=-DFLAG[,-DFLAG...] ...
   e.g. ablate.py base= no_mfma=-DPABL_NO_MFMA --shape 128 16000 512 2 3
-Known switches: ABL_NO_REDUCE / ABL_NO_MV1 / ABL_NO_WAIT (cmps_wave.hip), ABL2_NO_LOSS / ABL2_NO_CHAIN / ABL2_NO_PRIO /
-ABL2_CHAIN_NOWAIT / FWD2_NO_STAGGER / FWD2_LOSS_PRIO=n (cmps_wave2.hip), PABL_NO_MFMA / PABL_NO_REDUCE /
-GRAD_VALU_PER_MFMA=n (cmps_pair.hip).  Runs on the GPU box (hipcc is available there); libraries go to gpurun_out/.
+Every build gets -DCMPS_DIAG; known switches (all inert without it): CMPS_DIAG_NO_LOSS / CMPS_DIAG_NO_CHAIN (cmps_wave2.hip:
+only the chain wave / only the loss wave of the forward runs), PABL_NO_MFMA / PABL_NO_REDUCE / GRAD_VALU_PER_MFMA=n
+(cmps_pair.hip).  tests/test_capi_load.py compiles each of them so that they cannot rot.
+Runs on the GPU box (hipcc is available there); libraries go to gpurun_out/.
 """
 import os
 import subprocess
@@ -29,7 +30,7 @@ os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 for name, flags in variants.items():
     lib = os.path.join(ROOT, "gpurun_out", f"libcmps_{name}.so")
     subprocess.run([build._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Xarch_host", "-msse4.2",
-                    "-o", lib] + flags + [os.path.join(build.CSRC, s) for s in build.SOURCES], check=True)
+                    "-DCMPS_DIAG", "-o", lib] + flags + [os.path.join(build.CSRC, s) for s in build.SOURCES], check=True)
     env = dict(os.environ, CMPS_LIB=lib)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "time_kernels.py")] + shape, env=env,
                          capture_output=True, text=True).stdout

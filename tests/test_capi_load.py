@@ -4,6 +4,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -54,3 +56,36 @@ def test_workspace_bytes(hip_lib):
     assert 4_000_000 < fwd < 8_000_000                     # rotation table 4.1 MB + small tables
     stash = 1024 * 15999 * 64 * 8                          # one 512-B row of (y, H y) per clip-step
     assert stash < trn < stash * 1.05                     # the per-step state stash dominates (8.4 GB at C3)
+
+
+def test_options_default_and_errors(hip_lib):
+    """cmps_set_option / cmps_get_option (no device work): the rank-1 arithmetic defaults to BF16X3."""
+    from audio_mps_amd import _capi
+    h = ctypes.c_void_p()
+    assert hip_lib.cmps_create(32, ctypes.byref(h)) == _capi.CMPS_OK
+    assert hip_lib.cmps_get_option(h, _capi.CMPS_OPT_RANK1) == _capi.CMPS_RANK1_BF16X3
+    for v in (_capi.CMPS_RANK1_EXACT_F32, _capi.CMPS_RANK1_BF16X2, _capi.CMPS_RANK1_BF16X3):
+        assert hip_lib.cmps_set_option(h, _capi.CMPS_OPT_RANK1, v) == _capi.CMPS_OK
+        assert hip_lib.cmps_get_option(h, _capi.CMPS_OPT_RANK1) == v
+    assert hip_lib.cmps_set_option(h, _capi.CMPS_OPT_RANK1, 3) == _capi.CMPS_ERR_BAD_ARG
+    assert hip_lib.cmps_set_option(h, 99, 0) == _capi.CMPS_ERR_BAD_ARG
+    assert hip_lib.cmps_get_option(h, 99) == -1 and hip_lib.cmps_get_option(None, _capi.CMPS_OPT_RANK1) == -1
+    # CMPS_WS_FRESH is a request, not a layout: it does not change the size
+    assert hip_lib.cmps_workspace_bytes(8, 4, 64, _capi.CMPS_WS_TRAIN | _capi.CMPS_WS_FRESH) == \
+        hip_lib.cmps_workspace_bytes(8, 4, 64, _capi.CMPS_WS_TRAIN)
+    hip_lib.cmps_destroy(h)
+
+
+@pytest.mark.parametrize("source,flags", [
+    ("cmps_wave2.hip", ["-DCMPS_DIAG_NO_LOSS"]), ("cmps_wave2.hip", ["-DCMPS_DIAG_NO_CHAIN"]),
+    ("cmps_pair.hip", ["-DPABL_NO_MFMA"]), ("cmps_pair.hip", ["-DPABL_NO_REDUCE", "-DGRAD_VALU_PER_MFMA=8"]),
+])
+def test_diagnostic_switches_compile(source, flags, tmp_path):
+    """The timing-only switches of scripts/ablate.py live behind -DCMPS_DIAG; each must keep compiling for gfx950."""
+    import subprocess
+    from audio_mps_amd import build
+    out = os.path.join(tmp_path, "diag.o")
+    cmd = [build._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", "--cuda-device-only", "-DCMPS_DIAG"] + flags + \
+          [os.path.join(build.CSRC, source), "-o", out]
+    proc = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-3000:]
