@@ -55,6 +55,7 @@ int fail_hip(cmps_handle_t h, hipError_t e, const char* where) {
 int resolve_variant(const cmps_handle_s* h) {
     if (h->variant_req == CMPS_VARIANT_BLOCK) return CMPS_VARIANT_BLOCK;
     if (h->variant_req == CMPS_VARIANT_WAVE) return h->D <= 32 ? CMPS_VARIANT_WAVE : CMPS_VARIANT_BLOCK;
+    if (h->variant_req == CMPS_VARIANT_WAVE32) return h->D <= 32 ? CMPS_VARIANT_WAVE32 : CMPS_VARIANT_BLOCK;
     if (h->variant_req == CMPS_VARIANT_PAIR) return h->D > 32 ? CMPS_VARIANT_PAIR : CMPS_VARIANT_BLOCK;
     // AUTO: float32 everywhere; the bf16-operand MFMA kernels of D = 128 are opt-in (they change the arithmetic)
     return h->D <= 32 ? CMPS_VARIANT_WAVE : CMPS_VARIANT_BLOCK;
@@ -86,11 +87,11 @@ const char* cmps_last_error(cmps_handle_t h) { return h ? h->err.c_str() : "null
 
 int cmps_set_variant(cmps_handle_t h, int variant) {
     if (!h) return CMPS_ERR_BAD_ARG;
-    if (variant < CMPS_VARIANT_AUTO || variant > CMPS_VARIANT_PAIR)
+    if (variant < CMPS_VARIANT_AUTO || variant > CMPS_VARIANT_WAVE32)
         return fail(h, CMPS_ERR_BAD_ARG, "cmps_set_variant: unknown variant");
     if (variant == CMPS_VARIANT_PAIR && h->D <= 32)
         return fail(h, CMPS_ERR_UNSUPPORTED_D, "cmps_set_variant: the pair (MFMA) variant is for 32 < D <= 128");
-    if (variant == CMPS_VARIANT_WAVE && h->D > 32)
+    if ((variant == CMPS_VARIANT_WAVE || variant == CMPS_VARIANT_WAVE32) && h->D > 32)
         return fail(h, CMPS_ERR_UNSUPPORTED_D, "cmps_set_variant: the wave variant needs D <= 32");
     h->variant_req = variant;
     return CMPS_OK;
@@ -195,7 +196,9 @@ int cmps_psi_loss_fwd(cmps_handle_t h, const float* audio_dev, int B, int T, flo
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int variant = resolve_variant(h);
     hipError_t e;
-    if (variant == CMPS_VARIANT_WAVE)
+    if (variant == CMPS_VARIANT_WAVE && h->D <= 16)
+        e = launch_fwd_wave16(P, audio_dev, loss_dev, save_for_bwd != 0, s);
+    else if (variant == CMPS_VARIANT_WAVE || variant == CMPS_VARIANT_WAVE32)
         e = launch_fwd_wave2(P, audio_dev, loss_dev, save_for_bwd != 0, s);
     else if (variant == CMPS_VARIANT_PAIR)
         e = launch_fwd_pair(P, audio_dev, loss_dev, save_for_bwd != 0, s);
@@ -205,7 +208,7 @@ int cmps_psi_loss_fwd(cmps_handle_t h, const float* audio_dev, int B, int T, flo
     h->fwd_saved = save_for_bwd != 0;
     h->saved_B = B; h->saved_T = T; h->saved_audio = audio_dev; h->saved_loss = loss_dev;
     h->saved_variant = variant;
-    h->P.stash_layout = (variant == CMPS_VARIANT_WAVE) ? 1 : (variant == CMPS_VARIANT_PAIR ? 2 : 0);
+    h->P.stash_layout = (variant == CMPS_VARIANT_WAVE || variant == CMPS_VARIANT_WAVE32) ? 1 : (variant == CMPS_VARIANT_PAIR ? 2 : 0);
     return CMPS_OK;
 }
 
@@ -232,10 +235,12 @@ int cmps_psi_loss_bwd(cmps_handle_t h, const float* audio_dev, int B, int T, flo
         if (e != hipSuccess) return fail_hip(h, e, "cmps_psi_loss_bwd (pair reduce)");
         return CMPS_OK;
     }
-    hipError_t e = (h->saved_variant == CMPS_VARIANT_WAVE) ? launch_bwd_wave(P, audio_dev, h->rank1_mode, s)
-                                                           : launch_bwd_block(P, audio_dev, s);
+    const bool wave = h->saved_variant == CMPS_VARIANT_WAVE || h->saved_variant == CMPS_VARIANT_WAVE32;
+    hipError_t e = !wave ? launch_bwd_block(P, audio_dev, s)
+                 : (h->saved_variant == CMPS_VARIANT_WAVE && h->D <= 16) ? launch_bwd_wave16(P, audio_dev, s)
+                                                                         : launch_bwd_wave(P, audio_dev, h->rank1_mode, s);
     if (e != hipSuccess) return fail_hip(h, e, "cmps_psi_loss_bwd (scan)");
-    P.abar_fix = h->saved_variant == CMPS_VARIANT_WAVE ? 1 : 0;
+    P.abar_fix = wave ? 1 : 0;
     e = launch_reduce_finalize(P, h->saved_loss, grad_dev, s);
     if (e != hipSuccess) return fail_hip(h, e, "cmps_psi_loss_bwd (reduce)");
     return CMPS_OK;
@@ -272,7 +277,8 @@ int cmps_psi_sample(cmps_handle_t h, const float* noise_dev, int n, int length, 
     if (length > h->L.N)
         return fail(h, CMPS_ERR_BAD_ARG, "cmps_psi_sample: length exceeds T - 1 of cmps_set_params (the per-step tables)");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipError_t e = (resolve_variant(h) == CMPS_VARIANT_WAVE) ? launch_sample_wave(h->P, noise_dev, n, length, out_dev, s)
+    const int sv = resolve_variant(h);
+    hipError_t e = (sv == CMPS_VARIANT_WAVE || sv == CMPS_VARIANT_WAVE32) ? launch_sample_wave(h->P, noise_dev, n, length, out_dev, s)
                                                              : launch_sample_block(h->P, noise_dev, n, length, out_dev, s);
     if (e != hipSuccess) return fail_hip(h, e, "cmps_psi_sample");
     return CMPS_OK;

@@ -165,6 +165,8 @@ hipError_t launch_fwd_block(const Dev& P, const float* audio, float* loss, bool 
 hipError_t launch_bwd_block(const Dev& P, const float* audio, hipStream_t s);
 hipError_t launch_bwd_wave(const Dev& P, const float* audio, int rank1_mode, hipStream_t s);
 hipError_t launch_fwd_wave2(const Dev& P, const float* audio, float* loss, bool save, hipStream_t s);
+hipError_t launch_fwd_wave16(const Dev& P, const float* audio, float* loss, bool save, hipStream_t s);
+hipError_t launch_bwd_wave16(const Dev& P, const float* audio, hipStream_t s);
 hipError_t launch_fwd_pair(const Dev& P, const float* audio, float* loss, bool save, hipStream_t s);
 hipError_t launch_bwd_pair(const Dev& P, const float* audio, hipStream_t s);
 hipError_t launch_grad_pair(const Dev& P, const float* audio, hipStream_t s);

@@ -46,13 +46,16 @@ enum {
 enum {
     CMPS_VARIANT_AUTO = 0,
     CMPS_VARIANT_BLOCK = 1, /* one workgroup per clip, any D <= 128 */
-    CMPS_VARIANT_WAVE = 2,  /* one wavefront per clip, state and R in registers, D <= 32 */
-    CMPS_VARIANT_PAIR = 3   /* 32 < D <= 128: one workgroup per pair of clips, matrices as bf16 MFMA fragments, fp32 accumulate */
+    CMPS_VARIANT_WAVE = 2,  /* wavefront-per-clip kernels, state and R in registers, D <= 32: the 16-row lane layout
+                             * (cmps_wave16.hip) for D <= 16, the 32-row layout above that */
+    CMPS_VARIANT_PAIR = 3,  /* 32 < D <= 128: one workgroup per pair of clips, matrices as bf16 MFMA fragments, fp32 accumulate */
+    CMPS_VARIANT_WAVE32 = 4 /* the 32-row wave layout for every D <= 32 (zero padding below 32; cross-check of the 16-row layout) */
 };
 
 /* options (cmps_set_option / cmps_get_option) */
 enum {
-    CMPS_OPT_RANK1 = 1 /* arithmetic of the rank-1 gradient updates in the wave-per-clip reverse scan (D <= 32) */
+    CMPS_OPT_RANK1 = 1 /* arithmetic of the rank-1 gradient updates in the wave-per-clip reverse scan (32-row layout;
+                        * the 16-row layout of D <= 16 always uses exact fp32 MFMAs) */
 };
 /* values of CMPS_OPT_RANK1.  All three accumulate in fp32; they differ in how the two factors of every product
  * dR += a b^dagger enter the matrix cores:
@@ -75,7 +78,7 @@ int cmps_create(int D, cmps_handle_t* out);
 int cmps_destroy(cmps_handle_t h);
 const char* cmps_last_error(cmps_handle_t h);
 int cmps_set_variant(cmps_handle_t h, int variant);
-/* The variant the next launch will use (after AUTO resolution), CMPS_VARIANT_BLOCK or _WAVE. */
+/* The variant the next launch will use (after AUTO resolution): CMPS_VARIANT_BLOCK, _WAVE, _PAIR or _WAVE32. */
 int cmps_get_variant(cmps_handle_t h);
 /* Numerical options of the gradient path; the reference has one arithmetic (TensorFlow float32 kernels behind
  * train.py:89), so every value of every option must stay within the stated float32 tolerance of it.

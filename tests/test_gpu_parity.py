@@ -24,7 +24,7 @@ pytestmark = pytest.mark.gpu
 
 LOSS_RTOL = 1e-5
 GRAD_RTOL = 1e-4
-BLOCK, WAVE = 1, 2
+BLOCK, WAVE, WAVE32 = 1, 2, 4      # WAVE: the 16-row layout for D <= 16, the 32-row layout above; WAVE32: always 32 rows
 
 
 def _scan(D, variant):
@@ -64,7 +64,7 @@ def _check_against_oracle(m, audio, nthreads=0, loss_rtol=LOSS_RTOL, grad_rtol=G
 # ---------------------------------------------------------------------------------------------------
 # golden fixtures and oracle parity over shapes / variants
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("variant", [BLOCK, WAVE])
+@pytest.mark.parametrize("variant", [BLOCK, WAVE, WAVE32])
 @pytest.mark.parametrize("name", golden_names())
 def test_golden(name, variant):
     from audio_mps_amd.scan import unpack_grad
@@ -104,6 +104,30 @@ def test_chunk_boundaries(T):
     """T - 1 steps around the 64-step chunking of the wave kernels (1, 2, 63, 64, 65, 128, 192 steps)."""
     m, audio = _model(32, T, 5, WAVE, seed=T)
     _check_against_oracle(m, audio)
+
+
+@pytest.mark.parametrize("T", [2, 3, 8, 9, 10, 17, 33, 34, 65, 66, 130, 257])
+@pytest.mark.parametrize("D", [3, 16])
+def test_wave16_chunk_and_octet_boundaries(D, T):
+    """The 16-row layout (cmps_wave16.hip): T - 1 steps around its 32-step forward chunks, its 8-step reverse octets and the
+    64-step scalar chunks (1, 2, 7, 8, 9, 16, 32, 33, 64, 65, 129, 256 steps), full and partly used rows."""
+    m, audio = _model(D, T, 3, WAVE, seed=T + D)
+    _check_against_oracle(m, audio)
+
+
+def test_wave16_matches_wave32():
+    """D <= 16 in both lane layouts: same arithmetic up to float32 summation order."""
+    m1, audio = _model(16, 1500, 7, WAVE, seed=8)
+    m2, _ = _model(16, 1500, 7, WAVE32, seed=8)
+    assert m1._get_backend().variant == WAVE and m2._get_backend().variant == WAVE32
+    p1, p2 = m1.loss_per_clip(), m2.loss_per_clip()
+    assert np.max(np.abs(p1 - p2) / np.maximum(np.abs(p2), 1.0)) <= LOSS_RTOL
+    f1 = m1.grad_sums()[0].cpu().numpy()
+    f2 = m2.grad_sums()[0].cpu().numpy()
+    assert rel_inf(f1[:2 * 16 * 16], f2[:2 * 16 * 16]) <= GRAD_RTOL
+    assert rel_inf(f1[2 * 16 * 16:], f2[2 * 16 * 16:]) <= GRAD_RTOL
+    s1, s2 = m1.psi_evolve_with_data(), m2.psi_evolve_with_data()
+    assert np.max(np.abs(s1 - s2)) < 1e-5
 
 
 def test_single_clip_and_non_multiple_of_four():
