@@ -340,9 +340,12 @@ __global__ void k_states(Dev P, float* __restrict__ psi_out) {
     const bool act = i < D;
     float2 y = make_float2(0.f, 0.f);
     if (act) {
-        if (P.stash_layout == 1) {   // wave variant: 64 lanes x (y own, H y own); re on lane i, im on lane i + 32
+        if (P.stash_layout == 1) {   // 16-row wave layout: 64 lanes x (y own, H y own); re on lane i, im on lane i + 32
             const float* r = P.hst + row * 128;
             y = make_float2(r[2 * i], r[2 * (i + 32)]);
+        } else if (P.stash_layout == 3) {   // 32-row wave layout: 64 (y[n], (H y)[n]) pairs, n = 2 i + {re, im}
+            const float* r = P.hst + row * 128;
+            y = make_float2(r[4 * i], r[4 * i + 2]);
         } else if (P.stash_layout == 2) {
             // pair variant (cmps_pair.hip): per pair and step DP/32 waves x 64 lanes x float4 (y_a, y_b, ., .); lane =
             // 4 * (row group + 8 * K half) + (2 * clip + component), rows 32 w + 4 rg + 2 kh (+1)

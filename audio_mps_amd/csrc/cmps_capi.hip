@@ -208,7 +208,9 @@ int cmps_psi_loss_fwd(cmps_handle_t h, const float* audio_dev, int B, int T, flo
     h->fwd_saved = save_for_bwd != 0;
     h->saved_B = B; h->saved_T = T; h->saved_audio = audio_dev; h->saved_loss = loss_dev;
     h->saved_variant = variant;
-    h->P.stash_layout = (variant == CMPS_VARIANT_WAVE || variant == CMPS_VARIANT_WAVE32) ? 1 : (variant == CMPS_VARIANT_PAIR ? 2 : 0);
+    h->P.stash_layout = (variant == CMPS_VARIANT_WAVE && h->D <= 16) ? 1
+                      : (variant == CMPS_VARIANT_WAVE || variant == CMPS_VARIANT_WAVE32) ? 3
+                      : (variant == CMPS_VARIANT_PAIR ? 2 : 0);
     return CMPS_OK;
 }
 

@@ -16,8 +16,8 @@ namespace cmps {
 //   rho      : [N+1][DP] float2       rho_k[d] = exp(i (fl(f_d t_k) - fl(f_d t_{k+1}))), drift-corrected (cmps_prep.hip)
 //   rfix     : [2][NC][DP] double2    scratch of the drift correction
 //   stash    : [B][N][DP] float2      un-normalised rotating-frame state y_k (TRAIN only; block variant)
-//   hst      : [B][N][64][2] float    wave variant's stash (same region as `stash`): per lane (y_k own,
-//                                     ((R + R^dagger) y_k) own), 512 B per step
+//   hst      : [B][N][64][2] float    wave variants' stash (same region as `stash`), 512 B per step: pairs (y_k, (R + R^dagger) y_k)
+//                                     per real component n = 2 i + {re, im} (32-row layout) or per lane (16-row layout)
 //   scal     : [B][NC][2][64] float   per 64-step chunk: |y_k|^2 and e_k, one step per lane (wave variant)
 //   slabs    : [B][slab] float        per-clip gradient partials (TRAIN only)
 //   sums     : [slab] float           reduced partials, followed by [32][slab] double first-pass partial sums
@@ -87,7 +87,8 @@ struct Dev {
     const float2* rho;   // [N][DP]
     float2* stash;       // [B][N][DP]
     float* hst;          // [B][N][64][2] (wave variant)
-    int stash_layout;    // 0: stash [B][N][DP] float2 (block variant)  1: hst rows (wave variant)  2: pair rows (cmps_pair.hip)
+    int stash_layout;    // 0: stash [B][N][DP] float2 (block variant)  1: hst rows in lane order (cmps_wave16.hip)
+                         // 2: pair rows (cmps_pair.hip)  3: hst rows of (y[n], (H y)[n]) pairs, n = 2 i + {re, im} (cmps_wave2.hip)
     float* scal;         // [B][NC][2][64]
     float* slabs;        // [B][slab]
     float* sums;         // [slab]

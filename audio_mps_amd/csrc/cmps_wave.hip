@@ -85,7 +85,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
     v16f Rre = {}, Rim = {}, Qre = {}, Qim = {};
 
     const unsigned aBw = lds_addr(&bcB[w][0]) + i * 8 + h * 4, aBr = lds_addr(&bcB[w][0]) + h * 128;
-    const unsigned aYown = lds_addr(&stY[w][0]) + lane * 8;
+    const unsigned aYown = lds_addr(&stY[w][0]) + (2 * i + h) * 8;   // stash rows: 64 (y[n], (H y)[n]) pairs, n = 2 i + {re, im}
     const unsigned aRho = lds_addr(&stR[w][0]) + i * 8;
     const unsigned aScl = lds_addr(&scl[w][0]);
     const float4* rho4 = reinterpret_cast<const float4*>(P.rho);

@@ -9,9 +9,14 @@
 //   chain wave (waves 0-3 of the workgroup, raised priority): per step two interleaved mat-vec chains, one wave
 //     reduction, the rotation; writes y_k (256 B, split layout) into a ring in LDS; per 32-step chunk publishes
 //     `prod` = chunks written and stores the chunk's |y_k|^2 row.
-//   loss wave (waves 4-7): per step reads y_k back (own value + this half's 16 entries), H y_k, the per-lane product for
-//     e_k, the stash row (y_k, H y_k); per 32-step chunk the column sums, log(1 + e x / A) in the reference's operation
-//     order and the sequential float32 loss accumulation (model.py:279, 294); publishes `cons` = chunks consumed.
+//   loss wave (waves 4-7): nothing waits for it, so it works a whole 32-step chunk at a time ON THE MATRIX CORES: the 32 rows
+//     y_k of the chunk form Y [32 steps x 64 reals], and H Y^T is one real GEMM Y W (W = the 64 x 64 real form of
+//     H = R + R^dagger) = 2 tiles x 4 k-steps of v_mfma_f32_32x32x16_bf16.  Both operands are split EXACTLY into three bf16
+//     pieces (8 + 8 + 8 significand bits, by truncation) and six products per pair are accumulated in fp32
+//     (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid: 24 operand bits, what is dropped is <= 2^-23 |a||b|), so H y_k is
+//     fp32-faithful; 48 MFMAs per chunk replace 32 x 32 packed FMAs plus 9 LDS reads per step.  Then e_k = y_k . (H y_k)
+//     (products transposed through LDS, column sums), the stash rows (y_k, H y_k), log(1 + e x / A) in the reference's
+//     operation order and the sequential float32 loss accumulation (model.py:279, 294); publishes `cons`.
 //
 // One mat-vec on the chain, not two: y = ut + Q ut + s_k R ut = ut + M_k ut with M_k = Q + s_k R.  Forming M_k costs one
 // packed FMA per complex entry (16 per lane) against the two a second mat-vec costs, and it does not depend on the state:
@@ -29,7 +34,10 @@ namespace {
 
 constexpr int CH2 = 32;          // steps per chunk (ring half, rho staging, per-chunk scalar math)
 constexpr int RING = 2 * CH2;    // ring slots
-constexpr int PE2_LD = 33;       // row stride of the loss wave's product buffer
+constexpr int RLD = 68;          // floats per ring row: 64 (y_k as n = 2 i + {re, im}) + 4 of padding, so that the 32 rows the
+                                 // loss wave reads at one column offset (ds_read_b128, 16-lane groups) fall into distinct banks
+constexpr int PE2_LD = 36;       // row stride (floats) of the loss wave's product buffer [step][column]: 16-B aligned rows, the
+                                 // 32 rows read at one offset fall into distinct banks
 
 // progress counters in LDS, accessed with explicit DS instructions (a `volatile int*` cast would decay to a generic
 // pointer: flat accesses plus a vmcnt(0) wait that also drains the stash stores)
@@ -127,8 +135,8 @@ __global__ __launch_bounds__(128 * WAVES, 1) void k_fwd_wave2(Dev P, const float
                                                               float* __restrict__ loss_out) {
     __shared__ __attribute__((aligned(16))) float4 stR[WAVES][CH2 * 16];   // rho rows of the chain wave's chunk
     __shared__ __attribute__((aligned(16))) float2 bcU[WAVES][DPW];
-    __shared__ __attribute__((aligned(16))) float2 ring[WAVES][RING][DPW];  // y_k, interleaved (re, im) per component
-    __shared__ float pe[WAVES][64 * PE2_LD];
+    __shared__ __attribute__((aligned(16))) float ring[WAVES][RING][RLD];   // y_k, n = 2 i + {re, im}, rows padded (RLD)
+    __shared__ __attribute__((aligned(16))) float pe[WAVES][CH2 * PE2_LD]; // y_k[n] (H y_k)[n], [step][column]
     __shared__ int flags[WAVES][2];                                         // [clip][0: prod, 1: cons]
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int w = wv & (WAVES - 1), role = wv / WAVES;
@@ -143,6 +151,7 @@ __global__ __launch_bounds__(128 * WAVES, 1) void k_fwd_wave2(Dev P, const float
     const float A = P.A;
     float* sc = SAVE ? P.scal + scal_off(b, NC, 0) : nullptr;
     const unsigned aRing = lds_addr(&ring[w][0][0]);
+    constexpr int RROWB = RLD * 4;                                          // bytes per ring row
     const unsigned aProd = lds_addr(&flags[w][0]), aCons = lds_addr(&flags[w][1]);
 
     if (role == 0) {
@@ -196,7 +205,7 @@ __global__ __launch_bounds__(128 * WAVES, 1) void k_fwd_wave2(Dev P, const float
             }
             if (!DIAG_NO_LOSS && c >= 2)                              // the ring half about to be overwritten
                 while (flag_load(aCons) < c - 1) __builtin_amdgcn_s_sleep(1);
-            unsigned ay = aYw + (c & 1) * (CH2 * 256);
+            unsigned ay = aYw + (c & 1) * (CH2 * RROWB);
 #define CHAIN_STEP(KK)                                                                                        \
             {                                                                                                 \
                 const int kk_ = (KK);                                                                         \
@@ -209,7 +218,7 @@ __global__ __launch_bounds__(128 * WAVES, 1) void k_fwd_wave2(Dev P, const float
                 const float inv = __builtin_amdgcn_rsqf(vmax_s(nprev, 1e-12f));  /* model.py:332 */           \
                 const float y = inv * (u + swapadd(am.x, am.y));                                              \
                 lds_write32(ay, y);                                                                           \
-                ay += 256;                                                                                    \
+                ay += RROWB;                                                                                  \
                 const float yo = osig_of(y, hb);                                                              \
                 const v2f un = cmul2(mk2(y, yo), rho);                    /* rho_k y_k, normalised next step */ \
                 u = un.x;                                                                                     \
@@ -245,19 +254,48 @@ __global__ __launch_bounds__(128 * WAVES, 1) void k_fwd_wave2(Dev P, const float
     // ---------------------------------------------------------------------- loss wave
     if (DIAG_NO_LOSS) return;
     __builtin_amdgcn_s_setprio(0);
-    v2f MH[16];
+    // exact three-way bf16 split of two floats (even element in the low half of every packed word)
+    auto split3 = [](float fe, float fo, unsigned& H, unsigned& M, unsigned& L) {
+        const unsigned xe = __float_as_uint(fe), xo = __float_as_uint(fo);
+        H = __builtin_amdgcn_perm(xo, xe, 0x07060302u);
+        const float re = fe - __uint_as_float(xe & 0xFFFF0000u), ro = fo - __uint_as_float(xo & 0xFFFF0000u);
+        const unsigned me = __float_as_uint(re), mo = __float_as_uint(ro);
+        M = __builtin_amdgcn_perm(mo, me, 0x07060302u);
+        const float le = re - __uint_as_float(me & 0xFFFF0000u), lo = ro - __uint_as_float(mo & 0xFFFF0000u);
+        L = __builtin_amdgcn_perm(__float_as_uint(lo), __float_as_uint(le), 0x07060302u);   // <= 8 bits left: exact
+    };
+    auto frag = [](const unsigned (&f)[4]) { return __builtin_bit_cast(bf8, v4u{f[0], f[1], f[2], f[3]}); };
+    // B operand: W[m][n], the real 64 x 64 form of H = R + R^dagger acting on (re, im)-interleaved vectors,
+    //   (H y)[n = 2 i + c] = sum_m y[m = 2 j + c'] W[m][n]:  W = Hr_ij for c' = c,  -Hi_ij for (c', c) = (1, 0),  +Hi_ij for (0, 1).
+    // Lane (col = lane & 31, hk = lane >> 5) holds W[16 s + 8 hk + e][32 t + col], e = 0..7, for tile t and k-step s.
+    unsigned WH[2][4][4], WM[2][4][4], WL[2][4][4];
+    {
+        const int col = lane & 31, hk = lane >> 5;
 #pragma unroll
-    for (int m = 0; m < 16; ++m) {
-        const v2f r = ld2(&P.R[i * DPW + 16 * h + m]);
-        const v2f rt = ld2(&P.RT[i * DPW + 16 * h + m]);   // R[16h+m][i]
-        MH[m] = mk2(r.x + rt.x, r.y - rt.y);                // (R + R^dagger)[i][16h+m]
+        for (int t = 0; t < 2; ++t) {
+            const int n = 32 * t + col, ii = n >> 1, cc = n & 1;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                float wv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int m = 16 * ks + 8 * hk + e, jj = m >> 1, cp = m & 1;
+                    const float2 r = P.R[ii * DPW + jj], rt = P.RT[ii * DPW + jj];      // R[ii][jj], R[jj][ii]
+                    const float hr = r.x + rt.x, hi = r.y - rt.y;                         // (R + R^dagger)[ii][jj]
+                    wv[e] = cp == cc ? hr : (cc ? hi : -hi);
+                }
+#pragma unroll
+                for (int e2 = 0; e2 < 4; ++e2) split3(wv[2 * e2], wv[2 * e2 + 1], WH[t][ks][e2], WM[t][ks][e2], WL[t][ks][e2]);
+            }
+        }
     }
-    const unsigned aYr = aRing + h * 128, aYo = aRing + i * 8 + h * 4;
-    const unsigned aPEw = lds_addr(&pe[w][0]) + lane * (PE2_LD * 4);
-    float2* st = SAVE ? reinterpret_cast<float2*>(P.hst + (size_t)b * N * 128) + lane : nullptr;
+    // A operand: lane (row = lane & 31 = step of the chunk, hk) reads y_k[16 s + 8 hk + e] from the ring;
+    // C/D layout of a tile: column n = 32 t + (lane & 31), rows (steps) (r & 3) + 8 (r >> 2) + 4 (lane >> 5), r = 0..15
+    const int crow = lane & 31, chk = lane >> 5;
+    const float* ringw = &ring[w][0][0];
+    float* pew = &pe[w][0];
+    float2* st = SAVE ? reinterpret_cast<float2*>(P.hst + (size_t)b * N * 128) : nullptr;   // rows of 64 (y[n], (H y)[n]) pairs
     float loss = 0.f;
-    v4f qa[8], qb[8];
-    float ya = 0.f, yb = 0.f;
     for (int c = 0; c < NC2; ++c) {
         const int kbeg = c * CH2;
         const int cnt = (N - kbeg) < CH2 ? (N - kbeg) : CH2;
@@ -265,47 +303,72 @@ __global__ __launch_bounds__(128 * WAVES, 1) void k_fwd_wave2(Dev P, const float
         const float x0 = idx < T ? xrow[idx] : 0.f;
         const float x1 = idx + 1 < T ? xrow[idx + 1] : 0.f;
         if (!DIAG_NO_CHAIN)
-            while (flag_load(aProd) < c + 1) __builtin_amdgcn_s_sleep(1);
-        const unsigned off = (c & 1) * (CH2 * 256);
-        // Branch-free inner loop (branches around the counted waits make hipcc copy the 64 staging registers): every
-        // step issues the reads of the next one, clamped to the chunk's last row; an odd chunk ends with one repeated
-        // (idempotent) step, and the trailing dummy reads are retired after the loop.
-        const int last = cnt - 1;
-        rows_own_issue(aYr + off, aYo + off, qa, ya);
-#define LOSS_STEP(KK, Q, Y, QN, YN)                                                                     \
-        {                                                                                              \
-            const int kk_ = (KK) < last ? (KK) : last;                                                 \
-            const int kn_ = (KK) + 1 < last ? (KK) + 1 : last;                                         \
-            rows_own_issue(aYr + off + kn_ * 256, aYo + off + kn_ * 256, QN, YN);                      \
-            lds_wait_own9<9>(Q, Y);                                                                    \
-            const v2f ah = mv1(MH, Q);                                                                 \
-            const float hs = swapadd(ah.x, ah.y);                                                      \
-            lds_write32(aPEw + kk_ * 4, Y * hs);                                                       \
-            if (SAVE) st[(size_t)(kbeg + kk_) * 64] = make_float2(Y, hs);                              \
+            while (flag_load(aProd) < c + 1) __builtin_amdgcn_s_sleep(8);     // a chunk takes ~20000 cycles: poll rarely
+        const float* rh = ringw + (c & 1) * (CH2 * RLD);               // this chunk's 32 rows (rows >= cnt: stale, ignored below)
+        v16f acc0 = {}, acc1 = {};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const float4 f0 = *reinterpret_cast<const float4*>(rh + crow * RLD + 16 * ks + 8 * chk);
+            const float4 f1 = *reinterpret_cast<const float4*>(rh + crow * RLD + 16 * ks + 8 * chk + 4);
+            unsigned AH[4], AM[4], AL[4];
+            split3(f0.x, f0.y, AH[0], AM[0], AL[0]);
+            split3(f0.z, f0.w, AH[1], AM[1], AL[1]);
+            split3(f1.x, f1.y, AH[2], AM[2], AL[2]);
+            split3(f1.z, f1.w, AH[3], AM[3], AL[3]);
+#define MF6(ACC, T_)                                                                                           \
+            ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(AH), frag(WH[T_][ks]), ACC, 0, 0, 0);           \
+            ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(AH), frag(WM[T_][ks]), ACC, 0, 0, 0);           \
+            ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(AM), frag(WH[T_][ks]), ACC, 0, 0, 0);           \
+            ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(AH), frag(WL[T_][ks]), ACC, 0, 0, 0);           \
+            ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(AL), frag(WH[T_][ks]), ACC, 0, 0, 0);           \
+            ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(AM), frag(WM[T_][ks]), ACC, 0, 0, 0);
+            MF6(acc0, 0)
+            MF6(acc1, 1)
+#undef MF6
         }
-        for (int kk = 0; kk < cnt; kk += 2) {
-            LOSS_STEP(kk, qa, ya, qb, yb)
-            LOSS_STEP(kk + 1, qb, yb, qa, ya)
+        // y_k[n] in the C/D layout, products y (H y), stash rows
+        float yc0[16], yc1[16], pr[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int stp = (r & 3) + 8 * (r >> 2) + 4 * chk;
+            yc0[r] = rh[stp * RLD + crow];
+            yc1[r] = rh[stp * RLD + 32 + crow];
         }
-#undef LOSS_STEP
-        lds_wait_own9<0>(qa, ya);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pr[r] = yc0[r] * acc0[r] + yc1[r] * acc1[r];
+        if (SAVE) {
+            // Stash row (kbeg + step) = 64 pairs (y[n], (H y)[n]) = 512 contiguous bytes.  Register r holds step s0 = (r & 3) +
+            // 8 (r >> 2) in lanes 0-31 and step s0 + 4 in lanes 32-63, for n = 0..31 (tile 0) and n = 32..63 (tile 1): one
+            // v_permlane32_swap between the two tiles puts ALL of row s0 into one register and all of row s0 + 4 into the
+            // other, so every store instruction writes one whole row (lane = n).
+            char* sbase = reinterpret_cast<char*>(st + (size_t)kbeg * 64) + lane * 8;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int s0 = (r & 3) + 8 * (r >> 2);
+                const auto ys = __builtin_amdgcn_permlane32_swap(__float_as_uint(yc0[r]), __float_as_uint(yc1[r]), false, false);
+                const auto hs = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc0[r]), __float_as_uint(acc1[r]), false, false);
+                if (s0 < cnt)
+                    *reinterpret_cast<float2*>(sbase + s0 * 512) = make_float2(__uint_as_float(ys[0]), __uint_as_float(hs[0]));
+                if (s0 + 4 < cnt)
+                    *reinterpret_cast<float2*>(sbase + (s0 + 4) * 512) = make_float2(__uint_as_float(ys[1]), __uint_as_float(hs[1]));
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         flag_store(aCons, c + 1, lane);                                // every ring read has landed: the half is free
-        // e_k = sum over the 64 lanes of the stored products: lane (i, h) sums rows 32h..32h+31 of column i
+        // e_k = sum_n y_k[n] (H y_k)[n]: transpose the per-column products through LDS, then lane (k, hh) sums columns
+        // 16 hh .. 16 hh + 15 of row k and the two halves are added
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pew[((r & 3) + 8 * (r >> 2) + 4 * chk) * PE2_LD + crow] = pr[r];
+        __builtin_amdgcn_wave_barrier();
         float evec;
         {
-            const float* col = &pe[w][(32 * h) * PE2_LD + i];
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int l = 0; l < 32; l += 4) {
-                a0 += col[(l + 0) * PE2_LD];
-                a1 += col[(l + 1) * PE2_LD];
-                a2 += col[(l + 2) * PE2_LD];
-                a3 += col[(l + 3) * PE2_LD];
-            }
-            const float part = (a0 + a1) + (a2 + a3);
+            const float4* rowp = reinterpret_cast<const float4*>(pew + crow * PE2_LD + 16 * chk);
+            const float4 q0 = rowp[0], q1 = rowp[1], q2 = rowp[2], q3 = rowp[3];
+            const float part = ((q0.x + q0.y) + (q0.z + q0.w)) + ((q1.x + q1.y) + (q1.z + q1.w)) +
+                               (((q2.x + q2.y) + (q2.z + q2.w)) + ((q3.x + q3.y) + (q3.z + q3.w)));
             evec = swapadd(part, part);
         }
+        __builtin_amdgcn_wave_barrier();
         const float incv = x1 - x0;
         const float z = (evec * incv) / A;                             // model.py:294 operation order
         const float lv = -logf(1.0f + z);
