@@ -200,82 +200,104 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
     // The bf16 MFMA runs on the matrix pipe beside the VALU; accumulation is fp32 in all three forms.
     unsigned fH[7][4], fL[7][4];      // K-fragments: value v, register r holds slots 2r (low half) and 2r+1 (high half)
     unsigned fM[RANK1 == 2 ? 7 : 1][4];
-    float fsave[7];
+    float fsave[7], hold_e[7], hold_o[7];
+    auto split_pair = [&](int v, int reg, float ve, float vo) {
+        const unsigned xe = __float_as_uint(ve), xo = __float_as_uint(vo);
+        fH[v][reg] = __builtin_amdgcn_perm(xo, xe, 0x07060302u);
+        v2f lo;
+        lo.x = ve - __uint_as_float(xe & 0xFFFF0000u);
+        lo.y = vo - __uint_as_float(xo & 0xFFFF0000u);
+        if constexpr (RANK1 == 2) {
+            const unsigned me = __float_as_uint(lo.x), mo = __float_as_uint(lo.y);
+            fM[v][reg] = __builtin_amdgcn_perm(mo, me, 0x07060302u);
+            v2f l3;
+            l3.x = lo.x - __uint_as_float(me & 0xFFFF0000u);
+            l3.y = lo.y - __uint_as_float(mo & 0xFFFF0000u);
+            // at most 8 significand bits are left: the truncation to bf16 is exact
+            fL[v][reg] = __builtin_amdgcn_perm(__float_as_uint(l3.y), __float_as_uint(l3.x), 0x07060302u);
+        } else {
+            fL[v][reg] = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf2));
+        }
+    };
+    // Slots 7 and 6 of an octet are held raw and split only at slot 4: fragment register 3 of the PREVIOUS octet then stays
+    // intact through the steps of slots 7, 6 and 5, the window in which that octet's MFMAs are issued (below).
     auto record = [&](auto slot, const float (&val)[7]) {
         constexpr int PSLOT = decltype(slot)::value;
         if constexpr (PSLOT & 1) {
 #pragma unroll
             for (int v = 0; v < 7; ++v) fsave[v] = val[v];
-        } else {
+        } else if constexpr (PSLOT == 6) {
 #pragma unroll
-            for (int v = 0; v < 7; ++v) {
-                const unsigned xe = __float_as_uint(val[v]), xo = __float_as_uint(fsave[v]);
-                fH[v][PSLOT >> 1] = __builtin_amdgcn_perm(xo, xe, 0x07060302u);
-                v2f lo;
-                lo.x = val[v] - __uint_as_float(xe & 0xFFFF0000u);
-                lo.y = fsave[v] - __uint_as_float(xo & 0xFFFF0000u);
-                if constexpr (RANK1 == 2) {
-                    const unsigned me = __float_as_uint(lo.x), mo = __float_as_uint(lo.y);
-                    fM[v][PSLOT >> 1] = __builtin_amdgcn_perm(mo, me, 0x07060302u);
-                    v2f l3;
-                    l3.x = lo.x - __uint_as_float(me & 0xFFFF0000u);
-                    l3.y = lo.y - __uint_as_float(mo & 0xFFFF0000u);
-                    // at most 8 significand bits are left: the truncation to bf16 is exact
-                    fL[v][PSLOT >> 1] = __builtin_amdgcn_perm(__float_as_uint(l3.y), __float_as_uint(l3.x), 0x07060302u);
-                } else {
-                    fL[v][PSLOT >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf2));
-                }
+            for (int v = 0; v < 7; ++v) { hold_e[v] = val[v]; hold_o[v] = fsave[v]; }
+        } else {
+            if constexpr (PSLOT == 4) {
+#pragma unroll
+                for (int v = 0; v < 7; ++v) split_pair(v, 3, hold_e[v], hold_o[v]);
             }
+#pragma unroll
+            for (int v = 0; v < 7; ++v) split_pair(v, PSLOT >> 1, val[v], fsave[v]);
         }
     };
     // values: 0 a1 = 2 ebar n yhat, 1 ybar, 2 a2 = s ybar | 3 yhat, 4 yhat_osig, 5 u_k, 6 u_k_osig
-    // The 18 MFMAs of a finished octet (6 groups of 3) are issued at six points of the NEXT step (slot 7 writes no
-    // fragment register), each behind enough VALU work that the matrix pipe is free again: back to back they
-    // would hold the in-order wave for 18 x 32 cycles.
-    bool pend = false;                // a finished octet's fragments are waiting to be applied
-    auto mf_group = [&](auto gsel) {
-        constexpr int G = decltype(gsel)::value;       // 0..5: first three products of pair G; 6..11 (BF16X3): the other three
+    // The MFMAs of a finished octet (18, or 36 for BF16X3) are issued ONE (two) at a time at six points of each of the next
+    // three steps: a v_mfma_f32_32x32x16_bf16 occupies the matrix pipe for 32 cycles, and an in-order wave that issues the
+    // next one earlier simply waits (SQ_WAIT_INST_ANY was 118 cycles per step with three in a row).
+    // The hooks are unconditional: before the first octet the fragments are zero, so its three leading steps apply nothing.
+    bool pend = false;                // an octet has been recorded whose MFMAs are not all issued yet (decides the final flush)
+#pragma unroll
+    for (int v = 0; v < 7; ++v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { fH[v][r] = 0u; fL[v][r] = 0u; if constexpr (RANK1 == 2) fM[v][r] = 0u; }
+    }
+    constexpr int PER_PAIR = RANK1 == 2 ? 6 : 3, UNITS = 6 * PER_PAIR, PER_HOOK = RANK1 == 2 ? 2 : 1;
+    // hook points of a step: A-points 0..5 (both modes) and B-points 0..5 (BF16X3 only): point q = 0..17 over the three steps
+    // issues unit q (BF16X2) or unit 2 q at the A-point and unit 2 q + 1 at the B-point (BF16X3): never two MFMAs in a row
+    auto mf_unit = [&](auto usel) {
+        constexpr int U = decltype(usel)::value, PR = U / PER_PAIR, K = U % PER_PAIR;
         auto frag = [&](const unsigned (&f)[4]) { return __builtin_bit_cast(bf8, v4u{f[0], f[1], f[2], f[3]}); };
-        auto mf = [&](v16f& acc, int ia, int ib) {
-            if constexpr (RANK1 == 2 && G >= 6) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(fH[ia]), frag(fL[ib]), acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(fL[ia]), frag(fH[ib]), acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(fM[ia]), frag(fM[ib]), acc, 0, 0, 0);
-            } else {
-                auto second = [&](int idx) -> const unsigned (&)[4] {      // the next-lower 8 bits
-                    if constexpr (RANK1 == 2) return fM[idx]; else return fL[idx];
-                };
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(fH[ia]), frag(fH[ib]), acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(fH[ia]), frag(second(ib)), acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(second(ia)), frag(fH[ib]), acc, 0, 0, 0);
-            }
+        auto piece = [&](auto which, int idx) -> const unsigned (&)[4] {        // 0 hi, 1 second 8 bits, 2 third 8 bits
+            constexpr int W = decltype(which)::value;
+            if constexpr (W == 0) return fH[idx];
+            else if constexpr (W == 1) { if constexpr (RANK1 == 2) return fM[idx]; else return fL[idx]; }
+            else return fL[idx];
         };
-        constexpr int GP = G % 6;
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (GP == 0) mf(Rre, 0, 3);
-        if constexpr (GP == 1) mf(Rim, 0, 4);
-        if constexpr (GP == 2) mf(Qre, 1, 5);
-        if constexpr (GP == 3) mf(Qim, 1, 6);
-        if constexpr (GP == 4) mf(Rre, 2, 5);
-        if constexpr (GP == 5) mf(Rim, 2, 6);
-        __builtin_amdgcn_sched_barrier(0);
+        // products of a pair, in the order they are issued: (hi,hi) (hi,2nd) (2nd,hi) | (hi,3rd) (3rd,hi) (2nd,2nd)
+        constexpr int WA = K == 0 ? 0 : K == 1 ? 0 : K == 2 ? 1 : K == 3 ? 0 : K == 4 ? 2 : 1;
+        constexpr int WB = K == 0 ? 0 : K == 1 ? 1 : K == 2 ? 0 : K == 3 ? 2 : K == 4 ? 0 : 1;
+        auto mf = [&](v16f& acc, int ia, int ib) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(piece(std::integral_constant<int, WA>{}, ia)),
+                                                          frag(piece(std::integral_constant<int, WB>{}, ib)), acc, 0, 0, 0);
+        };
+        if constexpr (PR == 0) mf(Rre, 0, 3);
+        if constexpr (PR == 1) mf(Rim, 0, 4);
+        if constexpr (PR == 2) mf(Qre, 1, 5);
+        if constexpr (PR == 3) mf(Qim, 1, 6);
+        if constexpr (PR == 4) mf(Rre, 2, 5);
+        if constexpr (PR == 5) mf(Rim, 2, 6);
+    };
+    auto mf_hook = [&](auto qsel, auto bsel) {    // hook q = 0 .. 17 (three steps x six points), A- or B-point
+        constexpr int Q = decltype(qsel)::value;
+        constexpr bool BP = decltype(bsel)::value;
+        if constexpr (!BP || PER_HOOK == 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            mf_unit(std::integral_constant<int, PER_HOOK * Q + (BP ? 1 : 0)>{});
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
     auto flush_octet = [&]() {
-        mf_group(std::integral_constant<int, 0>{}); mf_group(std::integral_constant<int, 1>{});
-        mf_group(std::integral_constant<int, 2>{}); mf_group(std::integral_constant<int, 3>{});
-        mf_group(std::integral_constant<int, 4>{}); mf_group(std::integral_constant<int, 5>{});
-        if constexpr (RANK1 == 2) {
-            mf_group(std::integral_constant<int, 6>{}); mf_group(std::integral_constant<int, 7>{});
-            mf_group(std::integral_constant<int, 8>{}); mf_group(std::integral_constant<int, 9>{});
-            mf_group(std::integral_constant<int, 10>{}); mf_group(std::integral_constant<int, 11>{});
-        }
+#define FLUSH_Q(Q) mf_hook(std::integral_constant<int, (Q)>{}, std::false_type{}); mf_hook(std::integral_constant<int, (Q)>{}, std::true_type{});
+        FLUSH_Q(0) FLUSH_Q(1) FLUSH_Q(2) FLUSH_Q(3) FLUSH_Q(4) FLUSH_Q(5) FLUSH_Q(6) FLUSH_Q(7) FLUSH_Q(8)
+        FLUSH_Q(9) FLUSH_Q(10) FLUSH_Q(11) FLUSH_Q(12) FLUSH_Q(13) FLUSH_Q(14) FLUSH_Q(15) FLUSH_Q(16) FLUSH_Q(17)
+#undef FLUSH_Q
         pend = false;
     };
-    // a finished octet is applied at six points of the next step (slot 7); BF16X3 applies its second half at the same six
-    // points of the step after that (slot 6), before that step's record() overwrites fragment register 3
-#define MF_HOOK(G)                                                                                         \
-    if constexpr (decltype(slot)::value == 7) { if (pend) mf_group(std::integral_constant<int, (G)>{}); }  \
-    else if constexpr (RANK1 == 2 && decltype(slot)::value == 6) { if (pend) mf_group(std::integral_constant<int, (G) + 6>{}); }
+    static_assert(UNITS == 18 * PER_HOOK, "every hook issues PER_HOOK MFMAs");
+#define MF_HOOK_AB(H, BP)                                                                                      \
+    if constexpr (decltype(slot)::value >= 5) {                                                                \
+        mf_hook(std::integral_constant<int, (7 - (decltype(slot)::value >= 5 ? decltype(slot)::value : 7)) * 6 + (H)>{}, BP{}); \
+    }
+#define MF_HOOK(H) MF_HOOK_AB(H, std::false_type)
+#define MF_HOOKB(H) MF_HOOK_AB(H, std::true_type)
     auto chain_step = [&](const Pre& S, float uk, float uko, auto have_pre, int jn, bool exact, auto slot) -> Pre {
         // ---- chain, scalar part ----
         MF_HOOK(0)
@@ -287,12 +309,16 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
         rad_next = S.rad;
         const float ybar = (yhb - dot * S.yhp) * S.inv + S.pre;
         bcast_issue(aBw, aBr, ybar, qc);                               // 9 ops
+        MF_HOOKB(0)
         {   // M_k = Q + s_k R^dagger, in the shadow of the broadcast
             const v2f s2 = mk2(S.s, S.s);
 #pragma unroll
-            for (int m = 0; m < 16; ++m) MM[m] = __builtin_elementwise_fma(MRd[m], s2, MQ[m]);
+            for (int m = 0; m < 8; ++m) MM[m] = __builtin_elementwise_fma(MRd[m], s2, MQ[m]);
+            MF_HOOK(1)
+#pragma unroll
+            for (int m = 8; m < 16; ++m) MM[m] = __builtin_elementwise_fma(MRd[m], s2, MQ[m]);
         }
-        MF_HOOK(1)
+        MF_HOOKB(1)
         // ---- off-chain: pre of step k-1 (gives u_k) ----
         Pre Sn = S;
         if constexpr (decltype(have_pre)::value) {
@@ -305,20 +331,30 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
         MF_HOOK(2)
         lds_wait_lo<4>(qc);
         v2f am;
-        mv1_lo(MM, qc, am);
+        constexpr bool SPLIT_MV = RANK1 == 2 && decltype(slot)::value >= 5;   // BF16X3's B-points inside the mat-vec
+        if constexpr (SPLIT_MV) {
+            mv1_quarter<true>(MM[0], MM[1], MM[2], MM[3], qc[0], qc[1], am);
+            MF_HOOKB(2)
+            mv1_quarter<false>(MM[4], MM[5], MM[6], MM[7], qc[2], qc[3], am);
+        } else {
+            mv1_lo(MM, qc, am);
+        }
         MF_HOOK(3)
         lds_wait_hi<0>(qc);
-        mv1_hi(MM, qc, am);
+        if constexpr (SPLIT_MV) {
+            mv1_quarter<false>(MM[8], MM[9], MM[10], MM[11], qc[4], qc[5], am);
+            MF_HOOKB(3)
+            mv1_quarter<false>(MM[12], MM[13], MM[14], MM[15], qc[6], qc[7], am);
+        } else {
+            mv1_hi(MM, qc, am);
+        }
         MF_HOOK(4)
         const float md = swapadd(am.x, am.y);
         accS += md * uk;
         g = ybar + md;
+        MF_HOOKB(4)
         go = osig_of(g, hb);
-        if constexpr (decltype(slot)::value == 7) {
-            if (pend) { mf_group(std::integral_constant<int, 5>{}); if constexpr (RANK1 != 2) pend = false; }
-        } else if constexpr (RANK1 == 2 && decltype(slot)::value == 6) {
-            if (pend) { mf_group(std::integral_constant<int, 11>{}); pend = false; }
-        }
+        MF_HOOK(5)
         // ---- rank-1 gradient updates (A: rows i, B: columns j; K = {re, im}) ----
         //   Rbar += 2 ebar y y^dagger + s ybar u^dagger ;  Qbar += ybar u^dagger
         //   Re(a b^dagger): A = a (split), B = b (split);  Im(a b^dagger): A = a (split), B = -b_osig
@@ -336,6 +372,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
             const float val[7] = {a1, ybar, a2, S.yh, S.yho, uk, uko};
             record(slot, val);
         }
+        MF_HOOKB(5)
+        if constexpr (decltype(slot)::value == 5) pend = false;
         return Sn;
     };
 
@@ -373,6 +411,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
     if (pend) flush_octet();
     S = chain_step(S, u0, u0o, std::false_type{}, 0, true, std::integral_constant<int, -1>{});   // step 0: u_0 = psi_0
 #undef MF_HOOK
+#undef MF_HOOKB
+#undef MF_HOOK_AB
 
     // ---------------- per-clip slab ----------------
     float* slab = P.slabs + (size_t)b * P.slab_floats;

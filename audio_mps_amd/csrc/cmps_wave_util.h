@@ -45,16 +45,17 @@ __device__ __forceinline__ void pkfma_bh(v2f& acc, v2f a, v2f b) {   // acc += (
 __device__ __forceinline__ void pkfma_bh_conj(v2f& acc, v2f a, v2f b) {  // acc += (a.y, -a.x) * (b.y, b.y)
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "+v"(acc) : "v"(a), "v"(b));
 }
+// (one asm statement each: hipcc pads every statement boundary)
 __device__ __forceinline__ v2f cmul2(v2f a, v2f b) {            // a * b
     v2f acc;
-    pkmul_bl(acc, a, b);
-    pkfma_bh(acc, a, b);
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=&v"(acc) : "v"(a), "v"(b));
     return acc;
 }
 __device__ __forceinline__ v2f cmul2_conj_b(v2f a, v2f b) {     // a * conj(b) = a*Re b - i a*Im b
     v2f acc;
-    pkmul_bl(acc, a, b);
-    pkfma_bh_conj(acc, a, b);
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=&v"(acc) : "v"(a), "v"(b));
     return acc;
 }
 
@@ -98,6 +99,16 @@ __device__ __forceinline__ void mv1_hi(const v2f (&M)[16], const v4f (&q)[8], v2
         : "v"(M[8]), "v"(M[9]), "v"(M[10]), "v"(M[11]), "v"(M[12]), "v"(M[13]), "v"(M[14]), "v"(M[15]),
           "v"(lo2(q[4])), "v"(hi2(q[4])), "v"(lo2(q[5])), "v"(hi2(q[5])), "v"(lo2(q[6])), "v"(hi2(q[6])),
           "v"(lo2(q[7])), "v"(hi2(q[7])));
+}
+// a quarter of the chain (4 entries, 8 packed FMAs): lets a caller put something between two quarters
+template <bool FIRST>
+__device__ __forceinline__ void mv1_quarter(const v2f& m0, const v2f& m1, const v2f& m2, const v2f& m3, v4f qa, v4f qb, v2f& acc) {
+    if constexpr (FIRST)
+        asm(CM_FIRST(0, 1, 5) CM(0, 2, 6) CM(0, 3, 7) CM(0, 4, 8)
+            : "=&v"(acc) : "v"(m0), "v"(m1), "v"(m2), "v"(m3), "v"(lo2(qa)), "v"(hi2(qa)), "v"(lo2(qb)), "v"(hi2(qb)));
+    else
+        asm(CM(0, 1, 5) CM(0, 2, 6) CM(0, 3, 7) CM(0, 4, 8)
+            : "+v"(acc) : "v"(m0), "v"(m1), "v"(m2), "v"(m3), "v"(lo2(qa)), "v"(hi2(qa)), "v"(lo2(qb)), "v"(hi2(qb)));
 }
 // two matrices applied to the same vector, chains interleaved; in two halves so that the first can start as
 // soon as the first four broadcast reads have landed
