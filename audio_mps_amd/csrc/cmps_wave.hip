@@ -396,11 +396,13 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
 #define BWD_STEP8(P)                                                                                          \
         {                                                                                                     \
             const int jq = j - (7 - (P));                                                                     \
-            const int jr = jq & (CHB - 1), jc = jq & (CH - 1);                                                \
-            own_issue(aYown + jr * 512, aRho + jr * 256, aScl + jc * 32, yh_j, rho_j, c0_j, c1_j);            \
+            own_issue_off<(P) * 512, (P) * 256, (P) * 32>(aYo8, aRo8, aSo8, yh_j, rho_j, c0_j, c1_j);         \
             S = chain_step(S, 0.f, 0.f, std::true_type{}, jq, jq == jhi, std::integral_constant<int, (P)>{}); \
         }
         for (; j >= jlo; j -= 8) {
+            // rows of this octet in the staged chunk: j & 7 == 7 here, so row (j - 7 + P) = octet base + P
+            const unsigned aYo8 = aYown + ((j - 7) & (CHB - 1)) * 512, aRo8 = aRho + ((j - 7) & (CHB - 1)) * 256;
+            const unsigned aSo8 = aScl + ((j - 7) & (CH - 1)) * 32;
             BWD_STEP8(7) BWD_STEP8(6) BWD_STEP8(5) BWD_STEP8(4) BWD_STEP8(3) BWD_STEP8(2) BWD_STEP8(1) BWD_STEP8(0)
             pend = true;                               // applied during the next step (or by the final flush)
         }

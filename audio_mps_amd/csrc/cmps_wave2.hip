@@ -109,6 +109,10 @@ __device__ __forceinline__ void write_lane(float& vec, float val, int sel) {
     asm("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
         : "+v"(vec), "=&s"(keep) : "s"(val), "s"(sel));
 }
+template <int SEL>
+__device__ __forceinline__ void write_lane_c(float& vec, float val) {      // vec[lane SEL] = val, SEL a compile-time constant
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(vec) : "s"(val), "n"(SEL));
+}
 __device__ __forceinline__ float vmax_s(float s, float c) {     // one v_max_f32 (fmaxf adds a canonicalising second one)
     float r;
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "s"(s), "v"(c));
@@ -228,9 +232,41 @@ __global__ __launch_bounds__(128 * WAVES, 1) void k_fwd_wave2(Dev P, const float
                 xsq = y * y;                                                                                  \
                 write_lane(nvec, nprev, (kk_ - 1) & (CH2 - 1));                                               \
             }
-            CHAIN_STEP(0)
-            if (SAVE && c > 0 && lane < CH2) sc[(size_t)((c - 1) >> 1) * 128 + ((c - 1) & 1) * CH2 + lane] = nvec;
-            for (int kk = 1; kk < cnt; ++kk) CHAIN_STEP(kk)
+            // a full chunk runs unrolled with compile-time step numbers: every LDS offset is an immediate, the lane selects of
+            // v_readlane / v_writelane are constants (no M0 save / restore), no loop bookkeeping on the serial chain
+#define CHAIN_STEPC(KK)                                                                                       \
+            {                                                                                                 \
+                lds_wait_lo<5>(qu);                                                                           \
+                v2f am;                                                                                       \
+                float nprev;                                                                                  \
+                mv1r_lo(MM, qu, am, xsq);                                                                     \
+                lds_wait_hi_t_after<0>(qu, rho, am);                                                          \
+                mv1r_hi(MM, qu, am, xsq, nprev);                                                              \
+                const float inv = __builtin_amdgcn_rsqf(vmax_s(nprev, 1e-12f));                               \
+                const float y = inv * (u + swapadd(am.x, am.y));                                              \
+                lds_write32_imm<(KK) * RROWB>(ay, y);                                                         \
+                const float yo = osig_of(y, hb);                                                              \
+                const v2f un = cmul2(mk2(y, yo), rho);                                                        \
+                u = un.x;                                                                                     \
+                bcast_issue_tab_off<(((KK) + 1) & (CH2 - 1)) * 256>(aUw, aUr, u, aRho, qu, rho);              \
+                FORM_M(rdlane(sv, ((KK) + 1) & (CH2 - 1)))                                                    \
+                xsq = y * y;                                                                                  \
+                write_lane_c<((KK) + CH2 - 1) & (CH2 - 1)>(nvec, nprev);                                      \
+            }
+            if (cnt == CH2) {
+                CHAIN_STEPC(0)
+                if (SAVE && c > 0 && lane < CH2) sc[(size_t)((c - 1) >> 1) * 128 + ((c - 1) & 1) * CH2 + lane] = nvec;
+                CHAIN_STEPC(1) CHAIN_STEPC(2) CHAIN_STEPC(3) CHAIN_STEPC(4) CHAIN_STEPC(5) CHAIN_STEPC(6) CHAIN_STEPC(7)
+                CHAIN_STEPC(8) CHAIN_STEPC(9) CHAIN_STEPC(10) CHAIN_STEPC(11) CHAIN_STEPC(12) CHAIN_STEPC(13) CHAIN_STEPC(14)
+                CHAIN_STEPC(15) CHAIN_STEPC(16) CHAIN_STEPC(17) CHAIN_STEPC(18) CHAIN_STEPC(19) CHAIN_STEPC(20) CHAIN_STEPC(21)
+                CHAIN_STEPC(22) CHAIN_STEPC(23) CHAIN_STEPC(24) CHAIN_STEPC(25) CHAIN_STEPC(26) CHAIN_STEPC(27) CHAIN_STEPC(28)
+                CHAIN_STEPC(29) CHAIN_STEPC(30) CHAIN_STEPC(31)
+            } else {                                                   // the clip's last, partial chunk
+                CHAIN_STEP(0)
+                if (SAVE && c > 0 && lane < CH2) sc[(size_t)((c - 1) >> 1) * 128 + ((c - 1) & 1) * CH2 + lane] = nvec;
+                for (int kk = 1; kk < cnt; ++kk) CHAIN_STEP(kk)
+            }
+#undef CHAIN_STEPC
 #undef CHAIN_STEP
             lds_wait_hi_t<0>(qu, rho);                                 // everything of this chunk has landed
             flag_store(aProd, c + 1, lane);                            // publish (ordered behind the chunk's y rows)

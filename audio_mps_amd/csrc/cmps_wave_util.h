@@ -192,6 +192,23 @@ __device__ __forceinline__ void bcast_issue_tab(unsigned wr, unsigned rd, float 
                    "=&v"(t)
                  : "v"(wr), "v"(mine), "v"(rd), "v"(tab) : "memory");
 }
+// the same with a compile-time offset on the table address
+template <int TOFF>
+__device__ __forceinline__ void bcast_issue_tab_off(unsigned wr, unsigned rd, float mine, unsigned tab, v4f (&o)[8], v2f& t) {
+    asm volatile("ds_write_b32 %9, %10\n\t"
+                 "ds_read_b128 %0, %11\n\tds_read_b128 %1, %11 offset:16\n\t"
+                 "ds_read_b128 %2, %11 offset:32\n\tds_read_b128 %3, %11 offset:48\n\t"
+                 "ds_read_b128 %4, %11 offset:64\n\tds_read_b128 %5, %11 offset:80\n\t"
+                 "ds_read_b128 %6, %11 offset:96\n\tds_read_b128 %7, %11 offset:112\n\t"
+                 "ds_read_b64 %8, %12 offset:%13"
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]),
+                   "=&v"(t)
+                 : "v"(wr), "v"(mine), "v"(rd), "v"(tab), "n"(TOFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void lds_write32_imm(unsigned wr, float v) {
+    asm volatile("ds_write_b32 %0, %1 offset:%2" : : "v"(wr), "v"(v), "n"(OFF) : "memory");
+}
 // row read (no write): this half's 16 entries of a vector written earlier
 __device__ __forceinline__ void rows_issue(unsigned rd, v4f (&o)[8]) {
     asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\t"
@@ -209,6 +226,14 @@ __device__ __forceinline__ void lds_write32(unsigned wr, float v) {
 __device__ __forceinline__ void own_issue(unsigned ay, unsigned ar, unsigned as, v2f& yh, v2f& t, v4f& c0, v4f& c1) {
     asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %6 offset:16"
                  : "=&v"(yh), "=&v"(t), "=&v"(c0), "=&v"(c1) : "v"(ay), "v"(ar), "v"(as) : "memory");
+}
+// the same with compile-time row offsets on per-octet base addresses (keeps the address arithmetic out of the step)
+template <int OY, int OR, int OS>
+__device__ __forceinline__ void own_issue_off(unsigned ay, unsigned ar, unsigned as, v2f& yh, v2f& t, v4f& c0, v4f& c1) {
+    asm volatile("ds_read_b64 %0, %4 offset:%7\n\tds_read_b64 %1, %5 offset:%8\n\tds_read_b128 %2, %6 offset:%9\n\t"
+                 "ds_read_b128 %3, %6 offset:%10"
+                 : "=&v"(yh), "=&v"(t), "=&v"(c0), "=&v"(c1) : "v"(ay), "v"(ar), "v"(as), "n"(OY), "n"(OR), "n"(OS), "n"(OS + 16)
+                 : "memory");
 }
 // LDS operations of one wave complete in order, so "at most N outstanding" retires everything issued
 // before the last N; extra operations hipcc may have in flight only make the wait stricter.
