@@ -59,7 +59,9 @@ class DataParallel:
         flat: [G] float32 tensor on this rank's device (or CPU for gloo).  Returns (host float64 [G], B_global)."""
         if self.world_size == 1:
             return flat.detach().cpu().numpy().astype(np.float64), int(local_clips)
-        buf = torch.empty(flat.numel() + 1, dtype=torch.float32, device=flat.device)
+        # gloo has no device collectives on this build: its (rehearsal / CPU-test) path reduces on the host
+        red_dev = flat.device if self.backend == "nccl" else torch.device("cpu")
+        buf = torch.empty(flat.numel() + 1, dtype=torch.float32, device=red_dev)
         buf[:-1] = flat
         buf[-1] = float(local_clips)
         if self.time_collective and buf.is_cuda:

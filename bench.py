@@ -62,6 +62,9 @@ def parse_args(argv=None):
     p.add_argument("--launcher-selftest", action="store_true",
                    help="ranks only set up the process group (gloo on CPU) and do one all-reduce: tests the launcher")
     p.add_argument("--master-port", type=int, default=0)
+    p.add_argument("--rehearse-on-one-gpu", action="store_true",
+                   help="N > 1 ranks that all use cuda:0 and reduce over gloo on the host: exercises every line of the multi-rank "
+                        "path except RCCL itself on a one-GPU box (the line is marked and is NOT a scaling measurement)")
     return p.parse_args(argv)
 
 
@@ -194,18 +197,21 @@ def cpu_reference_style():
     return rows
 
 
-def profiled_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary (profiles/*pmc_summary.json:
-    FETCH_SIZE and WRITE_SIZE collected in separate passes of this same command, FETCH doubled as
-    MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950).  None if no profile is committed."""
+def profiled_traffic(kernel, D, T, B):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary OF THIS WORKLOAD
+    (profiles/*pmc_summary.json: FETCH_SIZE and WRITE_SIZE collected in separate passes of this same command, FETCH doubled as
+    MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950).  None if no such profile is committed."""
     import glob
+    import re
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.json")), key=os.path.getmtime)
     for path in reversed(files):
         try:
             with open(path) as fh:
-                d = json.load(fh)["kernels"]
-            for name, c in d.items():
-                if kernel in name:
+                doc = json.load(fh)
+            if f"D={D}, T={T}, B={B} " not in doc.get("workload", "") + " ":
+                continue
+            for name, c in doc["kernels"].items():
+                if re.search(r"\b" + re.escape(kernel) + r"\b", name):
                     dv = c["derived"]
                     return {"bytes": dv["hbm_read_bytes_per_launch_corrected"] + dv["hbm_write_bytes_per_launch"],
                             "source": os.path.relpath(path, ROOT)}
@@ -248,9 +254,11 @@ def worker(ARGS):
         raise SystemExit(f"bench.py: --gpus {ARGS.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    if ARGS.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dp = DataParallel(device=dev)
+    dp = DataParallel(backend="gloo" if ARGS.rehearse_on_one_gpu else None, device=dev)
     dp.time_collective = True
 
     D, T, B = ARGS.bond_dim, ARGS.T, ARGS.batch_per_gpu
@@ -261,7 +269,7 @@ def worker(ARGS):
     backend = HipScan(D, device=dev, variant=ARGS.variant, rank1=RANK1_MODES[ARGS.rank1])
     model = PsiCMPS(hp, seed=0, backend=backend)
     trainer = Trainer(model, hp, dp)
-    wave = backend.variant == _capi.CMPS_VARIANT_WAVE
+    wave = backend.variant in (_capi.CMPS_VARIANT_WAVE, _capi.CMPS_VARIANT_WAVE32)
     pair = backend.variant == _capi.CMPS_VARIANT_PAIR
 
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
@@ -316,16 +324,20 @@ def worker(ARGS):
         flops_bwd = 56.0 * D * D * B * N                         # 56 D^2 per (clip, sample)
         flops_fwd = 24.0 * D * D * B * N
         bytes_alg = 8.0 * B * T                                  # 4 B read forward + 4 B read in the reverse sweep
-        kern = {"fwd": {"name": "k_fwd_wave2 (forward scan, two waves per clip)" if wave else "k_fwd_block",
-                        "t": t_fwd, "flops": flops_fwd, "pmc": "k_fwd_wave" if wave else "k_fwd_block"},
+        wave16 = wave and D <= 16 and backend.variant == _capi.CMPS_VARIANT_WAVE
+        kern = {"fwd": {"name": "k_fwd_wave2 (forward scan: chain wave + loss wave on the matrix cores)" if wave else "k_fwd_block",
+                        "t": t_fwd, "flops": flops_fwd, "pmc": "k_fwd_wave2" if wave else "k_fwd_block"},
                 "bwd": {"name": "k_bwd_wave (reverse scan)" if wave else "k_bwd_block", "t": t_bwd, "flops": flops_bwd,
                         "pmc": "k_bwd_wave" if wave else "k_bwd_block"}}
+        if wave16:
+            kern["fwd"].update(name="k_fwd_wave16 (forward scan, 16-row layout: chain wave + loss wave)", pmc="k_fwd_wave16")
+            kern["bwd"].update(name="k_bwd_wave16 (reverse scan, 16-row layout: chain wave + gradient wave)", pmc="k_bwd_wave16")
         if pair:                                                 # D = 128: MFMA pair kernels (bf16 operands, fp32 accumulate)
             kern["fwd"].update(name="k_fwd_pair (forward scan, 4x4x4 bf16 MFMA)", pmc="k_fwd_pair")
             kern["bwd"].update(name="k_bwd_pair + k_grad_pair (reverse scan + gradient GEMM)", pmc="k_bwd_pair")
         dom = "fwd" if t_fwd >= t_bwd else "bwd"                 # the dominant kernel = the longer launch
         oth = "bwd" if dom == "fwd" else "fwd"
-        traffic = profiled_traffic(kern[dom]["pmc"]) if (D, T, B) in ((32, 16000, 1024), (128, 16000, 512), (16, 4096, 256)) else None
+        traffic = profiled_traffic(kern[dom]["pmc"], D, T, B)
         ach = kern[dom]["flops"] / kern[dom]["t"] / 1e12
         peak = BF16_PEAK_TFLOPS if pair else FP32_PEAK_TFLOPS
         whole = (flops_fwd + flops_bwd) / (1e-3 * ms_per_step) / 1e12
@@ -361,7 +373,7 @@ def worker(ARGS):
         if pair:
             dtype = "bf16 (mat-vec operands; fp32 state and accumulate)"
         elif wave:
-            dtype = "f32" if rank1 != 1 else "f32 (rank-1 gradient updates: bf16x2 split, 16 operand bits)"
+            dtype = "f32" if (rank1 != 1 or wave16) else "f32 (rank-1 gradient updates: bf16x2 split, 16 operand bits)"
         else:
             dtype = "f32"
         out = {
@@ -372,13 +384,15 @@ def worker(ARGS):
             "config": {"workload": f"{cfg_name}: PsiCMPS fwd+bwd scan, D={D}, T={T}, batch {B} per GPU"
                                    f" (global {B * world}), damped sine + noise, full optimiser step",
                        "parallelism": f"dp{world}", "kernel_variant": int(backend.variant),
-                       "rank1_updates": RANK1_LABEL[rank1] if wave else None},
+                       "rank1_updates": ("exact fp32 MFMA (16-row layout)" if wave16 else RANK1_LABEL[rank1]) if wave else None},
             "roofline": roofline,
             "final_loss": float(last),
             "per_rank_ms_per_step": {"min": float(np.min(per_rank_ms)), "max": float(np.max(per_rank_ms))},
             "rccl_world_size": rccl_world,
             "allreduce_us": allreduce_us,
         }
+        if ARGS.rehearse_on_one_gpu:
+            out["rehearsal"] = "all ranks share cuda:0 and reduce over gloo on the host: NOT a scaling measurement"
 
     # ---- outside the timed region: CPU baseline, parity of this very workload, precision A/B (rank 0, N = 1 only) ----
     if rank == 0 and world == 1 and not ARGS.no_cpu_baseline:
@@ -403,7 +417,7 @@ def worker(ARGS):
                                   "grad_err_by_tensor": gerr, "tolerance": {"loss": tol_l, "grad": tol_g},
                                   "ok": bool(loss_err <= tol_l and max(gerr.values()) <= tol_g),
                                   "against": "oracle/cmps_oracle.c float32 (parity UNPINNED: no reference-held vectors exist)"}
-        if wave and not ARGS.no_precision_ab:
+        if wave and not wave16 and not ARGS.no_precision_ab:
             ab = {}
             for name, mode in RANK1_MODES.items():               # accuracy first: the timed steps below move the parameters
                 backend.set_rank1(mode)
