@@ -424,12 +424,16 @@ int cmps_rho_loss_fwd(cmps_handle_t h, const float* audio_dev, int B, int T, flo
         return fail(h, CMPS_ERR_WORKSPACE, "cmps_rho_loss_fwd: save_for_bwd needs a CMPS_WS_TRAIN rho workspace");
     Dev P = h->P;
     P.B = B; P.T = T; P.N = T - 1;
-    // D <= 32 (and rank <= 32): the wave-per-clip kernels, unless the block variant was asked for
+    // D <= 32 (and rank <= 32): one wavefront per clip, unless the block variant was asked for -- the forward as row-array
+    // GEMMs on the matrix cores (cmps_rho_mfma.hip); CMPS_VARIANT_WAVE32 keeps the column-by-column kernel (cross-check)
     const bool wave = h->D <= 32 && h->W.rank <= 32 && h->variant_req != CMPS_VARIANT_BLOCK;
-    hipError_t e = wave ? launch_fwd_rho_wave(P, h->W, audio_dev, loss_dev, save_for_bwd != 0, static_cast<hipStream_t>(stream))
-                        : launch_fwd_rho(P, h->W, audio_dev, loss_dev, save_for_bwd != 0, static_cast<hipStream_t>(stream));
+    const bool mfma = wave && h->variant_req != CMPS_VARIANT_WAVE32 && h->W.rank > 8;   // below rank ~10 the column loop is faster
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = mfma ? launch_fwd_rho_mfma(P, h->W, audio_dev, loss_dev, save_for_bwd != 0, s)
+                 : wave ? launch_fwd_rho_wave(P, h->W, audio_dev, loss_dev, save_for_bwd != 0, s)
+                        : launch_fwd_rho(P, h->W, audio_dev, loss_dev, save_for_bwd != 0, s);
     if (e != hipSuccess) return fail_hip(h, e, "cmps_rho_loss_fwd");
-    h->W.stash_layout = wave ? 1 : 0;
+    h->W.stash_layout = mfma ? 2 : (wave ? 1 : 0);
     h->rho_saved = h->rho_bwd_ok = save_for_bwd != 0;
     h->rho_saved_B = B; h->rho_saved_steps = T - 1;
     h->saved_audio = audio_dev; h->saved_loss = loss_dev;
@@ -447,7 +451,7 @@ int cmps_rho_loss_bwd(cmps_handle_t h, const float* audio_dev, int B, int T, flo
     P.B = B; P.T = T; P.N = T - 1;
     P.slabs = h->W.slabs; P.sums = h->W.sums; P.slab_floats = h->W.slab_floats;   // the reduction runs on the rho slabs
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipError_t e = h->W.stash_layout == 1 ? launch_bwd_rho_wave(P, h->W, audio_dev, s) : launch_bwd_rho(P, h->W, audio_dev, s);
+    hipError_t e = h->W.stash_layout != 0 ? launch_bwd_rho_wave(P, h->W, audio_dev, s) : launch_bwd_rho(P, h->W, audio_dev, s);
     if (e != hipSuccess) return fail_hip(h, e, "cmps_rho_loss_bwd (scan)");
     e = launch_reduce_finalize(P, h->saved_loss, grad_dev, s);
     if (e == hipSuccess) e = launch_finalize_rho(P, h->W, grad_dev, s);

@@ -134,6 +134,7 @@ inline RhoLayout make_rho_layout(int D, int rank, int B, int T, int flags) {
 struct RhoDev {
     int rank;
     int stash_layout;    // 0: [B][N][rank][DP] float2 (cmps_rho.hip)  1: [B][N][rank][64] (y own, H y own) (cmps_rho_wave.hip)
+                         // 2: [B][N][rank][64] pairs (y[n], (H y)[n]), n = 2 i + {re, im} (cmps_rho_mfma.hip)
     float* scal;         // [B][NC][2][64]: tr rho'_k and e_k, one step per lane (wave kernels)
     const float2* phi0;  // [rank][DP]
     float2* stash;       // [B][N][rank][DP]
@@ -156,6 +157,7 @@ hipError_t launch_sample_rho(const Dev& P, const RhoDev& W, const float* noise, 
 hipError_t launch_fwd_legacy_wave(const Dev& P, const float* audio, float* loss, bool save, hipStream_t s);
 hipError_t launch_bwd_legacy_wave(const Dev& P, const float* audio, hipStream_t s);
 hipError_t launch_fwd_rho_wave(const Dev& P, const RhoDev& W, const float* audio, float* loss, bool save, hipStream_t s);
+hipError_t launch_fwd_rho_mfma(const Dev& P, const RhoDev& W, const float* audio, float* loss, bool save, hipStream_t s);
 hipError_t launch_bwd_rho_wave(const Dev& P, const RhoDev& W, const float* audio, hipStream_t s);
 hipError_t launch_prep(const Dev& P, const float* R_re, const float* R_im, const float* freqs,
                        const float* psi0_re, const float* psi0_im, float dt, bool rebuild_ttab,

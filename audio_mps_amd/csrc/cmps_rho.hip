@@ -303,7 +303,8 @@ __global__ __launch_bounds__(256) void k_states_rho(Dev P, RhoDev W, int steps, 
     float pn = 0.f;
     for (int idx = t; idx < r * D; idx += 256) {
         const int a = idx / D, d = idx % D;
-        const float2 y = W.stash_layout == 1 ? make_float2(stw[(a * 64 + d) * 2], stw[(a * 64 + d + 32) * 2]) : st[a * DP + d];
+        const float2 y = W.stash_layout == 1 ? make_float2(stw[(a * 64 + d) * 2], stw[(a * 64 + d + 32) * 2])
+                       : W.stash_layout == 2 ? make_float2(stw[(a * 64 + 2 * d) * 2], stw[(a * 64 + 2 * d + 1) * 2]) : st[a * DP + d];
         Y[idx] = y;
         pn += y.x * y.x + y.y * y.y;
     }

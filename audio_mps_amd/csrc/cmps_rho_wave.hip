@@ -138,7 +138,9 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_rho_wave(Dev P, RhoDev W,
     const unsigned aBw = lds_addr(&bcB[w][0]) + i * 8 + h * 4, aBr = lds_addr(&bcB[w][0]) + h * 128;
     const float4* rho4 = reinterpret_cast<const float4*>(P.rho);
     const float* xrow = audio + (size_t)b * T;
-    const float2* st = reinterpret_cast<const float2*>(W.stash) + (size_t)b * N * r * 64 + lane;
+    // stash rows of 64 pairs (y, H y): in lane order (layout 1, k_fwd_rho_wave) or per real component n = 2 i + {re, im}
+    // (layout 2, k_fwd_rho_mfma)
+    const float2* st = reinterpret_cast<const float2*>(W.stash) + (size_t)b * N * r * 64 + (W.stash_layout == 2 ? 2 * i + h : lane);
     const float* sc = W.scal + (size_t)b * NC * 128;
     const float A = P.A;
     for (int a = 0; a < r; ++a) G[w][a][lane] = 0.f;
