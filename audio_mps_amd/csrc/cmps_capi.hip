@@ -398,6 +398,7 @@ int cmps_rho_set_state(cmps_handle_t h, const float* phi_re_dev, const float* ph
     const bool train = (flags & CMPS_WS_TRAIN) != 0;
     W.stash = train ? reinterpret_cast<float2*>(ws + RL.off_stash) : nullptr;
     W.scal = train ? reinterpret_cast<float*>(ws + RL.off_scal) : nullptr;
+    W.p1 = (train && h->D <= 32) ? reinterpret_cast<float*>(ws + RL.off_p1) : nullptr;
     W.stash_layout = 0;
     W.slabs = train ? reinterpret_cast<float*>(ws + RL.off_slabs) : nullptr;
     W.sums = train ? reinterpret_cast<float*>(ws + RL.off_sums) : nullptr;
@@ -451,8 +452,10 @@ int cmps_rho_loss_bwd(cmps_handle_t h, const float* audio_dev, int B, int T, flo
     P.B = B; P.T = T; P.N = T - 1;
     P.slabs = h->W.slabs; P.sums = h->W.sums; P.slab_floats = h->W.slab_floats;   // the reduction runs on the rho slabs
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipError_t e = h->W.stash_layout != 0 ? launch_bwd_rho_wave(P, h->W, audio_dev, s) : launch_bwd_rho(P, h->W, audio_dev, s);
+    hipError_t e = h->W.stash_layout == 2 ? launch_bwd_rho_mfma(P, h->W, audio_dev, s)
+                 : h->W.stash_layout == 1 ? launch_bwd_rho_wave(P, h->W, audio_dev, s) : launch_bwd_rho(P, h->W, audio_dev, s);
     if (e != hipSuccess) return fail_hip(h, e, "cmps_rho_loss_bwd (scan)");
+    P.abar_fix = h->W.stash_layout == 2 ? 1 : 0;   // the MFMA scan sums Re(u^dagger (Q + s R^dagger) ybar); k_finalize removes the Q part
     e = launch_reduce_finalize(P, h->saved_loss, grad_dev, s);
     if (e == hipSuccess) e = launch_finalize_rho(P, h->W, grad_dev, s);
     if (e != hipSuccess) return fail_hip(h, e, "cmps_rho_loss_bwd (reduce)");

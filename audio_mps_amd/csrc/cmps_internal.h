@@ -109,7 +109,7 @@ struct Dev {
 // ---------------------------------------------------------------------------------------------
 struct RhoLayout {
     int rank;
-    size_t off_phi0, off_stash, off_scal, off_slabs, off_sums, total, slab_floats;
+    size_t off_phi0, off_stash, off_scal, off_slabs, off_sums, off_p1, total, slab_floats;
 };
 
 inline RhoLayout make_rho_layout(int D, int rank, int B, int T, int flags) {
@@ -126,6 +126,8 @@ inline RhoLayout make_rho_layout(int D, int rank, int B, int T, int flags) {
         L.off_scal = o;  o = align256(o + (size_t)B * ((N + 63) / 64) * 128 * sizeof(float));
         L.off_slabs = o; o = align256(o + (size_t)B * L.slab_floats * sizeof(float));
         L.off_sums = o;  o = align256(o + (L.slab_floats + 64) * sizeof(float) + 32 * L.slab_floats * sizeof(double));
+        // D <= 32: sum_k 2 ebar_k Y^T Y (real 64 x 64 form, four C/D tiles per clip), accumulated by k_fwd_rho_mfma for the reverse scan
+        L.off_p1 = o;    if (D <= 32) o = align256(o + (size_t)B * 4096 * sizeof(float));
     }
     L.total = o;
     return L;
@@ -136,6 +138,7 @@ struct RhoDev {
     int stash_layout;    // 0: [B][N][rank][DP] float2 (cmps_rho.hip)  1: [B][N][rank][64] (y own, H y own) (cmps_rho_wave.hip)
                          // 2: [B][N][rank][64] pairs (y[n], (H y)[n]), n = 2 i + {re, im} (cmps_rho_mfma.hip)
     float* scal;         // [B][NC][2][64]: tr rho'_k and e_k, one step per lane (wave kernels)
+    float* p1;           // [B][4][16][64]: the forward's part of Rbar (cmps_rho_mfma.hip), raw C/D tiles
     const float2* phi0;  // [rank][DP]
     float2* stash;       // [B][N][rank][DP]
     float* slabs;        // [B][slab]
@@ -158,6 +161,7 @@ hipError_t launch_fwd_legacy_wave(const Dev& P, const float* audio, float* loss,
 hipError_t launch_bwd_legacy_wave(const Dev& P, const float* audio, hipStream_t s);
 hipError_t launch_fwd_rho_wave(const Dev& P, const RhoDev& W, const float* audio, float* loss, bool save, hipStream_t s);
 hipError_t launch_fwd_rho_mfma(const Dev& P, const RhoDev& W, const float* audio, float* loss, bool save, hipStream_t s);
+hipError_t launch_bwd_rho_mfma(const Dev& P, const RhoDev& W, const float* audio, hipStream_t s);
 hipError_t launch_bwd_rho_wave(const Dev& P, const RhoDev& W, const float* audio, hipStream_t s);
 hipError_t launch_prep(const Dev& P, const float* R_re, const float* R_im, const float* freqs,
                        const float* psi0_re, const float* psi0_im, float dt, bool rebuild_ttab,

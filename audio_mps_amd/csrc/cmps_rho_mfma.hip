@@ -47,6 +47,15 @@ __device__ __forceinline__ void mfma6(v16f& acc, const unsigned (&AH)[4], const 
 // W = Mr_ij for c' = c, -Mi_ij for (c', c) = (1, 0), +Mi_ij for (0, 1)
 __device__ __forceinline__ float wform(float2 mij, int cp, int cc) { return cp == cc ? mij.x : (cc ? mij.y : -mij.y); }
 
+// pieces of eight registers x[8 s2 .. 8 s2 + 7] of a C/D tile as the K-fragment of k-step s2
+__device__ __forceinline__ void pieces8(const float (&x)[16], int s2, unsigned (&H)[4], unsigned (&M)[4], unsigned (&L)[4]) {
+#pragma unroll
+    for (int e2 = 0; e2 < 4; ++e2) split3(x[8 * s2 + 2 * e2], x[8 * s2 + 2 * e2 + 1], H[e2], M[e2], L[e2]);
+}
+__device__ __forceinline__ float dpp_nb(float x) {      // the value of lane n ^ 1
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, true));
+}
+
 }  // namespace
 
 template <bool SAVE>
@@ -97,6 +106,13 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_fwd_rho_mfma(Dev P, RhoDev W,
     float* sc = SAVE ? W.scal + (size_t)b * NC * 128 : nullptr;
     const float A = P.A;
     const float sgn = (col & 1) ? 1.f : -1.f;                  // Im lanes add rho_y * partner, Re lanes subtract it
+    // the part of the gradient that needs no cotangent: P1 = sum_k 2 ebar_k Y^T Y (real form of sum_k 2 ebar_k sum_a y_a y_a^dagger),
+    // a GEMM over the rows whose operands are the C/D tiles themselves (see k_bwd_rho_mfma)
+    v16f P1[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int z = 0; z < 2; ++z) P1[x][z] = v16f{};
     float loss = 0.f;
     for (int c = 0; c < NC; ++c) {
         const int kbeg = c * CH;
@@ -182,6 +198,28 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_fwd_rho_mfma(Dev P, RhoDev W,
                     if (s0 + 4 < r) sbase[(size_t)(s0 + 4) * 64] = make_float2(__uint_as_float(ys[1]), __uint_as_float(hs[1]));
                 }
             }
+            if (SAVE) {
+                // 2 ebar_k with the reverse scan's own operations (cmps_rho_wave.hip: zbv, tev)
+                const float inck = rdlane(incv, kk);
+                const float zb = -1.0f / (1.0f + (e * inck) / A);
+                const float te = 2.0f * (zb * inck / A);
+                float ty0[16], ty1[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) { ty0[q] = te * y0[q]; ty1[q] = te * y1[q]; }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    unsigned TH[2][4], TM[2][4], TL[2][4];
+                    pieces8(ty0, s2, TH[0], TM[0], TL[0]);
+                    pieces8(ty1, s2, TH[1], TM[1], TL[1]);
+#pragma unroll
+                    for (int tb = 0; tb < 2; ++tb) {
+                        unsigned VH[4], VM[4], VL[4];
+                        pieces8(tb ? y1 : y0, s2, VH, VM, VL);
+#pragma unroll
+                        for (int ta = 0; ta < 2; ++ta) mfma6(P1[ta][tb], TH[ta], TM[ta], TL[ta], VH, VM, VL);
+                    }
+                }
+            }
             // ---- u_a' = rho_k (.) y_a / sqrt(n): the partner component sits in the neighbouring lane ----
             const float sc1 = sqrtf(1.0f / fmaxf(n, 1e-12f));    // :201 (columns scale with the square root)
 #pragma unroll
@@ -202,6 +240,260 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_fwd_rho_mfma(Dev P, RhoDev W,
         }
     }
     if (lane == 0) loss_out[b] = loss;
+    if (SAVE) {
+        float* p1 = W.p1 + (size_t)b * 4096 + lane;
+#pragma unroll
+        for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) p1[((ta * 2 + tb) * 16 + q) * 64] = P1[ta][tb][q];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Reverse scan in the same row-array form (see k_bwd_rho_wave for the column-by-column statement of the adjoint).
+// Arrays are [32 rows a][64 reals n]; between steps they live in registers in the C/D layout of the 32x32 MFMA (column n on
+// the lane, 16 rows per lane and tile), where complex arithmetic needs only the neighbouring lane (n ^ 1, one DPP move):
+//   yhat = y / sqrt(n_k);  u_{k+1} = rho_k yhat;  fbar += dt_k Im(g conj(u_{k+1}));  yhb = conj(rho_k) g;
+//   dot = sum yhat . yhb;  ybar = (yhb - yhat dot) / sqrt(n_k) + 2 ebar_k (H y);   g <- ybar + ybar W'_k,  W'_k = form of Q + s_k R^dagger
+// (one GEMM, operands split into bf16 x 3 as in the forward).  The gradient sums are GEMMs that contract over the ROWS a:
+//   P2 += Ybar^T U_k,   P3 += (s_k Ybar)^T U_k,   P1 += (2 ebar_k Y)^T Y          (real 64 x 64 forms)
+// and a C/D-layout tile IS the operand of such a product, for both factors, with no lane movement (registers 8 s .. 8 s + 7
+// are the elements of k-step s in a permuted but COMMON row order); Qbar, Rbar are read off the real forms at the end.
+// sum_k x_k Re(u^dagger R^dagger ybar) for dA comes from the merged product as in the pure-state kernels (Dev::abar_fix).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_rho_mfma(Dev P, RhoDev W, const float* __restrict__ audio) {
+    __shared__ __attribute__((aligned(16))) float Brow[WAVES][32 * RRLD];     // ybar rows: A operand of the W' GEMM
+    __shared__ __attribute__((aligned(16))) float WQs[64 * 64], WDs[64 * 64]; // W forms of Q and R^dagger: [(t*4+ks)*8+e][lane]
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int col = lane & 31, hk = lane >> 5;
+    // every wave fills its share of the constant operands (before any wave may leave)
+    for (int v = w; v < 64; v += WAVES) {
+        const int t = v >> 5, ks = (v >> 3) & 3, e = v & 7;
+        const int n = 32 * t + col, ii = n >> 1, cc = n & 1;
+        const int m = 16 * ks + 8 * hk + e, jj = m >> 1, cp = m & 1;
+        const float2 qij = P.Q[ii * DPW + jj], rji = P.RT[ii * DPW + jj];           // R[jj][ii]
+        WQs[v * 64 + lane] = wform(qij, cp, cc);
+        WDs[v * 64 + lane] = wform(make_float2(rji.x, -rji.y), cp, cc);             // (R^dagger)[ii][jj]
+    }
+    __syncthreads();
+    const int b = blockIdx.x * WAVES + w;
+    if (b >= P.B) return;
+    const int N = P.N, T = P.T, NC = (N + CH - 1) / CH, r = W.rank;
+    float* Bw = &Brow[w][0];
+    const float* xrow = audio + (size_t)b * T;
+    const float2* st = reinterpret_cast<const float2*>(W.stash) + (size_t)b * N * r * 64;
+    const float* sc = W.scal + (size_t)b * NC * 128;
+    const float A = P.A;
+    const float sgn = (col & 1) ? 1.f : -1.f;        // rotation by rho: own*rho_x + sgn*partner*rho_y (conj: -sgn)
+    // rows of this lane: a(q) = (q & 3) + 8 (q >> 2) + 4 hk
+    // SEL 0: y_a(k) (.x of the stash pairs), SEL 1: (H y)_a(k); separate loads so that neither is held longer than it is used
+    auto load_rows = [&](int k, int sel, float (&v0)[16], float (&v1)[16]) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int a = (q & 3) + 8 * (q >> 2) + 4 * hk;
+            float t0 = 0.f, t1 = 0.f;
+            if (a < r) {
+                const float* row = reinterpret_cast<const float*>(st + ((size_t)k * r + a) * 64) + sel;
+                t0 = row[2 * col];
+                t1 = row[2 * (32 + col)];
+            }
+            v0[q] = t0; v1[q] = t1;
+        }
+    };
+    v16f P2[2][2], P3[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int z = 0; z < 2; ++z) { P2[x][z] = v16f{}; P3[x][z] = v16f{}; }
+    float g0[16], g1[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { g0[q] = 0.f; g1[q] = 0.f; }
+    float facc0 = 0.f, facc1 = 0.f, accA = 0.f, accS = 0.f;
+    float y0[16], y1[16];                            // y(k) on entry to step k; y(k-1) from the middle of the step on
+    load_rows(N - 1, 0, y0, y1);
+    for (int c = NC - 1; c >= 0; --c) {
+        const int kbeg = c * CH;
+        const int cnt = (N - kbeg) < CH ? (N - kbeg) : CH;
+        const int idx = kbeg + lane;
+        const float x0 = idx < T ? xrow[idx] : 0.f, x1 = idx + 1 < T ? xrow[idx + 1] : 0.f;
+        const float incv = x1 - x0;
+        const float nv = idx < N ? sc[(size_t)c * 128 + lane] : 1.f;
+        const float ev = idx < N ? sc[(size_t)c * 128 + 64 + lane] : 0.f;
+        const float invv = sqrtf(1.0f / fmaxf(nv, 1e-12f));
+        const float okv = nv > 1e-12f ? 1.f : 0.f;
+        const float exv = ev * incv;
+        const float zv = exv / A;
+        const float zbv = -1.0f / (1.0f + zv);
+        const float tev = 2.0f * (zbv * incv / A);
+        const float sv = incv / A;
+        const float dtv = idx < N ? P.dtk[idx] : 0.f;
+        if (idx < N) accA += zbv * (-exv / (A * A));
+        const float nbelow = kbeg > 0 ? sc[(size_t)(c - 1) * 128 + 63] : 1.f;          // tr rho' of the step below the chunk
+        const float invbelow = sqrtf(1.0f / fmaxf(nbelow, 1e-12f));
+        for (int kk = cnt - 1; kk >= 0; --kk) {
+            const int k = kbeg + kk;
+            const float s = rdlane(sv, kk), inv = rdlane(invv, kk), ok = rdlane(okv, kk), te = rdlane(tev, kk);
+            const float dtk = rdlane(dtv, kk);
+            const float invp = kk > 0 ? rdlane(invv, kk - 1) : invbelow;
+            const float2 rh0 = P.rho[(size_t)k * DPW + (col >> 1)], rh1 = P.rho[(size_t)k * DPW + 16 + (col >> 1)];
+            const int kp = k > 0 ? k - 1 : 0;
+            const float2 rp0 = P.rho[(size_t)kp * DPW + (col >> 1)], rp1 = P.rho[(size_t)kp * DPW + 16 + (col >> 1)];
+            float hy0[16], hy1[16];
+            load_rows(k, 1, hy0, hy1);                                    // lands during the first loop of phase A
+            // ---- phase A: ybar ----
+            float yb0[16], yb1[16];
+            float accd = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const float yh0 = y0[q] * inv, yh1 = y1[q] * inv;
+                const float gp0 = dpp_nb(g0[q]), gp1 = dpp_nb(g1[q]);
+                const float un0 = fmaf(sgn * rh0.y, dpp_nb(yh0), rh0.x * yh0);           // u_a(k+1) = rho_k yhat
+                const float un1 = fmaf(sgn * rh1.y, dpp_nb(yh1), rh1.x * yh1);
+                facc0 = fmaf(-sgn * dtk * gp0, un0, facc0);                              // Im(g conj(u)): +gi ur on Re lanes, -gr ui on Im lanes
+                facc1 = fmaf(-sgn * dtk * gp1, un1, facc1);
+                const float t0 = fmaf(-sgn * rh0.y, gp0, rh0.x * g0[q]);                 // conj(rho_k) g
+                const float t1 = fmaf(-sgn * rh1.y, gp1, rh1.x * g1[q]);
+                accd = fmaf(yh0, t0, accd);
+                accd = fmaf(yh1, t1, accd);
+                yb0[q] = t0;
+                yb1[q] = t1;
+            }
+            const float dot = ok * sum64(accd);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int row = (q & 3) + 8 * (q >> 2) + 4 * hk;
+                yb0[q] = fmaf(te, hy0[q], (yb0[q] - (y0[q] * inv) * dot) * inv);
+                yb1[q] = fmaf(te, hy1[q], (yb1[q] - (y1[q] * inv) * dot) * inv);
+                Bw[row * RRLD + col] = yb0[q];
+                Bw[row * RRLD + 32 + col] = yb1[q];
+            }
+            if (k > 0) load_rows(k - 1, 0, y0, y1);                       // in flight during the GEMM
+            // ---- ybar W'_k ----
+            v16f m0 = {}, m1 = {};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const float4 f0 = *reinterpret_cast<const float4*>(Bw + col * RRLD + 16 * ks + 8 * hk);
+                const float4 f1 = *reinterpret_cast<const float4*>(Bw + col * RRLD + 16 * ks + 8 * hk + 4);
+                unsigned AH[4], AM[4], AL[4];
+                split3(f0.x, f0.y, AH[0], AM[0], AL[0]);
+                split3(f0.z, f0.w, AH[1], AM[1], AL[1]);
+                split3(f1.x, f1.y, AH[2], AM[2], AL[2]);
+                split3(f1.z, f1.w, AH[3], AM[3], AL[3]);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    unsigned BH[4], BM[4], BL[4];
+#pragma unroll
+                    for (int e2 = 0; e2 < 4; ++e2) {
+                        const int v = (t * 4 + ks) * 8 + 2 * e2;
+                        split3(fmaf(s, WDs[v * 64 + lane], WQs[v * 64 + lane]),
+                               fmaf(s, WDs[(v + 1) * 64 + lane], WQs[(v + 1) * 64 + lane]), BH[e2], BM[e2], BL[e2]);
+                    }
+                    mfma6(t ? m1 : m0, AH, AM, AL, BH, BM, BL);
+                }
+            }
+            // ---- u_a(k) = rho_{k-1} y_a(k-1) / sqrt(tr)  (the initial column at k = 0); g <- ybar + M' ybar ----
+            float u0[16], u1[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                if (k > 0) {
+                    const float yp0 = y0[q] * invp, yp1 = y1[q] * invp;
+                    u0[q] = fmaf(sgn * rp0.y, dpp_nb(yp0), rp0.x * yp0);
+                    u1[q] = fmaf(sgn * rp1.y, dpp_nb(yp1), rp1.x * yp1);
+                } else {
+                    const int a = (q & 3) + 8 * (q >> 2) + 4 * hk;
+                    float v0 = 0.f, v1 = 0.f;
+                    if (a < r) {
+                        const float2 p0 = W.phi0[a * DPW + (col >> 1)], p1 = W.phi0[a * DPW + 16 + (col >> 1)];
+                        v0 = (col & 1) ? p0.y : p0.x;
+                        v1 = (col & 1) ? p1.y : p1.x;
+                    }
+                    u0[q] = v0;
+                    u1[q] = v1;
+                }
+                accS = fmaf(m0[q], u0[q], accS);
+                accS = fmaf(m1[q], u1[q], accS);
+                g0[q] = yb0[q] + m0[q];
+                g1[q] = yb1[q] + m1[q];
+            }
+            // ---- gradient GEMMs over the rows a (ybar is read back from its LDS rows: it is not kept in registers) ----
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                unsigned YH[2][4], YM[2][4], YL[2][4], SH[2][4], SM[2][4], SL[2][4];
+#pragma unroll
+                for (int e2 = 0; e2 < 4; ++e2) {
+                    const int qa = 8 * s2 + 2 * e2, qb = qa + 1;
+                    const int ra = (qa & 3) + 8 * (qa >> 2) + 4 * hk, rb = (qb & 3) + 8 * (qb >> 2) + 4 * hk;
+                    const float a0 = Bw[ra * RRLD + col], b0 = Bw[rb * RRLD + col];
+                    const float a1 = Bw[ra * RRLD + 32 + col], b1 = Bw[rb * RRLD + 32 + col];
+                    split3(a0, b0, YH[0][e2], YM[0][e2], YL[0][e2]);
+                    split3(a1, b1, YH[1][e2], YM[1][e2], YL[1][e2]);
+                    split3(s * a0, s * b0, SH[0][e2], SM[0][e2], SL[0][e2]);
+                    split3(s * a1, s * b1, SH[1][e2], SM[1][e2], SL[1][e2]);
+                }
+#pragma unroll
+                for (int tb = 0; tb < 2; ++tb) {
+                    unsigned UH[4], UM[4], UL[4];
+                    pieces8(tb ? u1 : u0, s2, UH, UM, UL);
+#pragma unroll
+                    for (int ta = 0; ta < 2; ++ta) {
+                        mfma6(P2[ta][tb], YH[ta], YM[ta], YL[ta], UH, UM, UL);
+                        mfma6(P3[ta][tb], SH[ta], SM[ta], SL[ta], UH, UM, UL);
+                    }
+                }
+            }
+        }
+    }
+    // ---- per-clip slab (layout of k_bwd_rho: the pure-state slab followed by the column cotangents) ----
+    float* slab = W.slabs + (size_t)b * W.slab_floats;
+    constexpr int DD = DPW * DPW;
+    for (int idx = lane; idx < (int)W.slab_floats; idx += 64) slab[idx] = 0.f;
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // complex 32 x 32 matrices from the real forms: tile (ta, tb) of P holds P[n = 32 ta + row(q)][n' = 32 tb + col];
+    //   Z_ij = sum z_i conj(w_j) = (P[2i][2j] + P[2i+1][2j+1]) + i (P[2i+1][2j] - P[2i][2j+1]): rows 2i, 2i+1 are registers q, q+1,
+    //   columns 2j, 2j+1 are neighbouring lanes; the even lanes write
+#pragma unroll
+    for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+            for (int q = 0; q < 16; q += 2) {
+                const int n = 32 * ta + (q & 3) + 8 * (q >> 2) + 4 * hk;     // even
+                const int i = n >> 1, j = (32 * tb + col) >> 1;
+                const float* p1 = W.p1 + (size_t)b * 4096 + ((ta * 2 + tb) * 16 + q) * 64 + lane;      // the forward's part
+                const float r_e = p1[0] + P3[ta][tb][q], r_o = p1[64] + P3[ta][tb][q + 1];
+                const float q_e = P2[ta][tb][q], q_o = P2[ta][tb][q + 1];
+                const float rpe = dpp_nb(r_e), rpo = dpp_nb(r_o), qpe = dpp_nb(q_e), qpo = dpp_nb(q_o);
+                if ((col & 1) == 0) {
+                    slab[i * DPW + j] = r_e + rpo;
+                    slab[DD + i * DPW + j] = r_o - rpe;
+                    slab[2 * DD + i * DPW + j] = q_e + qpo;
+                    slab[3 * DD + i * DPW + j] = q_o - qpe;
+                }
+            }
+    // fbar_i: sum over the rows of this lane (both halves) and over the lane pair of component i
+    {
+        const float f0 = swapadd(facc0, facc0), f1 = swapadd(facc1, facc1);           // + the other half's rows
+        const float t0 = f0 + dpp_nb(f0), t1 = f1 + dpp_nb(f1);
+        if (hk == 0 && (col & 1) == 0) {
+            slab[4 * DD + (col >> 1)] = t0;
+            slab[4 * DD + 16 + (col >> 1)] = t1;
+        }
+    }
+    float* tail = slab + 4 * DD + 3 * DPW + 2;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int a = (q & 3) + 8 * (q >> 2) + 4 * hk;
+        if (a < r) {
+            tail[((col & 1) ? r + a : a) * DPW + (col >> 1)] = g0[q];
+            tail[((col & 1) ? r + a : a) * DPW + 16 + (col >> 1)] = g1[q];
+        }
+    }
+    const float sumA = sum64(accA), sumS = sum64(accS);
+    // accS = sum_k Re(u^dagger (Q + s_k R^dagger) ybar); its Q part is removed by k_finalize from the reduced Qbar (Dev::abar_fix)
+    if (lane == 0) slab[4 * DD + 3 * DPW] = sumA - sumS / A;
 }
 
 hipError_t launch_fwd_rho_mfma(const Dev& P, const RhoDev& W, const float* audio, float* loss, bool save, hipStream_t s) {
@@ -210,6 +502,12 @@ hipError_t launch_fwd_rho_mfma(const Dev& P, const RhoDev& W, const float* audio
         hipLaunchKernelGGL(k_fwd_rho_mfma<true>, dim3(nb), dim3(64 * WAVES), 0, s, P, W, audio, loss);
     else
         hipLaunchKernelGGL(k_fwd_rho_mfma<false>, dim3(nb), dim3(64 * WAVES), 0, s, P, W, audio, loss);
+    return hipGetLastError();
+}
+
+hipError_t launch_bwd_rho_mfma(const Dev& P, const RhoDev& W, const float* audio, hipStream_t s) {
+    const unsigned nb = (unsigned)((P.B + WAVES - 1) / WAVES);
+    hipLaunchKernelGGL(k_bwd_rho_mfma, dim3(nb), dim3(64 * WAVES), 0, s, P, W, audio);
     return hipGetLastError();
 }
 

@@ -105,7 +105,9 @@ def test_sampling_two_level_system():
     (7, 256, 8, None, 1e-4, None),       # the reference tests' shape
     (7, 100, 3, 2, 0.5, 0.3),            # low rank, visible damping
     (16, 130, 4, 5, 1e-4, None),
-    (32, 96, 3, 32, 1e-4, None),         # full rank at the wave kernels' D
+    (32, 96, 3, 32, 1e-4, None),         # full rank at the wave kernels' D (row-array GEMM kernels, cmps_rho_mfma.hip)
+    (32, 150, 3, 17, 0.3, 0.4),          # GEMM kernels: ragged rank, visible damping, three 64-step chunks
+    (20, 129, 2, 9, 0.2, 0.5),           # GEMM kernels: padded D, the smallest rank they take, a one-step last chunk
     (40, 40, 2, 6, 1e-4, None),          # D > 32
     (72, 24, 2, 3, 1e-4, None),          # D > 64 (two-wave workgroups)
     (64, 12, 2, 40, 1e-4, None),         # more than 64 KB of LDS-resident columns in the reverse sweep
@@ -249,3 +251,28 @@ def test_rho_wave_and_block_kernels_agree(D, rank):
         assert rel_inf(ga[k], gb[k]) <= GRAD_RTOL, k
     ra, rb = m.rho_evolve_with_data(), blk.rho_evolve_with_data()
     assert rel_inf(ra, rb) <= 1e-5
+
+
+@pytest.mark.parametrize("D,rank,T,B", [(32, 32, 200, 5), (32, 11, 65, 3), (24, 24, 130, 9)])
+def test_rho_gemm_and_column_kernels_agree(D, rank, T, B):
+    """rank > 8 runs the scan as row-array GEMMs on the matrix cores (cmps_rho_mfma.hip, bf16 x 3 operand split);
+    CMPS_VARIANT_WAVE32 keeps the column-by-column float32 wave kernels (cmps_rho_wave.hip).  B = 9 leaves a partly
+    filled last workgroup.  Loss, gradients and the saved states must agree to float32 tolerance."""
+    from audio_mps_amd import RhoCMPS, _capi
+    from audio_mps_amd.scan import HipScan
+    m, audio = _rho_model(D, T, B, rank=rank, sigma=0.2, seed=13, rscale=0.5)
+    colk = RhoCMPS(m.hparams, data_iterator=audio, seed=13, backend=HipScan(D, variant=_capi.CMPS_VARIANT_WAVE32))
+    for k in m.variables:
+        colk.variables[k] = m.variables[k].copy()
+    a, b = m.loss_per_clip(), colk.loss_per_clip()
+    assert np.max(np.abs(a - b) / np.maximum(np.abs(b), 1.0)) <= LOSS_RTOL
+    la, ga = m.loss_and_grads()
+    lb, gb = colk.loss_and_grads()
+    assert abs(float(la) - float(lb)) <= LOSS_RTOL * max(abs(float(lb)), 1.0)
+    for k in ga:
+        assert rel_inf(ga[k], gb[k]) <= GRAD_RTOL, k
+    assert rel_inf(m.rho_evolve_with_data(), colk.rho_evolve_with_data()) <= 1e-5
+    # a second backward on fresh forward state gives the same gradients (the forward's P1 buffer is rewritten, not accumulated)
+    _, ga2 = m.loss_and_grads()
+    for k in ga:
+        np.testing.assert_array_equal(ga[k], ga2[k])
