@@ -3,7 +3,7 @@
 
 For every row: device time of one call at a stated shape (HIP events around the launches, median of a few rounds, inputs
 resident in HBM), the throughput in audio samples/s, and the same arithmetic on the host CPU (the numpy oracle, one
-process, a bounded sample) for scale.  Prints one JSON object; scripts/.. -> profiles/r1_next_rows.json.
+process, a bounded sample) for scale.  Prints one JSON object; scripts/.. -> profiles/r2_next_rows.json.
 """
 import json
 import os
@@ -83,9 +83,12 @@ for rank in (4, 32):
                                                               rm.variables["freqs"], np.zeros(32, np.float32), np.zeros(32, np.float32),
                                                               scaled_R=True, scaled_freqs=True), rm.variables["Wx"], rm.variables["Wy"], a[:4, :200])
     cpu = 4 * 200 / (time.perf_counter() - t0)
-    res[f"rho_cmps_rank{rank}"] = {"shape": f"D=32, rank={rank}, T={T}, B={B}, fwd+bwd", "kernel": "k_fwd_rho_wave + k_bwd_rho_wave (wave per clip)", "ms": ms,
+    res[f"rho_cmps_rank{rank}"] = {"shape": f"D=32, rank={rank}, T={T}, B={B}, fwd+bwd", "kernel": ("k_fwd_rho_mfma + k_bwd_rho_mfma (wave per clip, row-array GEMMs, bf16 x 3 operands)" if rank > 8 else
+                                              "k_fwd_rho_wave + k_bwd_rho_wave (wave per clip, column by column)"), "ms": ms,
                                    "samples_per_s": B * T / ms * 1e3, "cpu_numpy_samples_per_s": cpu,
-                                   "bound": "straight-line wave-per-clip kernels, 3 r D^2 complex MACs + 6 r exact fp32 MFMAs per step (issue / LDS latency)"}
+                                   "bound": ("matrix pipe + operand splitting: 144 (forward, training) + 144 (reverse) 32x32x16 bf16 MFMAs per step, independent of the rank up to 32"
+                                             if rank > 8 else
+                                             "straight-line wave-per-clip kernels, 3 r D^2 complex MACs + 6 r exact fp32 MFMAs per step (issue / LDS latency)")}
 
 # ---- rank 4: TFRecord reader (host, pure Python): records of 65536 float32 samples
 import tempfile
