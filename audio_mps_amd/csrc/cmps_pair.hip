@@ -173,6 +173,209 @@ __device__ __forceinline__ void rows_of(const f4& t, float& ra, float& rb) {
     rb = half_add(t[1], t[3]);
 }
 
+// ---- a mat-vec pair with the vector streamed through three 4-read buffers (48 VGPRs instead of 64 .. 128: with the whole
+// vector in registers next to two matrices' fragments the compiler parks fragments in AGPRs and copies two of them back
+// in front of every MFMA -- measured 57 v_accvgpr_read per step in the reverse scan) ----
+__device__ __forceinline__ void rd4g(unsigned addr, u4 (&o)[4]) {
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\t"
+                 "ds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48"
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]) : "v"(addr) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void rd_wait4(u4 (&o)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]) : "n"(N) : "memory");
+}
+// Sixteen (two matrices) or eight (one matrix) MFMAs as ONE asm statement: the A fragments are read straight from AGPRs
+// (constraint "a": they stay there for the whole kernel, no copies), the accumulators live in VGPRs where the VALU tail
+// reads them, and the instruction order is fixed -- four accumulators in rotation keep dependent MFMAs four instructions
+// apart, which is what the 2-pass 4x4x4 needs; the compiler cannot see inside, so the wait states between the last MFMA
+// and the first VALU read of an accumulator (s_nop 7) are part of the LAST group's text.
+#if defined(CMPS_DIAG) && defined(PABL_NO_MFMA)       // diagnostic builds only (scripts/ablate.py)
+#define PAIR_ASM(TEXT) "s_nop 0"
+#else
+#define PAIR_ASM(TEXT) TEXT
+#endif
+#define PAIR_G2_OPS(FA, FB, g, v)                                                                                              \
+    "a"(FA[8 * (g)]), "a"(FA[8 * (g) + 1]), "a"(FA[8 * (g) + 2]), "a"(FA[8 * (g) + 3]), "a"(FA[8 * (g) + 4]),                    \
+    "a"(FA[8 * (g) + 5]), "a"(FA[8 * (g) + 6]), "a"(FA[8 * (g) + 7]),                                                            \
+    "a"(FB[8 * (g)]), "a"(FB[8 * (g) + 1]), "a"(FB[8 * (g) + 2]), "a"(FB[8 * (g) + 3]), "a"(FB[8 * (g) + 4]),                    \
+    "a"(FB[8 * (g) + 5]), "a"(FB[8 * (g) + 6]), "a"(FB[8 * (g) + 7]),                                                            \
+    "v"(u2{v[0].x, v[0].y}), "v"(u2{v[0].z, v[0].w}), "v"(u2{v[1].x, v[1].y}), "v"(u2{v[1].z, v[1].w}),                          \
+    "v"(u2{v[2].x, v[2].y}), "v"(u2{v[2].z, v[2].w}), "v"(u2{v[3].x, v[3].y}), "v"(u2{v[3].z, v[3].w})
+template <int G, bool FIRST, bool LAST, int NT>
+__device__ __forceinline__ void mm2g(const u2 (&FA)[NT], const u2 (&FB)[NT], const u4 (&v)[4], Acc2& x, Acc2& y) {
+    if constexpr (FIRST && LAST) {
+        asm volatile(PAIR_ASM(
+                     "v_mfma_f32_4x4x4_16b_bf16 %0, %4, %20, 0\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %1, %12, %20, 0\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %2, %5, %21, 0\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %3, %13, %21, 0\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %0, %6, %22, %0\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %1, %14, %22, %1\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %2, %7, %23, %2\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %3, %15, %23, %3\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %0, %8, %24, %0\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %1, %16, %24, %1\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %2, %9, %25, %2\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %3, %17, %25, %3\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %0, %10, %26, %0\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %1, %18, %26, %1\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %2, %11, %27, %2\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %3, %19, %27, %3\n\t"
+                     "s_nop 7")
+                     : "=&v"(x.a), "=&v"(y.a), "=&v"(x.b), "=&v"(y.b) : PAIR_G2_OPS(FA, FB, G, v));
+    } else if constexpr (FIRST) {
+        asm volatile(PAIR_ASM(
+                     "v_mfma_f32_4x4x4_16b_bf16 %0, %4, %20, 0\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %1, %12, %20, 0\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %2, %5, %21, 0\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %3, %13, %21, 0\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %0, %6, %22, %0\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %1, %14, %22, %1\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %2, %7, %23, %2\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %3, %15, %23, %3\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %0, %8, %24, %0\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %1, %16, %24, %1\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %2, %9, %25, %2\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %3, %17, %25, %3\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %0, %10, %26, %0\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %1, %18, %26, %1\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %2, %11, %27, %2\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %3, %19, %27, %3")
+                     : "=&v"(x.a), "=&v"(y.a), "=&v"(x.b), "=&v"(y.b) : PAIR_G2_OPS(FA, FB, G, v));
+    } else if constexpr (LAST) {
+        asm volatile(PAIR_ASM(
+                     "v_mfma_f32_4x4x4_16b_bf16 %0, %4, %20, %0\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %1, %12, %20, %1\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %2, %5, %21, %2\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %3, %13, %21, %3\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %0, %6, %22, %0\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %1, %14, %22, %1\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %2, %7, %23, %2\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %3, %15, %23, %3\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %0, %8, %24, %0\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %1, %16, %24, %1\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %2, %9, %25, %2\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %3, %17, %25, %3\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %0, %10, %26, %0\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %1, %18, %26, %1\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %2, %11, %27, %2\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %3, %19, %27, %3\n\t"
+                     "s_nop 7")
+                     : "+v"(x.a), "+v"(y.a), "+v"(x.b), "+v"(y.b) : PAIR_G2_OPS(FA, FB, G, v));
+    } else {
+        asm volatile(PAIR_ASM(
+                     "v_mfma_f32_4x4x4_16b_bf16 %0, %4, %20, %0\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %1, %12, %20, %1\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %2, %5, %21, %2\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %3, %13, %21, %3\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %0, %6, %22, %0\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %1, %14, %22, %1\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %2, %7, %23, %2\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %3, %15, %23, %3\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %0, %8, %24, %0\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %1, %16, %24, %1\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %2, %9, %25, %2\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %3, %17, %25, %3\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %0, %10, %26, %0\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %1, %18, %26, %1\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %2, %11, %27, %2\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %3, %19, %27, %3")
+                     : "+v"(x.a), "+v"(y.a), "+v"(x.b), "+v"(y.b) : PAIR_G2_OPS(FA, FB, G, v));
+    }
+}
+#define PAIR_G1_OPS(FA, g, v)                                                                                                  \
+    "a"(FA[8 * (g)]), "a"(FA[8 * (g) + 1]), "a"(FA[8 * (g) + 2]), "a"(FA[8 * (g) + 3]), "a"(FA[8 * (g) + 4]),                    \
+    "a"(FA[8 * (g) + 5]), "a"(FA[8 * (g) + 6]), "a"(FA[8 * (g) + 7]),                                                            \
+    "v"(u2{v[0].x, v[0].y}), "v"(u2{v[0].z, v[0].w}), "v"(u2{v[1].x, v[1].y}), "v"(u2{v[1].z, v[1].w}),                          \
+    "v"(u2{v[2].x, v[2].y}), "v"(u2{v[2].z, v[2].w}), "v"(u2{v[3].x, v[3].y}), "v"(u2{v[3].z, v[3].w})
+template <int G, bool FIRST, bool LAST, int NT>
+__device__ __forceinline__ void mm1g(const u2 (&FA)[NT], const u4 (&v)[4], Acc4& x) {
+    if constexpr (FIRST) {
+        asm volatile(PAIR_ASM(
+                     "v_mfma_f32_4x4x4_16b_bf16 %0, %4, %12, 0\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %1, %5, %13, 0\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %2, %6, %14, 0\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %3, %7, %15, 0\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %0, %8, %16, %0\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %1, %9, %17, %1\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %2, %10, %18, %2\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %3, %11, %19, %3")
+                     : "=&v"(x.a), "=&v"(x.b), "=&v"(x.c), "=&v"(x.d) : PAIR_G1_OPS(FA, G, v));
+    } else if constexpr (LAST) {
+        asm volatile(PAIR_ASM(
+                     "v_mfma_f32_4x4x4_16b_bf16 %0, %4, %12, %0\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %1, %5, %13, %1\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %2, %6, %14, %2\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %3, %7, %15, %3\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %0, %8, %16, %0\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %1, %9, %17, %1\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %2, %10, %18, %2\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %3, %11, %19, %3\n\t"
+                     "s_nop 7")
+                     : "+v"(x.a), "+v"(x.b), "+v"(x.c), "+v"(x.d) : PAIR_G1_OPS(FA, G, v));
+    } else {
+        asm volatile(PAIR_ASM(
+                     "v_mfma_f32_4x4x4_16b_bf16 %0, %4, %12, %0\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %1, %5, %13, %1\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %2, %6, %14, %2\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %3, %7, %15, %3\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %0, %8, %16, %0\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %1, %9, %17, %1\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %2, %10, %18, %2\n\t"
+                     "v_mfma_f32_4x4x4_16b_bf16 %3, %11, %19, %3")
+                     : "+v"(x.a), "+v"(x.b), "+v"(x.c), "+v"(x.d) : PAIR_G1_OPS(FA, G, v));
+    }
+}
+// the vector at LDS address `addr` (PD / 32 groups of four 16-byte reads) against two matrices / one matrix.
+// SHADOW runs after the first reads are issued (work nothing on the chain waits for).
+template <int PD, typename Shadow>
+__device__ __forceinline__ void matvec2(const u2 (&FA)[PD / 4], const u2 (&FB)[PD / 4], unsigned addr, Acc2& x, Acc2& y, Shadow&& shadow) {
+    constexpr int NG = PD / 32;
+    u4 b0[4], b1[4], b2[4];
+    rd4g(addr, b0);
+    rd4g(addr + 64, b1);
+    if constexpr (NG > 2) rd4g(addr + 128, b2);
+    shadow();
+    if constexpr (NG == 2) {
+        rd_wait4<4>(b0); mm2g<0, true, false>(FA, FB, b0, x, y);
+        rd_wait4<0>(b1); mm2g<1, false, true>(FA, FB, b1, x, y);
+    } else if constexpr (NG == 3) {
+        rd_wait4<8>(b0); mm2g<0, true, false>(FA, FB, b0, x, y);
+        rd_wait4<4>(b1); mm2g<1, false, false>(FA, FB, b1, x, y);
+        rd_wait4<0>(b2); mm2g<2, false, true>(FA, FB, b2, x, y);
+    } else {
+        rd_wait4<8>(b0); mm2g<0, true, false>(FA, FB, b0, x, y);
+        rd4g(addr + 192, b0);
+        rd_wait4<8>(b1); mm2g<1, false, false>(FA, FB, b1, x, y);
+        rd_wait4<4>(b2); mm2g<2, false, false>(FA, FB, b2, x, y);
+        rd_wait4<0>(b0); mm2g<3, false, true>(FA, FB, b0, x, y);
+    }
+}
+template <int PD, typename Shadow>
+__device__ __forceinline__ void matvec1(const u2 (&FA)[PD / 4], unsigned addr, Acc4& x, Shadow&& shadow) {
+    constexpr int NG = PD / 32;
+    u4 b0[4], b1[4], b2[4];
+    rd4g(addr, b0);
+    rd4g(addr + 64, b1);
+    if constexpr (NG > 2) rd4g(addr + 128, b2);
+    shadow();
+    if constexpr (NG == 2) {
+        rd_wait4<4>(b0); mm1g<0, true, false>(FA, b0, x);
+        rd_wait4<0>(b1); mm1g<1, false, true>(FA, b1, x);
+    } else if constexpr (NG == 3) {
+        rd_wait4<8>(b0); mm1g<0, true, false>(FA, b0, x);
+        rd_wait4<4>(b1); mm1g<1, false, false>(FA, b1, x);
+        rd_wait4<0>(b2); mm1g<2, false, true>(FA, b2, x);
+    } else {
+        rd_wait4<8>(b0); mm1g<0, true, false>(FA, b0, x);
+        rd4g(addr + 192, b0);
+        rd_wait4<8>(b1); mm1g<1, false, false>(FA, b1, x);
+        rd_wait4<4>(b2); mm1g<2, false, false>(FA, b2, x);
+        rd_wait4<0>(b0); mm1g<3, false, true>(FA, b0, x);
+    }
+}
+
 // rho rows are staged through LDS one 32-step chunk at a time (a row per step straight from L2 / HBM costs its full
 // latency every step: the table is 16 MB at D = 128); the next chunk is loaded into registers at the start of a chunk and
 // committed to the other buffer in the middle of it
@@ -181,25 +384,23 @@ template <int D>
 struct RhoStage {
     __attribute__((aligned(16))) float2 row[2][RCH][D];
 };
-// D / 32 waves (tid < 2 D) move one chunk: 32 rows x D / 2 float4 = 8 float4 per thread
+// D / 32 waves (tid < 2 D) move one chunk: 32 rows x D / 2 float4 = 8 float4 per thread.  Eight named values, not an array
+// (the array went through scratch memory); all loads are issued before the first store.
 template <int D>
-__device__ __forceinline__ void rho_load(const Dev& P, int chunk, int tid, float4 (&r)[8]) {
+__device__ __forceinline__ void rho_stage(const Dev& P, RhoStage<D>& S, int chunk, int buf, int tid) {
     const float4* src = reinterpret_cast<const float4*>(P.rho);       // [N + 1][D] float2 = D / 2 float4 per row
     const int maxrow = P.N;                                            // the table has N + 1 rows
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    auto ld = [&](int i) {
         const int e = tid + 2 * D * i;
         int rowi = chunk * RCH + e / (D / 2);
         rowi = rowi < 0 ? 0 : (rowi > maxrow ? maxrow : rowi);
-        r[i] = src[(size_t)rowi * (D / 2) + e % (D / 2)];
-    }
-}
-template <int D>
-__device__ __forceinline__ void rho_commit(RhoStage<D>& S, int buf, int tid, const float4 (&r)[8]) {
-    asm volatile("" ::: "memory");      // all eight loads are issued before the first store (else: load, wait, store, x 8)
+        return src[(size_t)rowi * (D / 2) + e % (D / 2)];
+    };
+    const float4 r0 = ld(0), r1 = ld(1), r2 = ld(2), r3 = ld(3), r4 = ld(4), r5 = ld(5), r6 = ld(6), r7 = ld(7);
+    __builtin_amdgcn_sched_barrier(0);
     float4* dst = reinterpret_cast<float4*>(&S.row[buf][0][0]);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) dst[tid + 2 * D * i] = r[i];
+    dst[tid] = r0;             dst[tid + 2 * D] = r1;      dst[tid + 4 * D] = r2;      dst[tid + 6 * D] = r3;
+    dst[tid + 8 * D] = r4;     dst[tid + 10 * D] = r5;     dst[tid + 12 * D] = r6;     dst[tid + 14 * D] = r7;
 }
 
 // A fragments of one matrix for this lane: frag[t] = 4 bf16 = M_part[row][4t..4t+3]
@@ -279,11 +480,7 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
         float inv = 1.f;                                              // 1/sqrt(max(|y_{k-1}|^2, eps)) of this lane's clip
         float sv0 = 0.f, sv1 = 0.f;                                   // s = x / A of the current 64 steps, lane <-> step
         write_vec(L.vec[0][0], uta, utb);
-        {
-            float4 rpre[8];
-            rho_load<PD>(P, 0, tid, rpre);
-            rho_commit<PD>(RS, 0, tid, rpre);
-        }
+        rho_stage<PD>(P, RS, 0, 0, tid);
         __syncthreads();
         for (int k = 0; k <= N + 1; ++k) {
             const int p = k & 1;
@@ -295,9 +492,7 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
                     sv1 = ((in1 ? xr1[idx + 1] : 0.f) - (in0 ? xr1[idx] : 0.f)) / A;
                 }
                 if ((k & (RCH - 1)) == 0) {                            // next chunk of rho into the other buffer
-                    float4 rpre[8];
-                    rho_load<PD>(P, k / RCH + 1, tid, rpre);
-                    rho_commit<PD>(RS, (k / RCH + 1) & 1, tid, rpre);
+                    rho_stage<PD>(P, RS, k / RCH + 1, (k / RCH + 1) & 1, tid);
                 }
                 const float2 rha = RS.row[(k / RCH) & 1][k & (RCH - 1)][ia];   // rho_k of this lane's rows
                 const float2 rhb = RS.row[(k / RCH) & 1][k & (RCH - 1)][ib];
@@ -305,25 +500,8 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
                     inv = __builtin_amdgcn_rsqf(fmaxf(sum_waves<PWV>(&L.nrm[p][q][0]), 1e-12f));   // model.py:332
                 }
                 const unsigned aU = lds_addr_of(L.vec[p][0]) + rd_off;
-                u4 B0[8], B1[8];
-                Acc2 cR = {z4, z4}, cQ = {z4, z4};
-                rd8(aU, B0);
-                if constexpr (PD == 128) {
-                    rd8(aU + 128, B1);
-                    rd_wait<8>(B0);
-                    mm2<0>(FR, FQ, B0, cR, cQ);
-                    rd_wait<0>(B1);
-                    mm2<8>(FR, FQ, B1, cR, cQ);
-                } else if constexpr (PD == 96) {
-                    rd4(aU + 128, B1);
-                    rd_wait<4>(B0);
-                    mm2<0>(FR, FQ, B0, cR, cQ);
-                    rd_wait<0>(B1);
-                    mm2<8, NT, 4>(FR, FQ, B1, cR, cQ);
-                } else {
-                    rd_wait<0>(B0);
-                    mm2<0>(FR, FQ, B0, cR, cQ);
-                }
+                Acc2 cR, cQ;
+                matvec2<PD>(FR, FQ, aU, cR, cQ, [] {});
                 const int kl = k & (PCH - 1);
                 const float s = q ? rdl(sv1, kl) : rdl(sv0, kl);
                 float ra, rb, qa, qb;
@@ -379,26 +557,9 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
             }
             // ---- H y_{k-1}, the stash row, the partial of e_{k-1} ----
             const unsigned aY = lds_addr_of(L.vec[p][1]) + rd_off;
-            u4 B0[8], B1[8];
-            rd8(aY, B0);
-            if constexpr (PD == 128) rd8(aY + 128, B1);
-            if constexpr (PD == 96) rd4(aY + 128, B1);
-            const float2 yv = yf[p][w][lane];
-            Acc4 cH = {z4, z4, z4, z4};
-            if constexpr (PD == 128) {
-                rd_wait<8>(B0);
-                mm1<0>(FH, B0, cH);
-                rd_wait<0>(B1);
-                mm1<8>(FH, B1, cH);
-            } else if constexpr (PD == 96) {
-                rd_wait<4>(B0);
-                mm1<0>(FH, B0, cH);
-                rd_wait<0>(B1);
-                mm1<8, NT, 4>(FH, B1, cH);
-            } else {
-                rd_wait<0>(B0);
-                mm1<0>(FH, B0, cH);
-            }
+            Acc4 cH;
+            float2 yv;
+            matvec1<PD>(FH, aY, cH, [&] { yv = yf[p][w][lane]; });
             float ha, hb;                                              // ((R + R^dagger) y_{k-1}) rows ia / ib
             rows_of((cH.a + cH.b) + (cH.c + cH.d), ha, hb);
             if (SAVE) st[(size_t)(k - 1) * PWV * 64] = make_float4(yv.x, yv.y, ha, hb);
@@ -560,13 +721,10 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
     // rho: 32-step chunks staged in LDS, descending; chunk j lives in buffer j & 1 and is loaded when the sweep enters
     // chunk j + 1 (rows k and k - 1 of a step can straddle two chunks, so two are always resident)
     {
-        float4 rpre[8];
         const int cl = (N - 1) / RCH;
-        rho_load<PD>(P, cl, threadIdx.x, rpre);
-        rho_commit<PD>(RS, cl & 1, threadIdx.x, rpre);
+        rho_stage<PD>(P, RS, cl, cl & 1, threadIdx.x);
         if (cl > 0) {
-            rho_load<PD>(P, cl - 1, threadIdx.x, rpre);
-            rho_commit<PD>(RS, (cl - 1) & 1, threadIdx.x, rpre);
+            rho_stage<PD>(P, RS, cl - 1, (cl - 1) & 1, threadIdx.x);
         }
     }
     __syncthreads();
@@ -576,9 +734,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
         const int jl = k & (PCH - 1), cp = (k / PCH) & 1;
         if (jl == 0 && k > 0) chunk_rows(k / PCH - 1);                 // u_k needs inv_{k-1}: the chunk below, other buffer
         if ((k & (RCH - 1)) == RCH - 1 && k != N - 1 && k >= RCH) {    // entering rho chunk k / RCH: fetch the one below
-            float4 rpre[8];
-            rho_load<PD>(P, k / RCH - 1, threadIdx.x, rpre);
-            rho_commit<PD>(RS, (k / RCH - 1) & 1, threadIdx.x, rpre);
+            rho_stage<PD>(P, RS, k / RCH - 1, (k / RCH - 1) & 1, threadIdx.x);
         }
         const float2 rha = RS.row[(k / RCH) & 1][k & (RCH - 1)][ia], rhb = RS.row[(k / RCH) & 1][k & (RCH - 1)][ib];
         const int km = k > 0 ? k - 1 : 0;
@@ -596,35 +752,15 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
         st[(size_t)k * PWV * 64] = make_float4(ya, yb, yba, ybb);      // the row the gradient GEMM reads
         lds_barrier();
         const f4 z4 = {0.f, 0.f, 0.f, 0.f};
-        Acc2 cQ = {z4, z4}, cD = {z4, z4};
-        {
-            const unsigned aV = lds_addr_of(L.vec[p][0]) + rd_off;
-            u4 B0[8], B1[8];
-            rd8(aV, B0);
-            if constexpr (PD == 128) rd8(aV + 128, B1);
-            if constexpr (PD == 96) rd4(aV + 128, B1);
-            {   // off the chain, in the shadow of the reads and the MFMAs: u_{k+1} = rho_k yhat and the frequency gradient
-                // (meaningful in the Re lanes)
-                const float una = rha.x * yha + sgn * rha.y * dpp_mov<0xB1>(yha);
-                const float unb = rhb.x * yhb + sgn * rhb.y * dpp_mov<0xB1>(yhb);
-                facca += dt * (pga * una - ga * dpp_mov<0xB1>(una));
-                faccb += dt * (pgb * unb - gb * dpp_mov<0xB1>(unb));
-            }
-            if constexpr (PD == 128) {
-                rd_wait<8>(B0);
-                mm2<0>(FQ, FD, B0, cQ, cD);
-                rd_wait<0>(B1);
-                mm2<8>(FQ, FD, B1, cQ, cD);
-            } else if constexpr (PD == 96) {
-                rd_wait<4>(B0);
-                mm2<0>(FQ, FD, B0, cQ, cD);
-                rd_wait<0>(B1);
-                mm2<8, NT, 4>(FQ, FD, B1, cQ, cD);
-            } else {
-                rd_wait<0>(B0);
-                mm2<0>(FQ, FD, B0, cQ, cD);
-            }
-        }
+        Acc2 cQ, cD;
+        matvec2<PD>(FQ, FD, lds_addr_of(L.vec[p][0]) + rd_off, cQ, cD, [&] {
+            // off the chain, in the shadow of the reads and the MFMAs: u_{k+1} = rho_k yhat and the frequency gradient
+            // (meaningful in the Re lanes)
+            const float una = rha.x * yha + sgn * rha.y * dpp_mov<0xB1>(yha);
+            const float unb = rhb.x * yhb + sgn * rhb.y * dpp_mov<0xB1>(yhb);
+            facca += dt * (pga * una - ga * dpp_mov<0xB1>(una));
+            faccb += dt * (pgb * unb - gb * dpp_mov<0xB1>(unb));
+        });
         float qa, qb, da, db;
         rows_of(cQ.a + cQ.b, qa, qb);
         rows_of(cD.a + cD.b, da, db);
