@@ -19,6 +19,8 @@ namespace cmps {
 //   hst      : [B][N][64][2] float    wave variants' stash (same region as `stash`), 512 B per step: pairs (y_k, (R + R^dagger) y_k)
 //                                     per real component n = 2 i + {re, im} (32-row layout) or per lane (16-row layout)
 //   scal     : [B][NC][2][64] float   per 64-step chunk: |y_k|^2 and e_k, one step per lane (wave variant)
+//   gops     : [pairs][ceil(N/8)][5][2 clips][2 comps][DP] x 8 bf16   D > 32, TRAIN: operands of the gradient GEMM, written
+//                                     by the pair kernels' reverse scan (te y | ybar | s ybar | y | u), eight steps per 16 B
 //   slabs    : [B][slab] float        per-clip gradient partials (TRAIN only)
 //   sums     : [slab] float           reduced partials, followed by [32][slab] double first-pass partial sums
 // DP = D rounded up to a multiple of 32 (components >= D are zero padding and stay exactly zero).
@@ -26,7 +28,7 @@ namespace cmps {
 struct Layout {
     int D, DP, B, T, N, flags;
     size_t off_R, off_RT, off_Q, off_QT, off_psi0, off_freqs, off_ttab, off_dtk, off_rho, off_rfix,
-        off_stash, off_hst, off_scal, off_slabs, off_sums, total;
+        off_stash, off_hst, off_scal, off_slabs, off_sums, off_gops, total;
     size_t slab_floats;  // 4*DP*DP + 3*DP + 2
 };
 
@@ -57,6 +59,7 @@ inline Layout make_layout(int D, int B, int T, int flags) {
     L.off_scal = o;
     L.off_slabs = o;
     L.off_sums = o;
+    L.off_gops = o;
     if (flags & 1) {
         // the two variants never run on the same stash: their layouts share one region
         // D > 32: the pair kernels (D = 128) keep (y, H y) per step, 16 B per component; the block kernels use half of it
@@ -68,6 +71,8 @@ inline Layout make_layout(int D, int B, int T, int flags) {
         L.off_scal = o;  o = align256(o + (size_t)B * ((N + 63) / 64) * 128 * sizeof(float));
         L.off_slabs = o; o = align256(o + (size_t)B * L.slab_floats * sizeof(float));
         L.off_sums = o;  o = align256(o + (L.slab_floats + 64) * sizeof(float) + 32 * L.slab_floats * sizeof(double));
+        L.off_gops = o;
+        if (D > 32) o = align256(o + (size_t)((B + 1) / 2) * ((N + 7) / 8) * 20 * DP * 16);
     }
     L.total = o;
     return L;
@@ -90,6 +95,7 @@ struct Dev {
     int stash_layout;    // 0: stash [B][N][DP] float2 (block variant)  1: hst rows in lane order (cmps_wave16.hip)
                          // 2: pair rows (cmps_pair.hip)  3: hst rows of (y[n], (H y)[n]) pairs, n = 2 i + {re, im} (cmps_wave2.hip)
     float* scal;         // [B][NC][2][64]
+    void* gops;          // gradient-GEMM operands of the pair kernels (see the layout comment), D > 32 only
     float* slabs;        // [B][slab]
     float* sums;         // [slab]
     size_t slab_floats;

@@ -376,6 +376,77 @@ __device__ __forceinline__ void matvec1(const u2 (&FA)[PD / 4], unsigned addr, A
     }
 }
 
+// ---- the same mat-vec pair in statements of FOUR MFMAs with a caller-supplied piece of independent work after each (piece
+// 0 runs while the first LDS reads are in flight, pieces 1 .. 16 behind the MFMA quads): a 4x4x4 MFMA holds the matrix pipe
+// for 8 cycles but issues in 4, so a quad leaves room for four VALU instructions that cost nothing.  The compiler does not
+// know what the asm statements cost and would sink the work below all of them: every piece must end by pinning its results
+// (PAIR_PIN) so that it stays where it is called.
+template <int I> struct ic { static constexpr int value = I; };
+#define PAIR_PIN1(a) asm volatile("" : "+v"(a))
+#define PAIR_PIN2(a, b) asm volatile("" : "+v"(a), "+v"(b))
+#define PAIR_PIN4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+template <bool FIRST, bool LAST>
+__device__ __forceinline__ void quad2(const u2& fa0, const u2& fb0, const u2& fa1, const u2& fb1, const u4& v, Acc2& x, Acc2& y) {
+    const u2 lo = {v.x, v.y}, hi = {v.z, v.w};
+    if constexpr (FIRST) {
+        asm volatile(PAIR_ASM("v_mfma_f32_4x4x4_16b_bf16 %0, %4, %8, 0\n\t"
+                              "v_mfma_f32_4x4x4_16b_bf16 %1, %5, %8, 0\n\t"
+                              "v_mfma_f32_4x4x4_16b_bf16 %2, %6, %9, 0\n\t"
+                              "v_mfma_f32_4x4x4_16b_bf16 %3, %7, %9, 0")
+                     : "=&v"(x.a), "=&v"(y.a), "=&v"(x.b), "=&v"(y.b) : "a"(fa0), "a"(fb0), "a"(fa1), "a"(fb1), "v"(lo), "v"(hi));
+    } else if constexpr (LAST) {
+        asm volatile(PAIR_ASM("v_mfma_f32_4x4x4_16b_bf16 %0, %4, %8, %0\n\t"
+                              "v_mfma_f32_4x4x4_16b_bf16 %1, %5, %8, %1\n\t"
+                              "v_mfma_f32_4x4x4_16b_bf16 %2, %6, %9, %2\n\t"
+                              "v_mfma_f32_4x4x4_16b_bf16 %3, %7, %9, %3\n\t"
+                              "s_nop 7")
+                     : "+v"(x.a), "+v"(y.a), "+v"(x.b), "+v"(y.b) : "a"(fa0), "a"(fb0), "a"(fa1), "a"(fb1), "v"(lo), "v"(hi));
+    } else {
+        asm volatile(PAIR_ASM("v_mfma_f32_4x4x4_16b_bf16 %0, %4, %8, %0\n\t"
+                              "v_mfma_f32_4x4x4_16b_bf16 %1, %5, %8, %1\n\t"
+                              "v_mfma_f32_4x4x4_16b_bf16 %2, %6, %9, %2\n\t"
+                              "v_mfma_f32_4x4x4_16b_bf16 %3, %7, %9, %3")
+                     : "+v"(x.a), "+v"(y.a), "+v"(x.b), "+v"(y.b) : "a"(fa0), "a"(fb0), "a"(fa1), "a"(fb1), "v"(lo), "v"(hi));
+    }
+}
+template <int G, int NG, int NT, typename Piece>
+__device__ __forceinline__ void quads_of_group(const u2 (&FA)[NT], const u2 (&FB)[NT], const u4 (&v)[4], Acc2& x, Acc2& y, Piece&& piece) {
+    quad2<G == 0, false>(FA[8 * G], FB[8 * G], FA[8 * G + 1], FB[8 * G + 1], v[0], x, y);
+    piece(ic<4 * G + 1>{});
+    quad2<false, false>(FA[8 * G + 2], FB[8 * G + 2], FA[8 * G + 3], FB[8 * G + 3], v[1], x, y);
+    piece(ic<4 * G + 2>{});
+    quad2<false, false>(FA[8 * G + 4], FB[8 * G + 4], FA[8 * G + 5], FB[8 * G + 5], v[2], x, y);
+    piece(ic<4 * G + 3>{});
+    quad2<false, G == NG - 1>(FA[8 * G + 6], FB[8 * G + 6], FA[8 * G + 7], FB[8 * G + 7], v[3], x, y);
+    piece(ic<4 * G + 4>{});
+}
+template <int PD, typename Piece>
+__device__ __forceinline__ void matvec2p(const u2 (&FA)[PD / 4], const u2 (&FB)[PD / 4], unsigned addr, Acc2& x, Acc2& y, Piece&& piece) {
+    constexpr int NG = PD / 32;
+    u4 b0[4], b1[4], b2[4];
+    rd4g(addr, b0);
+    rd4g(addr + 64, b1);
+    if constexpr (NG > 2) rd4g(addr + 128, b2);
+    piece(ic<0>{});
+    if constexpr (NG == 2) {
+        rd_wait4<4>(b0); quads_of_group<0, NG>(FA, FB, b0, x, y, piece);
+        rd_wait4<0>(b1); quads_of_group<1, NG>(FA, FB, b1, x, y, piece);
+        piece(ic<9>{}); piece(ic<10>{}); piece(ic<11>{}); piece(ic<12>{});
+        piece(ic<13>{}); piece(ic<14>{}); piece(ic<15>{}); piece(ic<16>{});
+    } else if constexpr (NG == 3) {
+        rd_wait4<8>(b0); quads_of_group<0, NG>(FA, FB, b0, x, y, piece);
+        rd_wait4<4>(b1); quads_of_group<1, NG>(FA, FB, b1, x, y, piece);
+        rd_wait4<0>(b2); quads_of_group<2, NG>(FA, FB, b2, x, y, piece);
+        piece(ic<13>{}); piece(ic<14>{}); piece(ic<15>{}); piece(ic<16>{});
+    } else {
+        rd_wait4<8>(b0); quads_of_group<0, NG>(FA, FB, b0, x, y, piece);
+        rd4g(addr + 192, b0);
+        rd_wait4<8>(b1); quads_of_group<1, NG>(FA, FB, b1, x, y, piece);
+        rd_wait4<4>(b2); quads_of_group<2, NG>(FA, FB, b2, x, y, piece);
+        rd_wait4<0>(b0); quads_of_group<3, NG>(FA, FB, b0, x, y, piece);
+    }
+}
+
 // rho rows are staged through LDS one 32-step chunk at a time (a row per step straight from L2 / HBM costs its full
 // latency every step: the table is 16 MB at D = 128); the next chunk is loaded into registers at the start of a chunk and
 // committed to the other buffer in the middle of it
@@ -619,13 +690,16 @@ hipError_t launch_fwd_pair(const Dev& P, const float* audio, float* loss, bool s
 namespace cmps {
 
 // ------------------------------------------------------------------------------------------------
-// reverse scan: the cotangent recursion only; the rank-1 gradient contractions over (clip, step) are a GEMM and run in
-// k_grad_pair from the rows this kernel leaves behind (stash row k becomes (y_k, ybar_k)).
+// reverse scan: the cotangent recursion; the rank-1 gradient contractions over (clip, step) are a GEMM (k_grad_pair) whose
+// five operands this kernel writes in bf16, GEMM-ready (Dev::gops).
 //   yhat = y_k inv_k;  yhb = conj(rho_k) g;  ybar = (yhb - yhat rad_{k+1}) inv_k + te_k H y_k
 //   g    = ybar + Q ybar + s_k R^dagger ybar            (64 MFMAs, bf16 operands)
 //   fbar += dt_k Im(g conj(rho_k yhat));   Abar += zbar_k (-e_k x_k / A^2) + Re(d^dagger u_k) (-x_k / A^2)
 // rad_{k+1} = Re(u_{k+1}^dagger g_{k+1}) = 2 ebar_{k+1} e_{k+1} (Euler's theorem: everything downstream of u_{k+1} is
 // scale invariant except the loss term of step k+1, which is homogeneous of degree 2), 0 behind the last step.
+// Only  g -> conj(rho) g -> ybar -> bf16 -> LDS -> barrier -> mat-vec -> g  is on the chain: the part of ybar that does
+// not depend on g (c3 = te H y - ok yhat rad inv), u_k, the scalars and rho row of the next step and the GEMM operands are
+// computed / fetched in the shadow of the LDS reads and MFMAs of the step before.
 // ------------------------------------------------------------------------------------------------
 namespace {
 
@@ -634,6 +708,14 @@ template <int W>
 struct StepTab {
     __attribute__((aligned(16))) f4 row[W][2][PCH][2][2];              // [wave][chunk parity][step][clip][half]
 };
+
+constexpr int GB = 8;          // steps per 16-byte piece of a GEMM operand
+
+// gops index of the piece (pair, block, operand, clip, component, row): units of 16 bytes
+template <int PD>
+__device__ __forceinline__ size_t gop_index(size_t pair, int nblk, int blk, int op, int clip, int comp, int row) {
+    return ((((pair * nblk + blk) * 5 + op) * 2 + clip) * 2 + comp) * PD + row;
+}
 
 }  // namespace
 
@@ -679,7 +761,11 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
     const float* xr1 = audio + (size_t)b1 * T;
     const float* sc0 = P.scal + ((size_t)b0 * NC) * 128;
     const float* sc1 = P.scal + ((size_t)b1 * NC) * 128;
-    float4* st = reinterpret_cast<float4*>(P.stash) + ((size_t)blockIdx.x * N * PWV + w) * 64 + lane;
+    const float4* st = reinterpret_cast<const float4*>(P.stash) + ((size_t)blockIdx.x * N * PWV + w) * 64 + lane;
+    const int NBLK = (N + GB - 1) / GB;
+    // this lane's pieces: rows ia, ia + 1 (32 contiguous bytes) of component (c & 1), clip q
+    uint4* gbase = reinterpret_cast<uint4*>(P.gops) + gop_index<PD>(blockIdx.x, NBLK, 0, 0, q, odd ? 1 : 0, ia);
+    constexpr size_t GOP_STRIDE = (size_t)4 * PD, GBLK_STRIDE = (size_t)20 * PD;      // per operand / per block, in pieces
     const float A = P.A;
     const float sgn = odd ? 1.f : -1.f;                                // (rho x)_own = rho_re x_own + sgn rho_im x_partner
 
@@ -716,90 +802,167 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
         }
     };
 
-    float ga = 0.f, gb = 0.f, facca = 0.f, faccb = 0.f, accS = 0.f, rad_next = 0.f;
     chunk_rows((N - 1) / PCH);
+    if ((N - 1) / PCH > 0 && ((N - 1) & (PCH - 1)) == 0) chunk_rows((N - 1) / PCH - 1);   // step N - 2 lives in the chunk below
     // rho: 32-step chunks staged in LDS, descending; chunk j lives in buffer j & 1 and is loaded when the sweep enters
     // chunk j + 1 (rows k and k - 1 of a step can straddle two chunks, so two are always resident)
     {
         const int cl = (N - 1) / RCH;
         rho_stage<PD>(P, RS, cl, cl & 1, threadIdx.x);
-        if (cl > 0) {
-            rho_stage<PD>(P, RS, cl - 1, (cl - 1) & 1, threadIdx.x);
-        }
+        if (cl > 0) rho_stage<PD>(P, RS, cl - 1, (cl - 1) & 1, threadIdx.x);
     }
     __syncthreads();
+
+    // ---- state of the step about to run (k): everything the chain needs before the barrier is in registers ----
+    float ga = 0.f, gb = 0.f;                   // g: cotangent of u_{k+1}
+    float facca = 0.f, faccb = 0.f, accS = 0.f;
+    float4 rh, rhp;                             // rho_k and rho_{k-1}, rows ia | ib
+    f4 S0, S1, SP0, SP1;                        // scalar rows of steps k and k - 1 (fetched two steps ahead, behind the MFMAs)
+    float c3a, c3b;                             // te_k (H y_k) - ok_k yhat_k rad_{k+1} inv_k
     int p = 0;
-    // one step; `cur` = stash row k, `prv` = stash row k - 1 (both prefetched four steps ahead into a register ring)
-    auto step = [&](int k, const float4& cur, const float4& prv) {
-        const int jl = k & (PCH - 1), cp = (k / PCH) & 1;
-        if (jl == 0 && k > 0) chunk_rows(k / PCH - 1);                 // u_k needs inv_{k-1}: the chunk below, other buffer
-        if ((k & (RCH - 1)) == RCH - 1 && k != N - 1 && k >= RCH) {    // entering rho chunk k / RCH: fetch the one below
-            rho_stage<PD>(P, RS, k / RCH - 1, (k / RCH - 1) & 1, threadIdx.x);
-        }
-        const float2 rha = RS.row[(k / RCH) & 1][k & (RCH - 1)][ia], rhb = RS.row[(k / RCH) & 1][k & (RCH - 1)][ib];
-        const int km = k > 0 ? k - 1 : 0;
-        const float2 rpa = RS.row[(km / RCH) & 1][km & (RCH - 1)][ia], rpb = RS.row[(km / RCH) & 1][km & (RCH - 1)][ib];
-        const f4 S0 = TB.row[w][cp][jl][q][0], S1 = TB.row[w][cp][jl][q][1];
-        const float s = S0.x, inv = S0.y, ok = S0.z, te = S0.w, rad = S1.x, xa = S1.y, dt = S1.z;
-        const float ya = cur.x, yb = cur.y, ha = cur.z, hb = cur.w;
-        const float yha = ya * inv, yhb = yb * inv;
-        const float pga = dpp_mov<0xB1>(ga), pgb = dpp_mov<0xB1>(gb);
-        const float hba = rha.x * ga - sgn * rha.y * pga;              // conj(rho_k) g
-        const float hbb = rhb.x * gb - sgn * rhb.y * pgb;
-        const float yba = (hba - ok * yha * rad_next) * inv + te * ha;
-        const float ybb = (hbb - ok * yhb * rad_next) * inv + te * hb;
-        write_vec(L.vec[p][0], yba, ybb);
-        st[(size_t)k * PWV * 64] = make_float4(ya, yb, yba, ybb);      // the row the gradient GEMM reads
-        lds_barrier();
-        const f4 z4 = {0.f, 0.f, 0.f, 0.f};
-        Acc2 cQ, cD;
-        matvec2<PD>(FQ, FD, lds_addr_of(L.vec[p][0]) + rd_off, cQ, cD, [&] {
-            // off the chain, in the shadow of the reads and the MFMAs: u_{k+1} = rho_k yhat and the frequency gradient
-            // (meaningful in the Re lanes)
-            const float una = rha.x * yha + sgn * rha.y * dpp_mov<0xB1>(yha);
-            const float unb = rhb.x * yhb + sgn * rhb.y * dpp_mov<0xB1>(yhb);
-            facca += dt * (pga * una - ga * dpp_mov<0xB1>(una));
-            faccb += dt * (pgb * unb - gb * dpp_mov<0xB1>(unb));
-        });
-        float qa, qb, da, db;
-        rows_of(cQ.a + cQ.b, qa, qb);
-        rows_of(cD.a + cD.b, da, db);
-        // u_k = rho_{k-1} y_{k-1} inv_{k-1}  (psi_0 at k = 0)
-        float uka, ukb;
-        if (k > 0) {
-            const int jp = (k - 1) & (PCH - 1), cpp = ((k - 1) / PCH) & 1;
-            const float invp = TB.row[w][cpp][jp][q][0].y;
-            const float ypa = prv.x * invp, ypb = prv.y * invp;
-            uka = rpa.x * ypa + sgn * rpa.y * dpp_mov<0xB1>(ypa);
-            ukb = rpb.x * ypb + sgn * rpb.y * dpp_mov<0xB1>(ypb);
-        } else {
-            const float2 pa = P.psi0[ia], pb = P.psi0[ib];
-            uka = odd ? pa.y : pa.x;
-            ukb = odd ? pb.y : pb.x;
-        }
-        accS += (da * uka + db * ukb) * xa;
-        ga = yba + qa + s * da;
-        gb = ybb + qb + s * db;
-        rad_next = rad;
-        p ^= 1;
-    };
+    auto rho_rows = [&](int k) { return *reinterpret_cast<const float4*>(&RS.row[(k / RCH) & 1][k & (RCH - 1)][ia]); };
+    auto tab_row = [&](int k, int half) { return TB.row[w][(k / PCH) & 1][k & (PCH - 1)][q][half]; };
     // unconditional (clamped) loads: a select on the loaded value would force the wait right behind the load
     auto row_at = [&](int k) { return st[(size_t)(k > 0 ? k : 0) * PWV * 64]; };
-    float4 r0 = row_at(N - 1), r1 = row_at(N - 2), r2 = row_at(N - 3), r3 = row_at(N - 4);
-    int k = N - 1;
-    for (; k >= 3; k -= 4) {                                           // ring: r0 = row k, r1 = k - 1, r2 = k - 2, r3 = k - 3
-        step(k, r0, r1);
-        r0 = row_at(k - 4);
-        step(k - 1, r1, r2);
-        r1 = row_at(k - 5);
-        step(k - 2, r2, r3);
-        r2 = row_at(k - 6);
-        step(k - 3, r3, r0);
-        r3 = row_at(k - 7);
+    // ring of four stash rows: slot (k & 3) holds row k = (y_k a, y_k b, (H y_k) a, (H y_k) b)
+    float4 ring0, ring1, ring2, ring3;
+    {
+        const int k0 = N - 1;
+        ring0 = row_at(k0 - ((k0 - 0) & 3));
+        ring1 = row_at(k0 - ((k0 - 1) & 3));
+        ring2 = row_at(k0 - ((k0 - 2) & 3));
+        ring3 = row_at(k0 - ((k0 - 3) & 3));
+        const int k1 = k0 > 0 ? k0 - 1 : 0;
+        rh = rho_rows(k0);
+        S0 = tab_row(k0, 0);
+        S1 = tab_row(k0, 1);
+        rhp = rho_rows(k1);
+        SP0 = tab_row(k1, 0);
+        SP1 = tab_row(k1, 1);
+        const float4 cur = (k0 & 3) == 0 ? ring0 : (k0 & 3) == 1 ? ring1 : (k0 & 3) == 2 ? ring2 : ring3;
+        c3a = S0.w * cur.z;                     // rad_N = 0
+        c3b = S0.w * cur.w;
     }
-    if (k >= 0) step(k, r0, r1);
-    if (k >= 1) step(k - 1, r1, r2);
-    if (k >= 2) step(k - 2, r2, r3);
+    // GEMM operand pieces being assembled: [operand][row a / b][dword = two steps]; zero = "no contribution"
+    unsigned E[5][2][4];
+    float hold[5][2];
+#pragma unroll
+    for (int o = 0; o < 5; ++o)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            hold[o][r] = 0.f;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) E[o][r][d] = 0u;
+        }
+
+    const float2 psa = P.psi0[ia], psb = P.psi0[ib];
+    const float ps0a = odd ? psa.y : psa.x, ps0b = odd ? psb.y : psb.x;        // u_0 = psi_0
+    // one step; J = k & 7 (static: selects ring slots and the operand dword).  COND: `true` in full blocks.
+#define PAIR_BWD_STEP(J, CUR, PRV, COND)                                                                                            \
+    if (COND) {                                                                                                                    \
+        const int k = 8 * blk + (J);                                                                                               \
+        const int km2 = k > 1 ? k - 2 : 0;                                                                                         \
+        if ((k & (PCH - 1)) == 1 && k > 1) chunk_rows(k / PCH - 1);                 /* step k - 2: the chunk below */               \
+        if ((k & (RCH - 1)) == RCH - 1 && k != N - 1 && k >= RCH)                   /* entering rho chunk k / RCH: fetch the one below */ \
+            rho_stage<PD>(P, RS, k / RCH - 1, (k / RCH - 1) & 1, threadIdx.x);                                                     \
+        float4 nrh;                                                                                                                \
+        f4 nS0, nS1;                                                                                                               \
+        /* ---- the chain ---- */                                                                                                  \
+        const float pga = dpp_mov<0xB1>(ga), pgb = dpp_mov<0xB1>(gb);                                                              \
+        const float hba = rh.x * ga - sgn * rh.y * pga;              /* conj(rho_k) g */                                           \
+        const float hbb = rh.z * gb - sgn * rh.w * pgb;                                                                            \
+        float yba = fmaf(hba, S0.y, c3a), ybb = fmaf(hbb, S0.y, c3b);                                                              \
+        write_vec(L.vec[p][0], yba, ybb);                                                                                          \
+        lds_barrier();                                                                                                             \
+        Acc2 cQ, cD;                                                                                                               \
+        float uka, ukb, yha, yhb, ypa, ypb, una, unb;                                                                              \
+        matvec2p<PD>(FQ, FD, lds_addr_of(L.vec[p][0]) + rd_off, cQ, cD, [&](auto pc) {                                             \
+            constexpr int PI = decltype(pc)::value;                                                                                \
+            const float s = S0.x, inv = S0.y, te = S0.w, dt = S1.z, invp = SP0.y;                                                  \
+            if constexpr (PI == 0) {                                                                                               \
+                yha = CUR.x * inv; yhb = CUR.y * inv;                                                                              \
+                ypa = PRV.x * invp; ypb = PRV.y * invp;                                                                            \
+                PAIR_PIN4(yha, yhb, ypa, ypb);                                                                                     \
+            } else if constexpr (PI == 1) {          /* u_{k+1} = rho_k yhat */                                                    \
+                una = rh.x * yha + sgn * rh.y * dpp_mov<0xB1>(yha);                                                                \
+                unb = rh.z * yhb + sgn * rh.w * dpp_mov<0xB1>(yhb);                                                                \
+                PAIR_PIN2(una, unb);                                                                                               \
+            } else if constexpr (PI == 2) {          /* the frequency gradient (meaningful in the Re lanes) */                     \
+                facca += dt * (pga * una - ga * dpp_mov<0xB1>(una));                                                               \
+                faccb += dt * (pgb * unb - gb * dpp_mov<0xB1>(unb));                                                               \
+                PAIR_PIN2(facca, faccb);                                                                                           \
+            } else if constexpr (PI == 3) {          /* u_k = rho_{k-1} y_{k-1} inv_{k-1}  (psi_0 at k = 0) */                     \
+                const float ra = rhp.x * ypa + sgn * rhp.y * dpp_mov<0xB1>(ypa);                                                   \
+                const float rb = rhp.z * ypb + sgn * rhp.w * dpp_mov<0xB1>(ypb);                                                   \
+                uka = k > 0 ? ra : ps0a;                                                                                           \
+                ukb = k > 0 ? rb : ps0b;                                                                                           \
+                PAIR_PIN2(uka, ukb);                                                                                               \
+            } else if constexpr (PI == 4) {          /* the g-independent part of ybar_{k-1} */                                    \
+                const float radk = S1.x * SP0.z * invp;                /* rad_k ok_{k-1} inv_{k-1} */                              \
+                c3a = fmaf(SP0.w, PRV.z, -(ypa * radk));                                                                           \
+                c3b = fmaf(SP0.w, PRV.w, -(ypb * radk));                                                                           \
+                PAIR_PIN2(c3a, c3b);                                                                                               \
+            } else if constexpr (PI >= 5 && PI <= 9) {   /* GEMM operands of step k: te y | ybar | s ybar | y | u */                \
+                constexpr int o = PI - 5;                                                                                          \
+                const float va = o == 0 ? te * CUR.x : o == 1 ? yba : o == 2 ? s * yba : o == 3 ? CUR.x : uka;                     \
+                const float vb = o == 0 ? te * CUR.y : o == 1 ? ybb : o == 2 ? s * ybb : o == 3 ? CUR.y : ukb;                     \
+                if ((J) & 1) {                                                                                                     \
+                    hold[o][0] = va; hold[o][1] = vb;                                                                              \
+                    PAIR_PIN2(hold[o][0], hold[o][1]);                                                                             \
+                } else {                                                                                                           \
+                    E[o][0][(J) >> 1] = pk_bf16(va, hold[o][0]);                                                                   \
+                    E[o][1][(J) >> 1] = pk_bf16(vb, hold[o][1]);                                                                   \
+                    PAIR_PIN2(E[o][0][(J) >> 1], E[o][1][(J) >> 1]);                                                               \
+                }                                                                                                                  \
+            } else if constexpr (PI == 10) {                                                                                       \
+                CUR = row_at(k - 4);                                  /* this slot's next row (row k is dead from here on) */      \
+            } else if constexpr (PI == 16) {         /* scalars and rho row of step k - 2, behind the last MFMAs */                 \
+                nrh = rho_rows(km2);                                                                                               \
+                nS0 = tab_row(km2, 0);                                                                                             \
+                nS1 = tab_row(km2, 1);                                                                                             \
+            } else if constexpr (PI >= 11 && PI <= 15) {                                                                           \
+                if ((J) == 0) {                                       /* a block of eight steps is complete */                     \
+                    constexpr int o = PI - 11;                                                                                     \
+                    uint4* gp = gbase + (size_t)blk * GBLK_STRIDE + o * GOP_STRIDE;                                                \
+                    gp[0] = make_uint4(E[o][0][0], E[o][0][1], E[o][0][2], E[o][0][3]);                                            \
+                    gp[1] = make_uint4(E[o][1][0], E[o][1][1], E[o][1][2], E[o][1][3]);                                            \
+                }                                                                                                                  \
+            }                                                                                                                      \
+        });                                                                                                                        \
+        float qa, qb, da, db;                                                                                                      \
+        rows_of(cQ.a + cQ.b, qa, qb);                                                                                              \
+        rows_of(cD.a + cD.b, da, db);                                                                                              \
+        accS += (da * uka + db * ukb) * S1.y;                                                                                      \
+        ga = yba + qa + S0.x * da;                                                                                                 \
+        gb = ybb + qb + S0.x * db;                                                                                                 \
+        rh = rhp; S0 = SP0; S1 = SP1;                                                                                              \
+        rhp = nrh; SP0 = nS0; SP1 = nS1;                                                                                           \
+        p ^= 1;                                                                                                                    \
+    }
+
+    int blk = NBLK - 1;
+    if (N & (GB - 1)) {                                                // the partly filled top block
+        PAIR_BWD_STEP(7, ring3, ring2, 8 * blk + 7 < N)
+        PAIR_BWD_STEP(6, ring2, ring1, 8 * blk + 6 < N)
+        PAIR_BWD_STEP(5, ring1, ring0, 8 * blk + 5 < N)
+        PAIR_BWD_STEP(4, ring0, ring3, 8 * blk + 4 < N)
+        PAIR_BWD_STEP(3, ring3, ring2, 8 * blk + 3 < N)
+        PAIR_BWD_STEP(2, ring2, ring1, 8 * blk + 2 < N)
+        PAIR_BWD_STEP(1, ring1, ring0, 8 * blk + 1 < N)
+        PAIR_BWD_STEP(0, ring0, ring3, true)
+        --blk;
+    }
+    for (; blk >= 0; --blk) {
+        PAIR_BWD_STEP(7, ring3, ring2, true)
+        PAIR_BWD_STEP(6, ring2, ring1, true)
+        PAIR_BWD_STEP(5, ring1, ring0, true)
+        PAIR_BWD_STEP(4, ring0, ring3, true)
+        PAIR_BWD_STEP(3, ring3, ring2, true)
+        PAIR_BWD_STEP(2, ring2, ring1, true)
+        PAIR_BWD_STEP(1, ring1, ring0, true)
+        PAIR_BWD_STEP(0, ring0, ring3, true)
+    }
+#undef PAIR_BWD_STEP
     // ---- the pair's slab: f | psi0bar_re | psi0bar_im | A (the R / Q sections are written by k_grad_pair) ----
     float* slab = P.slabs + (size_t)blockIdx.x * P.slab_floats;
     const int DD = PD * PD;
@@ -850,79 +1013,39 @@ namespace cmps {
 
 // ------------------------------------------------------------------------------------------------
 // gradient contraction: Rbar = sum_{clip,k} (te_k y_k) y_k^dagger + (s_k ybar_k) u_k^dagger,  Qbar = sum ybar_k u_k^dagger
-// as bf16 MFMA GEMMs (v_mfma_f32_32x32x16_bf16, fp32 accumulators resident for the whole pair) over the rows the two
-// scans left in the stash.  A complex outer product  C += a b^dagger  is two real GEMMs over K = (step, clip, {re, im}):
+// as bf16 MFMA GEMMs (v_mfma_f32_32x32x16_bf16, fp32 accumulators resident for the whole pair) over the operands the
+// reverse scan left in Dev::gops.  A complex outer product  C += a b^dagger  is two real GEMMs over K = (step, {re, im}):
 //   Re C = [a_re | a_im] [b_re | b_im]^T,   Im C = [a_im | -a_re] [b_re | b_im]^T.
-// One MFMA covers K = 16 = 4 steps x 2 clips x {re, im}; wave w owns the row block 32w..32w+31 of all four outputs.
+// One MFMA covers K = 16 = 8 steps x {re, im} of one clip: the K half (lane >> 5) is the component, and a lane's eight K
+// values are ONE 16-byte piece of the operand array -- the kernel is loads and MFMAs only (no conversion, no VALU fill).
+// Wave w owns the row block 32w..32w+31 of all four outputs.
 // ------------------------------------------------------------------------------------------------
 namespace {
 
 typedef short bf8 __attribute__((ext_vector_type(8)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 
-constexpr int GS = 4;                                   // steps per MFMA group
-#ifndef GRAD_VALU_PER_MFMA
-#define GRAD_VALU_PER_MFMA 12                           // VALU instructions of the fill scheduled behind every MFMA
-#endif
-template <int D>
-struct GradLds {
-    // [buffer][operand: te y, ybar, s ybar, y, u][re / im][row][(clip, step in group)] bf16
-    __attribute__((aligned(16))) unsigned short op[2][5][2][D][2 * GS];
-    __attribute__((aligned(16))) f4 tab[D / 32][2][PCH][2];         // per wave: (s, te, inv, -) per step and clip
-};
-
-__device__ __forceinline__ bf8 neg_if(bf8 v, unsigned mask) {
-    u4 t = __builtin_bit_cast(u4, v);
-    t.x ^= mask; t.y ^= mask; t.z ^= mask; t.w ^= mask;
+__device__ __forceinline__ bf8 as_bf8(uint4 v, unsigned mask) {
+    u4 t = {v.x ^ mask, v.y ^ mask, v.z ^ mask, v.w ^ mask};
     return __builtin_bit_cast(bf8, t);
 }
 
 }  // namespace
 
 template <int PD>
-__global__ __launch_bounds__(2 * PD, 1) void k_grad_pair(Dev P, const float* __restrict__ audio) {
-    constexpr int PWV = PD / 32;
-    __shared__ GradLds<PD> G;
+__global__ __launch_bounds__(2 * PD, 1) void k_grad_pair(Dev P) {
+    constexpr int PWV = PD / 32, NP = 10 * PD;                      // 16-byte pieces per (block, clip): [operand][component][row]
+    // Every piece is needed by several waves (the B operands by all of them): it is fetched from HBM once, by one thread,
+    // and shared through LDS (two stages); the fetch runs three iterations ahead in registers (5 pieces per thread each).
+    __shared__ __attribute__((aligned(16))) uint4 stage[2][NP];
+    const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    // producer view of a lane (the scans' layout): rows ia / ib, component (c & 1), clip q
-    const int c = lane & 3, q = c >> 1, rg = (lane >> 2) & 7, kh = lane >> 5;
-    const bool odd = (c & 1) != 0;
-    const int ia = 32 * w + 4 * rg + 2 * kh, ib = ia + 1;
-    // consumer view (32x32x16 MFMA): row / column = lane & 31, K half = lane >> 5
-    const int mr = lane & 31, mh = lane >> 5;
-    const int N = P.N, T = P.T, NC = (N + PCH - 1) / PCH;
-    const int b0 = 2 * blockIdx.x, b1 = (b0 + 1 < P.B) ? b0 + 1 : b0;
-    const bool two = b1 != b0;
-    const float wq = (q == 0 || two) ? 1.f : 0.f;
-    const float* xr0 = audio + (size_t)b0 * T;
-    const float* xr1 = audio + (size_t)b1 * T;
-    const float* sc0 = P.scal + ((size_t)b0 * NC) * 128;
-    const float* sc1 = P.scal + ((size_t)b1 * NC) * 128;
-    const float4* st = reinterpret_cast<const float4*>(P.stash) + ((size_t)blockIdx.x * N * PWV + w) * 64 + lane;
-    const float A = P.A;
-    const float sgn = odd ? 1.f : -1.f;
-
-    auto chunk_rows = [&](int cj) {
-        const int idx = cj * PCH + lane;
-        const bool in = idx < N;
-#pragma unroll
-        for (int qq = 0; qq < 2; ++qq) {
-            const float* xr = qq ? xr1 : xr0;
-            const float* sc = qq ? sc1 : sc0;
-            const float x0 = idx < T ? xr[idx] : 0.f, x1 = idx + 1 < T ? xr[idx + 1] : 0.f;
-            const float inc = x1 - x0;
-            const float nv = in ? sc[(size_t)cj * 128 + lane] : 1.f;
-            const float ev = in ? sc[(size_t)cj * 128 + 64 + lane] : 0.f;
-            const float z = (ev * inc) / A;
-            const float zbar = -1.0f / (1.0f + z);
-            f4 r;
-            r.x = inc / A;
-            r.y = in ? 2.0f * (zbar * inc / A) : 0.f;
-            r.z = 1.0f / sqrtf(fmaxf(nv, 1e-12f));
-            r.w = 0.f;
-            G.tab[w][cj & 1][lane][qq] = r;
-        }
-    };
+    const int mr = lane & 31, mh = lane >> 5;                          // row / column, K half = component
+    const int N = P.N, NBLK = (N + GB - 1) / GB;
+    const bool two = 2 * blockIdx.x + 1 < P.B;
+    const int NIT = two ? 2 * NBLK : NBLK;                             // (block, clip) iterations; an odd batch has no second clip
+    const uint4* g = reinterpret_cast<const uint4*>(P.gops) + gop_index<PD>(blockIdx.x, NBLK, 0, 0, 0, 0, 0);
+    const unsigned nmask = mh ? 0x80008000u : 0u;
 
     f16v Rre[PWV], Rim[PWV], Qre[PWV], Qim[PWV];                   // this wave's row block x PWV column blocks
 #pragma unroll
@@ -930,96 +1053,37 @@ __global__ __launch_bounds__(2 * PD, 1) void k_grad_pair(Dev P, const float* __r
 #pragma unroll
         for (int r = 0; r < 16; ++r) Rre[cb][r] = Rim[cb][r] = Qre[cb][r] = Qim[cb][r] = 0.f;
 
-    // producer: fill one group's operand rows (this lane's two rows, component and clip; 4 steps -> one 8-byte store each).
-    // The stash rows and rho rows of a group are fetched one whole group ahead (prefetch), so their latency hides behind
-    // the previous group's MFMAs.
-    float ypa = 0.f, ypb = 0.f, invp = 1.f;                           // y_{k-1} and inv_{k-1} carried across groups
-    float2 rpa = make_float2(1.f, 0.f), rpb = rpa;                     // rho_{k-1}
-    float4 prow[GS];
-    float2 pra[GS], prb[GS];
-    auto prefetch = [&](int g) {
-#pragma unroll
-        for (int s4 = 0; s4 < GS; ++s4) {
-            const int k = g * GS + s4;
-            const bool in = k < N;
-            const int kc = in ? k : N - 1;                            // clamped, unconditional loads (no select behind them)
-            prow[s4] = st[(size_t)kc * PWV * 64];
-            pra[s4] = P.rho[(size_t)kc * PD + ia];
-            prb[s4] = P.rho[(size_t)kc * PD + ib];
-        }
+    // piece j of this thread: index e = tid + 2 PD j in [operand][component][row] order; its place in gops
+    // (five named values, not an array: arrays handed to lambdas by reference end up in scratch memory)
+    struct Five { uint4 v0, v1, v2, v3, v4; };
+    auto src_of = [&](const uint4* gb, int j) {
+        const int e = tid + 2 * PD * j;
+        const int op = e / (2 * PD), rest = e % (2 * PD);              // rest = component * PD + row
+        return gb[op * 4 * PD + rest];
     };
-    auto fill = [&](int g, int buf) {
-        float v[5][2][GS];
-#pragma unroll
-        for (int s4 = 0; s4 < GS; ++s4) {
-            const int k = g * GS + s4;
-            const bool in = k < N;
-            float4 row = prow[s4];
-            if (!in) row = make_float4(0.f, 0.f, 0.f, 0.f);
-            f4 sr = {0.f, 0.f, 1.f, 0.f};
-            if (in) sr = G.tab[w][(k / PCH) & 1][k & (PCH - 1)][q];
-            const float s = sr.x, te = sr.y * wq;
-            float uka, ukb;
-            if (k == 0) {
-                const float2 pa = P.psi0[ia], pb = P.psi0[ib];
-                uka = odd ? pa.y : pa.x;
-                ukb = odd ? pb.y : pb.x;
-            } else {
-                const float ta = ypa * invp, tb = ypb * invp;
-                uka = rpa.x * ta + sgn * rpa.y * dpp_mov<0xB1>(ta);
-                ukb = rpb.x * tb + sgn * rpb.y * dpp_mov<0xB1>(tb);
-            }
-            const float yba = row.z * wq, ybb = row.w * wq;
-            v[0][0][s4] = te * row.x; v[0][1][s4] = te * row.y;
-            v[1][0][s4] = yba;        v[1][1][s4] = ybb;
-            v[2][0][s4] = s * yba;    v[2][1][s4] = s * ybb;
-            v[3][0][s4] = row.x;      v[3][1][s4] = row.y;
-            v[4][0][s4] = in ? uka : 0.f; v[4][1][s4] = in ? ukb : 0.f;
-            if (in) {
-                ypa = row.x; ypb = row.y; invp = sr.z;
-                rpa = pra[s4];
-                rpb = prb[s4];
-            }
-        }
-#pragma unroll
-        for (int o = 0; o < 5; ++o) {
-            unsigned short* da = &G.op[buf][o][odd ? 1 : 0][ia][q * GS];
-            unsigned short* db = &G.op[buf][o][odd ? 1 : 0][ib][q * GS];
-            // (integer rounding: measured 13 % faster here than v_cvt_pk_bf16_f32 through inline asm)
-            *reinterpret_cast<uint2*>(da) = make_uint2(bf16_rne(v[o][0][0]) | (unsigned)bf16_rne(v[o][0][1]) << 16,
-                                                       bf16_rne(v[o][0][2]) | (unsigned)bf16_rne(v[o][0][3]) << 16);
-            *reinterpret_cast<uint2*>(db) = make_uint2(bf16_rne(v[o][1][0]) | (unsigned)bf16_rne(v[o][1][1]) << 16,
-                                                       bf16_rne(v[o][1][2]) | (unsigned)bf16_rne(v[o][1][3]) << 16);
-        }
+    auto fetch = [&](int it) {
+        const int itc = it < NIT ? it : NIT - 1;                       // clamped, unconditional loads
+        const int blk = two ? itc >> 1 : itc, clip = two ? itc & 1 : 0;
+        const uint4* gb = g + (size_t)blk * 20 * PD + clip * 2 * PD;
+        Five r;
+        r.v0 = src_of(gb, 0); r.v1 = src_of(gb, 1); r.v2 = src_of(gb, 2); r.v3 = src_of(gb, 3); r.v4 = src_of(gb, 4);
+        return r;
     };
-
-    const int NG = (N + GS - 1) / GS;
-    chunk_rows(0);
-    prefetch(0);
-    fill(0, 0);
-    prefetch(1);
-    __syncthreads();
-    const unsigned nmask = mh ? 0x80008000u : 0u;
-    for (int g = 0; g < NG; ++g) {
-        const int buf = g & 1;
-        // per-step scalars of the chunk group g + 1 starts (the rare branch stays outside the interleaved block below)
-        if (((g + 1) * GS & (PCH - 1)) == 0 && (g + 1) * GS < N) chunk_rows((g + 1) * GS / PCH);
-        // Unconditional (rows past the end are zeros): fill, prefetch and the MFMAs of group g form one basic block, and the
-        // schedule barriers at its end interleave them -- one MFMA (32+ cycles on the matrix pipe), a dozen VALU
-        // instructions of the fill, and so on -- instead of fill-then-MFMA.
-        fill(g + 1, buf ^ 1);
-        prefetch(g + 2);
-        // A fragments of this wave's row block: Re form (h ? X_im : X_re), Im form (h ? -X_re : X_im)
+    auto commit = [&](int buf, const Five& r) {
+        uint4* d = &stage[buf][tid];
+        d[0] = r.v0; d[2 * PD] = r.v1; d[4 * PD] = r.v2; d[6 * PD] = r.v3; d[8 * PD] = r.v4;
+    };
+    auto mac = [&](int buf) {
+        const uint4* S = stage[buf];
         bf8 aRe[3], aIm[3];
 #pragma unroll
-        for (int o = 0; o < 3; ++o) {
-            aRe[o] = *reinterpret_cast<const bf8*>(&G.op[buf][o][mh][32 * w + mr][0]);
-            aIm[o] = neg_if(*reinterpret_cast<const bf8*>(&G.op[buf][o][mh ^ 1][32 * w + mr][0]), nmask);
+        for (int a = 0; a < 3; ++a) {
+            aRe[a] = as_bf8(S[(2 * a + mh) * PD + 32 * w + mr], 0u);
+            aIm[a] = as_bf8(S[(2 * a + (mh ^ 1)) * PD + 32 * w + mr], nmask);
         }
 #pragma unroll
         for (int cb = 0; cb < PWV; ++cb) {
-            const bf8 by = *reinterpret_cast<const bf8*>(&G.op[buf][3][mh][32 * cb + mr][0]);
-            const bf8 bu = *reinterpret_cast<const bf8*>(&G.op[buf][4][mh][32 * cb + mr][0]);
+            const bf8 by = as_bf8(S[(6 + mh) * PD + 32 * cb + mr], 0u), bu = as_bf8(S[(8 + mh) * PD + 32 * cb + mr], 0u);
             Rre[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aRe[0], by, Rre[cb], 0, 0, 0);
             Rim[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aIm[0], by, Rim[cb], 0, 0, 0);
             Qre[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aRe[1], bu, Qre[cb], 0, 0, 0);
@@ -1027,13 +1091,25 @@ __global__ __launch_bounds__(2 * PD, 1) void k_grad_pair(Dev P, const float* __r
             Rre[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aRe[2], bu, Rre[cb], 0, 0, 0);
             Rim[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aIm[2], bu, Rim[cb], 0, 0, 0);
         }
-#pragma unroll
-        for (int i = 0; i < 6 * PWV; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, GRAD_VALU_PER_MFMA, 0);
-        }
-        lds_barrier();
+    };
+    Five r0 = fetch(0), r1 = fetch(1), r2 = fetch(2);
+    commit(0, r0);
+    r0 = fetch(3);
+    lds_barrier();
+    // iteration it: stage it & 1 holds its operands; the set fetched two iterations ago goes to the other stage
+#define GRAD_ITER(IT, RNEXT)                                         \
+    if ((IT) < NIT) {                                                \
+        commit(((IT) + 1) & 1, RNEXT);                               \
+        RNEXT = fetch((IT) + 4);                                     \
+        mac((IT) & 1);                                               \
+        lds_barrier();                                               \
     }
+    for (int it = 0; it < NIT; it += 3) {
+        GRAD_ITER(it, r1)
+        GRAD_ITER(it + 1, r2)
+        GRAD_ITER(it + 2, r0)
+    }
+#undef GRAD_ITER
     float* slab = P.slabs + (size_t)blockIdx.x * P.slab_floats;
     constexpr int DD = PD * PD;
 #pragma unroll
@@ -1050,10 +1126,11 @@ __global__ __launch_bounds__(2 * PD, 1) void k_grad_pair(Dev P, const float* __r
 }
 
 hipError_t launch_grad_pair(const Dev& P, const float* audio, hipStream_t s) {
+    (void)audio;
     const unsigned nb = (unsigned)((P.B + 1) / 2);
-    if (P.DP == 128) hipLaunchKernelGGL(k_grad_pair<128>, dim3(nb), dim3(256), 0, s, P, audio);
-    else if (P.DP == 96) hipLaunchKernelGGL(k_grad_pair<96>, dim3(nb), dim3(192), 0, s, P, audio);
-    else if (P.DP == 64) hipLaunchKernelGGL(k_grad_pair<64>, dim3(nb), dim3(128), 0, s, P, audio);
+    if (P.DP == 128) hipLaunchKernelGGL(k_grad_pair<128>, dim3(nb), dim3(256), 0, s, P);
+    else if (P.DP == 96) hipLaunchKernelGGL(k_grad_pair<96>, dim3(nb), dim3(192), 0, s, P);
+    else if (P.DP == 64) hipLaunchKernelGGL(k_grad_pair<64>, dim3(nb), dim3(128), 0, s, P);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
