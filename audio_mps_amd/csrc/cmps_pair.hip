@@ -51,7 +51,11 @@ __device__ __forceinline__ float rdl(float v, int lane) {
 // workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. waits every step for the
 // stash row's store to reach L2 (~1.5 us; measured: it was 80 % of the step)
 __device__ __forceinline__ void lds_barrier() {
+#if defined(CMPS_DIAG) && defined(PABL_NO_BARRIER)    // diagnostic builds only (scripts/ablate.py): results are wrong
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
 }
 // sum over the two lane halves: lower lanes get a0 + a0', upper lanes get a1 + a1'  (see cmps_wave_util.h::swapadd)
 __device__ __forceinline__ float half_add(float a0, float a1) {
@@ -426,7 +430,9 @@ __device__ __forceinline__ void matvec2p(const u2 (&FA)[PD / 4], const u2 (&FB)[
     u4 b0[4], b1[4], b2[4];
     rd4g(addr, b0);
     rd4g(addr + 64, b1);
+#if !(defined(CMPS_DIAG) && defined(PABL_HALF_READS))
     if constexpr (NG > 2) rd4g(addr + 128, b2);
+#endif
     piece(ic<0>{});
     if constexpr (NG == 2) {
         rd_wait4<4>(b0); quads_of_group<0, NG>(FA, FB, b0, x, y, piece);
@@ -439,11 +445,18 @@ __device__ __forceinline__ void matvec2p(const u2 (&FA)[PD / 4], const u2 (&FB)[
         rd_wait4<0>(b2); quads_of_group<2, NG>(FA, FB, b2, x, y, piece);
         piece(ic<13>{}); piece(ic<14>{}); piece(ic<15>{}); piece(ic<16>{});
     } else {
+#if defined(CMPS_DIAG) && defined(PABL_HALF_READS)    // diagnostic builds only: half of the vector is read, and used twice
+        rd_wait4<4>(b0); quads_of_group<0, NG>(FA, FB, b0, x, y, piece);
+        rd_wait4<0>(b1); quads_of_group<1, NG>(FA, FB, b1, x, y, piece);
+        quads_of_group<2, NG>(FA, FB, b0, x, y, piece);
+        quads_of_group<3, NG>(FA, FB, b1, x, y, piece);
+#else
         rd_wait4<8>(b0); quads_of_group<0, NG>(FA, FB, b0, x, y, piece);
         rd4g(addr + 192, b0);
         rd_wait4<8>(b1); quads_of_group<1, NG>(FA, FB, b1, x, y, piece);
         rd_wait4<4>(b2); quads_of_group<2, NG>(FA, FB, b2, x, y, piece);
         rd_wait4<0>(b0); quads_of_group<3, NG>(FA, FB, b0, x, y, piece);
+#endif
     }
 }
 
@@ -710,6 +723,11 @@ struct StepTab {
 };
 
 constexpr int GB = 8;          // steps per 16-byte piece of a GEMM operand
+#if defined(CMPS_DIAG) && defined(PABL_NO_EXPORT)     // diagnostic builds only (scripts/ablate.py): no GEMM operands written
+constexpr bool PAIR_EXPORT = false;
+#else
+constexpr bool PAIR_EXPORT = true;
+#endif
 
 // gops index of the piece (pair, block, operand, clip, component, row): units of 16 bytes
 template <int PD>
@@ -823,15 +841,25 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
     auto rho_rows = [&](int k) { return *reinterpret_cast<const float4*>(&RS.row[(k / RCH) & 1][k & (RCH - 1)][ia]); };
     auto tab_row = [&](int k, int half) { return TB.row[w][(k / PCH) & 1][k & (PCH - 1)][q][half]; };
     // unconditional (clamped) loads: a select on the loaded value would force the wait right behind the load
+#if defined(CMPS_DIAG) && defined(PABL_NO_STASHREAD)  // diagnostic builds only: every fetch hits the same (cached) row
+    auto row_at = [&](int k) { return st[(size_t)(k > 0 ? k & 7 : 0) * PWV * 64]; };
+#else
     auto row_at = [&](int k) { return st[(size_t)(k > 0 ? k : 0) * PWV * 64]; };
-    // ring of four stash rows: slot (k & 3) holds row k = (y_k a, y_k b, (H y_k) a, (H y_k) b)
-    float4 ring0, ring1, ring2, ring3;
+#endif
+    // ring of eight stash rows: slot (k & 7) holds row k = (y_k a, y_k b, (H y_k) a, (H y_k) b), fetched seven steps (~5 us)
+    // before its first use: under load the stash stream's latency is several microseconds (with a ring of four the scan
+    // spent 665 of its 1744 cycles per step in s_waitcnt)
+    float4 ring0, ring1, ring2, ring3, ring4, ring5, ring6, ring7;
     {
         const int k0 = N - 1;
-        ring0 = row_at(k0 - ((k0 - 0) & 3));
-        ring1 = row_at(k0 - ((k0 - 1) & 3));
-        ring2 = row_at(k0 - ((k0 - 2) & 3));
-        ring3 = row_at(k0 - ((k0 - 3) & 3));
+        ring0 = row_at(k0 - ((k0 - 0) & 7));
+        ring1 = row_at(k0 - ((k0 - 1) & 7));
+        ring2 = row_at(k0 - ((k0 - 2) & 7));
+        ring3 = row_at(k0 - ((k0 - 3) & 7));
+        ring4 = row_at(k0 - ((k0 - 4) & 7));
+        ring5 = row_at(k0 - ((k0 - 5) & 7));
+        ring6 = row_at(k0 - ((k0 - 6) & 7));
+        ring7 = row_at(k0 - ((k0 - 7) & 7));
         const int k1 = k0 > 0 ? k0 - 1 : 0;
         rh = rho_rows(k0);
         S0 = tab_row(k0, 0);
@@ -839,7 +867,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
         rhp = rho_rows(k1);
         SP0 = tab_row(k1, 0);
         SP1 = tab_row(k1, 1);
-        const float4 cur = (k0 & 3) == 0 ? ring0 : (k0 & 3) == 1 ? ring1 : (k0 & 3) == 2 ? ring2 : ring3;
+        const float4 cur = row_at(k0);              // (a second fetch of that row: selecting the slot at run time put the ring into scratch memory)
         c3a = S0.w * cur.z;                     // rad_N = 0
         c3b = S0.w * cur.w;
     }
@@ -902,7 +930,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
                 c3a = fmaf(SP0.w, PRV.z, -(ypa * radk));                                                                           \
                 c3b = fmaf(SP0.w, PRV.w, -(ypb * radk));                                                                           \
                 PAIR_PIN2(c3a, c3b);                                                                                               \
-            } else if constexpr (PI >= 5 && PI <= 9) {   /* GEMM operands of step k: te y | ybar | s ybar | y | u */                \
+            } else if constexpr (PI >= 5 && PI <= 9 && PAIR_EXPORT) {   /* GEMM operands of step k: te y | ybar | s ybar | y | u */ \
                 constexpr int o = PI - 5;                                                                                          \
                 const float va = o == 0 ? te * CUR.x : o == 1 ? yba : o == 2 ? s * yba : o == 3 ? CUR.x : uka;                     \
                 const float vb = o == 0 ? te * CUR.y : o == 1 ? ybb : o == 2 ? s * ybb : o == 3 ? CUR.y : ukb;                     \
@@ -915,12 +943,12 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
                     PAIR_PIN2(E[o][0][(J) >> 1], E[o][1][(J) >> 1]);                                                               \
                 }                                                                                                                  \
             } else if constexpr (PI == 10) {                                                                                       \
-                CUR = row_at(k - 4);                                  /* this slot's next row (row k is dead from here on) */      \
+                CUR = row_at(k - 8);                                  /* this slot's next row (row k is dead from here on) */      \
             } else if constexpr (PI == 16) {         /* scalars and rho row of step k - 2, behind the last MFMAs */                 \
                 nrh = rho_rows(km2);                                                                                               \
                 nS0 = tab_row(km2, 0);                                                                                             \
                 nS1 = tab_row(km2, 1);                                                                                             \
-            } else if constexpr (PI >= 11 && PI <= 15) {                                                                           \
+            } else if constexpr (PI >= 11 && PI <= 15 && PAIR_EXPORT) {                                                            \
                 if ((J) == 0) {                                       /* a block of eight steps is complete */                     \
                     constexpr int o = PI - 11;                                                                                     \
                     uint4* gp = gbase + (size_t)blk * GBLK_STRIDE + o * GOP_STRIDE;                                                \
@@ -942,25 +970,25 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
 
     int blk = NBLK - 1;
     if (N & (GB - 1)) {                                                // the partly filled top block
-        PAIR_BWD_STEP(7, ring3, ring2, 8 * blk + 7 < N)
-        PAIR_BWD_STEP(6, ring2, ring1, 8 * blk + 6 < N)
-        PAIR_BWD_STEP(5, ring1, ring0, 8 * blk + 5 < N)
-        PAIR_BWD_STEP(4, ring0, ring3, 8 * blk + 4 < N)
+        PAIR_BWD_STEP(7, ring7, ring6, 8 * blk + 7 < N)
+        PAIR_BWD_STEP(6, ring6, ring5, 8 * blk + 6 < N)
+        PAIR_BWD_STEP(5, ring5, ring4, 8 * blk + 5 < N)
+        PAIR_BWD_STEP(4, ring4, ring3, 8 * blk + 4 < N)
         PAIR_BWD_STEP(3, ring3, ring2, 8 * blk + 3 < N)
         PAIR_BWD_STEP(2, ring2, ring1, 8 * blk + 2 < N)
         PAIR_BWD_STEP(1, ring1, ring0, 8 * blk + 1 < N)
-        PAIR_BWD_STEP(0, ring0, ring3, true)
+        PAIR_BWD_STEP(0, ring0, ring7, true)
         --blk;
     }
     for (; blk >= 0; --blk) {
-        PAIR_BWD_STEP(7, ring3, ring2, true)
-        PAIR_BWD_STEP(6, ring2, ring1, true)
-        PAIR_BWD_STEP(5, ring1, ring0, true)
-        PAIR_BWD_STEP(4, ring0, ring3, true)
+        PAIR_BWD_STEP(7, ring7, ring6, true)
+        PAIR_BWD_STEP(6, ring6, ring5, true)
+        PAIR_BWD_STEP(5, ring5, ring4, true)
+        PAIR_BWD_STEP(4, ring4, ring3, true)
         PAIR_BWD_STEP(3, ring3, ring2, true)
         PAIR_BWD_STEP(2, ring2, ring1, true)
         PAIR_BWD_STEP(1, ring1, ring0, true)
-        PAIR_BWD_STEP(0, ring0, ring3, true)
+        PAIR_BWD_STEP(0, ring0, ring7, true)
     }
 #undef PAIR_BWD_STEP
     // ---- the pair's slab: f | psi0bar_re | psi0bar_im | A (the R / Q sections are written by k_grad_pair) ----
