@@ -347,14 +347,10 @@ __global__ void k_states(Dev P, float* __restrict__ psi_out) {
             const float* r = P.hst + row * 128;
             y = make_float2(r[4 * i], r[4 * i + 2]);
         } else if (P.stash_layout == 2) {
-            // pair variant (cmps_pair.hip): per pair and step DP/32 waves x 64 lanes x float4 (y_a, y_b, ., .); lane =
-            // 4 * (row group + 8 * K half) + (2 * clip + component), rows 32 w + 4 rg + 2 kh (+1)
-            const int b = (int)(row / N), PWV = DP / 32;
-            const int w = i >> 5, rg = (i & 31) >> 2, kh = (i & 3) >> 1, which = i & 1;
-            const int lane = 4 * (rg + 8 * kh) + 2 * (b & 1);
-            const float4* r = reinterpret_cast<const float4*>(P.stash) + (((size_t)(b >> 1) * N + k) * PWV + w) * 64 + lane;
-            const float4 re = r[0], im = r[1];
-            y = which ? make_float2(re.y, im.y) : make_float2(re.x, im.x);
+            // pair variant (cmps_pair.hip): per pair and step [y | H y][clip][re | im][DP] float32
+            const int b = (int)(row / N);
+            const float* r = reinterpret_cast<const float*>(P.stash) + ((((size_t)(b >> 1) * N + k) * 2 + 0) * 2 + (b & 1)) * 2 * DP;
+            y = make_float2(r[i], r[DP + i]);
         } else {
             y = P.stash[row * DP + i];
         }

@@ -503,41 +503,70 @@ __device__ __forceinline__ void load_frags(u2 (&frag)[NT], F&& elem) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
-// forward: 8 waves per workgroup.  Waves 0-3 ("chain") carry the recurrence u -> y -> u' with the R and Q fragments;
-// waves 4-7 ("loss") hold the H = R + R^dagger fragments and do everything nothing waits for: H y_{k-1}, e_{k-1}, the
-// stash row, the per-step scalars and the loss.  Both kinds own the same (row, component, clip) per lane, meet at ONE
-// LDS-only barrier per step, and share each SIMD's issue slots and matrix pipe (a lone wave issues one instruction per
-// ~5.4 cycles; the split also keeps each wave's fragments in arch VGPRs -- the 4-wave version copied 48 of them out of
-// AGPRs every step).
+// forward: 8 waves per workgroup.  Waves 0-3 ("chain") carry the recurrence u -> y -> u' with the R and Q fragments and meet
+// at ONE LDS-only barrier per step.  Waves 4-7 ("loss") do everything nothing waits for -- H y, e = Re(y^dagger H y), the
+// stash rows, the per-step scalars and the loss -- and do it EIGHT STEPS AT A TIME: the chain leaves every y_k in an LDS
+// ring (bf16 images for the matrix cores, float32 for the dot product), and  H [y_k .. y_{k+7}]  of both clips is one
+// 32 x 32 tile of v_mfma_f32_32x32x16_bf16 per loss wave (columns = (component, step, clip); 2 D / 16 MFMAs per batch, spread
+// two per step over the following batch so that no step's barrier waits for them).  Per step a loss wave issues about a
+// dozen instructions instead of ~160 (32 4x4x4 MFMAs, 16 LDS reads and the VALU tail per step before), and both kinds share
+// a SIMD's issue slots, so this is what the chain gets back.
+// Stash (Dev::stash, pair layout): per pair and step  [y | H y][clip][re | im][D] float32.
 // ------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int FB = 8;                                   // steps per loss-wave batch
+template <int D>
+struct FwdRing {
+    static constexpr int BROW = D * 2 + 16, FROW = D * 4 + 16;         // padded rows (bank spread, see PairLds)
+    __attribute__((aligned(16))) unsigned char b[2 * FB][2][4][BROW];  // [slot][clip][re | im | -im | dummy] bf16
+    __attribute__((aligned(16))) unsigned char f[2 * FB][2][2][FROW];  // [slot][clip][re | im] float32
+    __attribute__((aligned(16))) float nrm[2 * FB][2][4];              // [slot][clip][chain wave]: partial |y|^2
+    __attribute__((aligned(16))) float ee[2][2 * FB][4];               // [batch parity][step in batch * 2 + clip][loss wave]
+};
+
+typedef short bf8v __attribute__((ext_vector_type(8)));
+typedef float f16t __attribute__((ext_vector_type(16)));
+
+// float index of (pair, step, y / H y, clip, component, row) in the pair stash
+template <int PD>
+__device__ __forceinline__ size_t pair_stash_index(size_t pair, int N, int step, int yh, int clip, int comp, int row) {
+    return (((((pair * N + step) * 2 + yh) * 2 + clip) * 2 + comp) * PD) + row;
+}
+
+}  // namespace
+
 template <int PD, bool SAVE>
 __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __restrict__ audio,
                                                         float* __restrict__ loss_out) {
     constexpr int PWV = PD / 32, NT = PD / 4, VROW = PairLds<PD>::VROW;
+    constexpr int BROW = FwdRing<PD>::BROW, FROW = FwdRing<PD>::FROW;
     __shared__ PairLds<PD> L;
     __shared__ RhoStage<PD> RS;
-    __shared__ __attribute__((aligned(8))) float2 yf[2][PWV][64];       // y_k in float32, [parity][chain wave][lane]
+    __shared__ FwdRing<PD> RG;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int w = wv % PWV;
     const bool loss_wave = wv >= PWV;
-    const int c = lane & 3, q = c >> 1, rg = (lane >> 2) & 7, kh = lane >> 5;
-    const bool odd = (c & 1) != 0;
     const int N = P.N, T = P.T, NC = (N + PCH - 1) / PCH;
     const int b0 = 2 * blockIdx.x, b1 = (b0 + 1 < P.B) ? b0 + 1 : b0;   // an odd batch repeats its last clip (not stored)
     const bool two = b1 != b0;
-    const int ia = 32 * w + 4 * rg + 2 * kh, ib = ia + 1;              // the two (adjacent) rows this lane owns after rows_of
-    const int arow = 32 * w + 4 * rg + c;                              // the row of this lane's A operand
-    // LDS addressing (see PairLds): read 256 B of array  kh == 0 ? (odd ? im : re) : (odd ? re : -im)  of clip q
-    const int rd_arr = kh == 0 ? (odd ? 1 : 0) : (odd ? 0 : 2);
-    const int rd_off = (rd_arr * 2 + q) * VROW;
     const float* xr0 = audio + (size_t)b0 * T;
     const float* xr1 = audio + (size_t)b1 * T;
     const float A = P.A;
-    const f4 z4 = {0.f, 0.f, 0.f, 0.f};
     const int tid = threadIdx.x;
+    // both kinds run the same number of iterations (one barrier each): batch bt of the loss waves multiplies batch bt - 1 and
+    // finishes batch bt - 2
+    const int NBT = (N - 1) / FB + 3;
 
     if (!loss_wave) {
         // ================================================================== chain waves
+        const int c = lane & 3, q = c >> 1, rg = (lane >> 2) & 7, kh = lane >> 5;
+        const bool odd = (c & 1) != 0;
+        const int ia = 32 * w + 4 * rg + 2 * kh, ib = ia + 1;          // the two (adjacent) rows this lane owns after rows_of
+        const int arow = 32 * w + 4 * rg + c;                          // the row of this lane's A operand
+        // LDS addressing (see PairLds): read 256 B of array  kh == 0 ? (odd ? im : re) : (odd ? re : -im)  of clip q
+        const int rd_arr = kh == 0 ? (odd ? 1 : 0) : (odd ? 0 : 2);
+        const int rd_off = (rd_arr * 2 + q) * VROW;
         __builtin_amdgcn_s_setprio(3);      // both kinds share a SIMD's matrix pipe: the serial chain goes first
         u2 FR[NT], FQ[NT];
         {
@@ -559,6 +588,9 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
             *reinterpret_cast<unsigned*>(base + wr1 + ia * 2) = pk;
             *reinterpret_cast<unsigned*>(base + wr2 + ia * 2) = pk ^ 0x80008000u;
         };
+        // the ring rows of this lane within a slot: bf16 (own array, and -im / dummy), float32
+        const int rb1 = (q * 4 + (odd ? 1 : 0)) * BROW + ia * 2, rb2 = (q * 4 + (odd ? 2 : 3)) * BROW + ia * 2;
+        const int rf = (q * 2 + (odd ? 1 : 0)) * FROW + ia * 4;
         const float2 pa = P.psi0[ia], pb = P.psi0[ib];
         float uta = odd ? pa.y : pa.x, utb = odd ? pb.y : pb.x;      // ut_0 = psi_0 (both clips)
         float inv = 1.f;                                              // 1/sqrt(max(|y_{k-1}|^2, eps)) of this lane's clip
@@ -566,7 +598,7 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
         write_vec(L.vec[0][0], uta, utb);
         rho_stage<PD>(P, RS, 0, 0, tid);
         __syncthreads();
-        for (int k = 0; k <= N + 1; ++k) {
+        for (int k = 0; k < FB * NBT; ++k) {
             const int p = k & 1;
             if (k < N) {
                 if ((k & (PCH - 1)) == 0) {                            // increments of the next 64 steps, one per lane
@@ -581,7 +613,7 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
                 const float2 rha = RS.row[(k / RCH) & 1][k & (RCH - 1)][ia];   // rho_k of this lane's rows
                 const float2 rhb = RS.row[(k / RCH) & 1][k & (RCH - 1)][ib];
                 if (k >= 1) {                                          // |y_{k-1}|^2, published by the previous iteration
-                    inv = __builtin_amdgcn_rsqf(fmaxf(sum_waves<PWV>(&L.nrm[p][q][0]), 1e-12f));   // model.py:332
+                    inv = __builtin_amdgcn_rsqf(fmaxf(sum_waves<PWV>(&RG.nrm[(k - 1) & (2 * FB - 1)][q][0]), 1e-12f));   // model.py:332
                 }
                 const unsigned aU = lds_addr_of(L.vec[p][0]) + rd_off;
                 Acc2 cR, cQ;
@@ -594,14 +626,20 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
                 const float yna = inv * (uta + (qa + s * ra));         // y_k, rows ia / ib
                 const float ynb = inv * (utb + (qb + s * rb));
                 const float nn = clip_sum(yna * yna + ynb * ynb);
-                if (lane == 0 || lane == 2) L.nrm[p ^ 1][q][w] = nn;
+                const int slot = k & (2 * FB - 1);
+                if (lane == 0 || lane == 2) RG.nrm[slot][q][w] = nn;
                 // ut_{k+1} = rho_k y_k (un-normalised): own component with the partner's (re <-> im) through DPP
                 const float pya = dpp_mov<0xB1>(yna), pyb = dpp_mov<0xB1>(ynb);
                 uta = rha.x * yna + (odd ? rha.y : -rha.y) * pya;
                 utb = rhb.x * ynb + (odd ? rhb.y : -rhb.y) * pyb;
                 write_vec(L.vec[p ^ 1][0], uta, utb);
-                write_vec(L.vec[p ^ 1][1], yna, ynb);
-                yf[p ^ 1][w][lane] = make_float2(yna, ynb);
+                {   // y_k for the loss waves: bf16 images and float32
+                    unsigned char* rbase = &RG.b[slot][0][0][0];
+                    const unsigned pk = pk_bf16(yna, ynb);
+                    *reinterpret_cast<unsigned*>(rbase + rb1) = pk;
+                    *reinterpret_cast<unsigned*>(rbase + rb2) = pk ^ 0x80008000u;
+                    *reinterpret_cast<float2*>(&RG.f[slot][0][0][0] + rf) = make_float2(yna, ynb);
+                }
             }
             lds_barrier();
         }
@@ -609,71 +647,106 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
     }
 
     // ====================================================================== loss waves
-    u2 FH[NT];
+    // 32x32x16 MFMA views: A row / B column = lane & 31, K half = lane >> 5; D: column = lane & 31, rows (r & 3) + 8 (r >> 2) + 4 hk
+    const int n = lane & 31, hk = lane >> 5;
+    const int comp = n >> 4, sb = (n >> 1) & (FB - 1), clip = n & 1;   // the column of this lane: (component, step in batch, clip)
+    constexpr int KS = PD / 16, KT = 2 * KS;                            // MFMAs per batch: H_re [y_re | y_im] and H_im [-y_im | y_re]
+    u4 FHre[KS], FHim[KS];                                             // H = R + R^dagger, rows 32 w + n, K = 16 t + 8 hk ..
     {
-        const float2* Rrow = P.R + (size_t)arow * PD;
-        const float2* RTrow = P.RT + (size_t)arow * PD;     // RT[i][j] = R[j][i]
-        if (kh == 0)
-            load_frags(FH, [&](int j) { return Rrow[j].x + RTrow[j].x; });
-        else
-            load_frags(FH, [&](int j) { return Rrow[j].y - RTrow[j].y; });
+        const float2* Rrow = P.R + (size_t)(32 * w + n) * PD;
+        const float2* RTrow = P.RT + (size_t)(32 * w + n) * PD;       // RT[i][j] = R[j][i]
+#pragma unroll
+        for (int t = 0; t < KS; ++t) {
+            unsigned rr[4], ii[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j0 = 16 * t + 8 * hk + 2 * e;
+                rr[e] = (unsigned)bf16_rne(Rrow[j0].x + RTrow[j0].x) | ((unsigned)bf16_rne(Rrow[j0 + 1].x + RTrow[j0 + 1].x) << 16);
+                ii[e] = (unsigned)bf16_rne(Rrow[j0].y - RTrow[j0].y) | ((unsigned)bf16_rne(Rrow[j0 + 1].y - RTrow[j0 + 1].y) << 16);
+            }
+            FHre[t] = u4{rr[0], rr[1], rr[2], rr[3]};
+            FHim[t] = u4{ii[0], ii[1], ii[2], ii[3]};
+        }
     }
-    float4* st = SAVE ? reinterpret_cast<float4*>(P.stash) + ((size_t)blockIdx.x * N * PWV + w) * 64 + lane : nullptr;
-    float* sc0 = SAVE ? P.scal + ((size_t)b0 * NC) * 128 : nullptr;
-    float* sc1 = SAVE ? P.scal + ((size_t)b1 * NC) * 128 : nullptr;
+    // byte offsets of this lane inside a ring slot: B operand rows (H_re part: own component; H_im part: -im for Re columns,
+    // re for Im columns), the float32 rows of its column
+    const int ob1 = (clip * 4 + comp) * BROW + 16 * hk, ob2 = (clip * 4 + (comp ? 0 : 2)) * BROW + 16 * hk;
+    const int of = (clip * 2 + comp) * FROW + (32 * w + 4 * hk) * 4;
+    float* stash = reinterpret_cast<float*>(P.stash);
+    float* sc_c = SAVE ? P.scal + ((size_t)(clip ? b1 : b0) * NC) * 128 : nullptr;
+    const float* xr_c = clip ? xr1 : xr0;
+    const bool clip_live = clip == 0 || two;
     float loss0 = 0.f, loss1 = 0.f;
-    float nv0 = 1.f, nv1 = 1.f, ev0 = 0.f, ev1 = 0.f;                 // per-chunk |y_k|^2 and e_k rows, lane <-> step
+    f16t acc;
     __syncthreads();
-    for (int k = 0; k <= N + 1; ++k) {
-        const int p = k & 1;
-        if (k >= 1 && k <= N) {
-            // ---- |y_{k-1}|^2 for the scalar rows ----
-            {
-                const float n = sum_waves<PWV>(&L.nrm[p][q][0]);
-                const int j = k - 1, jl = j & (PCH - 1);
-                const float n0 = rdl(n, 0), n1 = rdl(n, 2);
-                nv0 = lane == jl ? n0 : nv0;
-                nv1 = lane == jl ? n1 : nv1;
-                if (SAVE && w == 0 && (jl == PCH - 1 || j == N - 1)) {
-                    sc0[(size_t)(j / PCH) * 128 + lane] = nv0;
-                    if (two) sc1[(size_t)(j / PCH) * 128 + lane] = nv1;
-                }
-            }
-            // ---- H y_{k-1}, the stash row, the partial of e_{k-1} ----
-            const unsigned aY = lds_addr_of(L.vec[p][1]) + rd_off;
-            Acc4 cH;
-            float2 yv;
-            matvec1<PD>(FH, aY, cH, [&] { yv = yf[p][w][lane]; });
-            float ha, hb;                                              // ((R + R^dagger) y_{k-1}) rows ia / ib
-            rows_of((cH.a + cH.b) + (cH.c + cH.d), ha, hb);
-            if (SAVE) st[(size_t)(k - 1) * PWV * 64] = make_float4(yv.x, yv.y, ha, hb);
-            const float ep = clip_sum(yv.x * ha + yv.y * hb);
-            if (lane == 0 || lane == 2) L.ee[p ^ 1][q][w] = ep;
+    for (int bt = 0; bt < NBT; ++bt) {
+        const int pb = bt - 1;                                         // the batch being multiplied
+        const bool mul = pb >= 0 && FB * pb < N;
+        const unsigned char* bslot = &RG.b[(pb & 1) * FB + sb][0][0][0];
+        const unsigned char* fslot = &RG.f[(pb & 1) * FB + sb][0][0][0];
+#define PAIR_LOSS_STEP(J)                                                                                                  \
+        {                                                                                                                  \
+            if ((J) == 0 && bt >= 2 && FB * (bt - 2) < N) {          /* finish batch bt - 2: e of (step, clip) = lane & 15 */ \
+                const int fb = bt - 2, step = FB * fb + sb;                                                               \
+                const float e = sum_waves<PWV>(&RG.ee[fb & 1][n & 15][0]);                                                \
+                const bool in = step < N;                                                                                  \
+                const float x0 = in ? xr_c[step] : 0.f, x1 = (in && step + 1 < T) ? xr_c[step + 1] : 0.f;                  \
+                const float lv = in ? -logf(1.0f + (e * (x1 - x0)) / A) : 0.f;     /* model.py:294 operation order */       \
+                if (SAVE && w == 0 && lane < 2 * FB && in && clip_live)                                                     \
+                    sc_c[(size_t)(step / PCH) * 128 + 64 + (step & (PCH - 1))] = e;                                       \
+                _Pragma("unroll") for (int jj = 0; jj < FB; ++jj) {  /* model.py:279: sequential in time */                 \
+                    loss0 += rdl(lv, 2 * jj);                                                                              \
+                    loss1 += rdl(lv, 2 * jj + 1);                                                                          \
+                }                                                                                                          \
+            }                                                                                                              \
+            if (mul) {                                                                                                     \
+                _Pragma("unroll") for (int t = (J) * KT / FB; t < ((J) + 1) * KT / FB; ++t) {                              \
+                    const int tt = t < KS ? t : t - KS;                                                                    \
+                    const u4 bv = *reinterpret_cast<const u4*>(bslot + (t < KS ? ob1 : ob2) + 32 * tt);                    \
+                    /* asm, fragments straight from AGPRs (the chain waves' 128 fragment AGPRs leave this kernel 128 VGPRs) */ \
+                    if (t == 0)                                                                                            \
+                        asm volatile(PAIR_ASM("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0") : "=&v"(acc) : "a"(FHre[0]), "v"(bv));     \
+                    else if (t == KT - 1)       /* + the wait states before the VALU reads the tile (8 passes) */          \
+                        asm volatile(PAIR_ASM("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 7")          \
+                                     : "+v"(acc) : "a"(FHim[KS - 1]), "v"(bv));                                            \
+                    else if (t < KS)                                                                                       \
+                        asm volatile(PAIR_ASM("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0") : "+v"(acc) : "a"(FHre[tt]), "v"(bv));   \
+                    else                                                                                                   \
+                        asm volatile(PAIR_ASM("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0") : "+v"(acc) : "a"(FHim[tt]), "v"(bv));   \
+                }                                                                                                          \
+                if ((J) == FB - 1) {                                 /* the batch's epilogue */                            \
+                    const int step = FB * pb + sb;                                                                         \
+                    const bool in = step < N;                                                                              \
+                    float ep = 0.f;                                                                                        \
+                    f4 yv[4];                                                                                              \
+                    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                        \
+                        yv[g] = *reinterpret_cast<const f4*>(fslot + of + 32 * g);                                         \
+                        _Pragma("unroll") for (int i = 0; i < 4; ++i) ep = fmaf(yv[g][i], acc[4 * g + i], ep);            \
+                    }                                                                                                      \
+                    if (SAVE && in) {                 /* (the repeated clip of an odd batch too: the reverse scan reads it) */ \
+                        float* yp = stash + pair_stash_index<PD>(blockIdx.x, N, step, 0, clip, comp, 32 * w + 4 * hk);     \
+                        float* hp = stash + pair_stash_index<PD>(blockIdx.x, N, step, 1, clip, comp, 32 * w + 4 * hk);     \
+                        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                    \
+                            *reinterpret_cast<f4*>(yp + 8 * g) = yv[g];                                                    \
+                            *reinterpret_cast<f4*>(hp + 8 * g) = f4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]}; \
+                        }                                                                                                  \
+                    }                                                                                                      \
+                    ep = half_add(ep, ep);                             /* + the other row half */                         \
+                    {                                                                                                      \
+                        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(ep), __float_as_uint(ep), false, false); \
+                        ep = __uint_as_float(r[0]) + __uint_as_float(r[1]);          /* + the other component */            \
+                    }                                                                                                      \
+                    if (lane < 2 * FB) RG.ee[pb & 1][lane][w] = ep;                                                        \
+                    if (SAVE && w == 0 && lane < 2 * FB && in && clip_live)                                                 \
+                        sc_c[(size_t)(step / PCH) * 128 + (step & (PCH - 1))] =                                            \
+                            sum_waves<PWV>(&RG.nrm[(pb & 1) * FB + sb][clip][0]);                                          \
+                }                                                                                                          \
+            }                                                                                                              \
+            lds_barrier();                                                                                                 \
         }
-        if (k >= 2) {                                                  // e_{k-2}, published by the previous iteration
-            const float e = sum_waves<PWV>(&L.ee[p][q][0]);
-            const int j = k - 2, jl = j & (PCH - 1);
-            const float e0 = rdl(e, 0), e1 = rdl(e, 2);
-            ev0 = lane == jl ? e0 : ev0;
-            ev1 = lane == jl ? e1 : ev1;
-            if (jl == PCH - 1 || j == N - 1) {                         // a chunk of the loss is complete
-                const int base = j - jl, cnt = jl + 1, idx = base + lane;
-                const bool in0 = idx < T, in1 = idx + 1 < T;
-                const float inc0 = (in1 ? xr0[idx + 1] : 0.f) - (in0 ? xr0[idx] : 0.f);
-                const float inc1 = (in1 ? xr1[idx + 1] : 0.f) - (in0 ? xr1[idx] : 0.f);
-                const float lv0 = -logf(1.0f + (ev0 * inc0) / A);      // model.py:294 operation order
-                const float lv1 = -logf(1.0f + (ev1 * inc1) / A);
-                for (int jj = 0; jj < cnt; ++jj) {                     // model.py:279: sequential in time
-                    loss0 += rdl(lv0, jj);
-                    loss1 += rdl(lv1, jj);
-                }
-                if (SAVE && w == 0) {
-                    sc0[(size_t)(j / PCH) * 128 + 64 + lane] = ev0;
-                    if (two) sc1[(size_t)(j / PCH) * 128 + 64 + lane] = ev1;
-                }
-            }
-        }
-        lds_barrier();
+        PAIR_LOSS_STEP(0) PAIR_LOSS_STEP(1) PAIR_LOSS_STEP(2) PAIR_LOSS_STEP(3)
+        PAIR_LOSS_STEP(4) PAIR_LOSS_STEP(5) PAIR_LOSS_STEP(6) PAIR_LOSS_STEP(7)
+#undef PAIR_LOSS_STEP
     }
     if (w == 0 && lane == 0) {
         loss_out[b0] = loss0;
@@ -779,7 +852,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
     const float* xr1 = audio + (size_t)b1 * T;
     const float* sc0 = P.scal + ((size_t)b0 * NC) * 128;
     const float* sc1 = P.scal + ((size_t)b1 * NC) * 128;
-    const float4* st = reinterpret_cast<const float4*>(P.stash) + ((size_t)blockIdx.x * N * PWV + w) * 64 + lane;
+    const float* stf = reinterpret_cast<const float*>(P.stash);
     const int NBLK = (N + GB - 1) / GB;
     // this lane's pieces: rows ia, ia + 1 (32 contiguous bytes) of component (c & 1), clip q
     uint4* gbase = reinterpret_cast<uint4*>(P.gops) + gop_index<PD>(blockIdx.x, NBLK, 0, 0, q, odd ? 1 : 0, ia);
@@ -841,11 +914,17 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
     auto rho_rows = [&](int k) { return *reinterpret_cast<const float4*>(&RS.row[(k / RCH) & 1][k & (RCH - 1)][ia]); };
     auto tab_row = [&](int k, int half) { return TB.row[w][(k / PCH) & 1][k & (PCH - 1)][q][half]; };
     // unconditional (clamped) loads: a select on the loaded value would force the wait right behind the load
-#if defined(CMPS_DIAG) && defined(PABL_NO_STASHREAD)  // diagnostic builds only: every fetch hits the same (cached) row
-    auto row_at = [&](int k) { return st[(size_t)(k > 0 ? k & 7 : 0) * PWV * 64]; };
+    // row k of the stash for this lane: (y_k a, y_k b) and ((H y_k) a, (H y_k) b), rows ia | ia + 1 of component (c & 1), clip q
+    auto row_at = [&](int k) {
+#if defined(CMPS_DIAG) && defined(PABL_NO_STASHREAD)  // diagnostic builds only: every fetch hits the same (cached) rows
+        const int kc = k > 0 ? k & 7 : 0;
 #else
-    auto row_at = [&](int k) { return st[(size_t)(k > 0 ? k : 0) * PWV * 64]; };
+        const int kc = k > 0 ? k : 0;
 #endif
+        const float2 y = *reinterpret_cast<const float2*>(stf + pair_stash_index<PD>(blockIdx.x, N, kc, 0, q, odd ? 1 : 0, ia));
+        const float2 h = *reinterpret_cast<const float2*>(stf + pair_stash_index<PD>(blockIdx.x, N, kc, 1, q, odd ? 1 : 0, ia));
+        return make_float4(y.x, y.y, h.x, h.y);
+    };
     // ring of eight stash rows: slot (k & 7) holds row k = (y_k a, y_k b, (H y_k) a, (H y_k) b), fetched seven steps (~5 us)
     // before its first use: under load the stash stream's latency is several microseconds (with a ring of four the scan
     // spent 665 of its 1744 cycles per step in s_waitcnt)
