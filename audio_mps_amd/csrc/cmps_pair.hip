@@ -619,20 +619,20 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
                 Acc2 cR, cQ;
                 matvec2<PD>(FR, FQ, aU, cR, cQ, [] {});
                 const int kl = k & (PCH - 1);
-                const float s = q ? rdl(sv1, kl) : rdl(sv0, kl);
+                const float s0 = rdl(sv0, kl), s1 = rdl(sv1, kl);      // (both read: a readlane inside a select becomes a branch)
+                const float s = q ? s1 : s0;
                 float ra, rb, qa, qb;
                 rows_of(cR.a + cR.b, ra, rb);
                 rows_of(cQ.a + cQ.b, qa, qb);
                 const float yna = inv * (uta + (qa + s * ra));         // y_k, rows ia / ib
                 const float ynb = inv * (utb + (qb + s * rb));
-                const float nn = clip_sum(yna * yna + ynb * ynb);
-                const int slot = k & (2 * FB - 1);
-                if (lane == 0 || lane == 2) RG.nrm[slot][q][w] = nn;
-                // ut_{k+1} = rho_k y_k (un-normalised): own component with the partner's (re <-> im) through DPP
+                // the chain first: ut_{k+1} = rho_k y_k (un-normalised), own component with the partner's (re <-> im) through DPP
                 const float pya = dpp_mov<0xB1>(yna), pyb = dpp_mov<0xB1>(ynb);
                 uta = rha.x * yna + (odd ? rha.y : -rha.y) * pya;
                 utb = rhb.x * ynb + (odd ? rhb.y : -rhb.y) * pyb;
                 write_vec(L.vec[p ^ 1][0], uta, utb);
+                asm volatile("" ::: "memory");                         // (keeps the stores above ahead of what follows)
+                const int slot = k & (2 * FB - 1);
                 {   // y_k for the loss waves: bf16 images and float32
                     unsigned char* rbase = &RG.b[slot][0][0][0];
                     const unsigned pk = pk_bf16(yna, ynb);
@@ -640,6 +640,8 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
                     *reinterpret_cast<unsigned*>(rbase + rb2) = pk ^ 0x80008000u;
                     *reinterpret_cast<float2*>(&RG.f[slot][0][0][0] + rf) = make_float2(yna, ynb);
                 }
+                const float nn = clip_sum(yna * yna + ynb * ynb);
+                if (lane == 0 || lane == 2) RG.nrm[slot][q][w] = nn;
             }
             lds_barrier();
         }
@@ -677,29 +679,56 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
     const float* xr_c = clip ? xr1 : xr0;
     const bool clip_live = clip == 0 || two;
     float loss0 = 0.f, loss1 = 0.f;
-    f16t acc;
+    f16t acc, accE;                                                    // the tile being accumulated / the finished tile of the batch before
+    f4 yv[4];                                                          // y (float32) of this lane's column: rows 32 w + 8 g + 4 hk ..+3
+    float epE = 0.f;
     __syncthreads();
+    // Batch bt of the loop: multiplies batch pb = bt - 1 (two MFMAs per step), reads its float32 y (steps 0-3) and stores it
+    // (step 4); finishes batch pe = bt - 2 from the tile copied at the end of the iteration before: H y stores (step 0),
+    // e partial -> LDS (step 1), e, loss and the scalar rows (step 5).  Nothing is left for one step to do alone.
     for (int bt = 0; bt < NBT; ++bt) {
-        const int pb = bt - 1;                                         // the batch being multiplied
+        const int pb = bt - 1, pe = bt - 2;
         const bool mul = pb >= 0 && FB * pb < N;
+        const bool fin = pe >= 0 && FB * pe < N;
         const unsigned char* bslot = &RG.b[(pb & 1) * FB + sb][0][0][0];
         const unsigned char* fslot = &RG.f[(pb & 1) * FB + sb][0][0][0];
+        const int step_b = FB * pb + sb, step_e = FB * pe + sb;       // this lane's step in either batch
 #define PAIR_LOSS_STEP(J)                                                                                                  \
         {                                                                                                                  \
-            if ((J) == 0 && bt >= 2 && FB * (bt - 2) < N) {          /* finish batch bt - 2: e of (step, clip) = lane & 15 */ \
-                const int fb = bt - 2, step = FB * fb + sb;                                                               \
-                const float e = sum_waves<PWV>(&RG.ee[fb & 1][n & 15][0]);                                                \
-                const bool in = step < N;                                                                                  \
-                const float x0 = in ? xr_c[step] : 0.f, x1 = (in && step + 1 < T) ? xr_c[step + 1] : 0.f;                  \
-                const float lv = in ? -logf(1.0f + (e * (x1 - x0)) / A) : 0.f;     /* model.py:294 operation order */       \
-                if (SAVE && w == 0 && lane < 2 * FB && in && clip_live)                                                     \
-                    sc_c[(size_t)(step / PCH) * 128 + 64 + (step & (PCH - 1))] = e;                                       \
-                _Pragma("unroll") for (int jj = 0; jj < FB; ++jj) {  /* model.py:279: sequential in time */                 \
-                    loss0 += rdl(lv, 2 * jj);                                                                              \
-                    loss1 += rdl(lv, 2 * jj + 1);                                                                          \
+            if (fin) {                                                                                                     \
+                if ((J) == 0 && SAVE && step_e < N) {                /* H y of batch pe */                                 \
+                    float* hp = stash + pair_stash_index<PD>(blockIdx.x, N, step_e, 1, clip, comp, 32 * w + 4 * hk);       \
+                    _Pragma("unroll") for (int g = 0; g < 4; ++g)                                                          \
+                        *reinterpret_cast<f4*>(hp + 8 * g) = f4{accE[4 * g], accE[4 * g + 1], accE[4 * g + 2], accE[4 * g + 3]}; \
+                }                                                                                                          \
+                if ((J) == 1) {                                                                                            \
+                    float ep = half_add(epE, epE);                     /* + the other row half */                          \
+                    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(ep), __float_as_uint(ep), false, false); \
+                    ep = __uint_as_float(r[0]) + __uint_as_float(r[1]);              /* + the other component */            \
+                    if (lane < 2 * FB) RG.ee[pe & 1][lane][w] = ep;                                                        \
+                }                                                                                                          \
+                if ((J) == 5) {                                      /* e of (step, clip) = lane & 15, the loss, the e row */ \
+                    const float e = sum_waves<PWV>(&RG.ee[pe & 1][n & 15][0]);                                            \
+                    const bool in = step_e < N;                                                                            \
+                    const float x0 = in ? xr_c[step_e] : 0.f, x1 = (in && step_e + 1 < T) ? xr_c[step_e + 1] : 0.f;        \
+                    const float lv = in ? -logf(1.0f + (e * (x1 - x0)) / A) : 0.f;  /* model.py:294 operation order */      \
+                    if (SAVE && w == 0 && lane < 2 * FB && in && clip_live)                                                 \
+                        sc_c[(size_t)(step_e / PCH) * 128 + 64 + (step_e & (PCH - 1))] = e;                               \
+                    _Pragma("unroll") for (int jj = 0; jj < FB; ++jj) {  /* model.py:279: sequential in time */             \
+                        loss0 += rdl(lv, 2 * jj);                                                                          \
+                        loss1 += rdl(lv, 2 * jj + 1);                                                                      \
+                    }                                                                                                      \
                 }                                                                                                          \
             }                                                                                                              \
             if (mul) {                                                                                                     \
+                if ((J) < 4) yv[(J) & 3] = *reinterpret_cast<const f4*>(fslot + of + 32 * ((J) & 3));                      \
+                if ((J) == 4 && SAVE && step_b < N) {                /* y of batch pb (the repeated clip of an odd batch too) */ \
+                    float* yp = stash + pair_stash_index<PD>(blockIdx.x, N, step_b, 0, clip, comp, 32 * w + 4 * hk);       \
+                    _Pragma("unroll") for (int g = 0; g < 4; ++g) *reinterpret_cast<f4*>(yp + 8 * g) = yv[g];              \
+                    if (w == 0 && lane < 2 * FB && clip_live)                                                              \
+                        sc_c[(size_t)(step_b / PCH) * 128 + (step_b & (PCH - 1))] =                                        \
+                            sum_waves<PWV>(&RG.nrm[(pb & 1) * FB + sb][clip][0]);                                          \
+                }                                                                                                          \
                 _Pragma("unroll") for (int t = (J) * KT / FB; t < ((J) + 1) * KT / FB; ++t) {                              \
                     const int tt = t < KS ? t : t - KS;                                                                    \
                     const u4 bv = *reinterpret_cast<const u4*>(bslot + (t < KS ? ob1 : ob2) + 32 * tt);                    \
@@ -714,32 +743,12 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
                     else                                                                                                   \
                         asm volatile(PAIR_ASM("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0") : "+v"(acc) : "a"(FHim[tt]), "v"(bv));   \
                 }                                                                                                          \
-                if ((J) == FB - 1) {                                 /* the batch's epilogue */                            \
-                    const int step = FB * pb + sb;                                                                         \
-                    const bool in = step < N;                                                                              \
+                if ((J) == FB - 1) {                                 /* the tile is complete: e partial, hand the tile over */ \
                     float ep = 0.f;                                                                                        \
-                    f4 yv[4];                                                                                              \
-                    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                        \
-                        yv[g] = *reinterpret_cast<const f4*>(fslot + of + 32 * g);                                         \
+                    _Pragma("unroll") for (int g = 0; g < 4; ++g)                                                          \
                         _Pragma("unroll") for (int i = 0; i < 4; ++i) ep = fmaf(yv[g][i], acc[4 * g + i], ep);            \
-                    }                                                                                                      \
-                    if (SAVE && in) {                 /* (the repeated clip of an odd batch too: the reverse scan reads it) */ \
-                        float* yp = stash + pair_stash_index<PD>(blockIdx.x, N, step, 0, clip, comp, 32 * w + 4 * hk);     \
-                        float* hp = stash + pair_stash_index<PD>(blockIdx.x, N, step, 1, clip, comp, 32 * w + 4 * hk);     \
-                        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                    \
-                            *reinterpret_cast<f4*>(yp + 8 * g) = yv[g];                                                    \
-                            *reinterpret_cast<f4*>(hp + 8 * g) = f4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]}; \
-                        }                                                                                                  \
-                    }                                                                                                      \
-                    ep = half_add(ep, ep);                             /* + the other row half */                         \
-                    {                                                                                                      \
-                        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(ep), __float_as_uint(ep), false, false); \
-                        ep = __uint_as_float(r[0]) + __uint_as_float(r[1]);          /* + the other component */            \
-                    }                                                                                                      \
-                    if (lane < 2 * FB) RG.ee[pb & 1][lane][w] = ep;                                                        \
-                    if (SAVE && w == 0 && lane < 2 * FB && in && clip_live)                                                 \
-                        sc_c[(size_t)(step / PCH) * 128 + (step & (PCH - 1))] =                                            \
-                            sum_waves<PWV>(&RG.nrm[(pb & 1) * FB + sb][clip][0]);                                          \
+                    epE = ep;                                                                                              \
+                    accE = acc;                                                                                            \
                 }                                                                                                          \
             }                                                                                                              \
             lds_barrier();                                                                                                 \
