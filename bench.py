@@ -333,8 +333,8 @@ def worker(ARGS):
             kern["fwd"].update(name="k_fwd_wave16 (forward scan, 16-row layout: chain wave + loss wave)", pmc="k_fwd_wave16")
             kern["bwd"].update(name="k_bwd_wave16 (reverse scan, 16-row layout: chain wave + gradient wave)", pmc="k_bwd_wave16")
         if pair:                                                 # D = 128: MFMA pair kernels (bf16 operands, fp32 accumulate)
-            kern["fwd"].update(name="k_fwd_pair (forward scan, 4x4x4 bf16 MFMA)", pmc="k_fwd_pair")
-            kern["bwd"].update(name="k_bwd_pair + k_grad_pair (reverse scan + gradient GEMM)", pmc="k_bwd_pair")
+            kern["fwd"].update(name="k_fwd_pair (forward scan: 4x4x4 bf16 MFMA chain waves + 32x32x16 loss waves, eight steps per tile)", pmc="k_fwd_pair")
+            kern["bwd"].update(name="k_bwd_pair + k_grad_pair (reverse scan + streaming gradient GEMM)", pmc="k_bwd_pair")
         dom = "fwd" if t_fwd >= t_bwd else "bwd"                 # the dominant kernel = the longer launch
         oth = "bwd" if dom == "fwd" else "fwd"
         traffic = profiled_traffic(kern[dom]["pmc"], D, T, B)
