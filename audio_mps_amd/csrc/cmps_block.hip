@@ -447,15 +447,22 @@ hipError_t launch_reduce_only(const Dev& P, hipStream_t s) {
     return hipGetLastError();
 }
 
+// one thread per element of Rbar (a D-term double-precision sum each: 0.41 ms at D = 128 with eight workgroups), at least
+// eight workgroups (blocks 0 and 1 also reduce the loss and the Abar correction)
+static unsigned finalize_blocks(const Dev& P) {
+    const unsigned nb = (unsigned)((P.D * P.D + 255) / 256);
+    return nb < 8 ? 8 : nb;
+}
+
 hipError_t launch_reduce_finalize(const Dev& P, const float* loss, float* grad_out, hipStream_t s) {
     const hipError_t e = launch_reduce_only(P, s);     // its hipGetLastError() has consumed the launch status
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_finalize, dim3(8), dim3(256), 0, s, P, (const float*)P.sums, loss, grad_out);
+    hipLaunchKernelGGL(k_finalize, dim3(finalize_blocks(P)), dim3(256), 0, s, P, (const float*)P.sums, loss, grad_out);
     return hipGetLastError();
 }
 
 hipError_t launch_finalize_only(const Dev& P, const float* loss, float* grad_out, hipStream_t s) {
-    hipLaunchKernelGGL(k_finalize, dim3(8), dim3(256), 0, s, P, (const float*)P.sums, loss, grad_out);
+    hipLaunchKernelGGL(k_finalize, dim3(finalize_blocks(P)), dim3(256), 0, s, P, (const float*)P.sums, loss, grad_out);
     return hipGetLastError();
 }
 

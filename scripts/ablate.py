@@ -35,4 +35,4 @@ for name, flags in variants.items():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "time_kernels.py")] + shape, env=env,
                          capture_output=True, text=True).stdout
     print("==", name, " ".join(flags))
-    print("\n".join(l for l in out.splitlines() if "median" in l))
+    print("\n".join(l for l in out.splitlines() if "median" in l or "cycles per step" in l))

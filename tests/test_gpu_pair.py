@@ -28,7 +28,8 @@ def _pair_model(T, B, seed=3, D=128, **hpkw):
 
 @pytest.mark.parametrize("D,T,B", [(128, 2, 2), (128, 40, 2), (128, 65, 1), (128, 200, 4), (128, 300, 5),
                                    (64, 3, 1), (64, 130, 3), (64, 300, 6), (96, 150, 4),
-                                   (40, 60, 3), (100, 70, 3)])        # 40 and 100 run zero-padded to 64 and 128
+                                   (40, 60, 3), (100, 70, 3),         # 40 and 100 run zero-padded to 64 and 128
+                                   (128, 9, 2), (128, 17, 3), (64, 10, 2), (96, 8, 1)])   # one / two whole eight-step batches, 9 and 7 steps
 def test_pair_matches_bf16_oracle_and_float32(D, T, B):
     from audio_mps_amd.scan import unpack_grad
     m, audio = _pair_model(T, B, D=D)
