@@ -598,53 +598,69 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
         write_vec(L.vec[0][0], uta, utb);
         rho_stage<PD>(P, RS, 0, 0, tid);
         __syncthreads();
-        for (int k = 0; k < FB * NBT; ++k) {
-            const int p = k & 1;
-            if (k < N) {
-                if ((k & (PCH - 1)) == 0) {                            // increments of the next 64 steps, one per lane
-                    const int idx = k + lane;
-                    const bool in0 = idx < T, in1 = idx + 1 < T;
-                    sv0 = ((in1 ? xr0[idx + 1] : 0.f) - (in0 ? xr0[idx] : 0.f)) / A;     // model.py:263, 303
-                    sv1 = ((in1 ? xr1[idx + 1] : 0.f) - (in0 ? xr1[idx] : 0.f)) / A;
-                }
-                if ((k & (RCH - 1)) == 0) {                            // next chunk of rho into the other buffer
-                    rho_stage<PD>(P, RS, k / RCH + 1, (k / RCH + 1) & 1, tid);
-                }
-                const float2 rha = RS.row[(k / RCH) & 1][k & (RCH - 1)][ia];   // rho_k of this lane's rows
-                const float2 rhb = RS.row[(k / RCH) & 1][k & (RCH - 1)][ib];
-                if (k >= 1) {                                          // |y_{k-1}|^2, published by the previous iteration
-                    inv = __builtin_amdgcn_rsqf(fmaxf(sum_waves<PWV>(&RG.nrm[(k - 1) & (2 * FB - 1)][q][0]), 1e-12f));   // model.py:332
-                }
-                const unsigned aU = lds_addr_of(L.vec[p][0]) + rd_off;
-                Acc2 cR, cQ;
-                matvec2<PD>(FR, FQ, aU, cR, cQ, [] {});
-                const int kl = k & (PCH - 1);
-                const float s0 = rdl(sv0, kl), s1 = rdl(sv1, kl);      // (both read: a readlane inside a select becomes a branch)
-                const float s = q ? s1 : s0;
-                float ra, rb, qa, qb;
-                rows_of(cR.a + cR.b, ra, rb);
-                rows_of(cQ.a + cQ.b, qa, qb);
-                const float yna = inv * (uta + (qa + s * ra));         // y_k, rows ia / ib
-                const float ynb = inv * (utb + (qb + s * rb));
-                // the chain first: ut_{k+1} = rho_k y_k (un-normalised), own component with the partner's (re <-> im) through DPP
-                const float pya = dpp_mov<0xB1>(yna), pyb = dpp_mov<0xB1>(ynb);
-                uta = rha.x * yna + (odd ? rha.y : -rha.y) * pya;
-                utb = rhb.x * ynb + (odd ? rhb.y : -rhb.y) * pyb;
-                write_vec(L.vec[p ^ 1][0], uta, utb);
-                asm volatile("" ::: "memory");                         // (keeps the stores above ahead of what follows)
-                const int slot = k & (2 * FB - 1);
-                {   // y_k for the loss waves: bf16 images and float32
-                    unsigned char* rbase = &RG.b[slot][0][0][0];
-                    const unsigned pk = pk_bf16(yna, ynb);
-                    *reinterpret_cast<unsigned*>(rbase + rb1) = pk;
-                    *reinterpret_cast<unsigned*>(rbase + rb2) = pk ^ 0x80008000u;
-                    *reinterpret_cast<float2*>(&RG.f[slot][0][0][0] + rf) = make_float2(yna, ynb);
-                }
-                const float nn = clip_sum(yna * yna + ynb * ynb);
-                if (lane == 0 || lane == 2) RG.nrm[slot][q][w] = nn;
-            }
-            lds_barrier();
+        // Eight steps per block with the step-in-block J static: the LDS parities and ring slots are immediates, the chunk
+        // boundaries (increments every 64 steps, rho staging every 32) can only fall on J = 0, and in blocks that lie entirely
+        // below N no step is conditional (about 15 scalar instructions per step less than the plain loop).
+#define PAIR_FWD_STEP(J, LIVE)                                                                                             \
+        {                                                                                                                  \
+            constexpr int p = (J) & 1;                                                                                     \
+            if (LIVE) {                                                                                                    \
+                const int k = FB * bt + (J);                                                                               \
+                if ((J) == 0 && (bt & (PCH / FB - 1)) == 0) {          /* increments of the next 64 steps, one per lane */  \
+                    const int idx = k + lane;                                                                              \
+                    const bool in0 = idx < T, in1 = idx + 1 < T;                                                           \
+                    sv0 = ((in1 ? xr0[idx + 1] : 0.f) - (in0 ? xr0[idx] : 0.f)) / A;     /* model.py:263, 303 */            \
+                    sv1 = ((in1 ? xr1[idx + 1] : 0.f) - (in0 ? xr1[idx] : 0.f)) / A;                                       \
+                }                                                                                                          \
+                if ((J) == 0 && (bt & (RCH / FB - 1)) == 0)            /* next chunk of rho into the other buffer */        \
+                    rho_stage<PD>(P, RS, k / RCH + 1, (k / RCH + 1) & 1, tid);                                             \
+                const float2* rrow = &RS.row[(bt / (RCH / FB)) & 1][(bt & (RCH / FB - 1)) * FB + (J)][0];                  \
+                const float2 rha = rrow[ia], rhb = rrow[ib];           /* rho_k of this lane's rows */                     \
+                const int hb_ = bt & 1;                                /* the ring half of this block */                   \
+                if ((J) > 0 || bt > 0) {                               /* |y_{k-1}|^2, published by the previous iteration */ \
+                    const float* np_ = (J) > 0 ? &RG.nrm[hb_ * FB + (J) - 1][q][0] : &RG.nrm[(hb_ ^ 1) * FB + FB - 1][q][0]; \
+                    inv = __builtin_amdgcn_rsqf(fmaxf(sum_waves<PWV>(np_), 1e-12f));     /* model.py:332 */                \
+                }                                                                                                          \
+                const unsigned aU = lds_addr_of(L.vec[p][0]) + rd_off;                                                     \
+                Acc2 cR, cQ;                                                                                               \
+                matvec2<PD>(FR, FQ, aU, cR, cQ, [] {});                                                                    \
+                const int kl = (bt & (PCH / FB - 1)) * FB + (J);                                                           \
+                const float s0 = rdl(sv0, kl), s1 = rdl(sv1, kl);      /* (both read: a readlane inside a select becomes a branch) */ \
+                const float s = q ? s1 : s0;                                                                               \
+                float ra, rb, qa, qb;                                                                                      \
+                rows_of(cR.a + cR.b, ra, rb);                                                                              \
+                rows_of(cQ.a + cQ.b, qa, qb);                                                                              \
+                const float yna = inv * (uta + (qa + s * ra));         /* y_k, rows ia / ib */                             \
+                const float ynb = inv * (utb + (qb + s * rb));                                                             \
+                /* the chain first: ut_{k+1} = rho_k y_k (un-normalised), own component with the partner's (re <-> im) through DPP */ \
+                const float pya = dpp_mov<0xB1>(yna), pyb = dpp_mov<0xB1>(ynb);                                            \
+                uta = rha.x * yna + (odd ? rha.y : -rha.y) * pya;                                                          \
+                utb = rhb.x * ynb + (odd ? rhb.y : -rhb.y) * pyb;                                                          \
+                write_vec(L.vec[p ^ 1][0], uta, utb);                                                                      \
+                asm volatile("" ::: "memory");                         /* (keeps the stores above ahead of what follows) */ \
+                {   /* y_k for the loss waves: bf16 images and float32 */                                                  \
+                    unsigned char* rbase = &RG.b[hb_ * FB + (J)][0][0][0];                                                 \
+                    const unsigned pk = pk_bf16(yna, ynb);                                                                 \
+                    *reinterpret_cast<unsigned*>(rbase + rb1) = pk;                                                        \
+                    *reinterpret_cast<unsigned*>(rbase + rb2) = pk ^ 0x80008000u;                                          \
+                    *reinterpret_cast<float2*>(&RG.f[hb_ * FB + (J)][0][0][0] + rf) = make_float2(yna, ynb);               \
+                }                                                                                                          \
+                const float nn = clip_sum(yna * yna + ynb * ynb);                                                          \
+                if (lane == 0 || lane == 2) RG.nrm[hb_ * FB + (J)][q][w] = nn;                                             \
+            }                                                                                                              \
+            lds_barrier();                                                                                                 \
         }
+        int bt = 0;
+        for (; FB * bt + FB <= N; ++bt) {                                  // whole blocks
+            PAIR_FWD_STEP(0, true) PAIR_FWD_STEP(1, true) PAIR_FWD_STEP(2, true) PAIR_FWD_STEP(3, true)
+            PAIR_FWD_STEP(4, true) PAIR_FWD_STEP(5, true) PAIR_FWD_STEP(6, true) PAIR_FWD_STEP(7, true)
+        }
+        for (; bt < NBT; ++bt) {                                           // the last steps and the loss waves' run-out
+            PAIR_FWD_STEP(0, FB * bt + 0 < N) PAIR_FWD_STEP(1, FB * bt + 1 < N) PAIR_FWD_STEP(2, FB * bt + 2 < N)
+            PAIR_FWD_STEP(3, FB * bt + 3 < N) PAIR_FWD_STEP(4, FB * bt + 4 < N) PAIR_FWD_STEP(5, FB * bt + 5 < N)
+            PAIR_FWD_STEP(6, FB * bt + 6 < N) PAIR_FWD_STEP(7, FB * bt + 7 < N)
+        }
+#undef PAIR_FWD_STEP
         return;
     }
 
