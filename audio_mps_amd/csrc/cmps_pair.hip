@@ -826,6 +826,11 @@ constexpr bool PAIR_EXPORT = false;
 #else
 constexpr bool PAIR_EXPORT = true;
 #endif
+#if defined(CMPS_DIAG) && defined(PABL_NO_EXPORT_STORES)   // diagnostic builds only: operands packed but never stored
+constexpr bool PAIR_EXPORT_STORES = false;
+#else
+constexpr bool PAIR_EXPORT_STORES = true;
+#endif
 
 // gops index of the piece (pair, block, operand, clip, component, row): units of 16 bytes
 template <int PD>
@@ -989,6 +994,16 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
 
     const float2 psa = P.psi0[ia], psb = P.psi0[ib];
     const float ps0a = odd ? psa.y : psa.x, ps0b = odd ? psb.y : psb.x;        // u_0 = psi_0
+#if defined(CMPS_DIAG) && defined(PABL_TIMING)        // diagnostic builds only: where a step's cycles go (s_memtime stamps, consumed a step late)
+    unsigned long long tA = 0, tB = 0, tC = 0, tA1 = 0, tB1 = 0, tC1 = 0, tC2 = 0, accPre = 0, accMv = 0, accTail = 0, accN = 0;
+#define PAIR_BSTAMP_A() { if (tC2) { accPre += tA1 - tC2; accMv += tB1 - tA1; accTail += tC1 - tB1; ++accN; } tC2 = tC1; tA = __builtin_readcyclecounter(); }
+#define PAIR_BSTAMP_B() tB = __builtin_readcyclecounter()
+#define PAIR_BSTAMP_C() { asm volatile("" : "+v"(ga), "+v"(gb)); tC = __builtin_readcyclecounter(); tA1 = tA; tB1 = tB; tC1 = tC; }
+#else
+#define PAIR_BSTAMP_A()
+#define PAIR_BSTAMP_B()
+#define PAIR_BSTAMP_C()
+#endif
     // one step; J = k & 7 (static: selects ring slots and the operand dword).  COND: `true` in full blocks.
 #define PAIR_BWD_STEP(J, CUR, PRV, COND)                                                                                            \
     if (COND) {                                                                                                                    \
@@ -1006,6 +1021,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
         float yba = fmaf(hba, S0.y, c3a), ybb = fmaf(hbb, S0.y, c3b);                                                              \
         write_vec(L.vec[p][0], yba, ybb);                                                                                          \
         lds_barrier();                                                                                                             \
+        PAIR_BSTAMP_A();                                                                                                           \
         Acc2 cQ, cD;                                                                                                               \
         float uka, ukb, yha, yhb, ypa, ypb, una, unb;                                                                              \
         matvec2p<PD>(FQ, FD, lds_addr_of(L.vec[p][0]) + rd_off, cQ, cD, [&](auto pc) {                                             \
@@ -1052,7 +1068,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
                 nrh = rho_rows(km2);                                                                                               \
                 nS0 = tab_row(km2, 0);                                                                                             \
                 nS1 = tab_row(km2, 1);                                                                                             \
-            } else if constexpr (PI >= 11 && PI <= 15 && PAIR_EXPORT) {                                                            \
+            } else if constexpr (PI >= 11 && PI <= 15 && PAIR_EXPORT && PAIR_EXPORT_STORES) {                                      \
                 if ((J) == 0) {                                       /* a block of eight steps is complete */                     \
                     constexpr int o = PI - 11;                                                                                     \
                     uint4* gp = gbase + (size_t)blk * GBLK_STRIDE + o * GOP_STRIDE;                                                \
@@ -1061,6 +1077,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
                 }                                                                                                                  \
             }                                                                                                                      \
         });                                                                                                                        \
+        PAIR_BSTAMP_B();                                                                                                           \
         float qa, qb, da, db;                                                                                                      \
         rows_of(cQ.a + cQ.b, qa, qb);                                                                                              \
         rows_of(cD.a + cD.b, da, db);                                                                                              \
@@ -1070,6 +1087,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
         rh = rhp; S0 = SP0; S1 = SP1;                                                                                              \
         rhp = nrh; SP0 = nS0; SP1 = nS1;                                                                                           \
         p ^= 1;                                                                                                                    \
+        PAIR_BSTAMP_C();                                                                                                           \
     }
 
     int blk = NBLK - 1;
@@ -1095,6 +1113,14 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
         PAIR_BWD_STEP(0, ring0, ring7, true)
     }
 #undef PAIR_BWD_STEP
+#if defined(CMPS_DIAG) && defined(PABL_TIMING)
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        printf("reverse scan, cycles per step: tail end -> barrier exit %.1f, reads + MFMAs + pieces %.1f, tail %.1f\n",
+               (double)accPre / accN, (double)accMv / accN, (double)accTail / accN);
+#endif
+#undef PAIR_BSTAMP_A
+#undef PAIR_BSTAMP_B
+#undef PAIR_BSTAMP_C
     // ---- the pair's slab: f | psi0bar_re | psi0bar_im | A (the R / Q sections are written by k_grad_pair) ----
     float* slab = P.slabs + (size_t)blockIdx.x * P.slab_floats;
     const int DD = PD * PD;

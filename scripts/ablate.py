@@ -5,7 +5,8 @@ usage: ablate.py [--shape D T B ROUNDS VARIANT] name=-DFLAG[,-DFLAG...] ...
   e.g. ablate.py base= no_mfma=-DPABL_NO_MFMA --shape 128 16000 512 2 3
 Every build gets -DCMPS_DIAG; known switches (all inert without it): CMPS_DIAG_NO_LOSS / CMPS_DIAG_NO_CHAIN (cmps_wave2.hip:
 only the chain wave / only the loss wave of the forward runs), PABL_NO_MFMA / PABL_NO_REDUCE / PABL_NO_BARRIER /
-PABL_NO_EXPORT / PABL_NO_STASHREAD / PABL_HALF_READS (cmps_pair.hip).  tests/test_capi_load.py compiles each of them so that they cannot rot.
+PABL_NO_EXPORT / PABL_NO_EXPORT_STORES / PABL_NO_STASHREAD / PABL_HALF_READS / PABL_TIMING (s_memtime stamps
+inside k_bwd_pair, printed per launch) (cmps_pair.hip).  tests/test_capi_load.py compiles each of them so that they cannot rot.
 Runs on the GPU box (hipcc is available there); libraries go to gpurun_out/.
 """
 import os
