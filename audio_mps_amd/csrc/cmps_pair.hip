@@ -886,6 +886,9 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
     const int NBLK = (N + GB - 1) / GB;
     // this lane's pieces: rows ia, ia + 1 (32 contiguous bytes) of component (c & 1), clip q
     uint4* gbase = reinterpret_cast<uint4*>(P.gops) + gop_index<PD>(blockIdx.x, NBLK, 0, 0, q, odd ? 1 : 0, ia);
+    // after the piece exchange (see the flush below): lanes of row groups 0..3 store their own row ia and row ia + 16 (from the
+    // lane 16 above), lanes of row groups 4..7 store row ia - 15 (from the lane 16 below) and their own row ia + 1
+    const int goff1 = rg >= 4 ? -15 : 0, goff2 = rg >= 4 ? 1 : 16;
     constexpr size_t GOP_STRIDE = (size_t)4 * PD, GBLK_STRIDE = (size_t)20 * PD;      // per operand / per block, in pieces
     const float A = P.A;
     const float sgn = odd ? 1.f : -1.f;                                // (rho x)_own = rho_re x_own + sgn rho_im x_partner
@@ -1070,10 +1073,19 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
                 nS1 = tab_row(km2, 1);                                                                                             \
             } else if constexpr (PI >= 11 && PI <= 15 && PAIR_EXPORT && PAIR_EXPORT_STORES) {                                      \
                 if ((J) == 0) {                                       /* a block of eight steps is complete */                     \
+                    /* Row groups rg and rg + 4 (lanes 16 apart) trade one piece each so that one store instruction writes the    \
+                       rows 16 (rg >> 2) .. + 15 of each of its four (clip, component) arrays COMPLETELY: 256 contiguous bytes     \
+                       per array instead of sixteen 16-byte pieces 32 bytes apart (the stores were ~240 cycles each: the L2's     \
+                       write path is limited by requests, and every 64-byte request carried 16 useful bytes). */                  \
                     constexpr int o = PI - 11;                                                                                     \
                     uint4* gp = gbase + (size_t)blk * GBLK_STRIDE + o * GOP_STRIDE;                                                \
-                    gp[0] = make_uint4(E[o][0][0], E[o][0][1], E[o][0][2], E[o][0][3]);                                            \
-                    gp[1] = make_uint4(E[o][1][0], E[o][1][1], E[o][1][2], E[o][1][3]);                                            \
+                    unsigned x_[4], y_[4];                                                                                         \
+                    _Pragma("unroll") for (int d = 0; d < 4; ++d) {                                                                \
+                        const auto r = __builtin_amdgcn_permlane16_swap(E[o][0][d], E[o][1][d], false, false);                     \
+                        x_[d] = r[0]; y_[d] = r[1];                                                                                \
+                    }                                                                                                              \
+                    gp[goff1] = make_uint4(x_[0], x_[1], x_[2], x_[3]);                                                            \
+                    gp[goff2] = make_uint4(y_[0], y_[1], y_[2], y_[3]);                                                            \
                 }                                                                                                                  \
             }                                                                                                                      \
         });                                                                                                                        \
