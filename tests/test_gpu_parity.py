@@ -431,3 +431,29 @@ def test_reference_default_clip_length():
     from float64 grows with the number of steps as well)."""
     m, audio = _model(32, 65536, 6, WAVE, seed=5)
     _check_against_oracle(m, audio, nthreads=6, grad_rtol=2e-4)
+
+
+@pytest.mark.parametrize("D,T,B,variant", [(32, 700, 9, WAVE), (12, 300, 5, WAVE), (48, 90, 3, BLOCK), (128, 130, 5, 3), (64, 77, 2, 3)])
+def test_runs_are_bit_reproducible(D, T, B, variant):
+    """Two forward + reverse passes on the same input give the same BITS (per-clip losses and the reduced gradient sums):
+    every cross-wave / cross-clip reduction runs in a fixed order, nothing is accumulated with atomics, and no kernel reads
+    what another wave is still writing (a race would show up here as run-to-run noise)."""
+    from audio_mps_amd import HParams, PsiCMPS
+    from audio_mps_amd.scan import HipScan
+    hp = HParams(minibatch_size=B, bond_dim=D)
+    audio = torch.from_numpy(make_audio(B, T, hp.delta_t, 31)).cuda()
+    be = HipScan(D, variant=variant)
+    m = PsiCMPS(hp, seed=3, backend=be)
+    be.set_params(m.effective_params(), B, T, train=True)
+    ref = None
+    for _ in range(3):
+        be.forward(audio, save_for_bwd=True)
+        be.backward()
+        torch.cuda.synchronize()
+        cur = (be._loss.clone().cpu().numpy(), be._grad.clone().cpu().numpy())
+        assert np.all(np.isfinite(cur[0])) and np.all(np.isfinite(cur[1]))
+        if ref is None:
+            ref = cur
+        else:
+            np.testing.assert_array_equal(cur[0], ref[0])
+            np.testing.assert_array_equal(cur[1], ref[1])
