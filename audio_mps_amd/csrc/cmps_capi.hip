@@ -483,10 +483,14 @@ int cmps_rho_sample(cmps_handle_t h, const float* noise_dev, int n, int length, 
     if (length > h->L.N) return fail(h, CMPS_ERR_BAD_ARG, "cmps_rho_sample: length exceeds T - 1 of cmps_set_params");
     if (save_states && (!(h->rho_flags & CMPS_WS_TRAIN) || (size_t)n * length > (size_t)h->rho_B * (h->rho_T - 1)))
         return fail(h, CMPS_ERR_WORKSPACE, "cmps_rho_sample: save_states needs a CMPS_WS_TRAIN rho workspace with B_max*(T-1) >= n*length");
-    hipError_t e = launch_sample_rho(h->P, h->W, noise_dev, n, length, out_dev, save_states != 0, static_cast<hipStream_t>(stream));
+    // D <= 32 (rank <= 32): the row-array GEMM sampler, one wavefront per path (cmps_rho_mfma.hip); CMPS_VARIANT_BLOCK keeps the
+    // general workgroup-per-path kernel (cross-check; 93 us per step at rank 32 against 2 us)
+    const bool mfma = h->D <= 32 && h->W.rank <= 32 && h->variant_req != CMPS_VARIANT_BLOCK;
+    hipError_t e = mfma ? launch_sample_rho_mfma(h->P, h->W, noise_dev, n, length, out_dev, save_states != 0, static_cast<hipStream_t>(stream))
+                        : launch_sample_rho(h->P, h->W, noise_dev, n, length, out_dev, save_states != 0, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail_hip(h, e, "cmps_rho_sample");
     h->rho_saved = save_states != 0;
-    h->W.stash_layout = 0;
+    h->W.stash_layout = mfma ? 2 : 0;
     h->rho_bwd_ok = false;
     h->rho_saved_B = n; h->rho_saved_steps = length;
     return CMPS_OK;

@@ -168,6 +168,8 @@ hipError_t launch_bwd_legacy_wave(const Dev& P, const float* audio, hipStream_t 
 hipError_t launch_fwd_rho_wave(const Dev& P, const RhoDev& W, const float* audio, float* loss, bool save, hipStream_t s);
 hipError_t launch_fwd_rho_mfma(const Dev& P, const RhoDev& W, const float* audio, float* loss, bool save, hipStream_t s);
 hipError_t launch_bwd_rho_mfma(const Dev& P, const RhoDev& W, const float* audio, hipStream_t s);
+hipError_t launch_sample_rho_mfma(const Dev& P, const RhoDev& W, const float* noise, int n, int length, float* out, bool save,
+                                  hipStream_t s);
 hipError_t launch_bwd_rho_wave(const Dev& P, const RhoDev& W, const float* audio, hipStream_t s);
 hipError_t launch_prep(const Dev& P, const float* R_re, const float* R_im, const float* freqs,
                        const float* psi0_re, const float* psi0_im, float dt, bool rebuild_ttab,

@@ -496,12 +496,145 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_rho_mfma(Dev P, RhoDev W,
     if (lane == 0) slab[4 * DD + 3 * DPW] = sumA - sumS / A;
 }
 
+// ------------------------------------------------------------------------------------------------
+// RhoCMPS.sample / rho_evolve_with_sampling / purity (model.py:86-116, 160-167) in the same row-array form: one wavefront per
+// path.  The sample needs the expectation BEFORE the update, so a step is  V = U W_R  and  QU = U W_Q  (constant operands:
+// their bf16 pieces are split once), then  e = 2 sum U . V  (= Re tr((R + R^dagger) rho), :189-196),  inc = e dt + noise,
+// s = inc / A,  Y = (U + QU) + s V,  n = sum Y^2,  U' = rho_k (.) Y / sqrt(n).  Noise is [n_paths][length] (one 64-step chunk
+// per lane load), the waveform is written back the same way.  Stash (save): layout 2 rows of (y[n], 0).
+// ------------------------------------------------------------------------------------------------
+template <bool SAVE>
+__global__ __launch_bounds__(64 * WAVES, 1) void k_sample_rho_mfma(Dev P, RhoDev W, const float* __restrict__ noise, int n_paths,
+                                                                   int length, float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float Urow[WAVES][32 * RRLD];
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int b = blockIdx.x * WAVES + w;
+    if (b >= n_paths) return;
+    const int r = W.rank;
+    const int col = lane & 31, hk = lane >> 5;
+    float* U = &Urow[w][0];
+    // bf16 pieces of the W forms of R and Q: lane (col, hk) holds W[16 ks + 8 hk + e][32 t + col], e = 0..7
+    unsigned RH[2][4][4], RM[2][4][4], RL[2][4][4], QH[2][4][4], QM[2][4][4], QL[2][4][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int n = 32 * t + col, ii = n >> 1, cc = n & 1;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            float wr[8], wq[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int m = 16 * ks + 8 * hk + e, jj = m >> 1, cp = m & 1;
+                wr[e] = wform(P.R[ii * DPW + jj], cp, cc);
+                wq[e] = wform(P.Q[ii * DPW + jj], cp, cc);
+            }
+#pragma unroll
+            for (int e2 = 0; e2 < 4; ++e2) {
+                split3(wr[2 * e2], wr[2 * e2 + 1], RH[t][ks][e2], RM[t][ks][e2], RL[t][ks][e2]);
+                split3(wq[2 * e2], wq[2 * e2 + 1], QH[t][ks][e2], QM[t][ks][e2], QL[t][ks][e2]);
+            }
+        }
+    }
+    for (int a = 0; a < 32; ++a) {                                   // rows a < rank of U = phi_a (model.py:127-136), the rest zero
+        float v = 0.f;
+        if (a < r) {
+            const float2 p = W.phi0[a * DPW + (lane >> 1)];
+            v = (lane & 1) ? p.y : p.x;
+        }
+        U[a * RRLD + lane] = v;
+    }
+    const float* nrow = noise + (size_t)b * length;
+    float* orow = out + (size_t)b * length;
+    float2* st = SAVE ? reinterpret_cast<float2*>(W.stash) + (size_t)b * length * r * 64 : nullptr;
+    const float A = P.A;
+    const float sgn = (col & 1) ? 1.f : -1.f;                        // Im lanes add rho_y * partner, Re lanes subtract it
+    float samp = 0.f;
+    for (int kbeg = 0; kbeg < length; kbeg += CH) {
+        const int cnt = (length - kbeg) < CH ? (length - kbeg) : CH;
+        const float nzv = kbeg + lane < length ? nrow[kbeg + lane] : 0.f;
+        float outv = 0.f;
+        for (int kk = 0; kk < cnt; ++kk) {
+            const int k = kbeg + kk;
+            const float2 rh0 = P.rho[(size_t)k * DPW + (col >> 1)], rh1 = P.rho[(size_t)k * DPW + 16 + (col >> 1)];
+            v16f v0 = {}, v1 = {}, q0 = {}, q1 = {};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const float4 f0 = *reinterpret_cast<const float4*>(U + col * RRLD + 16 * ks + 8 * hk);
+                const float4 f1 = *reinterpret_cast<const float4*>(U + col * RRLD + 16 * ks + 8 * hk + 4);
+                unsigned AH[4], AM[4], AL[4];
+                split3(f0.x, f0.y, AH[0], AM[0], AL[0]);
+                split3(f0.z, f0.w, AH[1], AM[1], AL[1]);
+                split3(f1.x, f1.y, AH[2], AM[2], AL[2]);
+                split3(f1.z, f1.w, AH[3], AM[3], AL[3]);
+                mfma6(v0, AH, AM, AL, RH[0][ks], RM[0][ks], RL[0][ks]);
+                mfma6(v1, AH, AM, AL, RH[1][ks], RM[1][ks], RL[1][ks]);
+                mfma6(q0, AH, AM, AL, QH[0][ks], QM[0][ks], QL[0][ks]);
+                mfma6(q1, AH, AM, AL, QH[1][ks], QM[1][ks], QL[1][ks]);
+            }
+            // C/D layout: column n = 32 t + col, rows (q & 3) + 8 (q >> 2) + 4 hk
+            float u0[16], u1[16];
+            float acce = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int row = (q & 3) + 8 * (q >> 2) + 4 * hk;
+                u0[q] = U[row * RRLD + col];
+                u1[q] = U[row * RRLD + 32 + col];
+                acce = fmaf(u0[q], v0[q], acce);
+                acce = fmaf(u1[q], v1[q], acce);
+            }
+            const float e = 2.0f * sum64(acce);                      // Re tr((Rt + Rt^dagger) rho), :189-196
+            const float inc = e * P.dt + rdlane(nzv, kk);            // :162
+            samp += inc;                                             // :163
+            const float s = inc / A;                                 // :164, 175
+            float y0[16], y1[16];
+            float accn = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                y0[q] = fmaf(s, v0[q], u0[q] + q0[q]);
+                y1[q] = fmaf(s, v1[q], u1[q] + q1[q]);
+                accn = fmaf(y0[q], y0[q], accn);
+                accn = fmaf(y1[q], y1[q], accn);
+            }
+            const float n = sum64(accn);
+            const float sc1 = sqrtf(1.0f / fmaxf(n, 1e-12f));        // :165
+            if (SAVE) {
+                float2* sbase = st + (size_t)k * r * 64 + lane;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int s0 = (q & 3) + 8 * (q >> 2);
+                    const auto ys = __builtin_amdgcn_permlane32_swap(__float_as_uint(y0[q]), __float_as_uint(y1[q]), false, false);
+                    if (s0 < r) sbase[(size_t)s0 * 64] = make_float2(__uint_as_float(ys[0]), 0.f);
+                    if (s0 + 4 < r) sbase[(size_t)(s0 + 4) * 64] = make_float2(__uint_as_float(ys[1]), 0.f);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int row = (q & 3) + 8 * (q >> 2) + 4 * hk;
+                const float t0 = sc1 * y0[q], t1 = sc1 * y1[q];
+                U[row * RRLD + col] = fmaf(sgn * rh0.y, dpp_nb(t0), rh0.x * t0);
+                U[row * RRLD + 32 + col] = fmaf(sgn * rh1.y, dpp_nb(t1), rh1.x * t1);
+            }
+            outv = lane == kk ? A * samp : outv;                     // :116
+        }
+        if (kbeg + lane < length) orow[kbeg + lane] = outv;
+    }
+}
+
 hipError_t launch_fwd_rho_mfma(const Dev& P, const RhoDev& W, const float* audio, float* loss, bool save, hipStream_t s) {
     const unsigned nb = (unsigned)((P.B + WAVES - 1) / WAVES);
     if (save)
         hipLaunchKernelGGL(k_fwd_rho_mfma<true>, dim3(nb), dim3(64 * WAVES), 0, s, P, W, audio, loss);
     else
         hipLaunchKernelGGL(k_fwd_rho_mfma<false>, dim3(nb), dim3(64 * WAVES), 0, s, P, W, audio, loss);
+    return hipGetLastError();
+}
+
+hipError_t launch_sample_rho_mfma(const Dev& P, const RhoDev& W, const float* noise, int n, int length, float* out, bool save,
+                                  hipStream_t s) {
+    const unsigned nb = (unsigned)((n + WAVES - 1) / WAVES);
+    if (save)
+        hipLaunchKernelGGL(k_sample_rho_mfma<true>, dim3(nb), dim3(64 * WAVES), 0, s, P, W, noise, n, length, out);
+    else
+        hipLaunchKernelGGL(k_sample_rho_mfma<false>, dim3(nb), dim3(64 * WAVES), 0, s, P, W, noise, n, length, out);
     return hipGetLastError();
 }
 

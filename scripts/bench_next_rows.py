@@ -90,6 +90,23 @@ for rank in (4, 32):
                                              if rank > 8 else
                                              "straight-line wave-per-clip kernels, 3 r D^2 complex MACs + 6 r exact fp32 MFMAs per step (issue / LDS latency)")}
 
+# ---- rank 3b: RhoCMPS.sample (row-array GEMM sampler, one wavefront per path), D = 32, rank 32 and 4: 64 paths x 4000 steps
+for rank in (32, 4):
+    hp = HParams(minibatch_size=64, bond_dim=32, initial_rank=rank, sigma=0.05)
+    rm = RhoCMPS(hp, seed=2)
+    n, length = 64, 4000
+    noise = (0.05 * np.sqrt(hp.delta_t) * np.random.default_rng(0).standard_normal((length, n))).astype(np.float32)
+    rm.sample(n, length, noise=noise)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rm.sample(n, length, noise=noise)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3                      # host-timed (includes the upload of the noise and the download of the waveform)
+    res[f"sample_rho_rank{rank}"] = {"shape": f"D=32, rank={rank}, {n} paths x {length} steps", "kernel": "k_sample_rho_mfma (wave per path, two row-array GEMMs per step)",
+                                     "ms": ms, "samples_per_s": n * length / ms * 1e3, "us_per_step": ms * 1e3 / length,
+                                     "bound": "serial: 96 32x32x16 bf16 MFMAs per step on one SIMD's matrix pipe (~1.5 us) + the operand splits; "
+                                              "the workgroup-per-path kernel (CMPS_VARIANT_BLOCK) takes 93 us per step at rank 32, 12.7 us at rank 4"}
+
 # ---- rank 4: TFRecord reader (host, pure Python): records of 65536 float32 samples
 import tempfile
 with tempfile.TemporaryDirectory() as td:

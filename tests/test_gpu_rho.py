@@ -276,3 +276,23 @@ def test_rho_gemm_and_column_kernels_agree(D, rank, T, B):
     _, ga2 = m.loss_and_grads()
     for k in ga:
         np.testing.assert_array_equal(ga[k], ga2[k])
+
+
+@pytest.mark.parametrize("D,rank,length,n", [(32, 32, 150, 5), (20, 9, 130, 3), (32, 1, 70, 2)])
+def test_rho_gemm_sampler_matches_block_sampler(D, rank, length, n):
+    """D <= 32 samples with the row-array GEMM kernel (one wavefront per path, cmps_rho_mfma.hip); CMPS_VARIANT_BLOCK keeps the
+    workgroup-per-path kernel.  Same noise in, same waveform, states and purity out (float32 tolerance; n = 5 leaves a partly
+    filled workgroup, length 130 / 150 a partial 64-step chunk)."""
+    from audio_mps_amd import RhoCMPS
+    from audio_mps_amd.scan import HipScan
+    m, _ = _rho_model(D, 8, 2, rank=rank, sigma=0.1, seed=17, rscale=0.3, A=5.0, data=False)
+    blk = RhoCMPS(m.hparams, seed=17, backend=HipScan(D, variant=1))
+    for k in m.variables:
+        blk.variables[k] = m.variables[k].copy()
+    rng = np.random.default_rng(8)
+    noise = (0.1 * np.sqrt(m.hparams.delta_t) * rng.standard_normal((length, n))).astype(np.float32)
+    wa, wb = m.sample(n, length, noise=noise), blk.sample(n, length, noise=noise)
+    scale = max(float(np.max(np.abs(wb))), 1e-6)
+    assert np.max(np.abs(wa - wb)) <= 1e-4 * scale
+    assert rel_inf(m.rho_evolve_with_sampling(n, length, noise=noise), blk.rho_evolve_with_sampling(n, length, noise=noise)) <= 1e-4
+    np.testing.assert_allclose(m.purity(n, length, noise=noise), blk.purity(n, length, noise=noise), rtol=1e-4, atol=1e-6)
