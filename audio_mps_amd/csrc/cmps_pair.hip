@@ -339,7 +339,9 @@ __device__ __forceinline__ void matvec2(const u2 (&FA)[PD / 4], const u2 (&FB)[P
     u4 b0[4], b1[4], b2[4];
     rd4g(addr, b0);
     rd4g(addr + 64, b1);
+#if !(defined(CMPS_DIAG) && defined(PABL_HALF_READS))
     if constexpr (NG > 2) rd4g(addr + 128, b2);
+#endif
     shadow();
     if constexpr (NG == 2) {
         rd_wait4<4>(b0); mm2g<0, true, false>(FA, FB, b0, x, y);
@@ -349,11 +351,18 @@ __device__ __forceinline__ void matvec2(const u2 (&FA)[PD / 4], const u2 (&FB)[P
         rd_wait4<4>(b1); mm2g<1, false, false>(FA, FB, b1, x, y);
         rd_wait4<0>(b2); mm2g<2, false, true>(FA, FB, b2, x, y);
     } else {
+#if defined(CMPS_DIAG) && defined(PABL_HALF_READS)    // diagnostic builds only: half of the vector is read, and used twice
+        rd_wait4<4>(b0); mm2g<0, true, false>(FA, FB, b0, x, y);
+        rd_wait4<0>(b1); mm2g<1, false, false>(FA, FB, b1, x, y);
+        mm2g<2, false, false>(FA, FB, b0, x, y);
+        mm2g<3, false, true>(FA, FB, b1, x, y);
+#else
         rd_wait4<8>(b0); mm2g<0, true, false>(FA, FB, b0, x, y);
         rd4g(addr + 192, b0);
         rd_wait4<8>(b1); mm2g<1, false, false>(FA, FB, b1, x, y);
         rd_wait4<4>(b2); mm2g<2, false, false>(FA, FB, b2, x, y);
         rd_wait4<0>(b0); mm2g<3, false, true>(FA, FB, b0, x, y);
+#endif
     }
 }
 template <int PD, typename Shadow>
@@ -598,6 +607,16 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
         write_vec(L.vec[0][0], uta, utb);
         rho_stage<PD>(P, RS, 0, 0, tid);
         __syncthreads();
+#if defined(CMPS_DIAG) && defined(PABL_TIMING)        // diagnostic builds only: where a chain step's cycles go (s_memtime stamps, consumed a step late)
+        unsigned long long fA = 0, fB = 0, fC = 0, fA1 = 0, fB1 = 0, fC1 = 0, fC2 = 0, fPre = 0, fMv = 0, fTail = 0, fN = 0;
+#define PAIR_FSTAMP_A() { if (fC2) { fPre += fA1 - fC2; fMv += fB1 - fA1; fTail += fC1 - fB1; ++fN; } fC2 = fC1; fA = __builtin_readcyclecounter(); }
+#define PAIR_FSTAMP_B() fB = __builtin_readcyclecounter()
+#define PAIR_FSTAMP_C(x) { float x_ = x; asm volatile("" : "+v"(x_)); fC = __builtin_readcyclecounter(); fA1 = fA; fB1 = fB; fC1 = fC; }
+#else
+#define PAIR_FSTAMP_A()
+#define PAIR_FSTAMP_B()
+#define PAIR_FSTAMP_C(x)
+#endif
         // Eight steps per block with the step-in-block J static: the LDS parities and ring slots are immediates, the chunk
         // boundaries (increments every 64 steps, rho staging every 32) can only fall on J = 0, and in blocks that lie entirely
         // below N no step is conditional (about 15 scalar instructions per step less than the plain loop).
@@ -623,7 +642,9 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
                 }                                                                                                          \
                 const unsigned aU = lds_addr_of(L.vec[p][0]) + rd_off;                                                     \
                 Acc2 cR, cQ;                                                                                               \
+                PAIR_FSTAMP_A();                                                                                           \
                 matvec2<PD>(FR, FQ, aU, cR, cQ, [] {});                                                                    \
+                PAIR_FSTAMP_B();                                                                                           \
                 const int kl = (bt & (PCH / FB - 1)) * FB + (J);                                                           \
                 const float s0 = rdl(sv0, kl), s1 = rdl(sv1, kl);      /* (both read: a readlane inside a select becomes a branch) */ \
                 const float s = q ? s1 : s0;                                                                               \
@@ -647,6 +668,7 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
                 }                                                                                                          \
                 const float nn = clip_sum(yna * yna + ynb * ynb);                                                          \
                 if (lane == 0 || lane == 2) RG.nrm[hb_ * FB + (J)][q][w] = nn;                                             \
+                PAIR_FSTAMP_C(nn);                                                                                         \
             }                                                                                                              \
             lds_barrier();                                                                                                 \
         }
@@ -661,6 +683,14 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
             PAIR_FWD_STEP(6, FB * bt + 6 < N) PAIR_FWD_STEP(7, FB * bt + 7 < N)
         }
 #undef PAIR_FWD_STEP
+#if defined(CMPS_DIAG) && defined(PABL_TIMING)
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+            printf("forward chain wave, cycles per step: tail end -> first read issue (barrier) %.1f, reads + MFMAs %.1f, tail %.1f\n",
+                   (double)fPre / fN, (double)fMv / fN, (double)fTail / fN);
+#endif
+#undef PAIR_FSTAMP_A
+#undef PAIR_FSTAMP_B
+#undef PAIR_FSTAMP_C
         return;
     }
 
