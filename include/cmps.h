@@ -194,7 +194,8 @@ int cmps_legacy_loss_bwd(cmps_handle_t h, const float* audio_dev, int B, int T, 
  * cmps_rho_sample: RhoCMPS.sample / rho_evolve_with_sampling / purity (model.py:86-116): tf.scan of
  *   _rho_and_sample_update (:160-167) for pre-drawn noise_dev [n*length] ([path][step]); out_dev [n*length] = A * running
  *   sum.  save_states != 0 keeps the columns of every step (needs a CMPS_WS_TRAIN rho workspace sized for B_max >= n,
- *   T >= length + 1) for cmps_rho_states.
+ *   T >= length + 1) for cmps_rho_states.  Kernel selection follows cmps_set_variant like the loss entries: D <= 32 and
+ *   rank <= 32 run the row-array GEMM kernels (one wavefront per clip / path), CMPS_VARIANT_BLOCK the general ones.
  * cmps_rho_states: lab-frame normalised rho after every step of the last cmps_rho_loss_fwd(save_for_bwd=1) or
  *   cmps_rho_sample(save_states=1): rho_out_dev [B*steps*D*D*2] (rho_evolve_with_data, model.py:76-84 /
  *   rho_evolve_with_sampling, :86-92) and/or purity_out_dev [B*steps] = tr rho^2 (:94-101); either may be NULL.
