@@ -35,6 +35,21 @@ __global__ __launch_bounds__(256, 1) void k32(float* out, int iters) {
     for (int j = 0; j < 4; ++j) s += c[j][0];
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
+// v_mfma_f32_16x16x32_bf16 (the wider candidate for the mat-vecs: 4 of its 16 columns would be used), 4 accumulators
+__global__ __launch_bounds__(256, 1) void k16(float* out, int iters) {
+    s8 a = {1, 2, 3, 4, 5, 6, 7, 8}, b = {(short)threadIdx.x, 1, 2, 3, 4, 5, 6, 7};
+    f4 c[4];
+    for (int j = 0; j < 4; ++j) c[j] = f4{0, 0, 0, 0};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c[j], 0, 0, 0);
+    }
+    float s = 0;
+    for (int j = 0; j < 4; ++j) s += c[j][0];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
 template <typename K> void run(const char* name, K kern) {
     float* out; (void)hipMalloc(&out, 256 * 256 * 4);
     const int iters = 20000;
@@ -54,5 +69,6 @@ int main() {
     run("mfma 4x4x4_16b bf16, 4 accumulators", k4<4>);
     run("mfma 4x4x4_16b bf16, 8 accumulators", k4<8>);
     run("mfma 32x32x16 bf16, 4 accumulators", k32);
+    run("mfma 16x16x32 bf16, 4 accumulators", k16);
     return 0;
 }
