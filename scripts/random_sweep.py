@@ -27,8 +27,8 @@ for it in range(40):                                   # pure-state wave / block
     cfg = (D, T, B, round(sigma, 5), round(rs, 3), variant)
     note("psi loss", float(np.max(np.abs(per - ref["loss_per_clip"]) / np.maximum(np.abs(ref["loss_per_clip"]), 1))), cfg)
     note("psi grad", max(rel_inf(g[k], gr[k]) for k in ("Rbar", "fbar", "psi0bar", "Abar")), cfg)
-for it in range(8):                                    # pair kernels vs the bf16 emulation
-    D = int(rng.integers(33, 129)); T = int(rng.integers(2, 200)); B = int(rng.integers(1, 7))
+for it in range(14):                                   # pair kernels vs the bf16 emulation
+    D = int(rng.integers(33, 129)); T = int(rng.integers(2, 400)); B = int(rng.integers(1, 7))
     hp = HParams(minibatch_size=B, bond_dim=D)
     audio = make_audio(B, T, hp.delta_t, 100 + it)
     m = PsiCMPS(hp, data_iterator=audio, seed=it, backend=HipScan(D, variant=3))
@@ -36,8 +36,8 @@ for it in range(8):                                    # pair kernels vs the bf1
     em = O.psi_bf16_scan(oracle_hparams(hp), oracle_variables(m), audio)
     note("pair loss", float(np.max(np.abs(per - em["loss_per_clip"]) / np.maximum(np.abs(em["loss_per_clip"]), 1))), (D, T, B))
     note("pair grad", max(rel_inf(g[k], em[k]) for k in ("Rbar", "fbar", "psi0bar", "Abar")), (D, T, B))
-for it in range(10):                                   # RhoCMPS (wave for D <= 32, block above)
-    D = int(rng.integers(2, 41)); r = int(rng.integers(1, min(D, 12) + 1)); T = int(rng.integers(2, 150)); B = int(rng.integers(1, 6))
+for it in range(14):                                   # RhoCMPS (column kernels for rank <= 8, GEMM kernels above, block kernels for D > 32)
+    D = int(rng.integers(2, 41)); r = int(rng.integers(1, min(D, 32) + 1)); T = int(rng.integers(2, 150)); B = int(rng.integers(1, 6))
     hp = HParams(minibatch_size=B, bond_dim=D, initial_rank=r, sigma=float(10 ** rng.uniform(-4, -0.3)))
     audio = make_audio(B, T, hp.delta_t, 200 + it)
     m = RhoCMPS(hp, data_iterator=audio, seed=it)
