@@ -58,6 +58,19 @@ def test_workspace_bytes(hip_lib):
     assert stash < trn < stash * 1.05                     # the per-step state stash dominates (8.4 GB at C3)
 
 
+def test_workspace_bytes_pair_variant(hip_lib):
+    """32 < D <= 128 with CMPS_WS_TRAIN: the pair stash (y and H y, float32) plus the gradient GEMM's bf16 operand pieces
+    (five operands, eight steps per 16-byte piece) -- include/cmps.h / cmps_internal.h::make_layout."""
+    from audio_mps_amd import _capi
+    D, B, T = 128, 512, 16000
+    N, pairs = T - 1, B // 2
+    stash = pairs * N * 2 * 2 * 2 * D * 4                   # [pair][step][y | H y][clip][re | im][D] float32
+    gops = pairs * ((N + 7) // 8) * 5 * 2 * 2 * D * 16      # [pair][block][operand][clip][re | im][D] x 16 bytes
+    trn = hip_lib.cmps_workspace_bytes(D, B, T, _capi.CMPS_WS_TRAIN)
+    assert stash + gops < trn < (stash + gops) * 1.02       # 16.8 GB + 21.0 GB at BASELINE configs[4]
+    assert hip_lib.cmps_workspace_bytes(D, B, T, _capi.CMPS_WS_FWD_ONLY) < 64 * 1024 * 1024
+
+
 def test_options_default_and_errors(hip_lib):
     """cmps_set_option / cmps_get_option (no device work): the rank-1 arithmetic defaults to BF16X3."""
     from audio_mps_amd import _capi
