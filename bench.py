@@ -404,9 +404,17 @@ def worker(ARGS):
         Bs = sample.shape[0]
 
         def gpu_on_sample():
+            # the sample may hold more clips than the workload's batch (BASELINE C1 has 8): chunks of at most B clips, losses
+            # concatenated, gradient sums added
             backend.set_params(model.effective_params(), B, T, train=True)
-            per = backend.forward(d_sample, save_for_bwd=True).cpu().numpy()
-            g = unpack_grad(backend.backward().cpu().numpy(), D)
+            pers, flat = [], None
+            for s0 in range(0, Bs, B):
+                chunk = d_sample[s0:s0 + B].contiguous()
+                pers.append(backend.forward(chunk, save_for_bwd=True).cpu().numpy().copy())
+                gch = backend.backward().cpu().numpy().astype(np.float64)
+                flat = gch if flat is None else flat + gch
+            per = np.concatenate(pers)
+            g = unpack_grad(flat.astype(np.float32), D)
             loss_err = float(np.max(np.abs(per - ref["loss_per_clip"]) / np.maximum(np.abs(ref["loss_per_clip"]), 1.0)))
             gerr = {k: rel_inf(g[k], gr[k]) for k in ("Rbar", "fbar", "psi0bar", "Abar")}
             return loss_err, gerr
