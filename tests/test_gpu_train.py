@@ -108,3 +108,32 @@ def test_nccl_single_rank_collectives(tmp_path):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("args", [
+    ["--bond-dim", "4", "--T", "96", "--batch-per-gpu", "3", "--cpu-clips", "8"],                 # the sample (8 clips) exceeds the batch
+    ["--bond-dim", "12", "--T", "200", "--batch-per-gpu", "6", "--cpu-clips", "4"],               # 16-row kernels
+    ["--bond-dim", "32", "--T", "300", "--batch-per-gpu", "8", "--cpu-clips", "8"],               # hot path, with precision_ab
+    ["--bond-dim", "64", "--T", "120", "--batch-per-gpu", "4", "--cpu-clips", "4", "--variant", "3"],   # pair kernels
+    ["--bond-dim", "40", "--T", "80", "--batch-per-gpu", "2", "--cpu-clips", "2"],                # block kernels (AUTO above 32)
+])
+def test_bench_runs_at_small_shapes(args):
+    """bench.py end to end (child process) at shapes that take seconds: one JSON line with the contract's keys, the
+    in-bench parity check green.  Guards the code outside the timed region (it once assumed sample <= batch)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    proc = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1"] + args,
+                          capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    line = json.loads(proc.stdout.strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in line["roofline"], key
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in line["cpu_baseline"], key
+    assert line["steps"] == 2 and line["n_gpus"] == 1 and line["value"] > 0
+    assert line["parity_in_bench"]["ok"], line["parity_in_bench"]
