@@ -24,6 +24,7 @@ CMPS_VARIANT_BLOCK = 1
 CMPS_VARIANT_WAVE = 2
 CMPS_VARIANT_PAIR = 3
 CMPS_VARIANT_WAVE32 = 4
+CMPS_VARIANT_WIDE = 5
 
 CMPS_OPT_RANK1 = 1
 CMPS_RANK1_EXACT_F32 = 0

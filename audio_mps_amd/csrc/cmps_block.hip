@@ -346,6 +346,12 @@ __global__ void k_states(Dev P, float* __restrict__ psi_out) {
         } else if (P.stash_layout == 3) {   // 32-row wave layout: 64 (y[n], (H y)[n]) pairs, n = 2 i + {re, im}
             const float* r = P.hst + row * 128;
             y = make_float2(r[4 * i], r[4 * i + 2]);
+        } else if (P.stash_layout == 4) {
+            // wide variant (cmps_wide.hip): per pair and step [y | H y][wave][lane], lane = 8 q + i, q = (row half, component, clip)
+            const int b = (int)(row / N);
+            const float* r = reinterpret_cast<const float*>(P.stash) + (((size_t)(b >> 1) * N + k) * 2) * 4 * DP
+                             + (i >> 4) * 64 + (i & 7) + 8 * (((i >> 3) & 1) * 4 + (b & 1));
+            y = make_float2(r[0], r[16]);
         } else if (P.stash_layout == 2) {
             // pair variant (cmps_pair.hip): per pair and step [y | H y][clip][re | im][DP] float32
             const int b = (int)(row / N);

@@ -57,15 +57,17 @@ int resolve_variant(const cmps_handle_s* h) {
     if (h->variant_req == CMPS_VARIANT_WAVE) return h->D <= 32 ? CMPS_VARIANT_WAVE : CMPS_VARIANT_BLOCK;
     if (h->variant_req == CMPS_VARIANT_WAVE32) return h->D <= 32 ? CMPS_VARIANT_WAVE32 : CMPS_VARIANT_BLOCK;
     if (h->variant_req == CMPS_VARIANT_PAIR) return h->D > 32 ? CMPS_VARIANT_PAIR : CMPS_VARIANT_BLOCK;
-    // AUTO: float32 everywhere; the bf16-operand MFMA kernels of D = 128 are opt-in (they change the arithmetic)
-    return h->D <= 32 ? CMPS_VARIANT_WAVE : CMPS_VARIANT_BLOCK;
+    if (h->variant_req == CMPS_VARIANT_WIDE) return h->D > 32 ? CMPS_VARIANT_WIDE : CMPS_VARIANT_BLOCK;
+    // AUTO: the reference's float32 arithmetic at every D (fp32-faithful products, see cmps.h); the bf16-operand MFMA kernels
+    // of 32 < D <= 128 are opt-in (they change the arithmetic)
+    return h->D <= 32 ? CMPS_VARIANT_WAVE : CMPS_VARIANT_WIDE;
 }
 
 }  // namespace
 
 extern "C" {
 
-int cmps_version(void) { return 200; }
+int cmps_version(void) { return 300; }
 
 int cmps_create(int D, cmps_handle_t* out) {
     if (!out) return CMPS_ERR_BAD_ARG;
@@ -87,10 +89,10 @@ const char* cmps_last_error(cmps_handle_t h) { return h ? h->err.c_str() : "null
 
 int cmps_set_variant(cmps_handle_t h, int variant) {
     if (!h) return CMPS_ERR_BAD_ARG;
-    if (variant < CMPS_VARIANT_AUTO || variant > CMPS_VARIANT_WAVE32)
+    if (variant < CMPS_VARIANT_AUTO || variant > CMPS_VARIANT_WIDE)
         return fail(h, CMPS_ERR_BAD_ARG, "cmps_set_variant: unknown variant");
-    if (variant == CMPS_VARIANT_PAIR && h->D <= 32)
-        return fail(h, CMPS_ERR_UNSUPPORTED_D, "cmps_set_variant: the pair (MFMA) variant is for 32 < D <= 128");
+    if ((variant == CMPS_VARIANT_PAIR || variant == CMPS_VARIANT_WIDE) && h->D <= 32)
+        return fail(h, CMPS_ERR_UNSUPPORTED_D, "cmps_set_variant: the pair (bf16 MFMA) and wide (float32) variants are for 32 < D <= 128");
     if ((variant == CMPS_VARIANT_WAVE || variant == CMPS_VARIANT_WAVE32) && h->D > 32)
         return fail(h, CMPS_ERR_UNSUPPORTED_D, "cmps_set_variant: the wave variant needs D <= 32");
     h->variant_req = variant;
@@ -203,6 +205,8 @@ int cmps_psi_loss_fwd(cmps_handle_t h, const float* audio_dev, int B, int T, flo
         e = launch_fwd_wave2(P, audio_dev, loss_dev, save_for_bwd != 0, s);
     else if (variant == CMPS_VARIANT_PAIR)
         e = launch_fwd_pair(P, audio_dev, loss_dev, save_for_bwd != 0, s);
+    else if (variant == CMPS_VARIANT_WIDE)
+        e = launch_fwd_wide(P, audio_dev, loss_dev, save_for_bwd != 0, s);
     else
         e = launch_fwd_block(P, audio_dev, loss_dev, save_for_bwd != 0, s);
     if (e != hipSuccess) return fail_hip(h, e, "cmps_psi_loss_fwd");
@@ -211,7 +215,7 @@ int cmps_psi_loss_fwd(cmps_handle_t h, const float* audio_dev, int B, int T, flo
     h->saved_variant = variant;
     h->P.stash_layout = (variant == CMPS_VARIANT_WAVE && h->D <= 16) ? 1
                       : (variant == CMPS_VARIANT_WAVE || variant == CMPS_VARIANT_WAVE32) ? 3
-                      : (variant == CMPS_VARIANT_PAIR ? 2 : 0);
+                      : (variant == CMPS_VARIANT_PAIR ? 2 : variant == CMPS_VARIANT_WIDE ? 4 : 0);
     return CMPS_OK;
 }
 
@@ -236,6 +240,19 @@ int cmps_psi_loss_bwd(cmps_handle_t h, const float* audio_dev, int B, int T, flo
         e = launch_reduce_only(Pp, s);
         if (e == hipSuccess) e = launch_finalize_only(P, h->saved_loss, grad_dev, s);
         if (e != hipSuccess) return fail_hip(h, e, "cmps_psi_loss_bwd (pair reduce)");
+        return CMPS_OK;
+    }
+    if (h->saved_variant == CMPS_VARIANT_WIDE) {
+        // float32 reverse scan, then the gradient GEMM (operands split into bf16 pieces on the fly); one slab per PAIR of clips
+        hipError_t e = launch_bwd_wide(P, audio_dev, s);
+        if (e == hipSuccess) e = launch_grad_wide(P, audio_dev, h->rank1_mode == CMPS_RANK1_BF16X2 ? 2 : 3, s);
+        if (e != hipSuccess) return fail_hip(h, e, "cmps_psi_loss_bwd (wide scan)");
+        Dev Pp = P;
+        Pp.B = (B + 1) / 2;
+        e = launch_reduce_only(Pp, s);
+        P.abar_fix = 1;              // the merged mat-vec: k_finalize removes the Q part of sum Re(u^dagger (Q + s R^dagger) ybar)
+        if (e == hipSuccess) e = launch_finalize_only(P, h->saved_loss, grad_dev, s);
+        if (e != hipSuccess) return fail_hip(h, e, "cmps_psi_loss_bwd (wide reduce)");
         return CMPS_OK;
     }
     const bool wave = h->saved_variant == CMPS_VARIANT_WAVE || h->saved_variant == CMPS_VARIANT_WAVE32;

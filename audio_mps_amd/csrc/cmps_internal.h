@@ -20,7 +20,8 @@ namespace cmps {
 //                                     per real component n = 2 i + {re, im} (32-row layout) or per lane (16-row layout)
 //   scal     : [B][NC][2][64] float   per 64-step chunk: |y_k|^2 and e_k, one step per lane (wave variant)
 //   gops     : [pairs][ceil(N/8)][5][2 clips][2 comps][DP] x 8 bf16   D > 32, TRAIN: operands of the gradient GEMM, written
-//                                     by the pair kernels' reverse scan (te y | ybar | s ybar | y | u), eight steps per 16 B
+//                                     by the pair kernels' reverse scan (te y | ybar | s ybar | y | u), eight steps per 16 B;
+//                                     the wide kernels (cmps_wide.hip) keep ybar_k there: [pairs][N][4 DP] float
 //   slabs    : [B][slab] float        per-clip gradient partials (TRAIN only)
 //   sums     : [slab] float           reduced partials, followed by [32][slab] double first-pass partial sums
 // DP = D rounded up to a multiple of 32 (components >= D are zero padding and stay exactly zero).
@@ -94,6 +95,7 @@ struct Dev {
     float* hst;          // [B][N][64][2] (wave variant)
     int stash_layout;    // 0: stash [B][N][DP] float2 (block variant)  1: hst rows in lane order (cmps_wave16.hip)
                          // 2: pair rows (cmps_pair.hip)  3: hst rows of (y[n], (H y)[n]) pairs, n = 2 i + {re, im} (cmps_wave2.hip)
+                         // 4: wide rows (cmps_wide.hip): [pair][step][y | H y][wave][lane] float
     float* scal;         // [B][NC][2][64]
     void* gops;          // gradient-GEMM operands of the pair kernels (see the layout comment), D > 32 only
     float* slabs;        // [B][slab]
@@ -185,6 +187,9 @@ hipError_t launch_bwd_wave16(const Dev& P, const float* audio, hipStream_t s);
 hipError_t launch_fwd_pair(const Dev& P, const float* audio, float* loss, bool save, hipStream_t s);
 hipError_t launch_bwd_pair(const Dev& P, const float* audio, hipStream_t s);
 hipError_t launch_grad_pair(const Dev& P, const float* audio, hipStream_t s);
+hipError_t launch_fwd_wide(const Dev& P, const float* audio, float* loss, bool save, hipStream_t s);
+hipError_t launch_bwd_wide(const Dev& P, const float* audio, hipStream_t s);
+hipError_t launch_grad_wide(const Dev& P, const float* audio, int pieces, hipStream_t s);
 hipError_t launch_finalize_only(const Dev& P, const float* loss, float* grad_out, hipStream_t s);
 hipError_t launch_reduce_finalize(const Dev& P, const float* loss, float* grad_out, hipStream_t s);
 hipError_t launch_update_ancilla(const Dev& P, const float* psi_in, const float* signal, float t,

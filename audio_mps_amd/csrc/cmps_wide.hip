@@ -1,0 +1,794 @@
+// 32 < D <= 128 in float32 ("wide" kernels, CMPS_VARIANT_WIDE; what AUTO selects above D = 32).
+//
+// The reference computes this path in float32 / complex64 at every bond dimension (model.py:300-325); the bf16 pair
+// kernels (cmps_pair.hip) are an opt-in trade of accuracy for speed, and the block kernels (cmps_block.hip) re-read the
+// matrices from L2 every step.  These kernels keep the float32 arithmetic and make the matrices resident:
+//
+//   workgroup = one PAIR of clips, PD / 16 waves (PD = D padded to 64 / 96 / 128): two waves per SIMD at PD = 128.
+//   wave w owns rows 16 w .. 16 w + 15 of every matrix; lane = 8 q + i:
+//     mat-vec:    rows 16 w + i and 16 w + 8 + i, K slice q = columns q PD/8 .. (q + 1) PD/8 - 1; the two matrices of a scan
+//                 (R and Q forward, R^dagger and Q in the reverse scan) are 4 PD/8 float2 = PD/2 .. 128 VGPRs per lane;
+//     after it:   three halving stages (v_permlane32_swap, v_permlane16_swap, DPP row_ror:8) sum the eight K slices and
+//                 leave ONE float per lane: (row 16 w + 8 (q >> 2) + i, component (q >> 1) & 1, clip q & 1).
+//   The two clips of a pair ride in the two halves of v_pk_fma_f32: a broadcast vector lives in LDS as one float4
+//   (re clip0, re clip1, im clip0, im clip1) per component, a matrix entry is a (re, im) register pair, and the complex
+//   multiply-accumulate of both clips is four packed FMAs with op_sel broadcasts -- no swizzles.  The merged matrix
+//   M_k = Q + s_k R (s_k differs per clip) is formed on the fly, two packed FMAs per entry: 6 instructions per entry
+//   and clip pair instead of 8.
+//   H = R + R^dagger (the loss product H y of the forward) does not fit next to R and Q in the 256 architectural
+//   VGPRs a wave can address (AGPRs are no VALU operands), so it sits in LDS in lane order (PD^2 * 8 B: 128 KB at PD = 128).
+//
+// Forward  (k_fwd_wide):  one LDS-only barrier per step; the loss product of step k - 1 shares step k's barrier interval.
+// Reverse  (k_bwd_wide):  the cotangent recursion g -> conj(rho) g -> ybar -> (Q + s R^dagger) ybar, analytic radial
+//                         derivative (see cmps_pair.hip); writes ybar_k (float32, lane order) for the gradient kernel.
+// Gradient (k_grad_wide): Rbar = sum (te y) y^dagger + (s ybar) u^dagger, Qbar = sum ybar u^dagger as
+//                         v_mfma_f32_32x32x16_bf16 GEMMs over K = (clip, step, {re, im}); every operand is split EXACTLY into
+//                         three bf16 pieces (8 + 8 + 8 significand bits) on the fly and the six significant piece products
+//                         are accumulated in fp32 (24 operand bits: what is dropped is <= 2^-23 |a||b|), the same
+//                         fp32-faithful product as CMPS_RANK1_BF16X3 of the D <= 32 kernels; CMPS_RANK1_BF16X2 keeps two
+//                         pieces / three products (16 operand bits).
+// Stash (Dev::stash, layout 4): [pair][step][y | H y][wave][lane] float32 (4 PD floats per vector: the lane order above);
+// ybar: the same vector shape per (pair, step) in Dev::gops.
+#include "cmps_internal.h"
+
+namespace cmps {
+
+namespace {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned u4w __attribute__((ext_vector_type(4)));
+typedef short bf8w __attribute__((ext_vector_type(8)));
+typedef float f16w __attribute__((ext_vector_type(16)));
+
+constexpr int WCH = 64;      // steps per chunk of per-step scalars (one step per lane)
+
+__device__ __forceinline__ v2f mkv2(float a, float b) { v2f r; r.x = a; r.y = b; return r; }
+__device__ __forceinline__ v2f lo_of(v4f q) { return __builtin_shufflevector(q, q, 0, 1); }
+__device__ __forceinline__ v2f hi_of(v4f q) { return __builtin_shufflevector(q, q, 2, 3); }
+__device__ __forceinline__ float wrdl(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+template <int CTRL>
+__device__ __forceinline__ float wdpp(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+// lanes l and l ^ 32: lower lanes receive x + x', upper lanes y + y'
+__device__ __forceinline__ float swap32_add(float x, float y) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// lanes l and l ^ 16: even 16-lane rows receive x + x', odd rows y + y'
+__device__ __forceinline__ float swap16_add(float x, float y) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// the value of lane l ^ 16
+__device__ __forceinline__ float partner16(float x, bool odd_row) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return odd_row ? __uint_as_float(r[0]) : __uint_as_float(r[1]);
+}
+// partial sums of the eight K slices (two rows x {re, im} x packed clips) -> this lane's own (row, component, clip)
+__device__ __forceinline__ float reduce_slices(v2f re0, v2f im0, v2f re1, v2f im1, bool clip1) {
+    const float tr0 = swap32_add(re0.x, re1.x), tr1 = swap32_add(re0.y, re1.y);       // row select (q bit 2)
+    const float ti0 = swap32_add(im0.x, im1.x), ti1 = swap32_add(im0.y, im1.y);
+    const float c0 = swap16_add(tr0, ti0), c1 = swap16_add(tr1, ti1);                 // component select (q bit 1)
+    const float keep = clip1 ? c1 : c0, give = clip1 ? c0 : c1;                       // clip select (q bit 0)
+    return keep + wdpp<0x128>(give);                                                  // row_ror:8: lane l ^ 8
+}
+// sum over the lanes of this wave that carry the same clip (q & 1); every lane receives its clip's total
+__device__ __forceinline__ float clip_wave_sum(float x) {
+    x += wdpp<0xB1>(x);           // quad_perm [1,0,3,2]
+    x += wdpp<0x4E>(x);           // quad_perm [2,3,0,1]
+    x += wdpp<0x141>(x);          // row_half_mirror: the other quad of this 8-lane group
+    x = swap16_add(x, x);
+    x = swap32_add(x, x);
+    return x;
+}
+__device__ __forceinline__ float rsq_newton(float m) {   // 1 / sqrt(m): v_rsq_f32 + one Newton step (same in all three kernels)
+    const float r = __builtin_amdgcn_rsqf(m);
+    return r * (1.5f - 0.5f * m * r * r);
+}
+__device__ __forceinline__ void wide_barrier() {          // orders LDS traffic only (__syncthreads() would also drain the stash stores)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// acc(two rows) += (Q + s R)[row][col] * x[col] for both clips:  s2 = (s clip0, s clip1) in SGPRs, x = (re c0, re c1 | im c0, im c1)
+__device__ __forceinline__ void col_merged(v2f& aRe0, v2f& aIm0, v2f& aRe1, v2f& aIm1, v2f r0, v2f q0, v2f r1, v2f q1, v2f s2,
+                                           v2f xre, v2f xim) {
+    v2f t0, t1, t2, t3;
+    asm("v_pk_fma_f32 %4, %8, %12, %9 op_sel_hi:[0,1,0]\n\t"              // m_re = R_re s + Q_re   (per clip)
+        "v_pk_fma_f32 %5, %8, %12, %9 op_sel:[1,0,1]\n\t"                 // m_im = R_im s + Q_im
+        "v_pk_fma_f32 %6, %10, %12, %11 op_sel_hi:[0,1,0]\n\t"
+        "v_pk_fma_f32 %7, %10, %12, %11 op_sel:[1,0,1]\n\t"
+        "v_pk_fma_f32 %0, %4, %13, %0\n\t"                                // Re += m_re x_re
+        "v_pk_fma_f32 %2, %6, %13, %2\n\t"
+        "v_pk_fma_f32 %1, %4, %14, %1\n\t"                                // Im += m_re x_im
+        "v_pk_fma_f32 %3, %6, %14, %3\n\t"
+        "v_pk_fma_f32 %0, %5, %14, %0 neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"  // Re -= m_im x_im
+        "v_pk_fma_f32 %2, %7, %14, %2 neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_pk_fma_f32 %1, %5, %13, %1\n\t"                                // Im += m_im x_re
+        "v_pk_fma_f32 %3, %7, %13, %3"
+        : "+v"(aRe0), "+v"(aIm0), "+v"(aRe1), "+v"(aIm1), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(r0), "v"(q0), "v"(r1), "v"(q1), "s"(s2), "v"(xre), "v"(xim));
+}
+// acc(two rows) += H[row][col .. col + 1] * y[col .. col + 1] for both clips; h = (re, im, re, im) of two adjacent columns
+__device__ __forceinline__ void col_pair_plain(v2f& aRe0, v2f& aIm0, v2f& aRe1, v2f& aIm1, v4f h0, v4f h1, v4f ya, v4f yb) {
+    asm("v_pk_fma_f32 %0, %4, %8, %0 op_sel_hi:[0,1,1]\n\t"                                    // Re += h_re y_re
+        "v_pk_fma_f32 %2, %6, %8, %2 op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %1, %4, %9, %1 op_sel_hi:[0,1,1]\n\t"                                    // Im += h_re y_im
+        "v_pk_fma_f32 %3, %6, %9, %3 op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %0, %4, %9, %0 op_sel:[1,0,0] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"         // Re -= h_im y_im
+        "v_pk_fma_f32 %2, %6, %9, %2 op_sel:[1,0,0] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_pk_fma_f32 %1, %4, %8, %1 op_sel:[1,0,0]\n\t"                                       // Im += h_im y_re
+        "v_pk_fma_f32 %3, %6, %8, %3 op_sel:[1,0,0]\n\t"
+        "v_pk_fma_f32 %0, %5, %10, %0 op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %2, %7, %10, %2 op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %1, %5, %11, %1 op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %3, %7, %11, %3 op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %0, %5, %11, %0 op_sel:[1,0,0] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_pk_fma_f32 %2, %7, %11, %2 op_sel:[1,0,0] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_pk_fma_f32 %1, %5, %10, %1 op_sel:[1,0,0]\n\t"
+        "v_pk_fma_f32 %3, %7, %10, %3 op_sel:[1,0,0]"
+        : "+v"(aRe0), "+v"(aIm0), "+v"(aRe1), "+v"(aIm1)
+        : "v"(lo_of(h0)), "v"(hi_of(h0)), "v"(lo_of(h1)), "v"(hi_of(h1)), "v"(lo_of(ya)), "v"(hi_of(ya)), "v"(lo_of(yb)),
+          "v"(hi_of(yb)));
+}
+
+template <int PD>
+struct WideGeom {
+    static constexpr int NW = PD / 16;          // waves per workgroup
+    static constexpr int NTH = 64 * NW;         // threads = 4 PD = (row, component, clip) positions of one vector
+    static constexpr int KC = PD / 8;           // columns per lane
+    static constexpr int VSL = KC + 1;          // float4 per K slice of a broadcast vector (one float4 of padding: bank spread)
+    static constexpr int VEC4 = 8 * VSL;        // float4 per broadcast vector
+    static constexpr size_t FWD_LDS = ((size_t)NW * KC * 64 + 4 * VEC4) * 16 + 2 * 2 * NW * 2 * 4;
+};
+// float4 index (and float offset inside it) of this lane's own value in a broadcast vector
+template <int PD>
+__device__ __forceinline__ int vec_float_index(int row, int comp, int clip) {
+    constexpr int KC = WideGeom<PD>::KC, VSL = WideGeom<PD>::VSL;
+    return ((row / KC) * VSL + row % KC) * 4 + comp * 2 + clip;
+}
+// float offset of the vector (pair, step, y / H y) in the stash
+template <int PD>
+__device__ __forceinline__ size_t wide_stash_vec(size_t pair, int N, int step, int yh) {
+    return ((pair * N + step) * 2 + yh) * (size_t)(4 * PD);
+}
+template <int PD>
+__device__ __forceinline__ size_t wide_ybar_vec(size_t pair, int N, int step) {
+    return (pair * N + step) * (size_t)(4 * PD);
+}
+
+// per-step scalars of one clip from what the forward stashed (|y_k|^2, e_k) and the audio, in the reference's operation order
+// (model.py:294, 303); shared by the reverse scan and the gradient kernel so that both see the same numbers
+struct StepScal { float s, inv, ok, te, rad, zex; };
+__device__ __forceinline__ StepScal step_scalars(float inc, float nv, float ev, float A) {
+    StepScal r;
+    const float ex = ev * inc;
+    const float z = ex / A;
+    const float zbar = -1.0f / (1.0f + z);
+    r.s = inc / A;
+    r.inv = rsq_newton(fmaxf(nv, 1e-12f));
+    r.ok = nv > 1e-12f ? 1.f : 0.f;
+    r.te = 2.0f * (zbar * inc / A);
+    r.rad = r.te * ev;
+    r.zex = zbar * ex;
+    return r;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------------------------------
+template <int PD, bool SAVE>
+__global__ __launch_bounds__(4 * PD) void k_fwd_wide(Dev P, const float* __restrict__ audio, float* __restrict__ loss_out) {
+    using G = WideGeom<PD>;
+    constexpr int NW = G::NW, KC = G::KC, VSL = G::VSL, VEC4 = G::VEC4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char wide_lds[];
+    v4f* Hl = reinterpret_cast<v4f*>(wide_lds);                   // [NW][KC][64]: H in lane order
+    v4f* uvec = Hl + NW * KC * 64;                                // [2][VEC4]
+    v4f* yvec = uvec + 2 * VEC4;                                  // [2][VEC4]
+    float* nrm = reinterpret_cast<float*>(yvec + 2 * VEC4);       // [2][NW][2]
+    float* ee = nrm + 2 * NW * 2;                                 // [2][NW][2]
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int q = lane >> 3, i = lane & 7;
+    const int rowsel = q >> 2, comp = (q >> 1) & 1, clip = q & 1;
+    const bool clip1 = clip != 0, im_lane = comp != 0;
+    const int row = 16 * w + 8 * rowsel + i;
+    const int N = P.N, T = P.T, NC = (N + WCH - 1) / WCH;
+    const int b0 = 2 * blockIdx.x, b1 = (b0 + 1 < P.B) ? b0 + 1 : b0;   // an odd batch repeats its last clip (not stored)
+    const bool two = b1 != b0;
+    const float* xr0 = audio + (size_t)b0 * T;
+    const float* xr1 = audio + (size_t)b1 * T;
+    const float A = P.A;
+
+    // ---- matrices: rows 16 w + i (a) and 16 w + 8 + i (b), columns q KC .. ----
+    v2f MR[2][KC], MQ[2][KC];
+    {
+        const int ra = 16 * w + i, rb = ra + 8, c0 = q * KC;
+#pragma unroll
+        for (int j = 0; j < KC; ++j) {
+            const float2 a = P.R[(size_t)ra * PD + c0 + j], b = P.R[(size_t)rb * PD + c0 + j];
+            const float2 c = P.Q[(size_t)ra * PD + c0 + j], d = P.Q[(size_t)rb * PD + c0 + j];
+            MR[0][j] = mkv2(a.x, a.y); MR[1][j] = mkv2(b.x, b.y);
+            MQ[0][j] = mkv2(c.x, c.y); MQ[1][j] = mkv2(d.x, d.y);
+        }
+        // H = R + R^dagger in lane order: float4 number rs KC/2 + jp of this lane = H[row_rs][c0 + 2 jp], H[row_rs][c0 + 2 jp + 1]
+#pragma unroll
+        for (int rr = 0; rr < KC; ++rr) {
+            const int rs = rr / (KC / 2), jp = rr % (KC / 2), r_ = rs ? rb : ra, c_ = c0 + 2 * jp;
+            const float2 x0 = P.R[(size_t)r_ * PD + c_], x1 = P.R[(size_t)r_ * PD + c_ + 1];
+            const float2 t0 = P.RT[(size_t)r_ * PD + c_], t1 = P.RT[(size_t)r_ * PD + c_ + 1];   // RT[i][j] = R[j][i]
+            Hl[(w * KC + rr) * 64 + lane] = v4f{x0.x + t0.x, x0.y - t0.y, x1.x + t1.x, x1.y - t1.y};
+        }
+    }
+    const int own_f = vec_float_index<PD>(row, comp, clip);
+    const int rd4 = q * VSL;                                      // first float4 of this lane's K slice
+    float* stash = reinterpret_cast<float*>(P.stash);
+    const size_t pos = (size_t)w * 64 + lane;
+
+    const float2 p0 = P.psi0[row];
+    float ut = im_lane ? p0.y : p0.x;                             // ut_0 = psi_0 (both clips)
+    reinterpret_cast<float*>(uvec)[own_f] = ut;
+    float yprev = 0.f;                                            // y_{k-1} of this lane (for e_{k-1} = y . H y)
+    float sv0 = 0.f, sv1 = 0.f;                                   // s = x / A of the current 64 steps, lane <-> step
+    float ebuf0 = 0.f, ebuf1 = 0.f, nbuf0 = 0.f, nbuf1 = 0.f;     // wave 0: e_k, |y_k|^2 of the current chunk, lane <-> step
+    float loss0 = 0.f, loss1 = 0.f;
+    float2 rho_next = P.rho[row];                                 // rho_0
+    __syncthreads();
+
+    for (int k = 0; k <= N + 1; ++k) {
+        const int p = k & 1;
+        const bool chain = k < N, lossmv = k >= 1 && k <= N;
+        if (chain && (k & (WCH - 1)) == 0) {                      // increments of the next 64 steps, one per lane (model.py:263, 303)
+            const int idx = k + lane;
+            const bool in0 = idx < T, in1 = idx + 1 < T;
+            sv0 = ((in1 ? xr0[idx + 1] : 0.f) - (in0 ? xr0[idx] : 0.f)) / A;
+            sv1 = ((in1 ? xr1[idx + 1] : 0.f) - (in0 ? xr1[idx] : 0.f)) / A;
+        }
+        const float2 rho_k = rho_next;
+        if (k + 1 < N) rho_next = P.rho[(size_t)(k + 1) * PD + row];
+        // |y_{k-1}|^2 of both clips (published before the barrier of the previous iteration)
+        float n0 = 1.f, n1 = 1.f;
+        if (k >= 1) {
+            n0 = n1 = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) {
+                const float2 t = *reinterpret_cast<const float2*>(&nrm[(p * NW + ww) * 2]);
+                n0 += t.x; n1 += t.y;
+            }
+        }
+        const float inv = k >= 1 ? rsq_newton(fmaxf(clip1 ? n1 : n0, 1e-12f)) : 1.f;      // model.py:332
+        v2f cRe0 = mkv2(0.f, 0.f), cIm0 = cRe0, cRe1 = cRe0, cIm1 = cRe0;
+        v2f hRe0 = cRe0, hIm0 = cRe0, hRe1 = cRe0, hIm1 = cRe0;
+        if (chain) {
+            const int kl = k & (WCH - 1);
+            const v2f s2 = mkv2(wrdl(sv0, kl), wrdl(sv1, kl));
+            const v4f* uv = uvec + p * VEC4 + rd4;
+#pragma unroll
+            for (int j = 0; j < KC; ++j) {
+                const v4f x = uv[j];
+                col_merged(cRe0, cIm0, cRe1, cIm1, MR[0][j], MQ[0][j], MR[1][j], MQ[1][j], s2, lo_of(x), hi_of(x));
+            }
+        }
+        if (lossmv) {                                             // H y_{k-1}
+            const v4f* yv = yvec + p * VEC4 + rd4;
+            const v4f* hl = Hl + (size_t)w * KC * 64 + lane;
+#pragma unroll
+            for (int jp = 0; jp < KC / 2; ++jp)
+                col_pair_plain(hRe0, hIm0, hRe1, hIm1, hl[jp * 64], hl[(KC / 2 + jp) * 64], yv[2 * jp], yv[2 * jp + 1]);
+        }
+        if (chain) {
+            const float acc = reduce_slices(cRe0, cIm0, cRe1, cIm1, clip1);
+            const float y = inv * (ut + acc);                     // y_k = inv_{k-1} (ut + M_k ut)
+            const float nn = clip_wave_sum(y * y);
+            if (i == 0 && q < 2) nrm[((p ^ 1) * NW + w) * 2 + clip] = nn;
+            reinterpret_cast<float*>(yvec + (p ^ 1) * VEC4)[own_f] = y;
+            const float py = partner16(y, im_lane);
+            ut = rho_k.x * y + (im_lane ? rho_k.y : -rho_k.y) * py;      // ut_{k+1} = rho_k y_k (un-normalised)
+            reinterpret_cast<float*>(uvec + (p ^ 1) * VEC4)[own_f] = ut;
+            if (SAVE) stash[wide_stash_vec<PD>(blockIdx.x, N, k, 0) + pos] = y;
+            if (lossmv) {
+                const float hy = reduce_slices(hRe0, hIm0, hRe1, hIm1, clip1);
+                const float ep = clip_wave_sum(yprev * hy);
+                if (i == 0 && q < 2) ee[((p ^ 1) * NW + w) * 2 + clip] = ep;
+                if (SAVE) stash[wide_stash_vec<PD>(blockIdx.x, N, k - 1, 1) + pos] = hy;
+            }
+            yprev = y;
+        } else if (lossmv) {                                      // k == N: the last loss product
+            const float hy = reduce_slices(hRe0, hIm0, hRe1, hIm1, clip1);
+            const float ep = clip_wave_sum(yprev * hy);
+            if (i == 0 && q < 2) ee[((p ^ 1) * NW + w) * 2 + clip] = ep;
+            if (SAVE) stash[wide_stash_vec<PD>(blockIdx.x, N, k - 1, 1) + pos] = hy;
+        }
+        if (w == 0) {                                             // bookkeeping: e_{k-2}, |y_{k-1}|^2, the loss (sequential float32)
+            if (k >= 2) {
+                const int ke = k - 2;
+                float e0 = 0.f, e1 = 0.f;
+#pragma unroll
+                for (int ww = 0; ww < NW; ++ww) {
+                    const float2 t = *reinterpret_cast<const float2*>(&ee[(p * NW + ww) * 2]);
+                    e0 += t.x; e1 += t.y;
+                }
+                if (lane == (ke & (WCH - 1))) { ebuf0 = e0; ebuf1 = e1; }
+                if ((ke & (WCH - 1)) == WCH - 1 || ke == N - 1) {
+                    const int c = ke / WCH, idx = c * WCH + lane;
+                    const bool in = idx < N;
+                    const float i0 = in ? xr0[idx + 1] - xr0[idx] : 0.f, i1 = in ? xr1[idx + 1] - xr1[idx] : 0.f;
+                    const float l0 = in ? -logf(1.0f + (ebuf0 * i0) / A) : 0.f;        // model.py:294 operation order
+                    const float l1 = in ? -logf(1.0f + (ebuf1 * i1) / A) : 0.f;
+                    if (SAVE && in) {
+                        float* sc0 = P.scal + ((size_t)b0 * NC + c) * 128;
+                        sc0[lane] = nbuf0; sc0[64 + lane] = ebuf0;
+                        if (two) {
+                            float* sc1 = P.scal + ((size_t)b1 * NC + c) * 128;
+                            sc1[lane] = nbuf1; sc1[64 + lane] = ebuf1;
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < WCH; ++j) {               // model.py:279: sequential in time
+                        loss0 += wrdl(l0, j);
+                        loss1 += wrdl(l1, j);
+                    }
+                }
+            }
+            if (k >= 1 && lane == ((k - 1) & (WCH - 1))) { nbuf0 = n0; nbuf1 = n1; }
+        }
+        wide_barrier();
+    }
+    if (w == 0 && lane == 0) {
+        loss_out[b0] = loss0;
+        if (two) loss_out[b1] = loss1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// reverse scan
+//   yhat = y_k inv_k;  yhb = conj(rho_k) g;  ybar = (yhb - ok yhat rad_{k+1}) inv_k + te_k H y_k
+//   g    = ybar + (Q + s_k R^dagger) ybar
+//   fbar += dt_k Im(g conj(u_{k+1}));   Abar = -(sum zbar e x) / A^2 - (sum Re(u_k^dagger (Q + s R^dagger) ybar_k)) / A  (abar_fix)
+// rad_{k+1} = Re(u_{k+1}^dagger g_{k+1}) = te_{k+1} e_{k+1} (Euler: everything downstream of u_{k+1} is scale invariant except
+// the loss term of step k + 1, homogeneous of degree 2), 0 behind the last step.
+// ------------------------------------------------------------------------------------------------------------------------
+template <int PD>
+__global__ __launch_bounds__(4 * PD) void k_bwd_wide(Dev P, const float* __restrict__ audio) {
+    using G = WideGeom<PD>;
+    constexpr int NW = G::NW, KC = G::KC, VSL = G::VSL, VEC4 = G::VEC4;
+    __shared__ __attribute__((aligned(16))) v4f vec[2][VEC4];
+    __shared__ __attribute__((aligned(16))) v4f tab[NW][2][WCH][2][2];     // [wave][chunk parity][step][clip][half]
+    __shared__ float redA[NW];
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int q = lane >> 3, i = lane & 7;
+    const int rowsel = q >> 2, comp = (q >> 1) & 1, clip = q & 1;
+    const bool clip1 = clip != 0, im_lane = comp != 0;
+    const int row = 16 * w + 8 * rowsel + i;
+    const int N = P.N, T = P.T, NC = (N + WCH - 1) / WCH;
+    const int b0 = 2 * blockIdx.x, b1 = (b0 + 1 < P.B) ? b0 + 1 : b0;
+    const bool two = b1 != b0;
+    const float wq = (!clip1 || two) ? 1.f : 0.f;                 // weight of this lane's clip (0: the repeated clip)
+    const float* xr0 = audio + (size_t)b0 * T;
+    const float* xr1 = audio + (size_t)b1 * T;
+    const float* sc0 = P.scal + ((size_t)b0 * NC) * 128;
+    const float* sc1 = P.scal + ((size_t)b1 * NC) * 128;
+    const float A = P.A;
+    const float sgn = im_lane ? 1.f : -1.f;                       // (rho x)_own = rho_re x_own + sgn rho_im x_partner
+
+    v2f MD[2][KC], MQ[2][KC];                                     // R^dagger and Q (Hermitian)
+    {
+        const int ra = 16 * w + i, rb = ra + 8, c0 = q * KC;
+#pragma unroll
+        for (int j = 0; j < KC; ++j) {
+            const float2 a = P.RT[(size_t)ra * PD + c0 + j], b = P.RT[(size_t)rb * PD + c0 + j];   // R^dagger[i][j] = conj(RT[i][j])
+            const float2 c = P.Q[(size_t)ra * PD + c0 + j], d = P.Q[(size_t)rb * PD + c0 + j];
+            MD[0][j] = mkv2(a.x, -a.y); MD[1][j] = mkv2(b.x, -b.y);
+            MQ[0][j] = mkv2(c.x, c.y); MQ[1][j] = mkv2(d.x, d.y);
+        }
+    }
+    const int own_f = vec_float_index<PD>(row, comp, clip);
+    const int rd4 = q * VSL;
+    const float* stf = reinterpret_cast<const float*>(P.stash);
+    float* ybs = reinterpret_cast<float*>(P.gops);
+    const size_t pos = (size_t)w * 64 + lane;
+
+    // every wave builds its own copy of a chunk's scalar rows (no cross-wave hand-over): lane <-> step
+    float accA = 0.f, svA0 = 0.f, svA1 = 0.f, svB0 = 0.f, svB1 = 0.f;      // s of chunk parity 0 / 1, lane <-> step
+    auto chunk_rows = [&](int cj) {
+        const int idx = cj * WCH + lane;
+        const bool in = idx < N;
+        const float dtv = in ? P.dtk[idx] : 0.f;
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+            const float* xr = qq ? xr1 : xr0;
+            const float* sc = qq ? sc1 : sc0;
+            const float x0 = idx < T ? xr[idx] : 0.f, x1 = idx + 1 < T ? xr[idx + 1] : 0.f;
+            const float nv = in ? sc[(size_t)cj * 128 + lane] : 1.f;
+            const float ev = in ? sc[(size_t)cj * 128 + 64 + lane] : 0.f;
+            const StepScal r = step_scalars(x1 - x0, nv, ev, A);
+            tab[w][cj & 1][lane][qq][0] = v4f{r.s, r.inv, r.ok, r.te};
+            tab[w][cj & 1][lane][qq][1] = v4f{r.rad, dtv, 0.f, 0.f};
+            if (cj & 1) { if (qq) svB1 = r.s; else svB0 = r.s; } else { if (qq) svA1 = r.s; else svA0 = r.s; }
+            if (in && w == 0 && (qq == 0 || two)) accA += r.zex;
+        }
+    };
+    chunk_rows((N - 1) / WCH);
+    if ((N - 1) / WCH > 0) chunk_rows((N - 1) / WCH - 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    auto tab_row = [&](int k, int half) { return tab[w][(k / WCH) & 1][k & (WCH - 1)][clip][half]; };
+    // stash row k for this lane: y own, y of the partner component (lane ^ 16), H y own; clamped, unconditional loads
+    struct Row { float y, yp, h; };
+    auto row_at = [&](int k) {
+        const int kc = k > 0 ? k : 0;
+        const float* base = stf + wide_stash_vec<PD>(blockIdx.x, N, kc, 0);
+        Row r;
+        r.y = base[pos];
+        r.yp = base[pos ^ 16];
+        r.h = base[4 * PD + pos];
+        return r;
+    };
+    auto rho_row = [&](int k) { return P.rho[(size_t)(k > 0 ? k : 0) * PD + row]; };
+
+    const int k0 = N - 1;
+    Row ring0 = row_at(k0 - ((k0 - 0) & 3)), ring1 = row_at(k0 - ((k0 - 1) & 3));
+    Row ring2 = row_at(k0 - ((k0 - 2) & 3)), ring3 = row_at(k0 - ((k0 - 3) & 3));
+    float2 rh = rho_row(k0), rhp = rho_row(k0 - 1);
+    v4f S0 = tab_row(k0, 0), S1 = tab_row(k0, 1);
+    v4f SP0 = tab_row(k0 > 0 ? k0 - 1 : 0, 0), SP1 = tab_row(k0 > 0 ? k0 - 1 : 0, 1);
+    float g = 0.f, unext = 0.f, facc = 0.f, accS = 0.f;
+    float c3;
+    {
+        const Row cur = row_at(k0);
+        c3 = S0.w * cur.h;                                        // rad_N = 0
+    }
+    const float2 ps = P.psi0[row];
+    const float ps0 = im_lane ? ps.y : ps.x;
+    int p = 0;
+    __syncthreads();
+
+    auto step = [&](int k, Row& CUR, const Row& PRV) {
+        const int km2 = k > 1 ? k - 2 : 0;
+        if ((k & (WCH - 1)) == WCH - 1 && k != N - 1 && k >= WCH) chunk_rows(k / WCH - 1);   // entering chunk k / WCH: build the one below
+        const float2 nrh = rho_row(k - 2);
+        // ---- the chain ----
+        const float pg = partner16(g, im_lane);
+        const float hb = rh.x * g - sgn * rh.y * pg;              // conj(rho_k) g
+        const float yb = fmaf(hb, S0.y, c3);
+        reinterpret_cast<float*>(vec[p])[own_f] = yb;
+        ybs[wide_ybar_vec<PD>(blockIdx.x, N, k) + pos] = yb;
+        wide_barrier();
+        const int kl = k & (WCH - 1);
+        const bool par = ((k / WCH) & 1) != 0;
+        const v2f s2 = mkv2(wrdl(par ? svB0 : svA0, kl), wrdl(par ? svB1 : svA1, kl));
+        v2f dRe0 = mkv2(0.f, 0.f), dIm0 = dRe0, dRe1 = dRe0, dIm1 = dRe0;
+        const v4f* yv = vec[p] + rd4;
+#pragma unroll
+        for (int j = 0; j < KC; ++j) {
+            const v4f x = yv[j];
+            col_merged(dRe0, dIm0, dRe1, dIm1, MD[0][j], MQ[0][j], MD[1][j], MQ[1][j], s2, lo_of(x), hi_of(x));
+        }
+        // ---- off the chain ----
+        facc += S1.y * (im_lane ? -pg : pg) * unext;              // dt_k Im(g conj(u_{k+1})): re lanes g_im u_re, im lanes -g_re u_im
+        const float invp = SP0.y;
+        const float yhp = PRV.y * invp, yhpp = PRV.yp * invp;
+        const float uk = k > 0 ? rhp.x * yhp + sgn * rhp.y * yhpp : ps0;       // u_k = rho_{k-1} yhat_{k-1}  (psi_0 at k = 0)
+        c3 = fmaf(SP0.w, PRV.h, -(yhp * (S1.x * SP0.z * invp)));               // the g-independent part of ybar_{k-1}
+        const v4f nS0 = tab_row(km2, 0), nS1 = tab_row(km2, 1);
+        CUR = row_at(k - 4);
+        const float d = reduce_slices(dRe0, dIm0, dRe1, dIm1, clip1);
+        accS += d * uk;
+        g = yb + d;
+        unext = uk;
+        rh = rhp; rhp = nrh;
+        S0 = SP0; S1 = SP1; SP0 = nS0; SP1 = nS1;
+        p ^= 1;
+    };
+    for (int blk = (N - 1) / 4; blk >= 0; --blk) {
+        const int kb = 4 * blk;
+        if (kb + 3 < N) step(kb + 3, ring3, ring2);
+        if (kb + 2 < N) step(kb + 2, ring2, ring1);
+        if (kb + 1 < N) step(kb + 1, ring1, ring0);
+        step(kb, ring0, ring3);
+    }
+
+    // ---- the pair's slab: f | psi0bar_re | psi0bar_im | A (the R / Q sections are written by k_grad_wide) ----
+    float* slab = P.slabs + (size_t)blockIdx.x * P.slab_floats;
+    constexpr int DD = PD * PD;
+    {
+        float f = facc * wq, g0 = g * wq;
+        f += wdpp<0x128>(f);                                      // + the other clip (lane ^ 8)
+        g0 += wdpp<0x128>(g0);
+        const float ft = f + partner16(f, im_lane);               // + the other component's share
+        if (!clip1) {
+            if (!im_lane) slab[4 * DD + row] = ft;
+            slab[4 * DD + (im_lane ? 2 * PD : PD) + row] = g0;
+        }
+    }
+    {
+        float t = accS * wq;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+        float a = accA;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+        if (lane == 0) redA[w] = -(a / (A * A)) - t / A;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float tot = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) tot += redA[ww];
+            slab[4 * DD + 3 * PD] = tot;
+            slab[4 * DD + 3 * PD + 1] = 0.f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// gradient contraction (see the header).  A complex outer product  C += a b^dagger  is two real GEMMs over K:
+//   Re C = [a_re | a_im] [b_re | b_im]^T,   Im C = [a_im | -a_re] [b_re | b_im]^T.
+// One MFMA covers K = 16 = {re, im} x 2 clips x 4 steps: the K half (lane >> 5) is the component and a lane's eight K values
+// are ONE 16-byte piece [clip][step] of an operand array op[piece][operand][component][row].  A unit = 4 steps of both clips.
+// Wave w (one per SIMD, 512 registers: 256 of them accumulators) owns the 32-row block w of Re / Im Rbar and Re / Im Qbar; the
+// operands of the next unit are built (loads, scaling, rotation, bf16 splits: VALU) in the same instruction stream as this
+// unit's MFMAs (matrix pipe), double-buffered in LDS, one barrier per unit.
+// ------------------------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int GU = 4;       // steps per unit
+
+// x = hi + mid + lo exactly, each with 8 significant bits: returned as bf16 bit patterns in the upper halves
+__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
+    h = __float_as_uint(x) & 0xFFFF0000u;
+    const float r1 = x - __uint_as_float(h);
+    m = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(m);
+    l = __float_as_uint(r2);                        // <= 8 significant bits: exact in bf16 (the low half is zero)
+}
+__device__ __forceinline__ unsigned pack_hi16(unsigned lo_word, unsigned hi_word) {   // (lo_word >> 16) | (hi_word & 0xFFFF0000)
+    return __builtin_amdgcn_perm(hi_word, lo_word, 0x07060302u);
+}
+__device__ __forceinline__ bf8w piece_bits(u4w v, unsigned mask) {
+    u4w t = {v.x ^ mask, v.y ^ mask, v.z ^ mask, v.w ^ mask};
+    return __builtin_bit_cast(bf8w, t);
+}
+
+}  // namespace
+
+template <int PD, int NPC>       // NPC = bf16 pieces per operand: 3 (six products, 24 bits) or 2 (three products, 16 bits)
+__global__ __launch_bounds__(2 * PD, 1) void k_grad_wide(Dev P, const float* __restrict__ audio) {
+    constexpr int PWV = PD / 32;                                  // waves = 32-row blocks; one wave per SIMD, 512 registers
+    constexpr int NTHR = 2 * PD;
+    constexpr int OPS = 5 * 2 * PD;                               // 16-byte pieces per (buffer, piece): [operand][component][row]
+    extern __shared__ __attribute__((aligned(16))) unsigned char wide_lds[];
+    u4w* ops = reinterpret_cast<u4w*>(wide_lds);                  // [2][NPC][OPS]
+    v4f* tab = reinterpret_cast<v4f*>(ops + 2 * NPC * OPS);       // [2][WCH][2]: (s, inv, ok, te) per (chunk parity, step, clip)
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int N = P.N, T = P.T, NC = (N + WCH - 1) / WCH, NU = (N + GU - 1) / GU;
+    const int b0 = 2 * blockIdx.x, b1 = (b0 + 1 < P.B) ? b0 + 1 : b0;
+    const bool two = b1 != b0;
+    const float A = P.A;
+    // ---- prep role: this thread = positions `tid` and `tid + 2 PD` of a stash vector (same lane, wave + PD / 32) ----
+    const int pq = lane >> 3, pi = lane & 7;
+    const int pcomp = (pq >> 1) & 1, pclip = pq & 1;
+    const int prow0 = 16 * (tid >> 6) + 8 * (pq >> 2) + pi;       // second position: row + PD / 2
+    const float psgn = pcomp ? 1.f : -1.f;
+    const float pwq = (pclip == 0 || two) ? 1.f : 0.f;            // the repeated clip of an odd batch contributes nothing
+    const float* stf = reinterpret_cast<const float*>(P.stash);
+    const float* ybs = reinterpret_cast<const float*>(P.gops);
+    // ---- MFMA role: wave w owns the 32-row block w of Re Rbar, Im Rbar, Re Qbar, Im Qbar ----
+    const int mr = lane & 31, mh = lane >> 5;
+    const unsigned imask = mh ? 0x80008000u : 0u;                 // Im form: K half 1 is -a_re
+
+    f16w Rre[PWV], Rim[PWV], Qre[PWV], Qim[PWV];
+#pragma unroll
+    for (int cb = 0; cb < PWV; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Rre[cb][r] = Rim[cb][r] = Qre[cb][r] = Qim[cb][r] = 0.f;
+
+    auto build_tab = [&](int cj) {                                // threads 0 .. 127: (step, clip) of chunk cj
+        if (tid < 2 * WCH && cj < NC) {
+            const int st = tid >> 1, cl = tid & 1, idx = cj * WCH + st;
+            const bool in = idx < N;
+            const float* xr = audio + (size_t)(cl ? b1 : b0) * T;
+            const float* sc = P.scal + ((size_t)(cl ? b1 : b0) * NC + cj) * 128;
+            const float x0 = idx < T ? xr[idx] : 0.f, x1 = idx + 1 < T ? xr[idx + 1] : 0.f;
+            const float nv = in ? sc[st] : 1.f, ev = in ? sc[64 + st] : 0.f;
+            const StepScal r = step_scalars(x1 - x0, nv, ev, A);
+            tab[((cj & 1) * WCH + st) * 2 + cl] = v4f{r.s, r.inv, r.ok, in ? r.te : 0.f};
+        }
+    };
+    // operands of unit u into buffer u & 1.  Loads are NOT clamped: rows one step below / up to four steps above the pair's
+    // range lie inside the caller's workspace (other sections of it), and every value derived from them is discarded by a
+    // select (never by a product with zero).
+    auto prep = [&](int u) {
+        const int kb = GU * u;
+        u4w* dst = ops + (size_t)(u & 1) * NPC * OPS;
+#pragma unroll
+        for (int hp = 0; hp < 2; ++hp) {
+            const int pos = tid + hp * NTHR, prow = prow0 + hp * (PD / 2);
+            const float2 ps = P.psi0[prow];
+            const float ps0 = pcomp ? ps.y : ps.x;
+            const float* ysrc = stf + wide_stash_vec<PD>(blockIdx.x, N, 0, 0) + (ptrdiff_t)(kb - 1) * (8 * PD) + pos;   // y_{kb-1}, own
+            const float* bsrc = ybs + wide_ybar_vec<PD>(blockIdx.x, N, 0) + (ptrdiff_t)kb * (4 * PD) + pos;             // ybar_kb
+            const float2* rsrc = P.rho + (ptrdiff_t)(kb - 1) * PD + prow;                                               // rho_{kb-1}
+            float TY[GU], SB[GU], YB[GU], YK[GU], UK[GU];
+            {
+                float Y[GU + 1], YP[GU];
+                float2 RH[GU];
+#pragma unroll
+                for (int j = 0; j <= GU; ++j) {
+                    Y[j] = ysrc[(ptrdiff_t)j * (8 * PD)];
+                    if (j < GU) {
+                        YP[j] = (ysrc - pos + (pos ^ 16))[(ptrdiff_t)j * (8 * PD)];
+                        RH[j] = rsrc[(ptrdiff_t)j * PD];
+                        YB[j] = bsrc[(ptrdiff_t)j * (4 * PD)];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < GU; ++j) {
+                    const int k = kb + j;
+                    const bool in = k < N;
+                    const v4f sk = tab[(((k / WCH) & 1) * WCH + (k & (WCH - 1))) * 2 + pclip];
+                    const int km = k > 0 ? k - 1 : 0;
+                    const float invp = tab[(((km / WCH) & 1) * WCH + (km & (WCH - 1))) * 2 + pclip].y;
+                    const float yk = Y[j + 1], yb = YB[j];
+                    const float uk = k > 0 ? RH[j].x * (Y[j] * invp) + psgn * RH[j].y * (YP[j] * invp) : ps0;
+                    TY[j] = in ? pwq * (sk.w * yk) : 0.f;      // te y
+                    SB[j] = in ? pwq * (sk.x * yb) : 0.f;      // s ybar
+                    YB[j] = in ? pwq * yb : 0.f;               // ybar
+                    YK[j] = in ? yk : 0.f;                     // y
+                    UK[j] = in ? uk : 0.f;                     // u
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < 5; ++o) {
+                unsigned w0[3], w1[3];
+#pragma unroll
+                for (int j = 0; j < GU; ++j) {
+                    const float v = o == 0 ? TY[j] : o == 1 ? SB[j] : o == 2 ? YB[j] : o == 3 ? YK[j] : UK[j];
+                    unsigned pc[3];
+                    split3(v, pc[0], pc[1], pc[2]);
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        if (j == 0) w0[a] = pc[a];
+                        else if (j == 1) w0[a] = pack_hi16(w0[a], pc[a]);
+                        else if (j == 2) w1[a] = pc[a];
+                        else w1[a] = pack_hi16(w1[a], pc[a]);
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < NPC; ++a) {
+                    unsigned* d = reinterpret_cast<unsigned*>(dst + (size_t)a * OPS + (o * 2 + pcomp) * PD + prow) + 2 * pclip;
+                    *reinterpret_cast<uint2*>(d) = make_uint2(w0[a], w1[a]);
+                }
+            }
+        }
+    };
+    // The significant piece products (piece indices a + b <= NPC - 1; NPC = 3: hi lo', mid mid', hi mid', lo hi', mid hi', hi hi';
+    // mid lo', lo mid', lo lo' are below 2^-23 |a||b|)
+    auto mac = [&](int u) {
+        const u4w* S = ops + (size_t)(u & 1) * NPC * OPS;
+#pragma unroll
+        for (int b = NPC - 1; b >= 0; --b) {
+            bf8w by[PWV], bu[PWV];
+#pragma unroll
+            for (int cb = 0; cb < PWV; ++cb) {
+                const u4w* Sb = S + (size_t)b * OPS + (6 + mh) * PD + 32 * cb + mr;
+                by[cb] = piece_bits(Sb[0], 0u);
+                bu[cb] = piece_bits(Sb[2 * PD], 0u);
+            }
+#pragma unroll
+            for (int a = NPC - 1 - b; a >= 0; --a) {
+                const u4w* Sre = S + (size_t)a * OPS + mh * PD + 32 * w + mr;
+                const u4w* Sim = S + (size_t)a * OPS + (mh ^ 1) * PD + 32 * w + mr;
+                const bf8w r1 = piece_bits(Sre[0], 0u), r2 = piece_bits(Sre[2 * PD], 0u), r3 = piece_bits(Sre[4 * PD], 0u);
+                const bf8w i1 = piece_bits(Sim[0], imask), i2 = piece_bits(Sim[2 * PD], imask), i3 = piece_bits(Sim[4 * PD], imask);
+#pragma unroll
+                for (int cb = 0; cb < PWV; ++cb) {
+                    Rre[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r1, by[cb], Rre[cb], 0, 0, 0);
+                    Rim[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(i1, by[cb], Rim[cb], 0, 0, 0);
+                    Qre[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r3, bu[cb], Qre[cb], 0, 0, 0);
+                    Qim[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(i3, bu[cb], Qim[cb], 0, 0, 0);
+                    Rre[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r2, bu[cb], Rre[cb], 0, 0, 0);
+                    Rim[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(i2, bu[cb], Rim[cb], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    // chunk tables: chunk c + 1 is built at the second unit of chunk c (the chunk below c is no longer read by then) and is
+    // first read fourteen units (barriers) later
+    build_tab(0);
+    __syncthreads();
+    prep(0);
+    __syncthreads();
+    for (int u = 0; u < NU; ++u) {
+        if (u + 1 < NU) prep(u + 1);              // independent of this unit's MFMAs: the compiler interleaves the two streams
+        mac(u);
+        if ((u & (WCH / GU - 1)) == 1) build_tab(u / (WCH / GU) + 1);
+        __syncthreads();
+    }
+
+    float* slab = P.slabs + (size_t)blockIdx.x * P.slab_floats;
+    constexpr int DD = PD * PD;
+#pragma unroll
+    for (int cb = 0; cb < PWV; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 * w + (r & 3) + 8 * (r >> 2) + 4 * mh;    // C/D layout of the 32x32 MFMA: column = lane & 31
+            const int o = row * PD + 32 * cb + mr;
+            slab[o] = Rre[cb][r];
+            slab[DD + o] = Rim[cb][r];
+            slab[2 * DD + o] = Qre[cb][r];
+            slab[3 * DD + o] = Qim[cb][r];
+        }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------------------------------
+template <typename K>
+static hipError_t wide_lds_attr(K kernel, size_t shm) {
+    if (shm <= 64 * 1024) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+}
+
+template <int PD>
+static hipError_t fwd_wide_t(const Dev& P, const float* audio, float* loss, bool save, hipStream_t s) {
+    const unsigned nb = (unsigned)((P.B + 1) / 2);
+    const size_t shm = WideGeom<PD>::FWD_LDS;
+    hipError_t e;
+    if (save) {
+        e = wide_lds_attr(k_fwd_wide<PD, true>, shm);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_fwd_wide<PD, true>), dim3(nb), dim3(4 * PD), shm, s, P, audio, loss);
+    } else {
+        e = wide_lds_attr(k_fwd_wide<PD, false>, shm);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_fwd_wide<PD, false>), dim3(nb), dim3(4 * PD), shm, s, P, audio, loss);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_fwd_wide(const Dev& P, const float* audio, float* loss, bool save, hipStream_t s) {
+    if (P.DP == 128) return fwd_wide_t<128>(P, audio, loss, save, s);
+    if (P.DP == 96) return fwd_wide_t<96>(P, audio, loss, save, s);
+    if (P.DP == 64) return fwd_wide_t<64>(P, audio, loss, save, s);
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_bwd_wide(const Dev& P, const float* audio, hipStream_t s) {
+    const unsigned nb = (unsigned)((P.B + 1) / 2);
+    if (P.DP == 128) hipLaunchKernelGGL(k_bwd_wide<128>, dim3(nb), dim3(512), 0, s, P, audio);
+    else if (P.DP == 96) hipLaunchKernelGGL(k_bwd_wide<96>, dim3(nb), dim3(384), 0, s, P, audio);
+    else if (P.DP == 64) hipLaunchKernelGGL(k_bwd_wide<64>, dim3(nb), dim3(256), 0, s, P, audio);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+template <int PD, int NPC>
+static hipError_t grad_wide_t(const Dev& P, const float* audio, hipStream_t s) {
+    const unsigned nb = (unsigned)((P.B + 1) / 2);
+    const size_t shm = (size_t)2 * NPC * 10 * PD * 16 + 2 * WCH * 2 * 16;
+    const hipError_t e = wide_lds_attr(k_grad_wide<PD, NPC>, shm);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_grad_wide<PD, NPC>), dim3(nb), dim3(2 * PD), shm, s, P, audio);
+    return hipGetLastError();
+}
+
+hipError_t launch_grad_wide(const Dev& P, const float* audio, int pieces, hipStream_t s) {
+    if (pieces == 3) {
+        if (P.DP == 128) return grad_wide_t<128, 3>(P, audio, s);
+        if (P.DP == 96) return grad_wide_t<96, 3>(P, audio, s);
+        if (P.DP == 64) return grad_wide_t<64, 3>(P, audio, s);
+    } else {
+        if (P.DP == 128) return grad_wide_t<128, 2>(P, audio, s);
+        if (P.DP == 96) return grad_wide_t<96, 2>(P, audio, s);
+        if (P.DP == 64) return grad_wide_t<64, 2>(P, audio, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace cmps

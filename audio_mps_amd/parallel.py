@@ -22,14 +22,17 @@ class DataParallel:
     time_collective = False       # bench.py sets it: HIP events around the all-reduce ("print the all-reduce us")
     collective_ms = None          # list of timed collectives (ms), created on first use
 
-    def __init__(self, backend: Optional[str] = None, device: Optional[torch.device] = None):
+    def __init__(self, backend: Optional[str] = None, device: Optional[torch.device] = None, force_group: bool = False):
+        """force_group: build the process group and run the collectives even when WORLD_SIZE is 1 (a one-rank RCCL
+        communicator: `bench.py --gpus 1 --spawn` uses it so that the N = 1 line crosses the same code as N > 1)."""
         self.rank = int(os.environ.get("RANK", "0"))
         self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.device = device
         self._own_group = False
         self.collective_ms = []
-        if self.world_size > 1:
+        self.collective = self.world_size > 1 or force_group      # take the collective branches
+        if self.collective:
             if backend is None:
                 backend = "nccl" if (device is not None and torch.device(device).type == "cuda") else "gloo"
             self.backend = backend
@@ -44,6 +47,10 @@ class DataParallel:
         else:
             self.backend = None
 
+    def _collective(self) -> bool:
+        # (objects built with __new__ in tests carry no `collective` attribute: world_size decides)
+        return getattr(self, "collective", self.world_size > 1)
+
     # -- sharding ---------------------------------------------------------------------------------
     def shard(self, global_batch: int) -> Tuple[int, int]:
         """(first clip, number of clips) of this rank; the remainder goes to the lowest ranks."""
@@ -57,7 +64,7 @@ class DataParallel:
     def allreduce_sums(self, flat: torch.Tensor, local_clips: int) -> Tuple[np.ndarray, int]:
         """Sum the per-rank gradient/loss sums and clip counts over all ranks.
         flat: [G] float32 tensor on this rank's device (or CPU for gloo).  Returns (host float64 [G], B_global)."""
-        if self.world_size == 1:
+        if not self._collective():
             return flat.detach().cpu().numpy().astype(np.float64), int(local_clips)
         # gloo has no device collectives on this build: its (rehearsal / CPU-test) path reduces on the host
         red_dev = flat.device if self.backend == "nccl" else torch.device("cpu")
@@ -86,7 +93,7 @@ class DataParallel:
 
     def gather_floats(self, value: float) -> np.ndarray:
         """One float from every rank -> array [world_size] (same on all ranks)."""
-        if self.world_size == 1:
+        if not self._collective():
             return np.array([float(value)])
         dev = self.device if self.backend == "nccl" else "cpu"
         mine = torch.tensor([float(value)], dtype=torch.float64, device=dev)
@@ -96,7 +103,7 @@ class DataParallel:
 
     def measured_world_size(self) -> int:
         """The number of ranks an actual all-reduce of ones adds up to, checked against dist.get_world_size()."""
-        if self.world_size == 1:
+        if not self._collective():
             return 1
         dev = self.device if self.backend == "nccl" else "cpu"
         one = torch.ones(1, dtype=torch.float32, device=dev)
@@ -107,14 +114,14 @@ class DataParallel:
         return n
 
     def barrier(self):
-        if self.world_size > 1:
+        if self._collective():
             if self.backend == "nccl" and self.device is not None:
                 dist.barrier(device_ids=[torch.device(self.device).index])
             else:
                 dist.barrier()
 
     def max_over_ranks(self, value: float) -> float:
-        if self.world_size == 1:
+        if not self._collective():
             return float(value)
         dev = self.device if self.backend == "nccl" else "cpu"
         t = torch.tensor([float(value)], dtype=torch.float64, device=dev)

@@ -62,11 +62,6 @@ class HipScan:
             raise _capi.CmpsError(code, f"cmps_create(D={D}) failed")
         self._h = h
         _capi.check(self._h, self._lib.cmps_set_variant(self._h, int(variant)))
-        if self.D > 32 and int(variant) == _capi.CMPS_VARIANT_AUTO:
-            import warnings
-            warnings.warn(f"bond dimension {self.D} > 32 with the AUTO variant runs the float32 block-per-clip kernels (exact "
-                          "float32, but ~25x slower than the MFMA pair kernels); pass variant=CMPS_VARIANT_PAIR (3) for the "
-                          "bf16-operand / fp32-accumulate path of BASELINE configs[4]", stacklevel=2)
         if rank1 is not None:
             self.set_rank1(rank1)
         self._ws = None

@@ -61,6 +61,9 @@ def parse_args(argv=None):
     p.add_argument("--spawn", action="store_true", help="go through the child-process launcher even at --gpus 1")
     p.add_argument("--launcher-selftest", action="store_true",
                    help="ranks only set up the process group (gloo on CPU) and do one all-reduce: tests the launcher")
+    p.add_argument("--force-collective", action="store_true",
+                   help="build the process group and run the all-reduce / barrier / gather collectives even at WORLD_SIZE 1 (a "
+                        "one-rank RCCL communicator); the launcher adds it for `--gpus 1 --spawn`")
     p.add_argument("--master-port", type=int, default=0)
     p.add_argument("--rehearse-on-one-gpu", action="store_true",
                    help="N > 1 ranks that all use cuda:0 and reduce over gloo on the host: exercises every line of the multi-rank "
@@ -81,6 +84,8 @@ def launch_children(args, argv) -> int:
     """Start N ranks as a child process tree, relay rank 0's JSON line, return the child's exit code."""
     port = args.master_port or _free_port()
     child_argv = [a for a in argv if a != "--spawn"]
+    if args.gpus == 1 and "--force-collective" not in child_argv:
+        child_argv.append("--force-collective")                  # N = 1 through the launcher crosses the RCCL code too
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + child_argv
     env = dict(os.environ)
@@ -258,7 +263,7 @@ def worker(ARGS):
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dp = DataParallel(backend="gloo" if ARGS.rehearse_on_one_gpu else None, device=dev)
+    dp = DataParallel(backend="gloo" if ARGS.rehearse_on_one_gpu else None, device=dev, force_group=ARGS.force_collective)
     dp.time_collective = True
 
     D, T, B = ARGS.bond_dim, ARGS.T, ARGS.batch_per_gpu
@@ -390,6 +395,7 @@ def worker(ARGS):
             "per_rank_ms_per_step": {"min": float(np.min(per_rank_ms)), "max": float(np.max(per_rank_ms))},
             "rccl_world_size": rccl_world,
             "allreduce_us": allreduce_us,
+            "collective_backend": dp.backend,                    # "nccl" (= RCCL), "gloo" (rehearsal) or None (N = 1 in process)
         }
         if ARGS.rehearse_on_one_gpu:
             out["rehearsal"] = "all ranks share cuda:0 and reduce over gloo on the host: NOT a scaling measurement"

@@ -41,21 +41,28 @@ enum {
                            * for something else since the previous call -- rebuild every cached table (see below) */
 };
 
-/* kernel variants (cmps_set_variant); AUTO picks the register-resident wave-per-clip kernel when the
- * bond dimension has one and the block-per-clip kernel otherwise. */
+/* kernel variants (cmps_set_variant); AUTO picks the register-resident wave-per-clip kernels for D <= 32 and the float32
+ * "wide" kernels above that: the reference's float32 / complex64 arithmetic (model.py:300-325) at every bond dimension.
+ * "float32" means: every mat-vec on the serial chains is an fp32 FMA chain; the products nothing waits for (the loss
+ * product H y of 17 <= D <= 32, the rank-1 gradient sums) run on the matrix cores with every operand split EXACTLY into three
+ * bf16 pieces and fp32 accumulation -- fp32-faithful (24 operand bits), not bit-identical to an fp32 FMA chain.  Only
+ * CMPS_VARIANT_BLOCK is plain fp32 FMA code throughout. */
 enum {
     CMPS_VARIANT_AUTO = 0,
     CMPS_VARIANT_BLOCK = 1, /* one workgroup per clip, any D <= 128 */
     CMPS_VARIANT_WAVE = 2,  /* wavefront-per-clip kernels, state and R in registers, D <= 32: the 16-row lane layout
                              * (cmps_wave16.hip) for D <= 16, the 32-row layout above that */
     CMPS_VARIANT_PAIR = 3,  /* 32 < D <= 128: one workgroup per pair of clips, matrices as bf16 MFMA fragments, fp32 accumulate */
-    CMPS_VARIANT_WAVE32 = 4 /* the 32-row wave layout for every D <= 32 (zero padding below 32; cross-check of the 16-row layout) */
+    CMPS_VARIANT_WAVE32 = 4, /* the 32-row wave layout for every D <= 32 (zero padding below 32; cross-check of the 16-row layout) */
+    CMPS_VARIANT_WIDE = 5   /* 32 < D <= 128 in float32 (what AUTO picks there): one workgroup per pair of clips, R / Q register
+                             * resident, float32 VALU mat-vecs; gradient GEMM with fp32-faithful split operands (CMPS_OPT_RANK1) */
 };
 
 /* options (cmps_set_option / cmps_get_option) */
 enum {
-    CMPS_OPT_RANK1 = 1 /* arithmetic of the rank-1 gradient updates in the wave-per-clip reverse scan (32-row layout;
-                        * the 16-row layout of D <= 16 always uses exact fp32 MFMAs) */
+    CMPS_OPT_RANK1 = 1 /* arithmetic of the rank-1 gradient sums: the wave-per-clip reverse scan of 17 <= D <= 32 (the 16-row layout
+                        * of D <= 16 always uses exact fp32 MFMAs) and the gradient GEMM of the wide kernels (32 < D <= 128:
+                        * BF16X2 = two pieces / three products, anything else = three pieces / six products) */
 };
 /* values of CMPS_OPT_RANK1.  All three accumulate in fp32; they differ in how the two factors of every product
  * dR += a b^dagger enter the matrix cores:

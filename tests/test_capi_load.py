@@ -34,6 +34,7 @@ def test_host_only_entry_points(hip_lib):
     assert hip_lib.cmps_get_variant(h) == _capi.CMPS_VARIANT_WAVE
     assert hip_lib.cmps_set_variant(h, _capi.CMPS_VARIANT_BLOCK) == _capi.CMPS_OK
     assert hip_lib.cmps_get_variant(h) == _capi.CMPS_VARIANT_BLOCK
+    assert hip_lib.cmps_set_variant(h, _capi.CMPS_VARIANT_WIDE) == _capi.CMPS_ERR_UNSUPPORTED_D     # 32 < D only
     assert hip_lib.cmps_set_variant(h, 7) == _capi.CMPS_ERR_BAD_ARG
     assert b"unknown variant" in hip_lib.cmps_last_error(h)
     # call order is enforced before anything touches the device
@@ -42,8 +43,10 @@ def test_host_only_entry_points(hip_lib):
     assert hip_lib.cmps_destroy(h) == _capi.CMPS_OK
     h64 = ctypes.c_void_p()
     assert hip_lib.cmps_create(64, ctypes.byref(h64)) == _capi.CMPS_OK
-    assert hip_lib.cmps_get_variant(h64) == _capi.CMPS_VARIANT_BLOCK
+    assert hip_lib.cmps_get_variant(h64) == _capi.CMPS_VARIANT_WIDE            # AUTO above 32: the float32 wide kernels
     assert hip_lib.cmps_set_variant(h64, _capi.CMPS_VARIANT_WAVE) == _capi.CMPS_ERR_UNSUPPORTED_D
+    assert hip_lib.cmps_set_variant(h64, _capi.CMPS_VARIANT_PAIR) == _capi.CMPS_OK
+    assert hip_lib.cmps_get_variant(h64) == _capi.CMPS_VARIANT_PAIR
     hip_lib.cmps_destroy(h64)
 
 

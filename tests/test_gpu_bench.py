@@ -1,0 +1,55 @@
+"""The N > 1 path of bench.py on the one-GPU box: every line of the multi-rank rank body -- process
+group, shard, all-reduce of the gradient sums, barrier + max-over-ranks timing, per-rank gather -- runs under the driver's
+`-m gpu` suite, so BASELINE configs[3] (8 x configs[2], sharding argument /root/reference/model.py:260, 267) is one
+command away from a tested state.  The launcher starts the ranks as child processes before this process's GPU use matters
+(bench.py never execs and never touches the GPU in the parent)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--bond-dim", "32", "--T", "600", "--batch-per-gpu", "16", "--no-cpu-baseline"]
+
+
+def _bench(args, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True,
+                          timeout=timeout)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, proc.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_two_rank_rehearsal_on_one_gpu():
+    """`bench.py --gpus 2 --rehearse-on-one-gpu`: two child ranks that share cuda:0 and all-reduce over gloo."""
+    rec = _bench(["--gpus", "2", "--rehearse-on-one-gpu", "--steps", "2", "--warmup", "1"] + SMALL)
+    assert rec["n_gpus"] == 2 and rec["rccl_world_size"] == 2 and rec["collective_backend"] == "gloo"
+    assert rec["steps"] == 2 and rec["warmup"] == 1 and rec["scaling"] == "weak"
+    pr = rec["per_rank_ms_per_step"]
+    assert 0.0 < pr["min"] <= pr["max"]
+    assert rec["value"] > 0 and rec["ms_per_step"] >= pr["max"] * 0.999          # max over ranks, barrier included
+    assert rec["config"]["parallelism"] == "dp2" and "global 32" in rec["config"]["workload"]
+    assert "rehearsal" in rec and rec["cpu_baseline"] is None
+    # whole-job aggregate: both ranks' samples over the max-over-ranks time
+    assert rec["value"] == pytest.approx(2 * 16 * 600 * 2 / (rec["ms_per_step"] * 2e-3), rel=1e-6)
+
+
+def test_one_rank_through_rccl_matches_in_process():
+    """`bench.py --gpus 1 --spawn`: one child rank with a real RCCL communicator (init with device_id, all-reduce of the
+    gradient buffer on the device, barrier(device_ids), all_gather) against the in-process N = 1 run of the same shape."""
+    shape = ["--bond-dim", "32", "--T", "4000", "--batch-per-gpu", "1024", "--no-cpu-baseline", "--steps", "10", "--warmup", "3"]
+    spawned = _bench(["--gpus", "1", "--spawn"] + shape)
+    inproc = _bench(["--gpus", "1"] + shape)
+    assert spawned["n_gpus"] == 1 and spawned["collective_backend"] == "nccl" and spawned["rccl_world_size"] == 1
+    assert spawned["allreduce_us"] is not None and 0.0 < spawned["allreduce_us"] < 5e4
+    assert inproc["collective_backend"] is None and inproc["allreduce_us"] is None
+    assert spawned["final_loss"] == pytest.approx(inproc["final_loss"], rel=1e-5)      # same parameters after the same steps
+    # the collective adds tens of microseconds to a ~3 ms step: the two rates agree (10 %: short runs on a shared clock domain)
+    assert spawned["value"] == pytest.approx(inproc["value"], rel=0.10), (spawned["value"], inproc["value"])
