@@ -44,12 +44,13 @@ def test_two_rank_rehearsal_on_one_gpu():
 def test_one_rank_through_rccl_matches_in_process():
     """`bench.py --gpus 1 --spawn`: one child rank with a real RCCL communicator (init with device_id, all-reduce of the
     gradient buffer on the device, barrier(device_ids), all_gather) against the in-process N = 1 run of the same shape."""
-    shape = ["--bond-dim", "32", "--T", "4000", "--batch-per-gpu", "1024", "--no-cpu-baseline", "--steps", "10", "--warmup", "3"]
+    # BASELINE configs[2] per GPU (the shape configs[3] runs on each of its 8 GPUs): an ~11 ms step, so that the one-rank
+    # collective (~0.1 - 0.4 ms with its host hand-over) stays inside the tolerance
+    shape = ["--no-cpu-baseline", "--steps", "6", "--warmup", "2"]
     spawned = _bench(["--gpus", "1", "--spawn"] + shape)
     inproc = _bench(["--gpus", "1"] + shape)
     assert spawned["n_gpus"] == 1 and spawned["collective_backend"] == "nccl" and spawned["rccl_world_size"] == 1
     assert spawned["allreduce_us"] is not None and 0.0 < spawned["allreduce_us"] < 5e4
     assert inproc["collective_backend"] is None and inproc["allreduce_us"] is None
     assert spawned["final_loss"] == pytest.approx(inproc["final_loss"], rel=1e-5)      # same parameters after the same steps
-    # the collective adds tens of microseconds to a ~3 ms step: the two rates agree (10 %: short runs on a shared clock domain)
-    assert spawned["value"] == pytest.approx(inproc["value"], rel=0.10), (spawned["value"], inproc["value"])
+    assert spawned["value"] == pytest.approx(inproc["value"], rel=0.10), (spawned["value"], inproc["value"], spawned["allreduce_us"])
