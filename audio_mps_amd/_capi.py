@@ -35,7 +35,8 @@ RANK1_NAMES = {0: "exact_f32", 1: "bf16x2", 2: "bf16x3"}
 # every symbol include/cmps.h declares
 SYMBOLS = (
     "cmps_version", "cmps_create", "cmps_destroy", "cmps_last_error", "cmps_set_variant",
-    "cmps_get_variant", "cmps_set_option", "cmps_get_option", "cmps_workspace_bytes", "cmps_set_params", "cmps_psi_loss_fwd",
+    "cmps_get_variant", "cmps_set_option", "cmps_get_option", "cmps_workspace_bytes", "cmps_set_params", "cmps_set_params_dev",
+    "cmps_apply_step_scratch_bytes", "cmps_psi_apply_step", "cmps_psi_loss_fwd",
     "cmps_psi_loss_bwd", "cmps_psi_update_ancilla", "cmps_psi_states", "cmps_psi_sample",
     "cmps_legacy_set_params", "cmps_legacy_loss_fwd", "cmps_legacy_loss_bwd",
     "cmps_rho_workspace_bytes", "cmps_rho_set_state", "cmps_rho_loss_fwd", "cmps_rho_loss_bwd",
@@ -73,6 +74,13 @@ def _declare(lib):
     lib.cmps_set_params.argtypes = [vp, vp, vp, vp, vp, vp, c_float, c_double, c_double, c_int, c_int,
                                     c_int, vp, c_size_t, vp]
     lib.cmps_set_params.restype = c_int
+    lib.cmps_set_params_dev.argtypes = [vp, vp, c_double, c_double, c_int, c_int, c_int, vp, c_size_t, vp]
+    lib.cmps_set_params_dev.restype = c_int
+    lib.cmps_apply_step_scratch_bytes.argtypes = [c_int]
+    lib.cmps_apply_step_scratch_bytes.restype = c_size_t
+    lib.cmps_psi_apply_step.argtypes = [vp, vp, vp, vp, vp, c_double, c_double, c_double, c_double, c_double, c_double, c_double,
+                                        c_double, c_double, c_int, vp, vp, vp, vp]
+    lib.cmps_psi_apply_step.restype = c_int
     lib.cmps_psi_loss_fwd.argtypes = [vp, vp, c_int, c_int, vp, c_int, vp]
     lib.cmps_psi_loss_fwd.restype = c_int
     lib.cmps_psi_loss_bwd.argtypes = [vp, vp, c_int, c_int, vp, vp]

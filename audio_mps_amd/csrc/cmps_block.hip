@@ -46,11 +46,12 @@ __global__ __launch_bounds__(NT) void k_fwd_block(Dev P, const float* __restrict
     float2 u = act ? P.psi0[t] : make_float2(0.f, 0.f);
     float loss = 0.f;
     float xprev = xrow[0];
+    const float A = dev_A(P);
     for (int k = 0; k < N; ++k) {
         const float xcur = xrow[k + 1];
         const float x = xcur - xprev;              // model.py:263
         xprev = xcur;
-        const float s = x / P.A;                   // model.py:303
+        const float s = x / A;                     // model.py:303
         if (act) su[t] = u;
         __syncthreads();
         float2 v = make_float2(0.f, 0.f), q = make_float2(0.f, 0.f);
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(NT) void k_fwd_block(Dev P, const float* __restrict
         const float pn = act ? (y.x * y.x + y.y * y.y) : 0.f;
         const float e = 2.0f * block_sum<NT>(pe, red);      // model.py:325
         const float n = block_sum<NT>(pn, red);
-        const float z = (e * x) / P.A;                      // model.py:294
+        const float z = (e * x) / A;                        // model.py:294
         loss += -logf(1.0f + z);                            // model.py:279
         if (save && act) P.stash[((size_t)b * N + k) * DP + t] = y;
         const float inv = 1.0f / sqrtf(fmaxf(n, 1e-12f));   // model.py:332
@@ -110,6 +111,7 @@ __global__ __launch_bounds__(NT) void k_bwd_block(Dev P, const float* __restrict
     for (int m = 0; m < EPT; ++m) Rb[m] = Qb[m] = zero;
     float facc = 0.f, Abar = 0.f;
     float2 g = zero;
+    const float A = dev_A(P);
 
     // state of step N-1
     float2 y = act ? st[(size_t)(N - 1) * DP + t] : zero;
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(NT) void k_bwd_block(Dev P, const float* __restrict
 
     for (int k = N - 1; k >= 0; --k) {
         const float x = xrow[k + 1] - xrow[k];
-        const float s = x / P.A;
+        const float s = x / A;
         const float2 rho = act ? P.rho[(size_t)k * DP + t] : make_float2(1.f, 0.f);
         if (act) facc += P.dtk[k] * (g.y * unext.x - g.x * unext.y);
         const float2 yhb = cmul_conj_a(rho, g);
@@ -142,10 +144,10 @@ __global__ __launch_bounds__(NT) void k_bwd_block(Dev P, const float* __restrict
         }
         const float e = 2.0f * block_sum<NT>(act ? (y.x * r.x + y.y * r.y) : 0.f, red);
         const float ex = e * x;
-        const float z = ex / P.A;
+        const float z = ex / A;
         const float zbar = -1.0f / (1.0f + z);
-        const float ebar = zbar * x / P.A;
-        Abar += zbar * (-ex / (P.A * P.A));
+        const float ebar = zbar * x / A;
+        Abar += zbar * (-ex / (A * A));
         ybar.x += 2.0f * ebar * (r.x + a.x);
         ybar.y += 2.0f * ebar * (r.y + a.y);
         if (act) syb[t] = ybar;
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(NT) void k_bwd_block(Dev P, const float* __restrict
             }
         }
         const float sbar = block_sum<NT>(act ? (d.x * uk.x + d.y * uk.y) : 0.f, red);
-        Abar += sbar * (-x / (P.A * P.A));
+        Abar += sbar * (-x / (A * A));
         const float te = 2.0f * ebar;
 #pragma unroll
         for (int m = 0; m < EPT; ++m) {
@@ -283,7 +285,7 @@ __global__ void k_finalize(Dev P, const float* __restrict__ sums, const float* _
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) p += __shfl_xor(p, off, 64);
-        if (threadIdx.x == 0) grad_out[2 * D * D + 3 * D] = (float)((double)sums[4 * DD + 3 * DP] + p / (double)P.A);
+        if (threadIdx.x == 0) grad_out[2 * D * D + 3 * D] = (float)((double)sums[4 * DD + 3 * DP] + p / (double)dev_A(P));
     }
     if (blockIdx.x == 0 && threadIdx.x < 64) {      // sum_b loss_b: one wave, strided partials then a fixed-order tree
         double ls = 0.0;
@@ -305,7 +307,7 @@ __global__ void k_update_ancilla(Dev P, const float* __restrict__ psi_in,
     float2* sv = sh + D;
     const int b = blockIdx.x, i = threadIdx.x;
     const bool act = i < D;
-    const float s = signal[b] / P.A;                                   // :303
+    const float s = signal[b] / dev_A(P);                                   // :303
     float2 psi = make_float2(0.f, 0.f), ph = make_float2(1.f, 0.f), u = psi;
     if (act) {
         psi = make_float2(psi_in[((size_t)b * D + i) * 2], psi_in[((size_t)b * D + i) * 2 + 1]);
@@ -410,12 +412,12 @@ __global__ __launch_bounds__(NT) void k_sample_block(Dev P, const float* __restr
         const float e = 2.0f * block_sum<NT>(act ? (u.x * v.x + u.y * v.y) : 0.f, red);   // model.py:319-325
         const float inc = e * P.dt + noise[(size_t)b * length + k];                        // :286
         samp += inc;                                                                       // :287
-        const float s = inc / P.A;                                                         // :288, :303
+        const float s = inc / dev_A(P);                                                         // :288, :303
         const float2 y = make_float2(u.x + q.x + s * v.x, u.y + q.y + s * v.y);
         const float n = block_sum<NT>(act ? (y.x * y.x + y.y * y.y) : 0.f, red);
         const float inv = 1.0f / sqrtf(fmaxf(n, 1e-12f));                                  // :289
         if (act) u = cmul(P.rho[(size_t)k * DP + t], cscale(inv, y));
-        if (t == 0) out[(size_t)b * length + k] = P.A * samp;                              // :251
+        if (t == 0) out[(size_t)b * length + k] = dev_A(P) * samp;                              // :251
         __syncthreads();
     }
 }

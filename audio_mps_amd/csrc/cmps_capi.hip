@@ -123,10 +123,10 @@ size_t cmps_workspace_bytes(int D, int B, int T, int flags) {
     return make_layout(D, B, T, flags & ~CMPS_WS_FRESH).total;
 }
 
-int cmps_set_params(cmps_handle_t h, const float* R_re_dev, const float* R_im_dev,
-                    const float* freqs_dev, const float* psi0_re_dev, const float* psi0_im_dev,
-                    float A, double sigma, double delta_t, int T, int B_max, int flags,
-                    void* workspace_dev, size_t workspace_bytes, void* stream) {
+static int set_params_impl(cmps_handle_t h, const float* R_re_dev, const float* R_im_dev,
+                           const float* freqs_dev, const float* psi0_re_dev, const float* psi0_im_dev,
+                           float A, const float* A_dev, double sigma, double delta_t, int T, int B_max, int flags,
+                           void* workspace_dev, size_t workspace_bytes, void* stream) {
     if (!h) return CMPS_ERR_BAD_ARG;
     if (!R_re_dev || !R_im_dev || !freqs_dev || !psi0_re_dev || !psi0_im_dev)
         return fail(h, CMPS_ERR_BAD_ARG, "cmps_set_params: null parameter pointer");
@@ -162,6 +162,7 @@ int cmps_set_params(cmps_handle_t h, const float* R_re_dev, const float* R_im_de
     P.sums = (flags & CMPS_WS_TRAIN) ? reinterpret_cast<float*>(ws + L.off_sums) : nullptr;
     P.slab_floats = L.slab_floats;
     P.A = A;
+    P.Adev = A_dev;
     // model.py:312: `- self.delta_t * self.sigma**2` is a Python float (double), cast to complex64,
     // multiplied in, then divided by 2. (exact halving)
     P.c_half = (float)(-delta_t * sigma * sigma) / 2.0f;
@@ -182,6 +183,42 @@ int cmps_set_params(cmps_handle_t h, const float* R_re_dev, const float* R_im_de
     h->fwd_saved = false;
     h->rho_set = false;               // the columns of rho_0 are handed over again after every parameter change
     h->rho_saved = false;
+    return CMPS_OK;
+}
+
+int cmps_set_params(cmps_handle_t h, const float* R_re_dev, const float* R_im_dev,
+                    const float* freqs_dev, const float* psi0_re_dev, const float* psi0_im_dev,
+                    float A, double sigma, double delta_t, int T, int B_max, int flags,
+                    void* workspace_dev, size_t workspace_bytes, void* stream) {
+    return set_params_impl(h, R_re_dev, R_im_dev, freqs_dev, psi0_re_dev, psi0_im_dev, A, nullptr, sigma, delta_t, T, B_max, flags,
+                           workspace_dev, workspace_bytes, stream);
+}
+
+int cmps_set_params_dev(cmps_handle_t h, const float* params_dev, double sigma, double delta_t, int T, int B_max, int flags,
+                        void* workspace_dev, size_t workspace_bytes, void* stream) {
+    if (!h) return CMPS_ERR_BAD_ARG;
+    if (!params_dev) return fail(h, CMPS_ERR_BAD_ARG, "cmps_set_params_dev: null parameter buffer");
+    const size_t DD = (size_t)h->D * h->D, D = (size_t)h->D;
+    return set_params_impl(h, params_dev, params_dev + DD, params_dev + 2 * DD, params_dev + 2 * DD + D, params_dev + 2 * DD + 2 * D,
+                           0.f, params_dev + 2 * DD + 3 * D, sigma, delta_t, T, B_max, flags, workspace_dev, workspace_bytes, stream);
+}
+
+size_t cmps_apply_step_scratch_bytes(int D) { return (D < 1 || D > 128) ? 0 : apply_step_scratch_bytes(D); }
+
+int cmps_psi_apply_step(cmps_handle_t h, float* vars_dev, float* adam_m_dev, float* adam_v_dev, const float* grad_sums_dev,
+                        double global_batch, double lr_t, double beta1, double beta2, double epsilon, double h_reg, double r_reg,
+                        double c_r, double c_h, int with_reg, float* params_dev, float* losses_dev, void* scratch_dev,
+                        void* stream) {
+    if (!h) return CMPS_ERR_BAD_ARG;
+    if (!vars_dev || !params_dev) return fail(h, CMPS_ERR_BAD_ARG, "cmps_psi_apply_step: null variable / parameter buffer");
+    const bool apply = grad_sums_dev != nullptr;
+    if (apply && (!adam_m_dev || !adam_v_dev || !losses_dev || !scratch_dev || !(global_batch > 0.0)))
+        return fail(h, CMPS_ERR_BAD_ARG, "cmps_psi_apply_step: an update needs the Adam slots, losses_dev, scratch_dev and a positive batch");
+    if (((uintptr_t)scratch_dev & 7) != 0) return fail(h, CMPS_ERR_BAD_ARG, "cmps_psi_apply_step: scratch_dev must be 8-byte aligned");
+    const hipError_t e = launch_apply_step(h->D, apply, apply ? 1.0 / global_batch : 0.0, lr_t, beta1, beta2, epsilon, h_reg, r_reg, c_r,
+                                           c_h, with_reg != 0, vars_dev, adam_m_dev, adam_v_dev, grad_sums_dev, params_dev, losses_dev,
+                                           static_cast<double*>(scratch_dev), static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail_hip(h, e, "cmps_psi_apply_step");
     return CMPS_OK;
 }
 

@@ -102,6 +102,7 @@ struct Dev {
     float* sums;         // [slab]
     size_t slab_floats;
     float A;
+    const float* Adev;   // non-null: A lives in device memory (cmps_set_params_dev: device-resident optimiser step) and `A` is unset
     float dt;            // (float)delta_t (model.py:16; also the python-float factor of model.py:286)
     float c_half;        // (float)(-delta_t * sigma^2) / 2   (model.py:312)
     int abar_fix;        // 1: the slabs' Abar holds -(sum_k Re(u^dagger (Q + s R^dagger) ybar)) / A (k_bwd_wave's merged mat-vec);
@@ -203,6 +204,14 @@ hipError_t launch_bwd_legacy(const Dev& P, const float* audio, hipStream_t s);
 hipError_t launch_finalize_legacy(const Dev& P, const float* loss, float* grad_out, hipStream_t s);
 hipError_t launch_sample_wave(const Dev& P, const float* noise, int n, int length, float* out, hipStream_t s);
 hipError_t launch_sample_block(const Dev& P, const float* noise, int n, int length, float* out, hipStream_t s);
+
+size_t apply_step_scratch_bytes(int D);
+hipError_t launch_apply_step(int D, bool apply, double inv_batch, double lr_t, double beta1, double beta2, double eps, double h_reg,
+                             double r_reg, double c_r, double c_h, bool with_reg, float* vars, float* am, float* av,
+                             const float* grad_sums, float* params_out, float* losses_out, double* scratch, hipStream_t s);
+
+// model.A (model.py:19) as the kernels see it: a launch argument, or -- device-resident training -- a word of device memory
+__device__ __forceinline__ float dev_A(const Dev& P) { return P.Adev ? *P.Adev : P.A; }
 
 // ---- small complex helpers (device) ----
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {

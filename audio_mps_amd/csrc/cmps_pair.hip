@@ -561,7 +561,7 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
     const bool two = b1 != b0;
     const float* xr0 = audio + (size_t)b0 * T;
     const float* xr1 = audio + (size_t)b1 * T;
-    const float A = P.A;
+    const float A = dev_A(P);
     const int tid = threadIdx.x;
     // both kinds run the same number of iterations (one barrier each): batch bt of the loss waves multiplies batch bt - 1 and
     // finishes batch bt - 2
@@ -920,7 +920,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
     // lane 16 above), lanes of row groups 4..7 store row ia - 15 (from the lane 16 below) and their own row ia + 1
     const int goff1 = rg >= 4 ? -15 : 0, goff2 = rg >= 4 ? 1 : 16;
     constexpr size_t GOP_STRIDE = (size_t)4 * PD, GBLK_STRIDE = (size_t)20 * PD;      // per operand / per block, in pieces
-    const float A = P.A;
+    const float A = dev_A(P);
     const float sgn = odd ? 1.f : -1.f;                                // (rho x)_own = rho_re x_own + sgn rho_im x_partner
 
     // every wave builds its own copy of the chunk's scalar rows (no cross-wave hand-over): lane <-> step

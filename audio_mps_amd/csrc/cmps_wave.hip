@@ -92,7 +92,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
     const float4* sty4 = reinterpret_cast<const float4*>(P.hst + (size_t)b * N * 128);
     const float* xrow = audio + (size_t)b * T;
     const float* sc = P.scal + scal_off(b, NC, 0);
-    const float A = P.A;
+    const float A = dev_A(P);
 
     float facc = 0.f;   // per lane: sum_k dtk * g_osig * u_own   (the two halves are added at the end)
     float accS = 0.f;   // per lane: sum_k (M_k ybar_k)_own u_own = sum_k Re(u^dagger Q ybar) + s_k Re(u^dagger R^dagger ybar); the Q part
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_sample_wave(Dev P, const floa
     const float4* rho4 = reinterpret_cast<const float4*>(P.rho);
     const float* nrow = noise + (size_t)b * length;
     float* orow = out + (size_t)b * length;
-    const float A = P.A, dt = P.dt;
+    const float A = dev_A(P), dt = P.dt;
     const float2 p0 = P.psi0[i];
     float u = hb ? p0.y : p0.x;
     float samp = 0.f;                                    // model.py:244 batch_zeros

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(128, 1) void k_fwd_wave16(Dev P, const float* __res
     const int b = blockIdx.x;
     const int N = P.N, T = P.T, NC2 = (N + CH16 - 1) / CH16, NC = (N + CH - 1) / CH;
     const float* xrow = audio + (size_t)b * T;
-    const float A = P.A;
+    const float A = dev_A(P);
     float* sc = SAVE ? P.scal + scal_off(b, NC, 0) : nullptr;
     const unsigned aRing = lds_addr(&ring[0][0]);
     const unsigned aProd = lds_addr(&flags[0]), aCons = lds_addr(&flags[1]);
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(128, 1) void k_bwd_wave16(Dev P, const float* __res
     const int kt = N - 1, otop = kt >> 3;
     const float* xrow = audio + (size_t)b * T;
     const float* sc = P.scal + scal_off(b, NC, 0);
-    const float A = P.A;
+    const float A = dev_A(P);
     const unsigned aRing = lds_addr(&ring[0]);
     const unsigned aProd = lds_addr(&flags[0]), aCons = lds_addr(&flags[1]);
     float* slab = P.slabs + (size_t)b * P.slab_floats;

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(128 * WAVES, 1) void k_fwd_wave2(Dev P, const float
     if (b >= P.B) return;      // both waves of the clip leave together
     const int N = P.N, T = P.T, NC2 = (N + CH2 - 1) / CH2, NC = (N + CH - 1) / CH;
     const float* xrow = audio + (size_t)b * T;
-    const float A = P.A;
+    const float A = dev_A(P);
     float* sc = SAVE ? P.scal + scal_off(b, NC, 0) : nullptr;
     const unsigned aRing = lds_addr(&ring[w][0][0]);
     constexpr int RROWB = RLD * 4;                                          // bytes per ring row

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(4 * PD) void k_fwd_wide(Dev P, const float* __restr
     const bool two = b1 != b0;
     const float* xr0 = audio + (size_t)b0 * T;
     const float* xr1 = audio + (size_t)b1 * T;
-    const float A = P.A;
+    const float A = dev_A(P);
 
     // ---- matrices: rows 16 w + i (a) and 16 w + 8 + i (b), columns q KC .. ----
     v2f MR[2][KC], MQ[2][KC];
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(4 * PD) void k_bwd_wide(Dev P, const float* __restr
     const float* xr1 = audio + (size_t)b1 * T;
     const float* sc0 = P.scal + ((size_t)b0 * NC) * 128;
     const float* sc1 = P.scal + ((size_t)b1 * NC) * 128;
-    const float A = P.A;
+    const float A = dev_A(P);
     const float sgn = im_lane ? 1.f : -1.f;                       // (rho x)_own = rho_re x_own + sgn rho_im x_partner
 
     v2f MD[2][KC], MQ[2][KC];                                     // R^dagger and Q (Hermitian)
@@ -568,7 +568,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_grad_wide(Dev P, const float* __r
     const int N = P.N, T = P.T, NC = (N + WCH - 1) / WCH, NU = (N + GU - 1) / GU;
     const int b0 = 2 * blockIdx.x, b1 = (b0 + 1 < P.B) ? b0 + 1 : b0;
     const bool two = b1 != b0;
-    const float A = P.A;
+    const float A = dev_A(P);
     // ---- prep role: this thread = positions `tid` and `tid + 2 PD` of a stash vector (same lane, wave + PD / 32) ----
     const int pq = lane >> 3, pi = lane & 7;
     const int pcomp = (pq >> 1) & 1, pclip = pq & 1;

@@ -23,6 +23,26 @@ def damped_sine(batch: int, input_length: int, delta_t: float, seed: int = 0) ->
     return wave.astype(np.float32)
 
 
+INPUT_KINDS = ("damped_sine", "damped_sine_noise", "bandlimited")
+
+
+def synthetic_audio(kind: str, batch: int, input_length: int, delta_t: float, seed: int = 0) -> np.ndarray:
+    """The synthetic inputs of SURVEY.md 8(d), float32 [batch, input_length]:
+       damped_sine        the reference's own generator (data.py:8-22), nothing added;
+       damped_sine_noise  the same plus 0.02 N(0, 1) white noise (every step carries signal, also before the onset);
+       bandlimited        x = 0.1 cumsum(N(0, 1)) / sqrt(T), clipped to [-1, 1] (a random walk: no silent stretch, no periodicity)."""
+    if kind == "damped_sine":
+        return damped_sine(batch, input_length, delta_t, seed=seed)
+    rng = np.random.default_rng(seed + 12345)
+    if kind == "damped_sine_noise":
+        x = damped_sine(batch, input_length, delta_t, seed=seed)
+        return (x + 0.02 * rng.standard_normal(x.shape)).astype(np.float32)
+    if kind == "bandlimited":
+        steps = rng.standard_normal((batch, input_length))
+        return np.clip(0.1 * np.cumsum(steps, axis=1) / np.sqrt(input_length), -1.0, 1.0).astype(np.float32)
+    raise ValueError(f"unknown synthetic input {kind!r}: one of {INPUT_KINDS}")
+
+
 def get_audio(datadir, dataset, hps, sample_duration: int = 2 ** 16, seed: int = 0) -> np.ndarray:
     """``get_audio(datadir, dataset, hps)`` (data.py:6); ``sample_duration`` is the reference's global
     FLAGS.sample_duration (train.py:27, data.py:10)."""

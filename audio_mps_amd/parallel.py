@@ -87,8 +87,33 @@ class DataParallel:
             host = buf.detach().cpu().numpy().astype(np.float64)
         return host[:-1], int(round(host[-1]))
 
+    def allreduce_device(self, flat: torch.Tensor) -> torch.Tensor:
+        """Sum `flat` over all ranks IN PLACE on the device (the device-resident optimiser step consumes it there); the global
+        clip count is known without communication (every rank knows the global batch and its shard).  RCCL reduces the device
+        buffer directly; the gloo rehearsal goes through the host."""
+        if not self._collective():
+            return flat
+        if self.backend == "nccl":
+            if self.time_collective:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+                e1.record()
+                self._pending_events = getattr(self, "_pending_events", []) + [(e0, e1)]
+            else:
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        else:
+            host = flat.detach().cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            flat.copy_(host)
+        return flat
+
     def collective_us(self) -> Optional[float]:
         """Mean HIP-event time of the timed all-reduces in microseconds (None when nothing was timed)."""
+        for e0, e1 in getattr(self, "_pending_events", []):      # device-side all-reduces: their events are read here, after the run
+            e1.synchronize()
+            self.collective_ms.append(e0.elapsed_time(e1))
+        self._pending_events = []
         return 1e3 * float(np.mean(self.collective_ms)) if self.collective_ms else None
 
     def gather_floats(self, value: float) -> np.ndarray:

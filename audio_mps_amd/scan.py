@@ -73,6 +73,7 @@ class HipScan:
         self._audio = None
         self._loss = None
         self._grad = torch.empty(grad_size(D), dtype=torch.float32, device=self.device)
+        self.timing = None            # a list: forward() / backward() then append HIP-event pairs around their launches (bench.py)
 
     # ------------------------------------------------------------------
     def __del__(self):
@@ -147,6 +148,33 @@ class HipScan:
             flags, ws_ptr, ws_bytes, self._stream()))
         self._B, self._T, self._train = B, T, train
 
+    def set_params_dev(self, params: torch.Tensor, sigma: float, delta_t: float, B: int, T: int, train: bool = True):
+        """cmps_set_params_dev: the effective parameters (A included) are read from the device buffer `params`
+        [2 D^2 + 3 D + 1] that cmps_psi_apply_step wrote -- no host copy, no synchronisation."""
+        if not (params.is_cuda and params.dtype == torch.float32 and params.numel() == 2 * self.D * self.D + 3 * self.D + 1):
+            raise ValueError("params must be a float32 CUDA tensor of 2 D^2 + 3 D + 1 elements")
+        ws_ptr, ws_bytes = self._ensure_ws(B, T, train)
+        flags = _capi.CMPS_WS_TRAIN if train else _capi.CMPS_WS_FWD_ONLY
+        if getattr(self, "_ws_fresh", False):
+            flags |= _capi.CMPS_WS_FRESH
+            self._ws_fresh = False
+        _capi.check(self._h, self._lib.cmps_set_params_dev(self._h, params.data_ptr(), float(sigma), float(delta_t), int(T), int(B),
+                                                           flags, ws_ptr, ws_bytes, self._stream()))
+        self._B, self._T, self._train = B, T, train
+
+    def apply_step(self, vars_: torch.Tensor, m: torch.Tensor, v: torch.Tensor, grad_sums: Optional[torch.Tensor], global_batch: int,
+                   lr_t: float, beta1: float, beta2: float, eps: float, h_reg: float, r_reg: float, c_r: float, c_h: float,
+                   with_reg: bool, params: torch.Tensor, losses: torch.Tensor):
+        """cmps_psi_apply_step: chain rule + regularisers + Adam + next effective parameters, on the device (grad_sums None: only
+        the effective parameters of `vars_`)."""
+        if getattr(self, "_opt_scratch", None) is None:
+            n = int(self._lib.cmps_apply_step_scratch_bytes(self.D))
+            self._opt_scratch = torch.empty((n + 7) // 8, dtype=torch.float64, device=self.device)
+        _capi.check(self._h, self._lib.cmps_psi_apply_step(
+            self._h, vars_.data_ptr(), m.data_ptr(), v.data_ptr(), grad_sums.data_ptr() if grad_sums is not None else None,
+            float(max(global_batch, 1)), float(lr_t), float(beta1), float(beta2), float(eps), float(h_reg), float(r_reg), float(c_r),
+            float(c_h), 1 if with_reg else 0, params.data_ptr(), losses.data_ptr(), self._opt_scratch.data_ptr(), self._stream()))
+
     def _check_audio(self, audio: torch.Tensor):
         if not (isinstance(audio, torch.Tensor) and audio.is_cuda and audio.dtype == torch.float32
                 and audio.dim() == 2 and audio.is_contiguous()):
@@ -161,10 +189,34 @@ class HipScan:
         B, T = self._check_audio(audio)
         if self._loss is None or self._loss.numel() != B:
             self._loss = torch.empty(B, dtype=torch.float32, device=self.device)
+        ev = self._event_pair()
         _capi.check(self._h, self._lib.cmps_psi_loss_fwd(
             self._h, audio.data_ptr(), B, T, self._loss.data_ptr(), 1 if save_for_bwd else 0, self._stream()))
+        self._event_close("fwd", ev)
         self._audio = audio
         return self._loss
+
+    # HIP events on the stream the kernels are launched on (torch's current stream is the one handed to the C ABI); they are read
+    # only after the caller has synchronised (timing_ms), so recording them never stalls the host
+    def _event_pair(self):
+        if self.timing is None:
+            return None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream(self.device))
+        return e0, e1
+
+    def _event_close(self, what, ev):
+        if ev is not None:
+            ev[1].record(torch.cuda.current_stream(self.device))
+            self.timing.append((what, ev[0], ev[1]))
+
+    def timing_ms(self):
+        """{'fwd': [ms ...], 'bwd': [ms ...]} of the launches recorded since `timing` was set to a list (synchronises)."""
+        torch.cuda.synchronize(self.device)
+        out = {"fwd": [], "bwd": []}
+        for what, e0, e1 in self.timing or []:
+            out[what].append(e0.elapsed_time(e1))
+        return out
 
     def backward(self) -> torch.Tensor:
         """Flat gradient sums [2D^2+3D+2] (device tensor): cmps_psi_loss_bwd after forward(save_for_bwd=True)."""
@@ -172,8 +224,10 @@ class HipScan:
         if audio is None:
             raise RuntimeError("backward() needs forward(save_for_bwd=True) first")
         B, T = audio.shape
+        ev = self._event_pair()
         _capi.check(self._h, self._lib.cmps_psi_loss_bwd(
             self._h, audio.data_ptr(), B, T, self._grad.data_ptr(), self._stream()))
+        self._event_close("bwd", ev)
         return self._grad
 
     def loss_and_grad_sums(self, audio: torch.Tensor):

@@ -58,25 +58,53 @@ class AdamOptimizer:
         self.v = {k[2:]: np.asarray(v) for k, v in sd.items() if k.startswith("v/")}
 
 
-class Trainer:
-    """One optimiser step = upload parameters, forward scan, reverse scan, (all-reduce), chain rule, Adam."""
+VAR_ORDER = ("A", "Rx", "Ry", "freqs", "psi_x", "psi_y")      # layout of the device-resident variable / Adam-slot buffers (include/cmps.h)
 
-    def __init__(self, model: PsiCMPS, hparams: HParams, dp: Optional[DataParallel] = None):
+
+class Trainer:
+    """One optimiser step = parameter tables, forward scan, reverse scan, (all-reduce), chain rule, Adam.
+
+    ``device_step=False``: the gradient sums come to the host, chain rule (model.chain_rule) and Adam (AdamOptimizer) run in
+    numpy, the parameters are uploaded again -- the tested reference implementation of the optimiser half.
+    ``device_step=True`` (PsiCMPS on the HIP backend): variables, Adam slots and effective parameters live on the GPU and
+    cmps_psi_apply_step does the optimiser half there; a step issues no device -> host copy.  ``step`` then returns the
+    losses as a 2-element device tensor under "losses_dev" unless ``sync=True``; ``sync_to_host()`` brings variables and
+    Adam state back (checkpoints, sampling, inspection)."""
+
+    HISTORY = 4096                # step records kept (a long run must not grow without bound)
+
+    def __init__(self, model: PsiCMPS, hparams: HParams, dp: Optional[DataParallel] = None, device_step: bool = False):
+        from collections import deque
         self.model = model
         self.hparams = hparams
         self.dp = dp if dp is not None else DataParallel()
         self.opt = AdamOptimizer(hparams.learning_rate)
         self.global_step = 0
-        self.history = []             # the dict of every step (the scalar summaries of train.py:62-66)
+        self.history = deque(maxlen=self.HISTORY)   # the dict of every step (the scalar summaries of train.py:62-66)
+        self.device_step = bool(device_step)
+        self._dev = None
+        if self.device_step and not isinstance(model, PsiCMPS):
+            raise ValueError("device_step: the device-resident optimiser step exists for PsiCMPS (the hot path) only")
 
-    def step(self, data=None) -> dict:
-        """``data``: this rank's shard [B_local, T] (or None to use model.data_iterator)."""
-        flat, b_local = self.model.grad_sums(data)
+    # -- host reference path ----------------------------------------------------------------------
+    def step(self, data=None, sync: bool = True, global_batch: Optional[int] = None) -> dict:
+        """``data``: this rank's shard [B_local, T] (or None to use model.data_iterator).  An empty shard (a short final batch
+        with fewer clips than ranks) skips the scan and contributes zeros to the all-reduce."""
+        if self.device_step:
+            return self._step_device(data, sync, global_batch)
+        D = self.model.bond_d
+        if data is not None and not callable(data) and len(data) == 0:
+            import torch
+            nflat = len(self.model._last) if getattr(self.model, "_last", None) is not None else None
+            dev = getattr(self.model._get_backend(), "device", None)
+            flat = torch.zeros(nflat or (2 * D * D + 3 * D + 2), dtype=torch.float32, device=dev if dev is not None else "cpu")
+            b_local = 0
+        else:
+            flat, b_local = self.model.grad_sums(data)
         host, b_global = self.dp.allreduce_sums(flat, b_local)
         total, grads = self.model.chain_rule(host, b_global, with_reg=True)       # train.py:55-60
         # sum_b loss_b sits at the end of the pure-state layout (2 D^2 + 3 D + 2 floats); RhoCMPS appends the column
         # cotangents behind it (include/cmps.h: cmps_rho_loss_bwd)
-        D = self.model.bond_d
         model_loss = host[2 * D * D + 3 * D + 1] / b_global
         self.opt.apply_gradients(self.model.variables, grads)                     # train.py:89
         self.global_step += 1
@@ -85,8 +113,76 @@ class Trainer:
         self.history.append(out)
         return out
 
+    # -- device-resident path ---------------------------------------------------------------------
+    def _device_state(self):
+        if self._dev is None:
+            import torch
+            be = self.model._get_backend()
+            D = self.model.bond_d
+            V = 2 * D * D + 3 * D + 1
+            host = np.concatenate([np.asarray(self.model.variables[k], dtype=np.float32).ravel() for k in VAR_ORDER])
+            st = {"vars": torch.from_numpy(host).to(be.device)}
+            for slot, src in (("m", self.opt.m), ("v", self.opt.v)):
+                h = np.concatenate([np.asarray(src.get(k, np.zeros_like(self.model.variables[k])), dtype=np.float32).ravel()
+                                    for k in VAR_ORDER])
+                st[slot] = torch.from_numpy(h).to(be.device)
+            st["params"] = torch.empty(V, dtype=torch.float32, device=be.device)
+            st["losses"] = torch.zeros(2, dtype=torch.float32, device=be.device)
+            self._dev = st
+            self._apply(None, 1)                                   # effective parameters of the current variables
+        return self._dev
+
+    def _apply(self, grad_sums, global_batch):
+        st, m, o = self._dev, self.model, self.opt
+        lr_t = o.lr * math.sqrt(1.0 - o.b2 ** max(o.t, 1)) / (1.0 - o.b1 ** max(o.t, 1))
+        m._get_backend().apply_step(st["vars"], st["m"], st["v"], grad_sums, global_batch, lr_t, o.b1, o.b2, o.eps,
+                                    m.h_reg, m.r_reg, float(m._c_r), float(m._c_h), True, st["params"], st["losses"])
+
+    def _step_device(self, data, sync, global_batch):
+        import torch
+        m = self.model
+        st = self._device_state()
+        be = m._get_backend()
+        D = m.bond_d
+        audio = m._to_device(m._batch(data))
+        b_local, T = audio.shape
+        if b_local > 0:
+            be.set_params_dev(st["params"], m.sigma, m.delta_t, b_local, T, train=True)
+            be.forward(audio, save_for_bwd=True)
+            flat = be.backward()
+        else:
+            flat = torch.zeros(2 * D * D + 3 * D + 2, dtype=torch.float32, device=be.device)
+        if global_batch is None:                                   # known without communication: the reference's batch is the global one
+            global_batch = b_local if self.dp.world_size == 1 else int(self.hparams.minibatch_size)
+        self.dp.allreduce_device(flat)
+        self.opt.t += 1
+        self._apply(flat, global_batch)
+        self.global_step += 1
+        out = {"global_step": self.global_step, "global_batch": int(global_batch), "losses_dev": st["losses"]}
+        if sync:
+            lo = st["losses"].cpu().numpy()
+            out.update(model_loss=float(lo[0]), total_loss=float(lo[1]))
+            del out["losses_dev"]
+            self.history.append(out)
+        return out
+
+    def sync_to_host(self):
+        """Device-resident state -> model.variables and the host AdamOptimizer's slots (checkpoints, sampling, inspection)."""
+        if self._dev is None:
+            return
+        D = self.model.bond_d
+        shapes = {"A": (), "Rx": (D, D), "Ry": (D, D), "freqs": (D,), "psi_x": (D,), "psi_y": (D,)}
+        for name, dst in (("vars", self.model.variables), ("m", self.opt.m), ("v", self.opt.v)):
+            flat = self._dev[name].cpu().numpy()
+            o = 0
+            for k in VAR_ORDER:
+                n = int(np.prod(shapes[k])) if shapes[k] else 1
+                dst[k] = np.asarray(flat[o:o + n].reshape(shapes[k]), dtype=np.float32).copy()
+                o += n
+
     # -- checkpoint / resume (train.py:93: save_checkpoint_secs=60, automatic restore from logdir) --
     def save(self, path: str):
+        self.sync_to_host()
         os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
         payload = {f"model/{k}": v for k, v in self.model.variables.items()}
         payload.update({f"adam/{k}": v for k, v in self.opt.state_dict().items()})
@@ -103,6 +199,7 @@ class Trainer:
                 self.model.variables[k] = np.asarray(z[f"model/{k}"], dtype=np.float32)
             self.opt.load_state_dict({k[5:]: z[k] for k in z.files if k.startswith("adam/")})
             self.global_step = int(z["global_step"])
+        self._dev = None                                            # the device-resident copy is rebuilt from the restored state
         return True
 
 
@@ -120,8 +217,11 @@ def build_parser():
     p.add_argument("--save_checkpoint_secs", type=float, default=60.0)                          # train.py:93
     p.add_argument("--seed", type=int, default=0)                                               # train.py:13
     p.add_argument("--kernel_variant", type=int, default=0,
-                   help="0 auto (float32: wave-per-clip kernels for D <= 32, block kernels above), 1 block, 2 wave, "
-                        "3 MFMA pair kernels (32 < D <= 128, bf16 mat-vec operands)")
+                   help="0 auto (float32: wave-per-clip kernels for D <= 32, wide kernels above), 1 block, 2 wave, "
+                        "3 MFMA pair kernels (32 < D <= 128, bf16 mat-vec operands), 5 float32 wide kernels (32 < D <= 128)")
+    p.add_argument("--host_optimizer", action="store_true",
+                   help="chain rule and Adam in numpy on the host (the reference implementation of the optimiser half) instead of "
+                        "the device-resident step (cmps_psi_apply_step)")
     return p
 
 
@@ -150,7 +250,8 @@ def main(argv=None, backend=None):
     start, count = dp.shard(hp.minibatch_size)
     cls = RhoCMPS if args.mps_model == "rho_mps" else PsiCMPS                                   # train.py:50-53
     model = cls(hp, seed=args.seed, backend=backend)
-    trainer = Trainer(model, hp, dp)
+    device_step = (cls is PsiCMPS and not args.host_optimizer and type(backend).__name__ == "HipScan")
+    trainer = Trainer(model, hp, dp, device_step=device_step)
     logdir = f"{args.logdir}/{args.dataset}/{hp.bond_dim}_{hp.delta_t}_{hp.minibatch_size}"    # train.py:94
     ckpt = os.path.join(logdir, "model.ckpt.npz")
     if trainer.restore(ckpt) and dp.rank == 0:
@@ -167,7 +268,7 @@ def main(argv=None, backend=None):
             full = get_audio(args.datadir, args.dataset, hp, args.sample_duration, seed=args.seed + trainer.global_step)
         # every rank reads the same global batch and keeps its shard (a short final batch of an epoch is sharded as it is)
         s0, c0 = dp.shard(full.shape[0]) if full.shape[0] != hp.minibatch_size else (start, count)
-        out = trainer.step(full[s0:s0 + c0])
+        out = trainer.step(full[s0:s0 + c0], global_batch=int(full.shape[0]))
         if dp.rank == 0:
             print(f"step {out['global_step']}: model_loss {out['model_loss']:.6f} total_loss {out['total_loss']:.6f}")
             if time.time() - last_save > args.save_checkpoint_secs or it == args.max_steps - 1:

@@ -6,25 +6,35 @@
 N = 1 runs in this process.  N > 1 with WORLD_SIZE unset makes this process a LAUNCHER: before anything touches
 the GPU it starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py`
 as a child process (one rank per GPU over RCCL), relays rank 0's JSON line and exits with the child's code
-(`--spawn` forces the same path at N = 1).  Under torch.distributed.run (WORLD_SIZE set) it is a rank.
+(`--spawn` forces the same path at N = 1, with a one-rank RCCL communicator).  Under torch.distributed.run (WORLD_SIZE set)
+it is a rank.
 
-A "step" is one complete optimiser step on one batch of synthetic audio already resident in HBM:
-parameter upload + table rebuild, forward scan, reverse scan, slab reduction, (one RCCL all-reduce of the
-gradient sums when N > 1), chain rule and Adam on the host.  Default workload at every N: BASELINE.json configs[2]
-per GPU -- D=32, T=16000, batch 1024 per GPU (configs[3] = the same per GPU on 8 GPUs), so scaling is weak.
-Inputs: the reference's damped sine (data.py:8-22) plus white noise, parameters by the reference's
-initialisation rules (model.py:36-39, 49, 218-219) with train.py:41-43 hyper-parameters, seed 0.
+A "step" is one complete optimiser step on one batch of synthetic audio already resident in HBM, exactly
+`audio_mps_amd.train.Trainer.step`: parameter tables, forward scan, reverse scan, slab reduction, (one RCCL all-reduce of the
+gradient sums when N > 1), chain rule + regularisers + Adam.  By default the optimiser half runs on the device
+(cmps_psi_apply_step: no device -> host copy inside a step); `--host-optimizer` runs it in numpy on the host (the tested
+reference implementation of that half).  Default workload at every N: BASELINE.json configs[2] per GPU -- D=32, T=16000,
+batch 1024 per GPU (configs[3] = the same per GPU on 8 GPUs), so scaling is weak.
+Inputs (`--input`): the reference's damped sine (data.py:8-22; SURVEY 8(d)'s generator, the default), the same plus white noise,
+or SURVEY 8(d)'s band-limited random walk; parameters by the reference's initialisation rules (model.py:36-39, 49, 218-219) with
+train.py:41-43 hyper-parameters, seed 0 (D > 64: SURVEY 8(d)'s scaled R_in, which keeps 1 + e x / A positive).
 
-Rank 0 prints ONE JSON line; `roofline` describes the dominant kernel, `cpu_baseline` is the plain-C restatement
-(oracle/cmps_oracle.c) timed on this host's cores on a bounded sample, `parity_in_bench` compares the GPU results on
-that same sample with the oracle's (outside the timed region), `precision_ab` times the three arithmetic modes of the
-rank-1 gradient updates side by side.
+Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (the longer of the two scan launches): `achieved` /
+`frac` are the contract's ALGORITHMIC flops (24 D^2 forward, 56 D^2 backward per clip-sample) over the launch time
+measured with HIP events on the launch stream; `executed` splits what the kernel really runs by pipe (fp32 VALU, matrix cores,
+eliminated algebraically) and `step_traffic` puts the whole step's counter bytes next to the algorithmic ones.
+`cpu_baseline` is the plain-C restatement (oracle/cmps_oracle.c) timed on this host's cores on a bounded sample,
+`parity_in_bench` compares the GPU results on that same sample with the oracle's (outside the timed region), `precision_ab` times
+the arithmetic modes of the rank-1 gradient sums side by side, `other_configs` runs BASELINE configs[0] (shape), [1] and [4]
+(float32 and bf16) for a few steps each with their own parity check.
 """
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
+import re
 import socket
 import subprocess
 import sys
@@ -41,6 +51,7 @@ HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec peak
 RANK1_MODES = {"exact_f32": 0, "bf16x2": 1, "bf16x3": 2}
 RANK1_LABEL = {0: "exact fp32 MFMA", 1: "bf16x2 split (16 operand bits), fp32 accumulate",
                2: "bf16x3 split (24 operand bits, fp32-faithful products), fp32 accumulate"}
+V_BLOCK, V_WAVE, V_PAIR, V_WAVE32, V_WIDE = 1, 2, 3, 4, 5
 
 
 def parse_args(argv=None):
@@ -52,11 +63,19 @@ def parse_args(argv=None):
     p.add_argument("--T", type=int, default=16000)
     p.add_argument("--batch-per-gpu", type=int, default=1024)
     p.add_argument("--variant", type=int, default=0,
-                   help="0 auto, 1 block-per-clip, 2 wave-per-clip, 3 MFMA pair kernels (needs --bond-dim 64 or 128; bf16 operands)")
+                   help="0 auto (float32: wave-per-clip kernels for D <= 32, wide kernels above), 1 block-per-clip, 2 wave-per-clip, "
+                        "3 MFMA pair kernels (32 < D <= 128; bf16 operands), 5 float32 wide kernels (32 < D <= 128)")
     p.add_argument("--rank1", choices=sorted(RANK1_MODES), default="bf16x3",
-                   help="arithmetic of the rank-1 gradient updates in the wave reverse scan (cmps_set_option)")
+                   help="arithmetic of the rank-1 gradient sums (cmps_set_option): wave reverse scan of 17 <= D <= 32, gradient GEMM of "
+                        "the wide kernels")
+    p.add_argument("--input", choices=["damped_sine", "damped_sine_noise", "bandlimited"], default="damped_sine",
+                   help="synthetic input (SURVEY 8(d)): the reference's damped sine (data.py:8-22), the same + 0.02 white noise, or "
+                        "0.1 cumsum(N(0,1)) / sqrt(T) clipped")
+    p.add_argument("--host-optimizer", action="store_true",
+                   help="chain rule + Adam in numpy on the host (D2H of the gradient sums every step) instead of cmps_psi_apply_step")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-precision-ab", action="store_true")
+    p.add_argument("--no-other-configs", action="store_true")
     p.add_argument("--cpu-clips", type=int, default=0, help="clips in the CPU sample (0 = 8 per thread)")
     p.add_argument("--spawn", action="store_true", help="go through the child-process launcher even at --gpus 1")
     p.add_argument("--launcher-selftest", action="store_true",
@@ -151,20 +170,24 @@ def oracle_model(model):
     return ohp, ov
 
 
-def cpu_baseline(model, D, T, seed, clips_arg):
-    """Times oracle/cmps_oracle.c (kind 'port': the reference itself is TensorFlow 1.x and cannot run here)
-    on a bounded sample of the same workload: forward + backward, float32, OpenMP over clips.  Returns the
-    baseline record, the sample and the oracle's outputs on it (for parity_in_bench / precision_ab)."""
+def oracle_on(model, data, nthreads):
     from oracle import cmps_oracle as O, c_oracle as C
-    cores = host_cores()
     ohp, ov = oracle_model(model)
     R, f, _, _ = O.effective_params(ohp, ov)
     p0 = O.psi_0(ov)
+    return C.psi_scan(data, R, f, p0, float(ov.A), ohp.delta_t, ohp.sigma, "f32", want_grad=True, nthreads=nthreads)
+
+
+def cpu_baseline(model, D, T, kind, seed, clips_arg):
+    """Times oracle/cmps_oracle.c (kind 'port': the reference itself is TensorFlow 1.x and cannot run here)
+    on a bounded sample of the same workload: forward + backward, float32, OpenMP over clips.  Returns the
+    baseline record, the sample and the oracle's outputs on it (for parity_in_bench / precision_ab)."""
+    cores = host_cores()
     clips = clips_arg if clips_arg > 0 else 8 * cores
-    data = make_audio_host(clips, T, ohp.delta_t, seed)
-    C.psi_scan(data[:cores], R, f, p0, float(ov.A), ohp.delta_t, ohp.sigma, "f32", want_grad=True, nthreads=cores)  # warm
+    data = make_audio_host(kind, clips, T, model.hparams.delta_t, seed)
+    oracle_on(model, data[:cores], cores)                        # warm
     t0 = time.perf_counter()
-    out = C.psi_scan(data, R, f, p0, float(ov.A), ohp.delta_t, ohp.sigma, "f32", want_grad=True, nthreads=cores)
+    out = oracle_on(model, data, cores)
     dt = time.perf_counter() - t0
     assert np.all(np.isfinite(out["loss_per_clip"]))
     rec = {"value": clips * T / dt, "unit": "samples/s", "cores": cores, "kind": "port",
@@ -182,7 +205,7 @@ def cpu_reference_style():
     for name, D, T, B, Bfull in (("C1", 4, 256, 8, 8), ("C2", 16, 4096, 256, 256), ("C3", 32, 16000, 64, 1024)):
         hp = O.HParams(minibatch_size=B, bond_dim=D)
         var = O.init_variables(hp, seed=0)
-        data = make_audio_host(B, T, hp.delta_t, seed=7)
+        data = make_audio_host("damped_sine_noise", B, T, hp.delta_t, seed=7)
         t0 = time.perf_counter()
         g = O.psi_loss_and_grads(hp, var, data, "f32")
         dt = time.perf_counter() - t0
@@ -202,34 +225,9 @@ def cpu_reference_style():
     return rows
 
 
-def profiled_traffic(kernel, D, T, B):
-    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary OF THIS WORKLOAD
-    (profiles/*pmc_summary.json: FETCH_SIZE and WRITE_SIZE collected in separate passes of this same command, FETCH doubled as
-    MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950).  None if no such profile is committed."""
-    import glob
-    import re
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.json")), key=os.path.getmtime)
-    for path in reversed(files):
-        try:
-            with open(path) as fh:
-                doc = json.load(fh)
-            if f"D={D}, T={T}, B={B} " not in doc.get("workload", "") + " ":
-                continue
-            for name, c in doc["kernels"].items():
-                if re.search(r"\b" + re.escape(kernel) + r"\b", name):
-                    dv = c["derived"]
-                    return {"bytes": dv["hbm_read_bytes_per_launch_corrected"] + dv["hbm_write_bytes_per_launch"],
-                            "source": os.path.relpath(path, ROOT)}
-        except Exception:
-            continue
-    return None
-
-
-def make_audio_host(B, T, delta_t, seed, noise=0.02):
-    from audio_mps_amd.data import damped_sine
-    rng = np.random.default_rng(seed + 12345)
-    x = damped_sine(B, T, delta_t, seed=seed)
-    return (x + noise * rng.standard_normal(x.shape)).astype(np.float32)
+def make_audio_host(kind, B, T, delta_t, seed):
+    from audio_mps_amd.data import synthetic_audio
+    return synthetic_audio(kind, B, T, delta_t, seed)
 
 
 def rel_inf(a, b):
@@ -238,8 +236,320 @@ def rel_inf(a, b):
     return float(np.max(np.abs(a - b)) / max(float(np.max(np.abs(b))), 1e-300))
 
 
+# ---------------------------------------------------------------------------------------------------
+# committed rocprofv3 summaries (profiles/*pmc_summary.json: scripts/profile_scan.sh + scripts/summarize_prof.py)
+# ---------------------------------------------------------------------------------------------------
+def profile_summary(D, T, B, variant):
+    """The newest committed PMC summary of THIS workload and kernel family (None if there is none)."""
+    want = {V_WAVE: "k_bwd_wave", V_WAVE32: "k_bwd_wave", V_PAIR: "k_bwd_pair", V_WIDE: "k_bwd_wide", V_BLOCK: "k_bwd_block"}[variant]
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.json")))
+    for path in reversed(files):                                 # names carry the round: the last one is the newest
+        try:
+            with open(path) as fh:
+                doc = json.load(fh)
+            if f"D={D}, T={T}, B={B} " not in doc.get("workload", "") + " ":
+                continue
+            if not any(want in name for name in doc["kernels"]):
+                continue
+            doc["_source"] = os.path.relpath(path, ROOT)
+            return doc
+        except Exception:
+            continue
+    return None
+
+
+def kernel_counters(doc, kernel):
+    if doc is None:
+        return None
+    for name, c in doc["kernels"].items():
+        if re.search(r"\b" + re.escape(kernel) + r"\b", name):
+            return c
+    return None
+
+
+# ---------------------------------------------------------------------------------------------------
+# what a kernel family executes per (clip, sample), in units of D^2 flop (fp32-equivalent), by pipe
+#   algorithmic (SURVEY 8(d)): forward 24 = Q u (8) + s R u (8) + R y (8); backward 56 = R^dagger y, R ybar, R^dagger R ybar,
+#   R^dagger ybar (4 x 8) + three rank-1 sums (3 x 8)
+# ---------------------------------------------------------------------------------------------------
+def executed_split(variant, D, rank1):
+    if variant in (V_WAVE, V_WAVE32) and not (variant == V_WAVE and D <= 16):
+        prod = {0: 1, 1: 3, 2: 6}[rank1]
+        return {"fwd": {"valu_fp32": 12, "mfma_fp32_equiv": 8, "mfma_products": 6, "eliminated": 4,
+                        "what": "merged (Q + s R) u mat-vec 8 + forming it 4 on the VALU; H y as a bf16x3 GEMM over 32-step chunks"},
+                "bwd": {"valu_fp32": 12, "mfma_fp32_equiv": 24, "mfma_products": prod, "eliminated": 20,
+                        "what": "merged (Q + s R^dagger) ybar 8 + forming it 4 on the VALU; H y read from the forward's stash (16 "
+                                "eliminated), the merge (4 eliminated); three rank-1 sums on the matrix cores"}}
+    if variant == V_WAVE:                                        # 16-row layout
+        return {"fwd": {"valu_fp32": 20, "mfma_fp32_equiv": 0, "mfma_products": 0, "eliminated": 4, "what": "chain wave 12, loss wave 8 (VALU)"},
+                "bwd": {"valu_fp32": 12, "mfma_fp32_equiv": 24, "mfma_products": 1, "eliminated": 20,
+                        "what": "merged mat-vec on the VALU; rank-1 sums as exact fp32 MFMAs (16x16x4) on the gradient wave"}}
+    if variant == V_WIDE:
+        prod = 3 if rank1 == 1 else 6
+        return {"fwd": {"valu_fp32": 20, "mfma_fp32_equiv": 0, "mfma_products": 0, "eliminated": 4,
+                        "what": "merged (Q + s R) u 12 and H y 8, all fp32 v_pk_fma"},
+                "bwd": {"valu_fp32": 12, "mfma_fp32_equiv": 24, "mfma_products": prod, "eliminated": 20,
+                        "what": "k_bwd_wide: merged (Q + s R^dagger) ybar on the VALU; k_grad_wide: rank-1 sums as split-bf16 GEMMs"}}
+    if variant == V_PAIR:
+        return {"fwd": {"valu_fp32": 0, "mfma_fp32_equiv": 24, "mfma_products": 1, "eliminated": 0, "what": "R u, Q u (4x4x4 bf16), H y (32x32x16 bf16)"},
+                "bwd": {"valu_fp32": 0, "mfma_fp32_equiv": 40, "mfma_products": 1, "eliminated": 16,
+                        "what": "Q ybar, R^dagger ybar (4x4x4 bf16) + the gradient GEMM; H y from the stash"}}
+    return {"fwd": {"valu_fp32": 24, "mfma_fp32_equiv": 0, "mfma_products": 0, "eliminated": 0, "what": "three fp32 mat-vecs"},
+            "bwd": {"valu_fp32": 56, "mfma_fp32_equiv": 0, "mfma_products": 0, "eliminated": 0, "what": "four fp32 mat-vecs + three rank-1 updates"}}
+
+
+KERNEL_NAMES = {
+    "wave": ("k_fwd_wave2", "k_fwd_wave2 (forward scan: chain wave + loss wave on the matrix cores)", "k_bwd_wave", "k_bwd_wave (reverse scan)"),
+    "wave16": ("k_fwd_wave16", "k_fwd_wave16 (forward scan, 16-row layout: chain wave + loss wave)", "k_bwd_wave16",
+               "k_bwd_wave16 (reverse scan, 16-row layout: chain wave + gradient wave)"),
+    "pair": ("k_fwd_pair", "k_fwd_pair (forward scan: 4x4x4 bf16 MFMA chain waves + 32x32x16 loss waves, eight steps per tile)", "k_bwd_pair",
+             "k_bwd_pair + k_grad_pair (reverse scan + streaming gradient GEMM)"),
+    "wide": ("k_fwd_wide", "k_fwd_wide (forward scan: float32 v_pk_fma mat-vecs, R / Q register resident, H in LDS)", "k_bwd_wide",
+             "k_bwd_wide + k_grad_wide (float32 reverse scan + split-bf16 gradient GEMM)"),
+    "block": ("k_fwd_block", "k_fwd_block", "k_bwd_block", "k_bwd_block"),
+}
+
+
+def family_of(variant, D):
+    if variant == V_WAVE and D <= 16:
+        return "wave16"
+    return {V_WAVE: "wave", V_WAVE32: "wave", V_PAIR: "pair", V_WIDE: "wide", V_BLOCK: "block"}[variant]
+
+
+def roofline_record(D, T, B, variant, rank1, t_fwd, t_bwd, ms_per_step):
+    """The contract's roofline object for the dominant kernel + the per-pipe split of what is executed + the step's traffic."""
+    N = T - 1
+    units = float(B) * N
+    fam = family_of(variant, D)
+    pmc_f, name_f, pmc_b, name_b = KERNEL_NAMES[fam]
+    pair = variant == V_PAIR
+    peak = BF16_PEAK_TFLOPS if pair else FP32_PEAK_TFLOPS
+    split = executed_split(variant, D, rank1)
+    alg = {"fwd": 24.0 * D * D * units, "bwd": 56.0 * D * D * units}
+    tt = {"fwd": t_fwd, "bwd": t_bwd}
+    dom = "fwd" if t_fwd >= t_bwd else "bwd"
+    oth = "bwd" if dom == "fwd" else "fwd"
+    doc = profile_summary(D, T, B, variant)
+
+    def pipes(which):
+        sp = split[which]
+        t = tt[which]
+        valu = sp["valu_fp32"] * D * D * units / t / 1e12
+        mf_eq = sp["mfma_fp32_equiv"] * D * D * units / t / 1e12
+        mf_raw = mf_eq * max(sp["mfma_products"], 1)
+        f32_matrix = fam == "wave16" or (fam == "wave" and rank1 == 0 and which == "bwd")
+        rec = {"valu_fp32_tflops": valu, "valu_frac_of_fp32_peak": valu / FP32_PEAK_TFLOPS,
+               "matrix_pipe_tflops_fp32_equiv": mf_eq, "matrix_pipe_tflops_issued": mf_raw,
+               "matrix_pipe_products_per_fp32_product": sp["mfma_products"],
+               "matrix_pipe_frac_of_its_peak": mf_raw / (FP32_PEAK_TFLOPS if f32_matrix else BF16_PEAK_TFLOPS),
+               "eliminated_frac_of_algorithmic": sp["eliminated"] / (24.0 if which == "fwd" else 56.0),
+               "frac_executed_fp32_equiv": (mf_eq if pair else valu + mf_eq) / peak,
+               "what": sp["what"]}
+        c = kernel_counters(doc, pmc_f if which == "fwd" else pmc_b)
+        if c is not None and "derived" in c:
+            dv = c["derived"]
+            wc = dv.get("wave_cycles_per_clip_step")
+            if wc:
+                rec["pmc"] = {"issue_busy_frac": dv.get("active_inst_any_cycles_per_clip_step", 0.0) / wc,
+                              "wait_frac": dv.get("wait_any_cycles_per_clip_step", 0.0) / wc,
+                              "issue_stall_frac": dv.get("wait_inst_any_cycles_per_clip_step", 0.0) / wc,
+                              "valu_insts_per_clip_step": dv.get("valu_insts_per_clip_step"),
+                              "mfma_insts_per_clip_step": dv.get("mfma_insts_per_clip_step"),
+                              "mfma_busy_cycles_per_clip_step": dv.get("mfma_busy_cycles_per_clip_step"),
+                              "wave_cycles_per_clip_step": wc, "source": doc["_source"]}
+        return rec
+
+    traffic = None
+    step_traffic = None
+    if doc is not None:
+        c = kernel_counters(doc, pmc_f if dom == "fwd" else pmc_b)
+        if c is not None:
+            dv = c["derived"]
+            traffic = dv.get("hbm_read_bytes_per_launch_corrected", 0.0) + dv.get("hbm_write_bytes_per_launch", 0.0)
+        tot = 0.0
+        per = {}
+        for name, c in doc["kernels"].items():
+            dv = c.get("derived", {})
+            b = dv.get("hbm_read_bytes_per_launch_corrected", 0.0) + dv.get("hbm_write_bytes_per_launch", 0.0)
+            short = name.split("::")[-1].split("<")[0]
+            per[short] = per.get(short, 0.0) + b
+            tot += b
+        step_traffic = {"bytes_per_step": tot, "algorithmic_bytes_per_step": 8.0 * B * T, "ratio": tot / (8.0 * B * T),
+                        "by_kernel": per, "achieved_GBs": tot / (1e-3 * ms_per_step) / 1e9,
+                        "frac_of_hbm_peak": tot / (1e-3 * ms_per_step) / 1e9 / HBM_PEAK_GBS,
+                        "what": "FETCH_SIZE x 2 + WRITE_SIZE of the scan launches of one step (rocprofv3 --pmc, separate passes; "
+                                "MI355X_MICROARCH.md corrections): implementation traffic = the per-step state stash, written by the "
+                                "forward and read by the reverse sweep", "source": doc["_source"]}
+    ach = alg[dom] / tt[dom] / 1e12
+    whole = (alg["fwd"] + alg["bwd"]) / (1e-3 * ms_per_step) / 1e12
+    bytes_alg = 8.0 * B * T
+    return {
+        "bound": "mfma",            # the contract's class for a compute-bound kernel (the other class is "hbm"): see `binding`
+        "binding": ("instruction issue of ONE wave per SIMD: fp32 VALU mat-vecs on the serial chain, rank-1 / loss products beside them on "
+                    "the matrix cores; 10 D^2 algorithmic flop per algorithmic byte, so never HBM") if not pair else
+                   "bf16 MFMA (4x4x4 batched) issue interval + one LDS round trip per step",
+        "kernel": name_f if dom == "fwd" else name_b, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+        "frac_is": "ALGORITHMIC flops (SURVEY 8(d)) / launch time / peak: includes work the kernel eliminates or runs on the other pipe; "
+                   "`executed` has the per-pipe rates",
+        "traffic": traffic, "traffic_source": doc["_source"] if doc is not None else None,
+        "algorithmic_bytes": 4.0 * B * T, "launch_ms": tt[dom] * 1e3, "flops_per_launch": alg[dom],
+        "executed": pipes(dom),
+        "other_kernel": {"kernel": name_b if dom == "fwd" else name_f, "achieved": alg[oth] / tt[oth] / 1e12,
+                         "frac": alg[oth] / tt[oth] / 1e12 / peak, "launch_ms": tt[oth] * 1e3, "executed": pipes(oth)},
+        "whole_step": {"flops": alg["fwd"] + alg["bwd"], "achieved": whole, "frac": whole / peak,
+                       "note": "80 D^2 algorithmic flop per (clip, sample) over the full optimiser step"},
+        "step_traffic": step_traffic,
+        "hbm": {"achieved_algorithmic": bytes_alg / (t_fwd + t_bwd) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac_algorithmic": bytes_alg / (t_fwd + t_bwd) / 1e9 / HBM_PEAK_GBS,
+                "note": "the audio itself, 8 B per (clip, sample): the scan is compute bound (BASELINE's 40 % of the HBM roofline is "
+                        "unreachable as stated: 100 % of fp32 peak would be 0.2 % of it)"},
+    }
+
+
 BASELINE_CONFIGS = {(4, 256, 8): "BASELINE configs[0] shape", (16, 4096, 256): "BASELINE configs[1]",
                     (32, 16000, 1024): "BASELINE configs[2]", (128, 16000, 512): "BASELINE configs[4]"}
+
+
+# ---------------------------------------------------------------------------------------------------
+# one configuration on this rank's GPU
+# ---------------------------------------------------------------------------------------------------
+class Run:
+    def __init__(self, D, T, B, variant, rank1, kind, dp, dev, world, rank, host_optimizer, config_id=3):
+        import torch
+        from audio_mps_amd import HParams, PsiCMPS
+        from audio_mps_amd.scan import HipScan
+        from audio_mps_amd.train import Trainer
+        self.D, self.T, self.B, self.kind, self.dp, self.dev, self.world = D, T, B, kind, dp, dev, world
+        self.hp = HParams(minibatch_size=B * world, bond_dim=D)      # train.py:41-43 defaults otherwise
+        self.seed = 1000 * config_id + rank
+        # resident in HBM before the timed region
+        self.audio = torch.from_numpy(make_audio_host(kind, B, T, self.hp.delta_t, self.seed)).to(dev)
+        self.backend = HipScan(D, device=dev, variant=variant, rank1=RANK1_MODES[rank1])
+        kw = {}
+        if D > 64:      # SURVEY 8(d): R_in = 0.5 / sqrt(D) (N(0,1) + i N(0,1)), zero diagonal, keeps 1 + e x / A > 0 (hard part viii)
+            rng = np.random.default_rng(0)
+            Rin = (0.5 / np.sqrt(D)) * (rng.standard_normal((D, D)) + 1j * rng.standard_normal((D, D)))
+            np.fill_diagonal(Rin, 0.0)
+            kw["R_in"] = Rin.astype(np.complex64)
+        self.model = PsiCMPS(self.hp, seed=0, backend=self.backend, **kw)
+        self.trainer = Trainer(self.model, self.hp, dp, device_step=not host_optimizer)
+        self.host_optimizer = host_optimizer
+        self.variant = int(self.backend.variant)
+
+    def step(self):
+        if self.host_optimizer:
+            self.trainer.step(self.audio)
+        else:
+            self.trainer.step(self.audio, sync=False, global_batch=self.B * self.world)
+
+    def last_loss(self):
+        if self.host_optimizer:
+            return float(self.trainer.history[-1]["model_loss"])
+        return float(self.trainer._dev["losses"].cpu().numpy()[0])
+
+    def timed(self, steps, warmup):
+        """W warm-up steps, then exactly K steps between barrier + synchronize on both sides; max over ranks."""
+        import torch
+        dp = self.dp
+        for _ in range(warmup):
+            self.step()
+        torch.cuda.synchronize()
+        dp.collective_us()                                           # drain the warm-up's collective events
+        dp.collective_ms.clear()
+        self.backend.timing = []
+        dp.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        torch.cuda.synchronize()
+        local = time.perf_counter() - t0
+        dp.barrier()
+        elapsed = dp.max_over_ranks(time.perf_counter() - t0)
+        tm = self.backend.timing_ms()
+        self.backend.timing = None
+        return {"elapsed": elapsed, "local": local, "t_fwd": float(np.mean(tm["fwd"])) * 1e-3,
+                "t_bwd": float(np.mean(tm["bwd"])) * 1e-3, "last": self.last_loss()}
+
+    def parity(self, sample, ref, pair):
+        """The GPU's per-clip loss and gradient sums on a host sample against the oracle's (chunks of at most B clips)."""
+        import torch
+        from audio_mps_amd.scan import unpack_grad
+        from oracle import c_oracle as C
+        be, D, B, T = self.backend, self.D, self.B, self.T
+        self.trainer.sync_to_host()
+        gr = C.unpack_grad(ref["grad"], D)
+        d_sample = torch.from_numpy(sample).to(self.dev)
+        Bs = sample.shape[0]
+        be.set_params(self.model.effective_params(), B, T, train=True)
+        pers, flat = [], None
+        for s0 in range(0, Bs, B):
+            chunk = d_sample[s0:s0 + B].contiguous()
+            pers.append(be.forward(chunk, save_for_bwd=True).cpu().numpy().copy())
+            gch = be.backward().cpu().numpy().astype(np.float64)
+            flat = gch if flat is None else flat + gch
+        per = np.concatenate(pers)
+        g = unpack_grad(flat.astype(np.float32), D)
+        loss_err = float(np.max(np.abs(per - ref["loss_per_clip"]) / np.maximum(np.abs(ref["loss_per_clip"]), 1.0)))
+        gerr = {k: rel_inf(g[k], gr[k]) for k in ("Rbar", "fbar", "psi0bar", "Abar")}
+        tol_l, tol_g = (2e-3, 3e-2) if pair else (1e-5, 1e-4)
+        return {"clips": Bs, "max_rel_loss_err": loss_err, "max_rel_grad_err": max(gerr.values()), "grad_err_by_tensor": gerr,
+                "tolerance": {"loss": tol_l, "grad": tol_g}, "ok": bool(loss_err <= tol_l and max(gerr.values()) <= tol_g),
+                "against": "oracle/cmps_oracle.c float32 (parity UNPINNED: no reference-held vectors exist)"}
+
+
+def dtype_label(variant, D, rank1):
+    if variant == V_PAIR:
+        return "bf16 (mat-vec operands; fp32 state and accumulate)"
+    if variant in (V_WAVE, V_WAVE32) and not (variant == V_WAVE and D <= 16):
+        tail = {1: "rank-1 gradient sums: bf16x2 split, 16 operand bits", 0: "rank-1 gradient sums: exact fp32 MFMA",
+                2: "rank-1 gradient sums: the same bf16x3 split"}[rank1]
+        return ("f32 (fp32 FMA chains on the serial path; loss product H y: bf16x3-split operands on the matrix cores, fp32 accumulate; "
+                + tail + ")")
+    if variant == V_WIDE:
+        return ("f32 (fp32 FMA chains for every mat-vec; rank-1 gradient sums: " +
+                ("bf16x2-split operands (16 bits)" if rank1 == 1 else "bf16x3-split operands (24 bits, fp32-faithful)") +
+                " on the matrix cores, fp32 accumulate)")
+    return "f32"
+
+
+def other_config_rows(ARGS, dp, dev):
+    """BASELINE configs[0] (shape), [1], [4] in float32 and [4] as named (bf16): a few steps each + parity on <= 16 CPU clips,
+    outside the headline's timed region -- driver-witnessed numbers for every single-GPU config."""
+    import torch
+    rows = []
+    cores = host_cores()
+    for name, D, T, B, variant, steps, cid in (
+            ("configs[0] shape: D=4, T=256, batch 8", 4, 256, 8, 0, 20, 1),
+            ("configs[1]: D=16, T=4096, batch 256", 16, 4096, 256, 0, 10, 2),
+            ("configs[4] in float32: D=128, T=16000, batch 512 (wide kernels)", 128, 16000, 512, 0, 3, 5),
+            ("configs[4] as named (bf16 operands, fp32 accumulate): pair kernels", 128, 16000, 512, V_PAIR, 3, 5)):
+        run = None
+        try:
+            run = Run(D, T, B, variant, ARGS.rank1, ARGS.input, dp, dev, 1, 0, ARGS.host_optimizer, config_id=cid)
+            r = run.timed(steps, 2)
+            ms = 1e3 * r["elapsed"] / steps
+            roof = roofline_record(D, T, B, run.variant, run.backend.rank1, r["t_fwd"], r["t_bwd"], ms)
+            clips = min(B, 16)
+            sample = make_audio_host(ARGS.input, clips, T, run.hp.delta_t, run.seed)
+            run.trainer.sync_to_host()
+            t0 = time.perf_counter()
+            ref = oracle_on(run.model, sample, cores)
+            cpu_s = time.perf_counter() - t0
+            par = run.parity(sample, ref, run.variant == V_PAIR)
+            rows.append({"config": name, "ms_per_step": ms, "value": B * T * steps / r["elapsed"], "unit": "samples/s", "steps": steps,
+                         "kernel_variant": run.variant, "dtype": dtype_label(run.variant, D, run.backend.rank1),
+                         "fwd_ms": r["t_fwd"] * 1e3, "bwd_ms": r["t_bwd"] * 1e3, "final_loss": r["last"],
+                         "dominant_kernel": roof["kernel"], "frac": roof["frac"], "peak": roof["peak"],
+                         "frac_executed_fp32_equiv": roof["executed"]["frac_executed_fp32_equiv"],
+                         "whole_step_frac": roof["whole_step"]["frac"],
+                         "cpu_port": {"value": clips * T / cpu_s, "unit": "samples/s", "cores": cores, "sample": f"{clips} clips, {cpu_s:.2f} s"},
+                         "parity_in_bench": par})
+        except Exception as exc:                                      # a failing side configuration must not take the headline down
+            rows.append({"config": name, "error": f"{type(exc).__name__}: {exc}"})
+        del run
+        torch.cuda.empty_cache()
+    return rows
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -247,10 +557,7 @@ BASELINE_CONFIGS = {(4, 256, 8): "BASELINE configs[0] shape", (16, 4096, 256): "
 # ---------------------------------------------------------------------------------------------------
 def worker(ARGS):
     import torch
-    from audio_mps_amd import HParams, PsiCMPS, _capi
     from audio_mps_amd.parallel import DataParallel
-    from audio_mps_amd.scan import HipScan, unpack_grad
-    from audio_mps_amd.train import Trainer
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -267,131 +574,38 @@ def worker(ARGS):
     dp.time_collective = True
 
     D, T, B = ARGS.bond_dim, ARGS.T, ARGS.batch_per_gpu
-    hp = HParams(minibatch_size=B * world, bond_dim=D)          # train.py:41-43 defaults otherwise
-    config_id = 3
-    audio_host = make_audio_host(B, T, hp.delta_t, seed=1000 * config_id + rank)
-    audio = torch.from_numpy(audio_host).to(dev)                 # resident in HBM before the timed region
-    backend = HipScan(D, device=dev, variant=ARGS.variant, rank1=RANK1_MODES[ARGS.rank1])
-    model = PsiCMPS(hp, seed=0, backend=backend)
-    trainer = Trainer(model, hp, dp)
-    wave = backend.variant in (_capi.CMPS_VARIANT_WAVE, _capi.CMPS_VARIANT_WAVE32)
-    pair = backend.variant == _capi.CMPS_VARIANT_PAIR
-
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-
-    def step(fwd_ms=None, bwd_ms=None):
-        # same sequence as Trainer.step, with HIP events around the two scan launches (on the stream they are launched on:
-        # torch's current stream is the one handed to the C ABI)
-        be = model._get_backend()
-        be.set_params(model.effective_params(), B, T, train=True)
-        ev[0].record()
-        be.forward(audio, save_for_bwd=True)
-        ev[1].record()
-        flat = be.backward()
-        ev[2].record()
-        host, b_global = dp.allreduce_sums(flat, B)              # D2H copy synchronises the stream
-        total, grads = model.chain_rule(host, b_global, with_reg=True)
-        trainer.opt.apply_gradients(model.variables, grads)
-        if fwd_ms is not None:
-            fwd_ms.append(ev[0].elapsed_time(ev[1]))
-            bwd_ms.append(ev[1].elapsed_time(ev[2]))
-        return host[-1] / b_global
-
-    def timed_run(steps, warmup):
-        fwd_ms, bwd_ms = [], []
-        for _ in range(warmup):
-            step()
-        dp.collective_ms.clear()
-        dp.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        last = 0.0
-        for _ in range(steps):
-            last = step(fwd_ms, bwd_ms)
-        torch.cuda.synchronize()
-        local = time.perf_counter() - t0
-        dp.barrier()
-        elapsed = dp.max_over_ranks(time.perf_counter() - t0)
-        return elapsed, local, last, float(np.mean(fwd_ms)) * 1e-3, float(np.mean(bwd_ms)) * 1e-3
-
-    elapsed, local_elapsed, last, t_fwd, t_bwd = timed_run(ARGS.steps, ARGS.warmup)
-    if not np.isfinite(last):
-        raise SystemExit(f"non-finite loss {last}")
+    run = Run(D, T, B, ARGS.variant, ARGS.rank1, ARGS.input, dp, dev, world, rank, ARGS.host_optimizer)
+    variant, rank1 = run.variant, run.backend.rank1
+    r = run.timed(ARGS.steps, ARGS.warmup)
+    if not np.isfinite(r["last"]):
+        raise SystemExit(f"non-finite loss {r['last']}")
     allreduce_us = dp.collective_us()                            # mean HIP-event time of the collective (None at N = 1)
-    per_rank_ms = dp.gather_floats(1e3 * local_elapsed / ARGS.steps)
+    per_rank_ms = dp.gather_floats(1e3 * r["local"] / ARGS.steps)
     rccl_world = dp.measured_world_size()                        # dist.get_world_size() after a GPU all-reduce of ones
 
     out = None
+    pair = variant == V_PAIR
+    fam = family_of(variant, D)
     if rank == 0:
-        N = T - 1
-        ms_per_step = 1e3 * elapsed / ARGS.steps
-        value = world * B * T * ARGS.steps / elapsed
-        flops_bwd = 56.0 * D * D * B * N                         # 56 D^2 per (clip, sample)
-        flops_fwd = 24.0 * D * D * B * N
-        bytes_alg = 8.0 * B * T                                  # 4 B read forward + 4 B read in the reverse sweep
-        wave16 = wave and D <= 16 and backend.variant == _capi.CMPS_VARIANT_WAVE
-        kern = {"fwd": {"name": "k_fwd_wave2 (forward scan: chain wave + loss wave on the matrix cores)" if wave else "k_fwd_block",
-                        "t": t_fwd, "flops": flops_fwd, "pmc": "k_fwd_wave2" if wave else "k_fwd_block"},
-                "bwd": {"name": "k_bwd_wave (reverse scan)" if wave else "k_bwd_block", "t": t_bwd, "flops": flops_bwd,
-                        "pmc": "k_bwd_wave" if wave else "k_bwd_block"}}
-        if wave16:
-            kern["fwd"].update(name="k_fwd_wave16 (forward scan, 16-row layout: chain wave + loss wave)", pmc="k_fwd_wave16")
-            kern["bwd"].update(name="k_bwd_wave16 (reverse scan, 16-row layout: chain wave + gradient wave)", pmc="k_bwd_wave16")
-        if pair:                                                 # D = 128: MFMA pair kernels (bf16 operands, fp32 accumulate)
-            kern["fwd"].update(name="k_fwd_pair (forward scan: 4x4x4 bf16 MFMA chain waves + 32x32x16 loss waves, eight steps per tile)", pmc="k_fwd_pair")
-            kern["bwd"].update(name="k_bwd_pair + k_grad_pair (reverse scan + streaming gradient GEMM)", pmc="k_bwd_pair")
-        dom = "fwd" if t_fwd >= t_bwd else "bwd"                 # the dominant kernel = the longer launch
-        oth = "bwd" if dom == "fwd" else "fwd"
-        traffic = profiled_traffic(kern[dom]["pmc"], D, T, B)
-        ach = kern[dom]["flops"] / kern[dom]["t"] / 1e12
-        peak = BF16_PEAK_TFLOPS if pair else FP32_PEAK_TFLOPS
-        whole = (flops_fwd + flops_bwd) / (1e-3 * ms_per_step) / 1e12
-        rank1 = backend.rank1
-        roofline = {
-            "bound": "compute: fp32 VALU issue (instruction-issue / latency bound scan)" if not pair
-                     else "compute: bf16 MFMA + per-step VALU/LDS tail",
-            "bound_class": "mfma",                               # the contract's class for a compute-bound kernel (not 'hbm')
-            "kernel": kern[dom]["name"], "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-            "frac": ach / peak,
-            "traffic": traffic["bytes"] if traffic else None, "traffic_source": traffic["source"] if traffic else None,
-            "algorithmic_bytes": 4.0 * B * T, "launch_ms": kern[dom]["t"] * 1e3,
-            "flops_per_launch": kern[dom]["flops"],
-            "whole_step": {"flops": flops_fwd + flops_bwd, "achieved": whole, "frac": whole / peak,
-                           "note": "80 D^2 algorithmic flop per (clip, sample) over the full optimiser step (host work included)"},
-            "note": "fp32 path: peak = 157.3 TFLOP/s (fp32 vector peak = f32-input MFMA peak); achieved = SURVEY 8(d) "
-                    "ALGORITHMIC flops (24 D^2 forward, 56 D^2 backward per clip-sample) / launch time, not executed flops: the "
-                    "reverse scan executes two mat-vecs on the VALU (H y is stashed by the forward) and its rank-1 updates on "
-                    f"the matrix pipe ({RANK1_LABEL[rank1]}); the scan is instruction-issue/latency bound, not HBM bound "
-                    "(10 D^2 flop per algorithmic byte)",
-            "other_kernel": {"kernel": kern[oth]["name"], "achieved": kern[oth]["flops"] / kern[oth]["t"] / 1e12,
-                             "frac": kern[oth]["flops"] / kern[oth]["t"] / 1e12 / peak,
-                             "launch_ms": kern[oth]["t"] * 1e3},
-            "hbm": {"achieved": bytes_alg / (t_fwd + t_bwd) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": bytes_alg / (t_fwd + t_bwd) / 1e9 / HBM_PEAK_GBS}}
-        if pair:
-            roofline["note"] = ("bf16-operand path (BASELINE configs[4]): peak = 2500 TFLOP/s dense bf16 MFMA; the mat-vecs use "
-                                "v_mfma_f32_4x4x4_16b_bf16 (two clips x {re, im} fill its four B columns), whose own ceiling is "
-                                "256 flop/cycle/SIMD = 629 TFLOP/s; the scans are per-step latency / issue bound")
+        ms_per_step = 1e3 * r["elapsed"] / ARGS.steps
+        value = world * B * T * ARGS.steps / r["elapsed"]
         cfg_name = BASELINE_CONFIGS.get((D, T, B), "custom shape")
         if world > 1 and (D, T, B) == (32, 16000, 1024):
             cfg_name = "BASELINE configs[3] (configs[2] per GPU)" if world == 8 else f"BASELINE configs[2] per GPU x {world}"
-        if pair:
-            dtype = "bf16 (mat-vec operands; fp32 state and accumulate)"
-        elif wave:
-            dtype = "f32" if (rank1 != 1 or wave16) else "f32 (rank-1 gradient updates: bf16x2 split, 16 operand bits)"
-        else:
-            dtype = "f32"
         out = {
             "metric": f"audio samples/sec (fwd+bwd) at D={D}, T={T}",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": ARGS.steps, "warmup": ARGS.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": dtype, "data": "synthetic",
+            "dtype": dtype_label(variant, D, rank1), "data": "synthetic",
             "config": {"workload": f"{cfg_name}: PsiCMPS fwd+bwd scan, D={D}, T={T}, batch {B} per GPU"
-                                   f" (global {B * world}), damped sine + noise, full optimiser step",
-                       "parallelism": f"dp{world}", "kernel_variant": int(backend.variant),
-                       "rank1_updates": ("exact fp32 MFMA (16-row layout)" if wave16 else RANK1_LABEL[rank1]) if wave else None},
-            "roofline": roofline,
-            "final_loss": float(last),
+                                   f" (global {B * world}), input {ARGS.input}, full optimiser step "
+                                   f"({'host numpy' if ARGS.host_optimizer else 'device-resident'} chain rule + Adam)",
+                       "parallelism": f"dp{world}", "kernel_variant": variant, "kernel_family": fam, "input": ARGS.input,
+                       "optimizer_step": "host" if ARGS.host_optimizer else "device (cmps_psi_apply_step)",
+                       "rank1_updates": (("exact fp32 MFMA (16-row layout)" if fam == "wave16" else RANK1_LABEL[rank1])
+                                         if fam in ("wave", "wave16", "wide") else None)},
+            "roofline": roofline_record(D, T, B, variant, rank1, r["t_fwd"], r["t_bwd"], ms_per_step),
+            "final_loss": float(r["last"]),
             "per_rank_ms_per_step": {"min": float(np.min(per_rank_ms)), "max": float(np.max(per_rank_ms))},
             "rccl_world_size": rccl_world,
             "allreduce_us": allreduce_us,
@@ -400,52 +614,35 @@ def worker(ARGS):
         if ARGS.rehearse_on_one_gpu:
             out["rehearsal"] = "all ranks share cuda:0 and reduce over gloo on the host: NOT a scaling measurement"
 
-    # ---- outside the timed region: CPU baseline, parity of this very workload, precision A/B (rank 0, N = 1 only) ----
+    # ---- outside the timed region: CPU baseline, parity of this very workload, precision A/B, the other configs (rank 0, N = 1) ----
     if rank == 0 and world == 1 and not ARGS.no_cpu_baseline:
-        cb, sample, ref = cpu_baseline(model, D, T, seed=1000 * config_id, clips_arg=ARGS.cpu_clips)
+        run.trainer.sync_to_host()                               # the oracle sees the variables the timed steps left behind
+        cb, sample, ref = cpu_baseline(run.model, D, T, ARGS.input, seed=run.seed, clips_arg=ARGS.cpu_clips)
         out["cpu_baseline"] = cb
-        from oracle import c_oracle as C
-        gr = C.unpack_grad(ref["grad"], D)
-        d_sample = torch.from_numpy(sample).to(dev)
-        Bs = sample.shape[0]
-
-        def gpu_on_sample():
-            # the sample may hold more clips than the workload's batch (BASELINE C1 has 8): chunks of at most B clips, losses
-            # concatenated, gradient sums added
-            backend.set_params(model.effective_params(), B, T, train=True)
-            pers, flat = [], None
-            for s0 in range(0, Bs, B):
-                chunk = d_sample[s0:s0 + B].contiguous()
-                pers.append(backend.forward(chunk, save_for_bwd=True).cpu().numpy().copy())
-                gch = backend.backward().cpu().numpy().astype(np.float64)
-                flat = gch if flat is None else flat + gch
-            per = np.concatenate(pers)
-            g = unpack_grad(flat.astype(np.float32), D)
-            loss_err = float(np.max(np.abs(per - ref["loss_per_clip"]) / np.maximum(np.abs(ref["loss_per_clip"]), 1.0)))
-            gerr = {k: rel_inf(g[k], gr[k]) for k in ("Rbar", "fbar", "psi0bar", "Abar")}
-            return loss_err, gerr
-
-        loss_err, gerr = gpu_on_sample()
-        tol_l, tol_g = (2e-3, 3e-2) if pair else (1e-5, 1e-4)
-        out["parity_in_bench"] = {"clips": Bs, "max_rel_loss_err": loss_err, "max_rel_grad_err": max(gerr.values()),
-                                  "grad_err_by_tensor": gerr, "tolerance": {"loss": tol_l, "grad": tol_g},
-                                  "ok": bool(loss_err <= tol_l and max(gerr.values()) <= tol_g),
-                                  "against": "oracle/cmps_oracle.c float32 (parity UNPINNED: no reference-held vectors exist)"}
-        if wave and not wave16 and not ARGS.no_precision_ab:
+        out["parity_in_bench"] = run.parity(sample, ref, pair)
+        if fam in ("wave", "wide") and not ARGS.no_precision_ab:
             ab = {}
-            for name, mode in RANK1_MODES.items():               # accuracy first: the timed steps below move the parameters
-                backend.set_rank1(mode)
-                _, ge = gpu_on_sample()
-                ab[name] = {"max_rel_grad_err_vs_f32_oracle": max(ge.values()), "products": RANK1_LABEL[mode]}
-            for name, mode in RANK1_MODES.items():
-                backend.set_rank1(mode)
-                el, _, _, tf_, tb_ = timed_run(5, 1)
-                ab[name].update({"ms_per_step": 1e3 * el / 5, "samples_per_s": B * T * 5 / el, "bwd_ms": tb_ * 1e3, "fwd_ms": tf_ * 1e3})
-            backend.set_rank1(RANK1_MODES[ARGS.rank1])
-            out["precision_ab"] = {"what": "rank-1 gradient updates of k_bwd_wave; everything else is identical fp32 code",
+            modes = RANK1_MODES if fam == "wave" else {"bf16x2": 1, "bf16x3": 2}
+            for name, mode in modes.items():                     # accuracy first: the timed steps below move the parameters
+                run.backend.set_rank1(mode)
+                pr = run.parity(sample, ref, False)
+                ab[name] = {"max_rel_grad_err_vs_f32_oracle": pr["max_rel_grad_err"], "products": RANK1_LABEL[mode]}
+            for name, mode in modes.items():
+                run.backend.set_rank1(mode)
+                rr = run.timed(5, 1)
+                ab[name].update({"ms_per_step": 1e3 * rr["elapsed"] / 5, "samples_per_s": B * T * 5 / rr["elapsed"],
+                                 "bwd_ms": rr["t_bwd"] * 1e3, "fwd_ms": rr["t_fwd"] * 1e3})
+            run.backend.set_rank1(RANK1_MODES[ARGS.rank1])
+            out["precision_ab"] = {"what": "rank-1 gradient sums (k_bwd_wave / k_grad_wide); everything else is identical fp32 code.  All "
+                                           "modes sit in float32 reorder noise of the oracle: the label 'fp32-faithful' of bf16x3 rests on its "
+                                           "operand-bit argument (24 bits kept), not on a difference this comparison can resolve",
                                    "headline_mode": ARGS.rank1, "modes": ab}
         if (D, T, B) == (32, 16000, 1024):
             out["cpu_baseline"]["reference_style"] = cpu_reference_style()
+            if not ARGS.no_other_configs:
+                del run
+                torch.cuda.empty_cache()
+                out["other_configs"] = other_config_rows(ARGS, dp, dev)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

@@ -119,6 +119,36 @@ int cmps_set_params(cmps_handle_t h, const float* R_re_dev, const float* R_im_de
                     void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /*
+ * cmps_set_params with every parameter -- model.A (model.py:19) included -- read from device memory:
+ *   params_dev [2 D^2 + 3 D + 1] = R_re [D*D] | R_im [D*D] | freqs [D] | psi0_re [D] | psi0_im [D] | A,
+ * the buffer cmps_psi_apply_step writes.  The scan kernels then load A from params_dev + 2 D^2 + 3 D, so a training loop needs
+ * no device -> host copy between steps.  Everything else as cmps_set_params.
+ */
+int cmps_set_params_dev(cmps_handle_t h, const float* params_dev, double sigma, double delta_t, int T, int B_max, int flags,
+                        void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/*
+ * Replaces: the optimiser half of a training step, which the reference runs inside session.run(train_op) --
+ * tf.train.AdamOptimizer(learning_rate).minimize(total_loss) (train.py:88-89; beta1 0.9, beta2 0.999, epsilon 1e-8:
+ * logging/graph.pbtxt:32102-32192), i.e. the chain rule from the effective parameters back to the trainable variables
+ * (adjoint of model.py:36-42, 49, 221-222), the regularisers total = loss + h_reg sum freqs^2 + r_reg sum |R|^2 of
+ * train.py:55-60 (with_reg != 0), the Adam update, and the next step's effective parameters (model.py:36-42, 49, 221-222).
+ *   vars_dev, adam_m_dev, adam_v_dev [2 D^2 + 3 D + 1]: A | Rx [D*D] | Ry [D*D] | freqs [D] | psi_x [D] | psi_y [D]  (in / out)
+ *   grad_sums_dev [2 D^2 + 3 D + 2]: the buffer of cmps_psi_loss_bwd, summed over all ranks; global_batch = clips it covers.
+ *     NULL: no update -- only params_dev is computed from vars_dev (the first step).
+ *   lr_t = learning_rate * sqrt(1 - beta2^t) / (1 - beta1^t) for the step count t the caller keeps (train.py:88 global_step).
+ *   c_r, c_h: the rsqrt(r_reg), rsqrt(h_reg) factors of model.py:36-39, 49 (1 when R_in / freqs_in were given).
+ *   params_dev [2 D^2 + 3 D + 1]: out, the input of cmps_set_params_dev.   losses_dev [2]: out, mean_b loss_b and the total loss
+ *   of the gradients consumed.   scratch_dev: cmps_apply_step_scratch_bytes(D) bytes, 8-byte aligned.
+ * One small kernel on `stream`; nothing is copied to the host.
+ */
+size_t cmps_apply_step_scratch_bytes(int D);
+int cmps_psi_apply_step(cmps_handle_t h, float* vars_dev, float* adam_m_dev, float* adam_v_dev, const float* grad_sums_dev,
+                        double global_batch, double lr_t, double beta1, double beta2, double epsilon, double h_reg, double r_reg,
+                        double c_r, double c_h, int with_reg, float* params_dev, float* losses_dev, void* scratch_dev,
+                        void* stream);
+
+/*
  * Replaces: PsiCMPS._build_loss_psi (model.py:257-267) = tf.foldl of _psi_and_loss_update
  * (model.py:276-282) over the T-1 increments, i.e. _update_ancilla_psi (:300-317), _inc_loss_psi
  * (:293-294), _expectation (:319-325), _normalize_psi (:327-334) per step.

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Profiling recipe (run on the GPU box through gpurun; raw output under gpurun_out/prof_<tag>, condensed into profiles/ by
-# scripts/summarize_prof.py).  usage: profile_r2.sh TAG D T B [extra bench.py flags ...]
+# scripts/summarize_prof.py).  usage: profile_scan.sh TAG D T B [extra bench.py flags ...]
 #   1) rocprofv3 --kernel-trace --stats of the bench command
 #   2) PMC passes, one counter group per run (FETCH_SIZE and WRITE_SIZE do not fit one pass; never combined with sys / hip /
 #      hsa traces); the program itself follows `--` (python3 bench.py ...), no wrapper in between.
@@ -9,7 +9,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 5 --warmup 2 --no-cpu-baseline --bond-dim $D --T $T --batch-per-gpu $B $*"
+ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-other-configs --bond-dim $D --T $T --batch-per-gpu $B $*"
 echo "python3 bench.py $ARGS" > $OUT/command.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py $ARGS > $OUT/trace.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE \

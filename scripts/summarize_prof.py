@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condense the rocprofv3 output of scripts/profile_r2.sh into the two files committed under profiles/:
+"""Condense the rocprofv3 output of scripts/profile_scan.sh into the two files committed under profiles/:
    <tag>_kernel_stats.csv  (the --kernel-trace --stats table, verbatim)
    <tag>_pmc_summary.json  (per-kernel averages of every collected counter + derived per-clip-step figures).
 usage: summarize_prof.py SRC_DIR TAG D T B
@@ -18,7 +18,8 @@ os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 stats = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))
 if stats:
     shutil.copy(stats[0], os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"))
-SCAN = ("k_fwd_wave", "k_bwd_wave", "k_fwd_pair", "k_bwd_pair", "k_grad_pair", "k_fwd_block", "k_bwd_block")
+SCAN = ("k_fwd_wave", "k_bwd_wave", "k_fwd_pair", "k_bwd_pair", "k_grad_pair", "k_fwd_block", "k_bwd_block", "k_fwd_wide", "k_bwd_wide",
+        "k_grad_wide", "k_apply_step", "k_reduce_slabs", "k_reduce_parts", "k_finalize", "k_pack", "k_rho_raw", "k_rho_fix")
 acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(src, "pmc_*", "*", "*counter_collection.csv")):
     per_dispatch = defaultdict(float)
@@ -30,7 +31,7 @@ for f in glob.glob(os.path.join(src, "pmc_*", "*", "*counter_collection.csv")):
     for (name, _, cname), v in per_dispatch.items():
         acc[name][cname].append(v)
 cmd = open(os.path.join(src, "command.txt")).read().strip() if os.path.exists(os.path.join(src, "command.txt")) else "python3 bench.py"
-out = {"command": cmd + "  (rocprofv3 --kernel-trace [--pmc ...] -- <that>, one pass per counter group; scripts/profile_r2.sh, "
+out = {"command": cmd + "  (rocprofv3 --kernel-trace [--pmc ...] -- <that>, one pass per counter group; scripts/profile_scan.sh, "
                         "condensed by scripts/summarize_prof.py)",
        "workload": f"D={D}, T={T}, B={B} ({B * N / 1e6:.2f}M clip-steps per launch)", "kernels": {}}
 for name, counters in acc.items():
@@ -43,7 +44,8 @@ for name, counters in acc.items():
             d[f"{key}_insts_per_clip_step"] = k[c] / steps
     if "SQ_WAVE_CYCLES" in k:
         d["wave_cycles_per_clip_step"] = k["SQ_WAVE_CYCLES"] * 4 / steps      # all waves of a clip together
-    for c, key in (("SQ_WAIT_ANY", "wait_any"), ("SQ_WAIT_INST_ANY", "wait_inst_any"), ("SQ_ACTIVE_INST_ANY", "active_inst_any")):
+    for c, key in (("SQ_WAIT_ANY", "wait_any"), ("SQ_WAIT_INST_ANY", "wait_inst_any"), ("SQ_ACTIVE_INST_ANY", "active_inst_any"),
+                   ("SQ_ACTIVE_INST_VALU", "active_inst_valu")):
         if c in k:
             d[f"{key}_cycles_per_clip_step"] = k[c] * 4 / steps
     if "SQ_VALU_MFMA_BUSY_CYCLES" in k:

@@ -99,6 +99,20 @@ def test_oracle_parity(D, T, B, sigma, variant):
     _check_against_oracle(m, audio)
 
 
+@pytest.mark.parametrize("kind", ["damped_sine", "damped_sine_noise", "bandlimited"])
+@pytest.mark.parametrize("D,T,B", [(32, 4000, 8), (16, 2048, 8), (64, 1200, 4)])
+def test_input_distributions(kind, D, T, B):
+    """SURVEY 8(d)'s inputs (bench.py --input): the reference's pure damped sine (data.py:8-22: silent before the onset), the same
+    with white noise, and the band-limited random walk 0.1 cumsum(N(0,1)) / sqrt(T), each against the oracle."""
+    from audio_mps_amd import HParams, PsiCMPS
+    from audio_mps_amd.data import synthetic_audio
+    hp = HParams(minibatch_size=B, bond_dim=D)
+    audio = synthetic_audio(kind, B, T, hp.delta_t, seed=D)
+    assert audio.dtype == np.float32 and audio.shape == (B, T) and np.max(np.abs(audio)) <= 1.2
+    m = PsiCMPS(hp, data_iterator=audio, seed=1, backend=_scan(D, 0))
+    _check_against_oracle(m, audio)
+
+
 @pytest.mark.parametrize("T", [2, 3, 64, 65, 66, 129, 193])
 def test_chunk_boundaries(T):
     """T - 1 steps around the 64-step chunking of the wave kernels (1, 2, 63, 64, 65, 128, 192 steps)."""

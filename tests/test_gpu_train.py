@@ -35,6 +35,64 @@ def test_trainer_tracks_oracle_trainer(tmp_path):
     assert t2.step()["total_loss"] == pytest.approx(t_hip.step()["total_loss"], rel=1e-6)
 
 
+@pytest.mark.parametrize("D,given", [(8, False), (16, False), (32, False), (12, True), (64, False)])
+def test_device_step_matches_host_trainer(D, given):
+    """cmps_psi_apply_step (chain rule of model.py:36-42, 49, 221-222 + regularisers train.py:55-60 + Adam train.py:89, all on the
+    device, no D2H inside a step) against the host implementation of the same half (model.chain_rule + AdamOptimizer), both on the
+    HIP scan: the same trajectory to 1e-6 over 20 steps, the same variables and Adam slots afterwards.  `given`: R_in / freqs_in
+    supplied (no rsqrt(reg) scaling, model.py:31-33, 44-46)."""
+    from audio_mps_amd import HParams, PsiCMPS
+    from audio_mps_amd.scan import HipScan
+    from audio_mps_amd.train import Trainer
+    hp = HParams(minibatch_size=6, bond_dim=D, learning_rate=0.01)
+    data = make_audio(6, 260, hp.delta_t, 5)
+    kw = {}
+    if given:
+        rng = np.random.default_rng(1)
+        kw = {"R_in": (0.3 * (rng.standard_normal((D, D)) + 1j * rng.standard_normal((D, D)))).astype(np.complex64),
+              "freqs_in": (100.0 * rng.standard_normal(D)).astype(np.float32)}
+    m_dev = PsiCMPS(hp, data_iterator=data, seed=0, backend=HipScan(D), **kw)
+    m_host = PsiCMPS(hp, data_iterator=data, seed=0, backend=HipScan(D), **kw)
+    if D > 32:
+        for m in (m_dev, m_host):
+            m.variables["Rx"] *= np.float32(0.5)
+            m.variables["Ry"] *= np.float32(0.5)
+    t_dev, t_host = Trainer(m_dev, hp, device_step=True), Trainer(m_host, hp)
+    hist = np.array([[t_dev.step()[k] for k in ("model_loss", "total_loss")] + [t_host.step()[k] for k in ("model_loss", "total_loss")]
+                     for _ in range(20)])
+    assert np.all(np.isfinite(hist))
+    np.testing.assert_allclose(hist[:, 0], hist[:, 2], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(hist[:, 1], hist[:, 3], rtol=1e-6, atol=1e-6)
+    assert hist[-1, 1] < hist[0, 1]
+    t_dev.sync_to_host()
+    for k in ("A", "Rx", "Ry", "freqs", "psi_x", "psi_y"):
+        np.testing.assert_allclose(m_dev.variables[k], m_host.variables[k], rtol=2e-5, atol=2e-6, err_msg=k)
+        np.testing.assert_allclose(t_dev.opt.m[k], t_host.opt.m[k], rtol=1e-3, atol=1e-9 + 1e-5 * np.max(np.abs(t_host.opt.m[k])), err_msg=k)
+    # sync=False keeps everything on the device: the losses come back as a device tensor, the step count advances
+    out = t_dev.step(sync=False)
+    assert "losses_dev" in out and out["losses_dev"].is_cuda and out["global_step"] == 21
+    # checkpoint of the device-resident state -> a host-path trainer continues the same trajectory
+    assert float(out["losses_dev"].cpu()[1]) == pytest.approx(t_host.step()["total_loss"], rel=1e-6, abs=1e-6)
+
+
+def test_empty_shard_contributes_zeros():
+    """A rank whose shard of a short final batch is empty skips the scan and adds zeros to the all-reduce (both optimiser paths)."""
+    from audio_mps_amd import HParams, PsiCMPS
+    from audio_mps_amd.scan import HipScan
+    from audio_mps_amd.train import Trainer
+    hp = HParams(minibatch_size=4, bond_dim=8, learning_rate=0.01)
+    data = make_audio(4, 100, hp.delta_t, 1)
+    for dev_step in (False, True):
+        m = PsiCMPS(hp, data_iterator=data, seed=0, backend=HipScan(8))
+        t = Trainer(m, hp, device_step=dev_step)
+        t.step()
+        before = {k: v.copy() for k, v in (t.sync_to_host() or m.variables).items()}
+        out = t.step(data[:0], global_batch=4)                       # nothing local: the update comes from the regularisers alone
+        t.sync_to_host()
+        assert out["model_loss"] == 0.0 and np.isfinite(out["total_loss"])
+        assert any(not np.array_equal(before[k], m.variables[k]) for k in before)
+
+
 def test_train_main_on_tfrecords(tmp_path):
     """train.py on a TFRecord dataset (data.py:25-43: batch -> shuffle(24) -> repeat, built once, get_next per step):
     `python -m audio_mps_amd.train --dataset guitar` for 3 steps on the HIP scan, against the same main() driven by the
