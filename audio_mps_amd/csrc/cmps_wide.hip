@@ -241,7 +241,11 @@ __global__ __launch_bounds__(4 * PD) void k_fwd_wide(Dev P, const float* __restr
 
     for (int k = 0; k <= N + 1; ++k) {
         const int p = k & 1;
+#if defined(CMPS_DIAG) && defined(WABL_NO_LOSSMV)    // diagnostic builds only (results are wrong): what the loss product costs
+        const bool chain = k < N, lossmv = false;
+#else
         const bool chain = k < N, lossmv = k >= 1 && k <= N;
+#endif
         if (chain && (k & (WCH - 1)) == 0) {                      // increments of the next 64 steps, one per lane (model.py:263, 303)
             const int idx = k + lane;
             const bool in0 = idx < T, in1 = idx + 1 < T;

@@ -80,7 +80,7 @@ def test_pair_variant_rules():
     with pytest.raises(_capi.CmpsError) as ei:
         HipScan(16, variant=PAIR)                      # the MFMA pair kernels are for 32 < D <= 128
     assert ei.value.code == _capi.CMPS_ERR_UNSUPPORTED_D
-    assert HipScan(128).variant == 1 and HipScan(64).variant == 1   # AUTO stays float32: the bf16-operand path is opt-in
+    assert HipScan(128).variant == 5 and HipScan(64).variant == 5   # AUTO stays float32 (the wide kernels): the bf16-operand path is opt-in
 
 
 @pytest.mark.parametrize("D,B", [(128, 3), (72, 2)])
