@@ -138,6 +138,16 @@ __device__ __forceinline__ void stage16_load(const float4* __restrict__ tab, int
     }
 }
 
+// In-kernel stamps of the serial chains (diagnostic builds only: -DCMPS_DIAG -DW16_TIMING, scripts/stamps_c2.py): s_memtime at
+// the phase boundaries of a chain step, pinned behind the value that ends the phase; block 0 prints the averages.
+#if defined(CMPS_DIAG) && defined(W16_TIMING)
+#define W16_STAMP(T_, DEP_) { asm volatile("" : "+v"(DEP_)); T_ = __builtin_readcyclecounter(); }
+#define W16_ON 1
+#else
+#define W16_STAMP(T_, DEP_)
+#define W16_ON 0
+#endif
+
 struct Pre16 {
     float yh, yho, yhp, un, uno, pre;
     v2f rho;
@@ -201,6 +211,10 @@ __global__ __launch_bounds__(128, 1) void k_fwd_wave16(Dev P, const float* __res
         }
         FORM_M16(rdlane(sv, 0))
         bcast16_tab(aUw, aUr, u, aRho, qu, rho);
+#if W16_ON
+        unsigned long long tA = 0, tB = 0, tC = 0, accWait = 0, accMv = 0, accTail = 0, accN = 0;
+        const unsigned long long tStart = __builtin_readcyclecounter();
+#endif
         for (int c = 0; c < NC2; ++c) {
             const int kbeg = c * CH16;
             const int cnt = (N - kbeg) < CH16 ? (N - kbeg) : CH16;
@@ -216,11 +230,16 @@ __global__ __launch_bounds__(128, 1) void k_fwd_wave16(Dev P, const float* __res
             unsigned ay = aYw + (c & 1) * (CH16 * 128);
             for (int kk = 0; kk < cnt; ++kk) {
                 wait16_t<0>(qu, rho);
+                W16_STAMP(tA, qu[1])
+#if W16_ON
+                if (tC) { accWait += tA - tC; ++accN; }
+#endif
                 float tot;
                 const v2f am = mv16r(MM, qu, xsq, tot);                // tot = 2 |y_{k-1}|^2
                 const float nprev = 0.5f * tot;
                 const float inv = __builtin_amdgcn_rsqf(fmaxf(nprev, 1e-12f));     // model.py:332
-                const float y = inv * (u + combine16(am.x, am.y));
+                float y = inv * (u + combine16(am.x, am.y));
+                W16_STAMP(tB, y)
                 lds_write32(ay, y);
                 ay += 128;
                 const float yo = osig_of(y, hb);
@@ -234,7 +253,14 @@ __global__ __launch_bounds__(128, 1) void k_fwd_wave16(Dev P, const float* __res
                 if (SAVE && kk == 0 && c > 0 && lane < CH16) {
                     sc[(size_t)((c - 1) >> 1) * 128 + ((c - 1) & 1) * CH16 + lane] = nvec;
                 }
+                W16_STAMP(tC, xsq)
+#if W16_ON
+                accMv += tB - tA; accTail += tC - tB;
+#endif
             }
+#if W16_ON
+            tC = 0;                                                    // the chunk hand-over is not a step
+#endif
             wait16_t<0>(qu, rho);                                      // everything of this chunk has landed
             flag_store16(aProd, c + 1, lane);                          // publish (ordered behind the chunk's y rows)
             if (c + 1 < NC2) {
@@ -245,6 +271,15 @@ __global__ __launch_bounds__(128, 1) void k_fwd_wave16(Dev P, const float* __res
             }
         }
 #undef FORM_M16
+#if W16_ON
+        if (blockIdx.x == 0 && lane == 0) {
+            const unsigned long long tEnd = __builtin_readcyclecounter();
+            printf("k_fwd_wave16 chain wave, cycles per step (%llu stamped steps of %d; whole loop %.1f per step incl. chunk hand-overs): "
+                   "tail end -> broadcast landed (LDS write -> read round trip, exposed) %.1f | mat-vec + wave reduction + normalisation -> y %.1f | "
+                   "y -> rotation, LDS write + reads issued, M_k formed %.1f\n", accN, N, (double)(tEnd - tStart) / N,
+                   (double)accWait / accN, (double)accMv / accN, (double)accTail / accN);
+        }
+#endif
         if (SAVE) {                                                    // |y_{N-1}|^2 closes the last row
             const float nlast = 0.5f * sum64(xsq);
             const int cl = NC2 - 1;
@@ -441,11 +476,19 @@ __global__ __launch_bounds__(128, 1) void k_bwd_wave16(Dev P, const float* __res
         const float2 p0 = P.psi0[i];
         const float u0 = hb ? p0.y : p0.x;
         float rad_next = 0.f;
+#if W16_ON
+        unsigned long long bA = 0, bB = 0, bC = 0, bD = 0, bHead = 0, bShadow = 0, bMv = 0, bTail2 = 0, bN = 0;
+        const unsigned long long bStart = __builtin_readcyclecounter();
+#endif
         // one step of the serial chain (see cmps_wave.hip / the header of cmps_block.hip for the adjoint); ring row 0 of slot
         // KS holds ybar interleaved (re, im) per component = the broadcast source; rows 1, 2 (yhat_k, u_k) one float per lane
         auto chain_step = [&](const Pre16& S, float uk, auto have_pre, bool exact, auto kslot, unsigned aW, unsigned aR,
                               unsigned aL) -> Pre16 {
             constexpr int OFF = decltype(kslot)::value * BSLOT;
+            W16_STAMP(bA, g)
+#if W16_ON
+            if (bD) { bTail2 += bA - bD; }
+#endif
             facc += S.dtk * (go * S.un);
             const v2f yhbp = cmul2_conj_b(mk2(g, go), S.rho);              // conj(rho_k) g
             const float yhb = yhbp.x;
@@ -455,6 +498,7 @@ __global__ __launch_bounds__(128, 1) void k_bwd_wave16(Dev P, const float* __res
             const float ybar = (yhb - dot * S.yhp) * S.inv + S.pre;
             write16_off<OFF + BROW>(aL, S.yh);                             // 1 op
             ring16_bcast<OFF>(aW, aR, ybar, qc);                           // 3 ops
+            W16_STAMP(bB, MM[0])
             {   // M_k = Q + s_k R^dagger, in the shadow of the broadcast
                 const v2f s2 = mk2(S.s, S.s);
 #pragma unroll
@@ -468,11 +512,16 @@ __global__ __launch_bounds__(128, 1) void k_bwd_wave16(Dev P, const float* __res
             }
             write16_off<OFF + 2 * BROW>(aL, uk);                           // 1 op
             wait16<1>(qc);
+            W16_STAMP(bC, qc[1])
             const v2f am = mv16(MM, qc);
             const float md = combine16(am.x, am.y);
             accS += md * uk;
             g = ybar + md;
             go = osig_of(g, hb);
+            W16_STAMP(bD, go)
+#if W16_ON
+            bHead += bB - bA; bShadow += bC - bB; bMv += bD - bC; ++bN;
+#endif
             return Sn;
         };
         const unsigned aWb = aRing + i * 8 + hq * 4, aRb = aRing + q * 32, aLb = aRing + lane * 4;
@@ -529,6 +578,15 @@ __global__ __launch_bounds__(128, 1) void k_bwd_wave16(Dev P, const float* __res
             wait16<0>(qc);
             flag_store16(aProd, otop + 1, lane);
         }
+#if W16_ON
+        if (blockIdx.x == 0 && lane == 0) {
+            const unsigned long long bEnd = __builtin_readcyclecounter();
+            printf("k_bwd_wave16 chain wave, cycles per step (%llu steps; whole loop %.1f per step): g -> conj(rho) g, ybar, LDS write + reads "
+                   "issued %.1f | M_k formed, next step's rows decoded (in the shadow of the broadcast) -> broadcast landed %.1f | mat-vec + "
+                   "combine -> g %.1f | between steps (row prefetch issue, staging, octet hand-over) %.1f\n", bN,
+                   (double)(bEnd - bStart) / bN, (double)bHead / bN, (double)bShadow / bN, (double)bMv / bN, (double)bTail2 / bN);
+        }
+#endif
         const float sumS = 0.5f * sum64(accS);                // every component is held twice
         const float sumA = sum64(accA);                       // one step per lane: no duplication
         const float ftot = swapadd(facc, facc);               // half 0: f(Re lane) + f(Im lane)
