@@ -142,7 +142,8 @@ struct WideGeom {
     static constexpr int KC = PD / 8;           // columns per lane
     static constexpr int VSL = KC + 1;          // float4 per K slice of a broadcast vector (one float4 of padding: bank spread)
     static constexpr int VEC4 = 8 * VSL;        // float4 per broadcast vector
-    static constexpr size_t FWD_LDS = ((size_t)NW * KC * 64 + 4 * VEC4) * 16 + 2 * 2 * NW * 2 * 4;
+    static constexpr size_t FWD_LDS = ((size_t)NW * KC * 64 + 4 * VEC4) * 16 + 2 * 2 * NW * 2 * 4;     // loss in the kernel
+    static constexpr size_t FWD_LDS_CHAIN = ((size_t)2 * VEC4) * 16 + 2 * NW * 2 * 4;                     // chain only (SAVE)
 };
 // float4 index (and float offset inside it) of this lane's own value in a broadcast vector
 template <int PD>
@@ -159,6 +160,25 @@ template <int PD>
 __device__ __forceinline__ size_t wide_ybar_vec(size_t pair, int N, int step) {
     return (pair * N + step) * (size_t)(4 * PD);
 }
+
+constexpr int GU = 4;       // steps per unit
+
+// x = hi + mid + lo exactly, each with 8 significant bits: returned as bf16 bit patterns in the upper halves
+__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
+    h = __float_as_uint(x) & 0xFFFF0000u;
+    const float r1 = x - __uint_as_float(h);
+    m = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(m);
+    l = __float_as_uint(r2);                        // <= 8 significant bits: exact in bf16 (the low half is zero)
+}
+__device__ __forceinline__ unsigned pack_hi16(unsigned lo_word, unsigned hi_word) {   // (lo_word >> 16) | (hi_word & 0xFFFF0000)
+    return __builtin_amdgcn_perm(hi_word, lo_word, 0x07060302u);
+}
+__device__ __forceinline__ bf8w piece_bits(u4w v, unsigned mask) {
+    u4w t = {v.x ^ mask, v.y ^ mask, v.z ^ mask, v.w ^ mask};
+    return __builtin_bit_cast(bf8w, t);
+}
+
 
 // per-step scalars of one clip from what the forward stashed (|y_k|^2, e_k) and the audio, in the reference's operation order
 // (model.py:294, 303); shared by the reverse scan and the gradient kernel so that both see the same numbers
@@ -182,16 +202,21 @@ __device__ __forceinline__ StepScal step_scalars(float inc, float nv, float ev, 
 // ------------------------------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------------------------------
+// SAVE = false (loss only, no stash in the workspace): the loss product H y_{k-1} runs inside the kernel, on the VALU, H in LDS.
+// SAVE = true (training): the kernel is the serial chain alone -- it stashes y_k and |y_k|^2 -- and H y, e_k = y_k . H y_k and
+// the loss follow as a GEMM over all (clip, step) pairs at once (k_hy_wide, k_loss_wide below): the in-kernel product costs
+// 128 of the 320 packed FMAs a wave issues per step (38 of 62 ms at configs[4]), the GEMM runs them on the matrix cores.
 template <int PD, bool SAVE>
 __global__ __launch_bounds__(4 * PD) void k_fwd_wide(Dev P, const float* __restrict__ audio, float* __restrict__ loss_out) {
     using G = WideGeom<PD>;
     constexpr int NW = G::NW, KC = G::KC, VSL = G::VSL, VEC4 = G::VEC4;
+    constexpr bool LOSS = !SAVE;                                  // the loss product in this kernel
     extern __shared__ __attribute__((aligned(16))) unsigned char wide_lds[];
-    v4f* Hl = reinterpret_cast<v4f*>(wide_lds);                   // [NW][KC][64]: H in lane order
-    v4f* uvec = Hl + NW * KC * 64;                                // [2][VEC4]
-    v4f* yvec = uvec + 2 * VEC4;                                  // [2][VEC4]
-    float* nrm = reinterpret_cast<float*>(yvec + 2 * VEC4);       // [2][NW][2]
-    float* ee = nrm + 2 * NW * 2;                                 // [2][NW][2]
+    v4f* Hl = reinterpret_cast<v4f*>(wide_lds);                   // [NW][KC][64]: H in lane order (LOSS only)
+    v4f* uvec = LOSS ? Hl + NW * KC * 64 : Hl;                    // [2][VEC4]
+    v4f* yvec = uvec + 2 * VEC4;                                  // [2][VEC4] (LOSS only)
+    float* nrm = reinterpret_cast<float*>(LOSS ? yvec + 2 * VEC4 : uvec + 2 * VEC4);       // [2][NW][2]
+    float* ee = nrm + 2 * NW * 2;                                 // [2][NW][2] (LOSS only)
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int q = lane >> 3, i = lane & 7;
     const int rowsel = q >> 2, comp = (q >> 1) & 1, clip = q & 1;
@@ -217,7 +242,7 @@ __global__ __launch_bounds__(4 * PD) void k_fwd_wide(Dev P, const float* __restr
         }
         // H = R + R^dagger in lane order: float4 number rs KC/2 + jp of this lane = H[row_rs][c0 + 2 jp], H[row_rs][c0 + 2 jp + 1]
 #pragma unroll
-        for (int rr = 0; rr < KC; ++rr) {
+        for (int rr = 0; LOSS && rr < KC; ++rr) {
             const int rs = rr / (KC / 2), jp = rr % (KC / 2), r_ = rs ? rb : ra, c_ = c0 + 2 * jp;
             const float2 x0 = P.R[(size_t)r_ * PD + c_], x1 = P.R[(size_t)r_ * PD + c_ + 1];
             const float2 t0 = P.RT[(size_t)r_ * PD + c_], t1 = P.RT[(size_t)r_ * PD + c_ + 1];   // RT[i][j] = R[j][i]
@@ -239,12 +264,12 @@ __global__ __launch_bounds__(4 * PD) void k_fwd_wide(Dev P, const float* __restr
     float2 rho_next = P.rho[row];                                 // rho_0
     __syncthreads();
 
-    for (int k = 0; k <= N + 1; ++k) {
+    for (int k = 0; k <= (LOSS ? N + 1 : N); ++k) {
         const int p = k & 1;
 #if defined(CMPS_DIAG) && defined(WABL_NO_LOSSMV)    // diagnostic builds only (results are wrong): what the loss product costs
         const bool chain = k < N, lossmv = false;
 #else
-        const bool chain = k < N, lossmv = k >= 1 && k <= N;
+        const bool chain = k < N, lossmv = LOSS && k >= 1 && k <= N;
 #endif
         if (chain && (k & (WCH - 1)) == 0) {                      // increments of the next 64 steps, one per lane (model.py:263, 303)
             const int idx = k + lane;
@@ -289,7 +314,7 @@ __global__ __launch_bounds__(4 * PD) void k_fwd_wide(Dev P, const float* __restr
             const float y = inv * (ut + acc);                     // y_k = inv_{k-1} (ut + M_k ut)
             const float nn = clip_wave_sum(y * y);
             if (i == 0 && q < 2) nrm[((p ^ 1) * NW + w) * 2 + clip] = nn;
-            reinterpret_cast<float*>(yvec + (p ^ 1) * VEC4)[own_f] = y;
+            if (LOSS) reinterpret_cast<float*>(yvec + (p ^ 1) * VEC4)[own_f] = y;
             const float py = partner16(y, im_lane);
             ut = rho_k.x * y + (im_lane ? rho_k.y : -rho_k.y) * py;      // ut_{k+1} = rho_k y_k (un-normalised)
             reinterpret_cast<float*>(uvec + (p ^ 1) * VEC4)[own_f] = ut;
@@ -307,7 +332,7 @@ __global__ __launch_bounds__(4 * PD) void k_fwd_wide(Dev P, const float* __restr
             if (i == 0 && q < 2) ee[((p ^ 1) * NW + w) * 2 + clip] = ep;
             if (SAVE) stash[wide_stash_vec<PD>(blockIdx.x, N, k - 1, 1) + pos] = hy;
         }
-        if (w == 0) {                                             // bookkeeping: e_{k-2}, |y_{k-1}|^2, the loss (sequential float32)
+        if (w == 0 && LOSS) {                                     // bookkeeping: e_{k-2}, |y_{k-1}|^2, the loss (sequential float32)
             if (k >= 2) {
                 const int ke = k - 2;
                 float e0 = 0.f, e1 = 0.f;
@@ -323,14 +348,6 @@ __global__ __launch_bounds__(4 * PD) void k_fwd_wide(Dev P, const float* __restr
                     const float i0 = in ? xr0[idx + 1] - xr0[idx] : 0.f, i1 = in ? xr1[idx + 1] - xr1[idx] : 0.f;
                     const float l0 = in ? -logf(1.0f + (ebuf0 * i0) / A) : 0.f;        // model.py:294 operation order
                     const float l1 = in ? -logf(1.0f + (ebuf1 * i1) / A) : 0.f;
-                    if (SAVE && in) {
-                        float* sc0 = P.scal + ((size_t)b0 * NC + c) * 128;
-                        sc0[lane] = nbuf0; sc0[64 + lane] = ebuf0;
-                        if (two) {
-                            float* sc1 = P.scal + ((size_t)b1 * NC + c) * 128;
-                            sc1[lane] = nbuf1; sc1[64 + lane] = ebuf1;
-                        }
-                    }
 #pragma unroll
                     for (int j = 0; j < WCH; ++j) {               // model.py:279: sequential in time
                         loss0 += wrdl(l0, j);
@@ -338,14 +355,223 @@ __global__ __launch_bounds__(4 * PD) void k_fwd_wide(Dev P, const float* __restr
                     }
                 }
             }
-            if (k >= 1 && lane == ((k - 1) & (WCH - 1))) { nbuf0 = n0; nbuf1 = n1; }
+        }
+        if (w == 0 && SAVE && k >= 1) {                           // |y_{k-1}|^2 rows of the scalar stash, one chunk per 64 steps
+            const int kn = k - 1;
+            if (lane == (kn & (WCH - 1))) { nbuf0 = n0; nbuf1 = n1; }
+            if ((kn & (WCH - 1)) == WCH - 1 || kn == N - 1) {
+                const int c = kn / WCH;
+                if (c * WCH + lane < N) {
+                    P.scal[((size_t)b0 * NC + c) * 128 + lane] = nbuf0;
+                    if (two) P.scal[((size_t)b1 * NC + c) * 128 + lane] = nbuf1;
+                }
+            }
         }
         wide_barrier();
     }
-    if (w == 0 && lane == 0) {
+    if (LOSS && w == 0 && lane == 0) {
         loss_out[b0] = loss0;
         if (two) loss_out[b1] = loss1;
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// H y_k, e_k = y_k . (H y_k) for every (clip, step) at once (training forward, after the chain kernel has stashed y_k):
+//   Re(H y) = [H_re | -H_im] [y_re; y_im],   Im(H y) = [H_re | -H_im] [y_im; -y_re]
+// as v_mfma_f32_32x32x16_bf16 GEMMs, A = the real form of H (32 rows per wave, K = 2 PD, split EXACTLY into three bf16 pieces once
+// per workgroup and kept in registers), B = 32 columns (step of an 8-step unit, clip, {Re, Im} form) split the same way on the
+// fly; the six significant piece products give an fp32-faithful H y (24 operand bits, fp32 accumulate).  One workgroup per
+// (pair, 512-step chunk): nothing here is serial in time.  Writes the H y half of the stash (lane order) and e_k into the
+// scalar stash; k_loss_wide then accumulates -log(1 + e x / A) sequentially in float32 (model.py:279, 294).
+// ------------------------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int HU = 8;                      // steps per unit (32 MFMA columns)
+constexpr int HCHUNK = 512;                // steps per workgroup
+
+template <int PD>
+struct HyGeom {
+    static constexpr int PROW = 2 * PD + 16;                      // bytes of one (step, clip, component) row of bf16 + bank-spread padding
+    static constexpr int PIECE = HU * 4 * PROW;                   // bytes of one piece of one unit: [step][clip][comp] rows
+    static constexpr int FROW = PD + 4;                           // floats of one float32 row + padding
+    static constexpr int FBUF = HU * 4 * FROW;                    // floats of one float32 unit buffer
+    static constexpr size_t LDS = (size_t)2 * 3 * PIECE + (size_t)4 * FBUF * 4 + 2 * (PD / 32) * 16 * 4;
+};
+
+}  // namespace
+
+template <int PD>
+__global__ __launch_bounds__(2 * PD, 1) void k_hy_wide(Dev P) {
+    using HG = HyGeom<PD>;
+    constexpr int PWV = PD / 32, NTHR = 2 * PD, KT = 2 * PD / 16, PROW = HG::PROW, PIECE = HG::PIECE, FROW = HG::FROW, FBUF = HG::FBUF;
+    extern __shared__ __attribute__((aligned(16))) unsigned char wide_lds[];
+    unsigned char* pcs = wide_lds;                                          // [2 buffers][3 pieces][PIECE]
+    float* yf = reinterpret_cast<float*>(wide_lds + 2 * 3 * PIECE);         // [2][FBUF]: y, float32
+    float* hf = yf + 2 * FBUF;                                              // [2][FBUF]: H y, float32
+    float* eacc = hf + 2 * FBUF;                                            // [2][PWV][16]
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int N = P.N, NC = (N + WCH - 1) / WCH;
+    const int b0 = 2 * blockIdx.x, b1 = (b0 + 1 < P.B) ? b0 + 1 : b0;
+    const bool two = b1 != b0;
+    const int k_lo = blockIdx.y * HCHUNK, k_hi = (k_lo + HCHUNK < N) ? k_lo + HCHUNK : N;
+    const int NU = (k_hi - k_lo + HU - 1) / HU;
+    float* stash = reinterpret_cast<float*>(P.stash);
+    const int mr = lane & 31, mh = lane >> 5;
+    // this lane's column of a unit: (step, clip, form)
+    const int cs = mr >> 2, cc = (mr >> 1) & 1, cf = mr & 1;
+
+    // ---- A operand: row 32 w + mr of [H_re | -H_im], K values 16 t + 8 mh .. + 7, three bf16 pieces ----
+    bf8w Ah[KT], Am[KT], Al[KT];
+    {
+        const int row = 32 * w + mr;
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+            unsigned ph[4], pm[4], pl[4];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = 16 * t + 8 * mh + e, part = k / PD, j = k % PD;
+                const float2 r = P.R[(size_t)row * PD + j], rt = P.RT[(size_t)row * PD + j];    // RT[i][j] = R[j][i]
+                const float v = part == 0 ? r.x + rt.x : -(r.y - rt.y);                          // H = R + R^dagger
+                unsigned h, m, l;
+                split3(v, h, m, l);
+                if (e & 1) {
+                    ph[e >> 1] = __builtin_amdgcn_perm(h, ph[e >> 1], 0x07060302u);
+                    pm[e >> 1] = __builtin_amdgcn_perm(m, pm[e >> 1], 0x07060302u);
+                    pl[e >> 1] = __builtin_amdgcn_perm(l, pl[e >> 1], 0x07060302u);
+                } else {
+                    ph[e >> 1] = h; pm[e >> 1] = m; pl[e >> 1] = l;
+                }
+            }
+            Ah[t] = __builtin_bit_cast(bf8w, u4w{ph[0], ph[1], ph[2], ph[3]});
+            Am[t] = __builtin_bit_cast(bf8w, u4w{pm[0], pm[1], pm[2], pm[3]});
+            Al[t] = __builtin_bit_cast(bf8w, u4w{pl[0], pl[1], pl[2], pl[3]});
+        }
+    }
+    // ---- prep role: positions tid and tid + 2 PD of a stash vector ----
+    const int pq = lane >> 3, pi = lane & 7;
+    const int pcomp = (pq >> 1) & 1, pclip = pq & 1;
+    const int prow0 = 16 * (tid >> 6) + 8 * (pq >> 2) + pi;
+
+    // y of unit u (steps k_lo + 8 u ..) -> bf16 pieces + float32 rows, buffer u & 1.  Unclamped loads: see k_grad_wide.
+    auto prep = [&](int u) {
+        const int kb = k_lo + HU * u;
+        unsigned char* pb = pcs + (size_t)(u & 1) * 3 * PIECE;
+        float* yb = yf + (size_t)(u & 1) * FBUF;
+#pragma unroll
+        for (int hp = 0; hp < 2; ++hp) {
+            const int pos = tid + hp * NTHR, prow = prow0 + hp * (PD / 2);
+            const float* src = stash + wide_stash_vec<PD>(blockIdx.x, N, 0, 0) + (ptrdiff_t)kb * (8 * PD) + pos;
+            float Y[HU];
+#pragma unroll
+            for (int j = 0; j < HU; ++j) Y[j] = src[(ptrdiff_t)j * (8 * PD)];
+#pragma unroll
+            for (int j = 0; j < HU; ++j) {
+                const float v = kb + j < k_hi ? Y[j] : 0.f;
+                unsigned h, m, l;
+                split3(v, h, m, l);
+                const int rowi = (j * 2 + pclip) * 2 + pcomp;
+                unsigned short* d = reinterpret_cast<unsigned short*>(pb + rowi * PROW) + prow;
+                d[0] = (unsigned short)(h >> 16);
+                *reinterpret_cast<unsigned short*>(reinterpret_cast<unsigned char*>(d) + PIECE) = (unsigned short)(m >> 16);
+                *reinterpret_cast<unsigned short*>(reinterpret_cast<unsigned char*>(d) + 2 * PIECE) = (unsigned short)(l >> 16);
+                yb[rowi * FROW + prow] = v;
+            }
+        }
+    };
+    // the tile of unit u, e partials, H y rows (float32) into hf
+    auto mac = [&](int u) {
+        const unsigned char* pb = pcs + (size_t)(u & 1) * 3 * PIECE;
+        f16w acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+            const int part = (16 * t) / PD, j0 = (16 * t) % PD + 8 * mh;
+            const int comp = part == 0 ? cf : 1 - cf;                  // Re form: [y_re; y_im]; Im form: [y_im; -y_re]
+            const unsigned neg = (part == 1 && cf == 1) ? 0x80008000u : 0u;
+            const unsigned char* src = pb + ((cs * 2 + cc) * 2 + comp) * PROW + j0 * 2;
+            const bf8w bh = piece_bits(*reinterpret_cast<const u4w*>(src), neg);
+            const bf8w bm = piece_bits(*reinterpret_cast<const u4w*>(src + PIECE), neg);
+            const bf8w bl = piece_bits(*reinterpret_cast<const u4w*>(src + 2 * PIECE), neg);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al[t], bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[t], bl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am[t], bm, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am[t], bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[t], bm, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[t], bh, acc, 0, 0, 0);
+        }
+        // C/D layout: column = lane & 31, rows (r & 3) + 8 (r >> 2) + 4 mh of this wave's 32
+        const int rowi = (cs * 2 + cc) * 2 + cf;
+        const float* yr = yf + (size_t)(u & 1) * FBUF + rowi * FROW + 32 * w + 4 * mh;
+        float* hr = hf + (size_t)(u & 1) * FBUF + rowi * FROW + 32 * w + 4 * mh;
+        float ep = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const v4f yv = *reinterpret_cast<const v4f*>(yr + 8 * g);
+            ep += yv.x * acc[4 * g] + yv.y * acc[4 * g + 1] + yv.z * acc[4 * g + 2] + yv.w * acc[4 * g + 3];
+            *reinterpret_cast<v4f*>(hr + 8 * g) = v4f{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+        }
+        ep = swap32_add(ep, ep);                                   // + the other row half
+        ep += wdpp<0xB1>(ep);                                      // + the other component (column ^ 1)
+        if (mh == 0 && cf == 0) eacc[((u & 1) * PWV + w) * 16 + (mr >> 1)] = ep;
+    };
+    // H y rows and e of unit u out to the stash (lane order: coalesced) / the scalar stash
+    auto writeout = [&](int u) {
+        const int kb = k_lo + HU * u;
+        const float* hb = hf + (size_t)(u & 1) * FBUF;
+#pragma unroll
+        for (int hp = 0; hp < 2; ++hp) {
+            const int pos = tid + hp * NTHR, prow = prow0 + hp * (PD / 2);
+            float* dst = stash + wide_stash_vec<PD>(blockIdx.x, N, 0, 1) + (ptrdiff_t)kb * (8 * PD) + pos;
+#pragma unroll
+            for (int j = 0; j < HU; ++j)
+                if (kb + j < k_hi) dst[(ptrdiff_t)j * (8 * PD)] = hb[((j * 2 + pclip) * 2 + pcomp) * FROW + prow];
+        }
+        if (tid < 16) {
+            const int j = tid >> 1, cl = tid & 1, k = kb + j;
+            float e = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < PWV; ++ww) e += eacc[((u & 1) * PWV + ww) * 16 + tid];
+            if (k < k_hi && (cl == 0 || two))
+                P.scal[((size_t)(cl ? b1 : b0) * NC + k / WCH) * 128 + 64 + (k & (WCH - 1))] = e;
+        }
+    };
+
+    prep(0);
+    __syncthreads();
+    for (int u = 0; u < NU; ++u) {
+        mac(u);
+        prep(u + 1);                    // (the unit behind the last one: zeros, into the idle buffer)
+        __syncthreads();
+        writeout(u);
+    }
+}
+
+// loss_b = sum_k -log(1 + (e_k x_k) / A), accumulated sequentially in float32 in time order (model.py:279, 294): one wavefront per
+// clip, the logarithms of 64 steps at a time (one step per lane), then 64 ordered adds
+__global__ __launch_bounds__(64) void k_loss_wide(Dev P, const float* __restrict__ audio, float* __restrict__ loss_out) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int N = P.N, NC = (N + WCH - 1) / WCH;
+    const float* xr = audio + (size_t)b * P.T;
+    const float* sc = P.scal + (size_t)b * NC * 128;
+    const float A = dev_A(P);
+    float loss = 0.f;
+    float en = lane < N ? sc[64 + lane] : 0.f, x0n = lane < N ? xr[lane] : 0.f, x1n = lane < N ? xr[lane + 1] : 0.f;
+    for (int c = 0; c < NC; ++c) {
+        const float e = en, inc = x1n - x0n;
+        const bool in = c * WCH + lane < N;
+        const int idx = (c + 1) * WCH + lane;
+        if (c + 1 < NC) {
+            en = idx < N ? sc[(size_t)(c + 1) * 128 + 64 + lane] : 0.f;
+            x0n = idx < N ? xr[idx] : 0.f;
+            x1n = idx < N ? xr[idx + 1] : 0.f;
+        }
+        const float lv = in ? -logf(1.0f + (e * inc) / A) : 0.f;
+#pragma unroll
+        for (int j = 0; j < WCH; ++j) loss += wrdl(lv, j);
+    }
+    if (lane == 0) loss_out[b] = loss;
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -539,24 +765,6 @@ __global__ __launch_bounds__(4 * PD) void k_bwd_wide(Dev P, const float* __restr
 // ------------------------------------------------------------------------------------------------------------------------
 namespace {
 
-constexpr int GU = 4;       // steps per unit
-
-// x = hi + mid + lo exactly, each with 8 significant bits: returned as bf16 bit patterns in the upper halves
-__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
-    h = __float_as_uint(x) & 0xFFFF0000u;
-    const float r1 = x - __uint_as_float(h);
-    m = __float_as_uint(r1) & 0xFFFF0000u;
-    const float r2 = r1 - __uint_as_float(m);
-    l = __float_as_uint(r2);                        // <= 8 significant bits: exact in bf16 (the low half is zero)
-}
-__device__ __forceinline__ unsigned pack_hi16(unsigned lo_word, unsigned hi_word) {   // (lo_word >> 16) | (hi_word & 0xFFFF0000)
-    return __builtin_amdgcn_perm(hi_word, lo_word, 0x07060302u);
-}
-__device__ __forceinline__ bf8w piece_bits(u4w v, unsigned mask) {
-    u4w t = {v.x ^ mask, v.y ^ mask, v.z ^ mask, v.w ^ mask};
-    return __builtin_bit_cast(bf8w, t);
-}
-
 }  // namespace
 
 template <int PD, int NPC>       // NPC = bf16 pieces per operand: 3 (six products, 24 bits) or 2 (three products, 16 bits)
@@ -709,8 +917,12 @@ __global__ __launch_bounds__(2 * PD, 1) void k_grad_wide(Dev P, const float* __r
     prep(0);
     __syncthreads();
     for (int u = 0; u < NU; ++u) {
-        if (u + 1 < NU) prep(u + 1);              // independent of this unit's MFMAs: the compiler interleaves the two streams
+        // mac first in program order: its LDS reads may alias prep's LDS writes as far as the compiler knows, so only this order
+        // lets prep's loads and arithmetic start under the MFMAs (21.4 -> 16.7 ms at configs[4]; forcing a finer interleave
+        // with sched_group_barrier made it slower: 26 ms).  prep is unconditional (one basic block); the unit behind the last one
+        // builds zeros from in-workspace rows (see prep) into the idle buffer.
         mac(u);
+        prep(u + 1);
         if ((u & (WCH / GU - 1)) == 1) build_tab(u / (WCH / GU) + 1);
         __syncthreads();
     }
@@ -742,13 +954,18 @@ static hipError_t wide_lds_attr(K kernel, size_t shm) {
 template <int PD>
 static hipError_t fwd_wide_t(const Dev& P, const float* audio, float* loss, bool save, hipStream_t s) {
     const unsigned nb = (unsigned)((P.B + 1) / 2);
-    const size_t shm = WideGeom<PD>::FWD_LDS;
     hipError_t e;
     if (save) {
+        // the serial chain, then H y / e_k for all (clip, step) pairs as one GEMM launch, then the sequential loss sums
+        const size_t shm = WideGeom<PD>::FWD_LDS_CHAIN, shm_hy = HyGeom<PD>::LDS;
         e = wide_lds_attr(k_fwd_wide<PD, true>, shm);
+        if (e == hipSuccess) e = wide_lds_attr(k_hy_wide<PD>, shm_hy);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((k_fwd_wide<PD, true>), dim3(nb), dim3(4 * PD), shm, s, P, audio, loss);
+        hipLaunchKernelGGL((k_hy_wide<PD>), dim3(nb, (unsigned)((P.N + HCHUNK - 1) / HCHUNK)), dim3(2 * PD), shm_hy, s, P);
+        hipLaunchKernelGGL(k_loss_wide, dim3((unsigned)P.B), dim3(64), 0, s, P, audio, loss);
     } else {
+        const size_t shm = WideGeom<PD>::FWD_LDS;
         e = wide_lds_attr(k_fwd_wide<PD, false>, shm);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((k_fwd_wide<PD, false>), dim3(nb), dim3(4 * PD), shm, s, P, audio, loss);

@@ -286,8 +286,9 @@ def executed_split(variant, D, rank1):
                         "what": "merged mat-vec on the VALU; rank-1 sums as exact fp32 MFMAs (16x16x4) on the gradient wave"}}
     if variant == V_WIDE:
         prod = 3 if rank1 == 1 else 6
-        return {"fwd": {"valu_fp32": 20, "mfma_fp32_equiv": 0, "mfma_products": 0, "eliminated": 4,
-                        "what": "merged (Q + s R) u 12 and H y 8, all fp32 v_pk_fma"},
+        return {"fwd": {"valu_fp32": 12, "mfma_fp32_equiv": 8, "mfma_products": 6, "eliminated": 4,
+                        "what": "k_fwd_wide: merged (Q + s R) u, fp32 v_pk_fma (8 + 4 forming it); k_hy_wide: H y for all (clip, step) pairs "
+                                "as a bf16x3-split GEMM; k_loss_wide: the sequential float32 loss sums"},
                 "bwd": {"valu_fp32": 12, "mfma_fp32_equiv": 24, "mfma_products": prod, "eliminated": 20,
                         "what": "k_bwd_wide: merged (Q + s R^dagger) ybar on the VALU; k_grad_wide: rank-1 sums as split-bf16 GEMMs"}}
     if variant == V_PAIR:
@@ -304,7 +305,7 @@ KERNEL_NAMES = {
                "k_bwd_wave16 (reverse scan, 16-row layout: chain wave + gradient wave)"),
     "pair": ("k_fwd_pair", "k_fwd_pair (forward scan: 4x4x4 bf16 MFMA chain waves + 32x32x16 loss waves, eight steps per tile)", "k_bwd_pair",
              "k_bwd_pair + k_grad_pair (reverse scan + streaming gradient GEMM)"),
-    "wide": ("k_fwd_wide", "k_fwd_wide (forward scan: float32 v_pk_fma mat-vecs, R / Q register resident, H in LDS)", "k_bwd_wide",
+    "wide": ("k_fwd_wide", "k_fwd_wide + k_hy_wide + k_loss_wide (float32 forward chain, R / Q register resident; H y as a split-bf16 GEMM)", "k_bwd_wide",
              "k_bwd_wide + k_grad_wide (float32 reverse scan + split-bf16 gradient GEMM)"),
     "block": ("k_fwd_block", "k_fwd_block", "k_bwd_block", "k_bwd_block"),
 }
