@@ -434,9 +434,8 @@ int cmps_rho_set_state(cmps_handle_t h, const float* phi_re_dev, const float* ph
     if (!phi_re_dev || !phi_im_dev || rank < 1 || B_max < 1 || T < 2)
         return fail(h, CMPS_ERR_BAD_ARG, "cmps_rho_set_state: bad argument");
     if (T > h->L.T) return fail(h, CMPS_ERR_BAD_ARG, "cmps_rho_set_state: T exceeds T of cmps_set_params (the per-step tables)");
+    if (rank > 128) return fail(h, CMPS_ERR_UNSUPPORTED_D, "cmps_rho_set_state: rank above 128");
     const size_t rD = (size_t)rank * h->D;
-    if (rD > ((flags & CMPS_WS_TRAIN) ? 5000u : 6500u))
-        return fail(h, CMPS_ERR_UNSUPPORTED_D, "cmps_rho_set_state: rank * D too large for the LDS-resident columns");
     if (!rho_workspace_dev) return fail(h, CMPS_ERR_WORKSPACE, "cmps_rho_set_state: null workspace");
     if (((uintptr_t)rho_workspace_dev & 255) != 0)
         return fail(h, CMPS_ERR_WORKSPACE, "cmps_rho_set_state: workspace must be 256-byte aligned");
@@ -455,6 +454,8 @@ int cmps_rho_set_state(cmps_handle_t h, const float* phi_re_dev, const float* ph
     W.scal = train ? reinterpret_cast<float*>(ws + RL.off_scal) : nullptr;
     W.p1 = (train && h->D <= 32) ? reinterpret_cast<float*>(ws + RL.off_p1) : nullptr;
     W.stash_layout = 0;
+    W.cols = rD > RHO_LDS_COLS_MAX ? reinterpret_cast<float2*>(ws + RL.off_cols) : nullptr;
+    W.cols_blocks = B_max;
     W.slabs = train ? reinterpret_cast<float*>(ws + RL.off_slabs) : nullptr;
     W.sums = train ? reinterpret_cast<float*>(ws + RL.off_sums) : nullptr;
     W.slab_floats = RL.slab_floats;
@@ -535,6 +536,8 @@ int cmps_rho_sample(cmps_handle_t h, const float* noise_dev, int n, int length, 
         return fail(h, CMPS_ERR_STATE, "cmps_rho_sample: call cmps_set_params and cmps_rho_set_state first");
     if (!noise_dev || !out_dev || n < 1 || length < 1) return fail(h, CMPS_ERR_BAD_ARG, "cmps_rho_sample: bad argument");
     if (length > h->L.N) return fail(h, CMPS_ERR_BAD_ARG, "cmps_rho_sample: length exceeds T - 1 of cmps_set_params");
+    if (h->W.cols && n > h->rho_B)
+        return fail(h, CMPS_ERR_WORKSPACE, "cmps_rho_sample: at this rank * D the columns live in the workspace: n must not exceed B_max");
     if (save_states && (!(h->rho_flags & CMPS_WS_TRAIN) || (size_t)n * length > (size_t)h->rho_B * (h->rho_T - 1)))
         return fail(h, CMPS_ERR_WORKSPACE, "cmps_rho_sample: save_states needs a CMPS_WS_TRAIN rho workspace with B_max*(T-1) >= n*length");
     // D <= 32 (rank <= 32): the row-array GEMM sampler, one wavefront per path (cmps_rho_mfma.hip); CMPS_VARIANT_BLOCK keeps the

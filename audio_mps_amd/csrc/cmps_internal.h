@@ -118,8 +118,12 @@ struct Dev {
 // ---------------------------------------------------------------------------------------------
 struct RhoLayout {
     int rank;
-    size_t off_phi0, off_stash, off_scal, off_slabs, off_sums, off_p1, total, slab_floats;
+    size_t off_phi0, off_stash, off_scal, off_slabs, off_sums, off_p1, off_cols, total, slab_floats;
 };
+
+// rank * D above which the block kernels' column arrays (4 rank D complex numbers in the reverse scan) no longer fit into 160 KB of
+// LDS and live in the workspace instead (RhoDev::cols): the reference's default rank = D (model.py:62-65) from D = 72 upwards
+constexpr size_t RHO_LDS_COLS_MAX = 5000;
 
 inline RhoLayout make_rho_layout(int D, int rank, int B, int T, int flags) {
     RhoLayout L{};
@@ -138,6 +142,9 @@ inline RhoLayout make_rho_layout(int D, int rank, int B, int T, int flags) {
         // D <= 32: sum_k 2 ebar_k Y^T Y (real 64 x 64 form, four C/D tiles per clip), accumulated by k_fwd_rho_mfma for the reverse scan
         L.off_p1 = o;    if (D <= 32) o = align256(o + (size_t)B * 4096 * sizeof(float));
     }
+    // column arrays of the block kernels when they do not fit into LDS: [B][4][rank][D] float2 (forward 2, sampler 3, reverse 4)
+    L.off_cols = o;
+    if (r * (size_t)D > RHO_LDS_COLS_MAX) o = align256(o + (size_t)B * 4 * r * D * sizeof(float2));
     L.total = o;
     return L;
 }
@@ -149,6 +156,8 @@ struct RhoDev {
     float* scal;         // [B][NC][2][64]: tr rho'_k and e_k, one step per lane (wave kernels)
     float* p1;           // [B][4][16][64]: the forward's part of Rbar (cmps_rho_mfma.hip), raw C/D tiles
     const float2* phi0;  // [rank][DP]
+    float2* cols;        // [cols_blocks][4][rank][D] column arrays of the block kernels when rank * D exceeds the LDS (else null)
+    int cols_blocks;
     float2* stash;       // [B][N][rank][DP]
     float* slabs;        // [B][slab]
     float* sums;         // [slab]

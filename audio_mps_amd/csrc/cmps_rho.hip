@@ -39,12 +39,15 @@ __device__ __forceinline__ float rblock_sum(float v, float* red) {
 // ------------------------------------------------------------------------------------------------
 template <int NT>
 __global__ __launch_bounds__(NT) void k_fwd_rho(Dev P, RhoDev W, const float* __restrict__ audio,
-                                                float* __restrict__ loss_out, int save) {
+                                                float* __restrict__ loss_out, int save, float2* gcols) {
     extern __shared__ float2 sh[];
     const int D = P.D, DP = P.DP, N = P.N, r = W.rank, rD = r * D;
-    float2* cur = sh;
-    float2* nxt = sh + rD;
-    float* red = reinterpret_cast<float*>(sh + 2 * rD);
+    // the column arrays live in LDS when they fit and in the workspace (RhoDev::cols, L1 / L2 resident) when they do not
+    // (rank * D above ~10000 here: the reference's default rank = D at D > 100, model.py:62-65)
+    float2* base = gcols ? gcols + (size_t)blockIdx.x * 4 * rD : sh;
+    float2* cur = base;
+    float2* nxt = base + rD;
+    float* red = reinterpret_cast<float*>(gcols ? sh : sh + 2 * rD);
     const int b = blockIdx.x, t = threadIdx.x;
     const bool act = t < D;
     const float* xrow = audio + (size_t)b * P.T;
@@ -104,14 +107,15 @@ __global__ __launch_bounds__(NT) void k_fwd_rho(Dev P, RhoDev W, const float* __
 // reverse sweep
 // ------------------------------------------------------------------------------------------------
 template <int NT, int EPT>
-__global__ __launch_bounds__(NT) void k_bwd_rho(Dev P, RhoDev W, const float* __restrict__ audio) {
+__global__ __launch_bounds__(NT) void k_bwd_rho(Dev P, RhoDev W, const float* __restrict__ audio, float2* gcols) {
     extern __shared__ float2 sh[];
     const int D = P.D, DP = P.DP, N = P.N, r = W.rank, rD = r * D;
-    float2* Y = sh;             // y_a of step k
-    float2* YB = sh + rD;       // yhb_a, then ybar_a
-    float2* U = sh + 2 * rD;    // H y_a, then u_a(k)
-    float2* G = sh + 3 * rD;    // cotangent of u_a(k+1)
-    float* red = reinterpret_cast<float*>(sh + 4 * rD);
+    float2* base = gcols ? gcols + (size_t)blockIdx.x * 4 * rD : sh;   // LDS, or the workspace when 4 r D complex numbers do not fit
+    float2* Y = base;             // y_a of step k
+    float2* YB = base + rD;       // yhb_a, then ybar_a
+    float2* U = base + 2 * rD;    // H y_a, then u_a(k)
+    float2* G = base + 3 * rD;    // cotangent of u_a(k+1)
+    float* red = reinterpret_cast<float*>(gcols ? sh : sh + 4 * rD);
     const int b = blockIdx.x, t = threadIdx.x;
     const bool act = t < D;
     const float* xrow = audio + (size_t)b * P.T;
@@ -290,22 +294,26 @@ __global__ void k_finalize_rho(Dev P, RhoDev W, float* __restrict__ grad_out) {
 // step from the stashed columns,  rho_k = phases_k (sum_a y_a y_a^dagger) phases_k^dagger / max(n, eps)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_states_rho(Dev P, RhoDev W, int steps, float* __restrict__ rho_out,
-                                                    float* __restrict__ purity_out) {
+                                                    float* __restrict__ purity_out, int direct) {
     extern __shared__ float2 sh[];
     const int D = P.D, DP = P.DP, r = W.rank;
-    float2* Y = sh;                                         // [r][D]
-    float2* ph = sh + r * D;                                // [D]
-    float* red = reinterpret_cast<float*>(sh + r * D + D);
+    // direct != 0: the r columns do not fit in LDS and are read from the stash (L1 / L2) every time they are needed
+    float2* Y = sh;                                         // [r][D] (direct == 0)
+    float2* ph = direct ? sh : sh + r * D;                  // [D]
+    float* red = reinterpret_cast<float*>(ph + D);
     const size_t row = blockIdx.x;                          // b * steps + k
     const int k = (int)(row % steps), t = threadIdx.x;
     const float2* st = W.stash + row * r * DP;
     const float* stw = reinterpret_cast<const float*>(W.stash) + row * r * 128;   // wave layout: [rank][64] (y own, H y own)
+    auto ldY = [&](int a, int d) {
+        return W.stash_layout == 1 ? make_float2(stw[(a * 64 + d) * 2], stw[(a * 64 + d + 32) * 2])
+             : W.stash_layout == 2 ? make_float2(stw[(a * 64 + 2 * d) * 2], stw[(a * 64 + 2 * d + 1) * 2]) : st[a * DP + d];
+    };
     float pn = 0.f;
     for (int idx = t; idx < r * D; idx += 256) {
         const int a = idx / D, d = idx % D;
-        const float2 y = W.stash_layout == 1 ? make_float2(stw[(a * 64 + d) * 2], stw[(a * 64 + d + 32) * 2])
-                       : W.stash_layout == 2 ? make_float2(stw[(a * 64 + 2 * d) * 2], stw[(a * 64 + 2 * d + 1) * 2]) : st[a * DP + d];
-        Y[idx] = y;
+        const float2 y = ldY(a, d);
+        if (!direct) Y[idx] = y;
         pn += y.x * y.x + y.y * y.y;
     }
     if (t < D) {
@@ -322,7 +330,7 @@ __global__ __launch_bounds__(256) void k_states_rho(Dev P, RhoDev W, int steps, 
         const int i = idx / D, j = idx % D;
         float2 o = make_float2(0.f, 0.f);
         for (int a = 0; a < r; ++a) {
-            const float2 yi = Y[a * D + i], yj = Y[a * D + j];
+            const float2 yi = direct ? ldY(a, i) : Y[a * D + i], yj = direct ? ldY(a, j) : Y[a * D + j];
             o.x += yi.x * yj.x + yi.y * yj.y;
             o.y += yi.y * yj.x - yi.x * yj.y;
         }
@@ -394,13 +402,14 @@ __global__ void k_update_ancilla_rho(Dev P, const float* __restrict__ rho_in, co
 // ------------------------------------------------------------------------------------------------
 template <int NT>
 __global__ __launch_bounds__(NT) void k_sample_rho(Dev P, RhoDev W, const float* __restrict__ noise, int length,
-                                                   float* __restrict__ out, int save) {
+                                                   float* __restrict__ out, int save, float2* gcols) {
     extern __shared__ float2 sh[];
     const int D = P.D, DP = P.DP, r = W.rank, rD = r * D;
-    float2* S = sh;             // u_a
-    float2* Vb = sh + rD;       // R u_a
-    float2* Wb = sh + 2 * rD;   // u_a + Q u_a
-    float* red = reinterpret_cast<float*>(sh + 3 * rD);
+    float2* base = gcols ? gcols + (size_t)blockIdx.x * 4 * rD : sh;
+    float2* S = base;             // u_a
+    float2* Vb = base + rD;       // R u_a
+    float2* Wb = base + 2 * rD;   // u_a + Q u_a
+    float* red = reinterpret_cast<float*>(gcols ? sh : sh + 3 * rD);
     const int b = blockIdx.x, t = threadIdx.x;
     const bool act = t < D;
     float2* st = save ? W.stash + (size_t)b * length * r * DP : nullptr;
@@ -475,31 +484,43 @@ hipError_t launch_pack_phi(const Dev& P, const RhoDev& W, const float* re, const
     return hipGetLastError();
 }
 
+// LDS a workgroup may use for the column arrays; beyond it they go to RhoDev::cols (the workspace)
+constexpr size_t RHO_LDS_MAX = 160 * 1024;
+static float2* cols_if_needed(const RhoDev& W, size_t want_lds_bytes, size_t& shm, int blocks) {
+    if (want_lds_bytes <= RHO_LDS_MAX) { shm = want_lds_bytes; return nullptr; }
+    shm = 1024;                                   // reduction scratch (and the phases of k_states_rho) only
+    return (W.cols && blocks <= W.cols_blocks) ? W.cols : reinterpret_cast<float2*>(1);   // 1: "needed but not provided"
+}
+
 hipError_t launch_fwd_rho(const Dev& P, const RhoDev& W, const float* audio, float* loss, bool save, hipStream_t s) {
-    const size_t shm = (size_t)2 * W.rank * P.D * sizeof(float2) + 128;
+    size_t shm;
+    float2* g = cols_if_needed(W, (size_t)2 * W.rank * P.D * sizeof(float2) + 128, shm, P.B);
+    if (g == reinterpret_cast<float2*>(1)) return hipErrorInvalidValue;
     hipError_t e;
     if (P.D <= 64) {
         if ((e = want_lds(k_fwd_rho<64>, shm)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_fwd_rho<64>, dim3(P.B), dim3(64), shm, s, P, W, audio, loss, save ? 1 : 0);
+        hipLaunchKernelGGL(k_fwd_rho<64>, dim3(P.B), dim3(64), shm, s, P, W, audio, loss, save ? 1 : 0, g);
     } else {
         if ((e = want_lds(k_fwd_rho<128>, shm)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_fwd_rho<128>, dim3(P.B), dim3(128), shm, s, P, W, audio, loss, save ? 1 : 0);
+        hipLaunchKernelGGL(k_fwd_rho<128>, dim3(P.B), dim3(128), shm, s, P, W, audio, loss, save ? 1 : 0, g);
     }
     return hipGetLastError();
 }
 
 hipError_t launch_bwd_rho(const Dev& P, const RhoDev& W, const float* audio, hipStream_t s) {
-    const size_t shm = (size_t)4 * W.rank * P.D * sizeof(float2) + 128;
+    size_t shm;
+    float2* g = cols_if_needed(W, (size_t)4 * W.rank * P.D * sizeof(float2) + 128, shm, P.B);
+    if (g == reinterpret_cast<float2*>(1)) return hipErrorInvalidValue;
     hipError_t e;
     if (P.D <= 32) {
         if ((e = want_lds(k_bwd_rho<64, 16>, shm)) != hipSuccess) return e;
-        hipLaunchKernelGGL((k_bwd_rho<64, 16>), dim3(P.B), dim3(64), shm, s, P, W, audio);
+        hipLaunchKernelGGL((k_bwd_rho<64, 16>), dim3(P.B), dim3(64), shm, s, P, W, audio, g);
     } else if (P.D <= 64) {
         if ((e = want_lds(k_bwd_rho<256, 16>, shm)) != hipSuccess) return e;
-        hipLaunchKernelGGL((k_bwd_rho<256, 16>), dim3(P.B), dim3(256), shm, s, P, W, audio);
+        hipLaunchKernelGGL((k_bwd_rho<256, 16>), dim3(P.B), dim3(256), shm, s, P, W, audio, g);
     } else {
         if ((e = want_lds(k_bwd_rho<1024, 16>, shm)) != hipSuccess) return e;
-        hipLaunchKernelGGL((k_bwd_rho<1024, 16>), dim3(P.B), dim3(1024), shm, s, P, W, audio);
+        hipLaunchKernelGGL((k_bwd_rho<1024, 16>), dim3(P.B), dim3(1024), shm, s, P, W, audio, g);
     }
     return hipGetLastError();
 }
@@ -511,11 +532,12 @@ hipError_t launch_finalize_rho(const Dev& P, const RhoDev& W, float* grad_out, h
 
 hipError_t launch_states_rho(const Dev& P, const RhoDev& W, int B, int steps, float* rho_out, float* purity_out,
                              hipStream_t s) {
-    const size_t shm = ((size_t)W.rank * P.D + P.D) * sizeof(float2) + 128;
+    size_t shm = ((size_t)W.rank * P.D + P.D) * sizeof(float2) + 128;
+    const int direct = shm > RHO_LDS_MAX ? 1 : 0;
+    if (direct) shm = (size_t)P.D * sizeof(float2) + 128;
     hipError_t e = want_lds(k_states_rho, shm);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_states_rho, dim3((unsigned)((size_t)B * steps)), dim3(256), shm, s, P, W, steps, rho_out,
-                       purity_out);
+    hipLaunchKernelGGL(k_states_rho, dim3((unsigned)((size_t)B * steps)), dim3(256), shm, s, P, W, steps, rho_out, purity_out, direct);
     return hipGetLastError();
 }
 
@@ -529,14 +551,16 @@ hipError_t launch_update_ancilla_rho(const Dev& P, const float* rho_in, const fl
 
 hipError_t launch_sample_rho(const Dev& P, const RhoDev& W, const float* noise, int n, int length, float* out,
                              bool save, hipStream_t s) {
-    const size_t shm = (size_t)3 * W.rank * P.D * sizeof(float2) + 128;
+    size_t shm;
+    float2* g = cols_if_needed(W, (size_t)3 * W.rank * P.D * sizeof(float2) + 128, shm, n);
+    if (g == reinterpret_cast<float2*>(1)) return hipErrorInvalidValue;
     hipError_t e;
     if (P.D <= 64) {
         if ((e = want_lds(k_sample_rho<64>, shm)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_sample_rho<64>, dim3(n), dim3(64), shm, s, P, W, noise, length, out, save ? 1 : 0);
+        hipLaunchKernelGGL(k_sample_rho<64>, dim3(n), dim3(64), shm, s, P, W, noise, length, out, save ? 1 : 0, g);
     } else {
         if ((e = want_lds(k_sample_rho<128>, shm)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_sample_rho<128>, dim3(n), dim3(128), shm, s, P, W, noise, length, out, save ? 1 : 0);
+        hipLaunchKernelGGL(k_sample_rho<128>, dim3(n), dim3(128), shm, s, P, W, noise, length, out, save ? 1 : 0, g);
     }
     return hipGetLastError();
 }

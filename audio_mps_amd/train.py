@@ -232,11 +232,6 @@ def main(argv=None, backend=None):
     args = build_parser().parse_args(argv)
     hp = HParams(delta_t=1.0 / args.sample_rate, h_reg=200.0 / (math.pi * args.sample_rate) ** 2)  # train.py:41-43
     hp.parse(args.hparams)
-    if args.mps_model == "rho_mps":
-        rank = hp.initial_rank if hp.initial_rank is not None else hp.bond_dim
-        if rank * hp.bond_dim > 5000:
-            raise SystemExit(f"rho_mps: initial_rank * bond_dim = {rank * hp.bond_dim} exceeds 5000 (the columns of rho are "
-                             "LDS-resident in the HIP kernels); lower --hparams=initial_rank=... or bond_dim")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if backend is None:
         import torch

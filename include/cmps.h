@@ -218,8 +218,9 @@ int cmps_legacy_loss_bwd(cmps_handle_t h, const float* audio_dev, int B, int T, 
  *
  * cmps_rho_workspace_bytes / cmps_rho_set_state: a second caller-owned, 256-B aligned workspace for the columns, their
  *   per-step stash (CMPS_WS_TRAIN: B_max * (T-1) * rank * D' * 8 bytes) and the reduction buffers.  Replaces `_rho_init`
- *   (model.py:119-132) + `tf.stack(batch_size * [self.rho_0])` (:136).  Returns CMPS_ERR_UNSUPPORTED_D when rank * D is too
- *   large for the LDS-resident columns (rank * D <= 5000 for training, 6500 forward-only).
+ *   (model.py:119-132) + `tf.stack(batch_size * [self.rho_0])` (:136).  Any rank <= 128 (the reference's default is rank = D,
+ *   model.py:62-65): up to rank * D = 5000 the general kernels keep their column arrays in LDS, above that in this workspace
+ *   (B_max * 4 * rank * D * 8 more bytes; cmps_rho_sample then needs n <= B_max).
  * cmps_rho_loss_fwd: RhoCMPS._build_loss_rho (model.py:133-144) = tf.foldl of _rho_and_loss_update (:152-158):
  *   _update_ancilla_rho (:172-187), _inc_loss_rho (:166), _expectation (:189-196), _normalize_rho (:198-203).
  *   loss_dev [B] per-clip loss; the caller takes the mean (:144).

@@ -111,6 +111,9 @@ def test_sampling_two_level_system():
     (40, 40, 2, 6, 1e-4, None),          # D > 32
     (72, 24, 2, 3, 1e-4, None),          # D > 64 (two-wave workgroups)
     (64, 12, 2, 40, 1e-4, None),         # more than 64 KB of LDS-resident columns in the reverse sweep
+    (80, 10, 2, None, 1e-4, 0.5),        # the reference's default rank = D (model.py:62-65) beyond rank * D = 5000: workspace columns
+    (96, 8, 2, None, 1e-4, 0.4),         # (96, 96)
+    (128, 6, 2, None, 1e-4, 0.3),        # (128, 128): the largest bond dimension, full rank
 ])
 def test_rho_loss_and_gradients_match_oracle(D, T, B, rank, sigma, rscale):
     m, audio = _rho_model(D, T, B, rank=rank, sigma=sigma, seed=D + T, rscale=rscale)
@@ -175,7 +178,7 @@ def test_rho_update_ancilla_matches_oracle():
     assert rel_inf(out, ref) <= 1e-5
 
 
-@pytest.mark.parametrize("D,rank,length,n", [(7, None, 256, 5), (2, None, 512, 2), (32, 4, 200, 3), (40, 3, 64, 2)])
+@pytest.mark.parametrize("D,rank,length,n", [(7, None, 256, 5), (2, None, 512, 2), (32, 4, 200, 3), (40, 3, 64, 2), (96, None, 12, 2)])
 def test_rho_sampling_matches_oracle(D, rank, length, n):
     sigma = 1.0 if D == 2 else 0.05
     m, _ = _rho_model(D, 8, 2, rank=rank, sigma=sigma, seed=D, rscale=0.2, A=1.0 if D == 2 else 10.0, data=False)
@@ -228,9 +231,10 @@ def test_rho_error_codes():
     from audio_mps_amd.scan import EffectiveParams
     be64.set_params(EffectiveParams(R=np.zeros((64, 64), np.complex64), freqs=np.zeros(64, np.float32),
                                     psi0=np.eye(64, dtype=np.complex64)[0], A=1.0, sigma=1.0, delta_t=1e-3), 1, 8, train=False)
-    with pytest.raises(_capi.CmpsError) as ei:               # rank * D beyond the LDS-resident limit
-        be64.rho_set_state(np.zeros((128, 64), np.complex64), 1, 8, train=True)
+    with pytest.raises(_capi.CmpsError) as ei:               # rank above 128
+        be64.rho_set_state(np.zeros((129, 64), np.complex64), 1, 8, train=True)
     assert ei.value.code == _capi.CMPS_ERR_UNSUPPORTED_D
+    be64.rho_set_state(np.zeros((128, 64), np.complex64), 1, 8, train=True)     # rank * D = 8192: columns in the workspace
 
 
 @pytest.mark.parametrize("D,rank", [(32, 5), (12, 12)])
