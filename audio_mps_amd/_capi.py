@@ -18,6 +18,7 @@ CMPS_ERR_STATE = 5
 CMPS_WS_FWD_ONLY = 0
 CMPS_WS_TRAIN = 1
 CMPS_WS_FRESH = 2
+CMPS_WS_REUSE_TABLES = 4
 
 CMPS_VARIANT_AUTO = 0
 CMPS_VARIANT_BLOCK = 1

@@ -120,7 +120,7 @@ int cmps_get_option(cmps_handle_t h, int option) {
 
 size_t cmps_workspace_bytes(int D, int B, int T, int flags) {
     if (D < 1 || D > 128 || B < 1 || T < 2) return 0;
-    return make_layout(D, B, T, flags & ~CMPS_WS_FRESH).total;
+    return make_layout(D, B, T, flags & ~(CMPS_WS_FRESH | CMPS_WS_REUSE_TABLES)).total;
 }
 
 static int set_params_impl(cmps_handle_t h, const float* R_re_dev, const float* R_im_dev,
@@ -132,8 +132,9 @@ static int set_params_impl(cmps_handle_t h, const float* R_re_dev, const float* 
         return fail(h, CMPS_ERR_BAD_ARG, "cmps_set_params: null parameter pointer");
     if (T < 2 || B_max < 1) return fail(h, CMPS_ERR_BAD_ARG, "cmps_set_params: need T >= 2 and B_max >= 1");
     if (!workspace_dev) return fail(h, CMPS_ERR_WORKSPACE, "cmps_set_params: null workspace");
-    const bool fresh = (flags & CMPS_WS_FRESH) != 0;
-    flags &= ~CMPS_WS_FRESH;
+    // the cached time table is trusted only when the caller says the workspace is untouched (and never with CMPS_WS_FRESH)
+    const bool fresh = (flags & CMPS_WS_FRESH) != 0 || (flags & CMPS_WS_REUSE_TABLES) == 0;
+    flags &= ~(CMPS_WS_FRESH | CMPS_WS_REUSE_TABLES);
     Layout L = make_layout(h->D, B_max, T, flags);
     if (workspace_bytes < L.total) {
         char buf[160];

@@ -140,8 +140,9 @@ class HipScan:
         f4 = 4
         flags = _capi.CMPS_WS_TRAIN if train else _capi.CMPS_WS_FWD_ONLY
         if getattr(self, "_ws_fresh", False):
-            flags |= _capi.CMPS_WS_FRESH
-            self._ws_fresh = False
+            self._ws_fresh = False              # (re)allocated since the last call: every table is rebuilt (the library's default)
+        else:
+            flags |= _capi.CMPS_WS_REUSE_TABLES  # this object owns the workspace and has not touched it: keep the time table
         _capi.check(self._h, self._lib.cmps_set_params(
             self._h, base, base + DD * f4, base + 2 * DD * f4, base + (2 * DD + D) * f4,
             base + (2 * DD + 2 * D) * f4, float(p.A), float(p.sigma), float(p.delta_t), int(T), int(B),
@@ -156,8 +157,9 @@ class HipScan:
         ws_ptr, ws_bytes = self._ensure_ws(B, T, train)
         flags = _capi.CMPS_WS_TRAIN if train else _capi.CMPS_WS_FWD_ONLY
         if getattr(self, "_ws_fresh", False):
-            flags |= _capi.CMPS_WS_FRESH
-            self._ws_fresh = False
+            self._ws_fresh = False              # (re)allocated since the last call: every table is rebuilt (the library's default)
+        else:
+            flags |= _capi.CMPS_WS_REUSE_TABLES  # this object owns the workspace and has not touched it: keep the time table
         _capi.check(self._h, self._lib.cmps_set_params_dev(self._h, params.data_ptr(), float(sigma), float(delta_t), int(T), int(B),
                                                            flags, ws_ptr, ws_bytes, self._stream()))
         self._B, self._T, self._train = B, T, train

@@ -102,10 +102,12 @@ class Trainer:
         else:
             flat, b_local = self.model.grad_sums(data)
         host, b_global = self.dp.allreduce_sums(flat, b_local)
-        total, grads = self.model.chain_rule(host, b_global, with_reg=True)       # train.py:55-60
+        if global_batch is not None:
+            b_global = int(global_batch)
+        total, grads = self.model.chain_rule(host, max(b_global, 1), with_reg=True)       # train.py:55-60
         # sum_b loss_b sits at the end of the pure-state layout (2 D^2 + 3 D + 2 floats); RhoCMPS appends the column
         # cotangents behind it (include/cmps.h: cmps_rho_loss_bwd)
-        model_loss = host[2 * D * D + 3 * D + 1] / b_global
+        model_loss = host[2 * D * D + 3 * D + 1] / max(b_global, 1)
         self.opt.apply_gradients(self.model.variables, grads)                     # train.py:89
         self.global_step += 1
         out = {"model_loss": float(model_loss), "total_loss": float(total), "global_step": self.global_step,

@@ -37,7 +37,10 @@ enum {
 enum {
     CMPS_WS_FWD_ONLY = 0, /* loss only */
     CMPS_WS_TRAIN = 1,    /* forward + backward (adds the per-step state stash and gradient slabs) */
-    CMPS_WS_FRESH = 2     /* OR-ed into `flags` of cmps_set_params: the workspace memory was (re)allocated, zeroed or used
+    CMPS_WS_REUSE_TABLES = 4, /* OR-ed into `flags` of cmps_set_params: the caller vouches that the workspace still holds what the
+                           * handle's previous cmps_set_params left in it -- the time table is then rebuilt only when T or delta_t
+                           * changed.  WITHOUT this flag every call rebuilds every table (the safe default for a C caller). */
+    CMPS_WS_FRESH = 2     /* (kept for v200 callers; now the default behaviour) the workspace memory was (re)allocated, zeroed or used
                            * for something else since the previous call -- rebuild every cached table (see below) */
 };
 
@@ -108,10 +111,11 @@ size_t cmps_workspace_bytes(int D, int B, int T, int flags);
  * A = model.A (model.py:19), sigma (model.py:21), delta_t (model.py:15), T = samples per clip.
  * Builds, on `stream`, inside `workspace_dev`: R^T, Q = -(delta_t sigma^2 / 2) R^dagger R, the float32
  * time table t_k, and the per-step phase-rotation table.
- * Caching contract: the time table depends only on (T, delta_t), so it is rebuilt only when the workspace ADDRESS, T or
- * delta_t differ from the handle's previous call.  The workspace is caller-owned memory: a caller that frees, reuses,
- * zeroes or re-obtains it (an allocator may hand back the same address) must pass CMPS_WS_FRESH once; everything else
- * in the workspace is rebuilt by every call.
+ * Caching contract: the time table depends only on (T, delta_t).  By default every call rebuilds it (~0.7 ms at T = 16000);
+ * a caller that keeps the workspace untouched between calls passes CMPS_WS_REUSE_TABLES and the table is rebuilt only when the
+ * workspace address, T or delta_t differ from the handle's previous call.  The workspace is caller-owned memory: after
+ * freeing, zeroing, re-obtaining (an allocator may hand back the same address) or sharing it, drop the flag for one call.
+ * Everything else in the workspace is rebuilt by every call.
  */
 int cmps_set_params(cmps_handle_t h, const float* R_re_dev, const float* R_im_dev,
                     const float* freqs_dev, const float* psi0_re_dev, const float* psi0_im_dev,

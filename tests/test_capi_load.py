@@ -86,7 +86,9 @@ def test_options_default_and_errors(hip_lib):
     assert hip_lib.cmps_set_option(h, _capi.CMPS_OPT_RANK1, 3) == _capi.CMPS_ERR_BAD_ARG
     assert hip_lib.cmps_set_option(h, 99, 0) == _capi.CMPS_ERR_BAD_ARG
     assert hip_lib.cmps_get_option(h, 99) == -1 and hip_lib.cmps_get_option(None, _capi.CMPS_OPT_RANK1) == -1
-    # CMPS_WS_FRESH is a request, not a layout: it does not change the size
+    # CMPS_WS_FRESH / CMPS_WS_REUSE_TABLES are requests, not layouts: they do not change the size
+    assert hip_lib.cmps_workspace_bytes(8, 4, 64, _capi.CMPS_WS_TRAIN | _capi.CMPS_WS_REUSE_TABLES) == \
+        hip_lib.cmps_workspace_bytes(8, 4, 64, _capi.CMPS_WS_TRAIN)
     assert hip_lib.cmps_workspace_bytes(8, 4, 64, _capi.CMPS_WS_TRAIN | _capi.CMPS_WS_FRESH) == \
         hip_lib.cmps_workspace_bytes(8, 4, 64, _capi.CMPS_WS_TRAIN)
     hip_lib.cmps_destroy(h)

@@ -58,8 +58,11 @@ def test_device_step_matches_host_trainer(D, given):
             m.variables["Rx"] *= np.float32(0.5)
             m.variables["Ry"] *= np.float32(0.5)
     t_dev, t_host = Trainer(m_dev, hp, device_step=True), Trainer(m_host, hp)
-    hist = np.array([[t_dev.step()[k] for k in ("model_loss", "total_loss")] + [t_host.step()[k] for k in ("model_loss", "total_loss")]
-                     for _ in range(20)])
+    hist = []
+    for _ in range(20):
+        a, b = t_dev.step(), t_host.step()
+        hist.append([a["model_loss"], a["total_loss"], b["model_loss"], b["total_loss"]])
+    hist = np.array(hist)
     assert np.all(np.isfinite(hist))
     np.testing.assert_allclose(hist[:, 0], hist[:, 2], rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(hist[:, 1], hist[:, 3], rtol=1e-6, atol=1e-6)
