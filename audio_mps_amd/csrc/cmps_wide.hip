@@ -448,35 +448,34 @@ __global__ __launch_bounds__(2 * PD, 1) void k_hy_wide(Dev P) {
             Al[t] = __builtin_bit_cast(bf8w, u4w{pl[0], pl[1], pl[2], pl[3]});
         }
     }
-    // ---- prep role: positions tid and tid + 2 PD of a stash vector ----
-    const int pq = lane >> 3, pi = lane & 7;
+    // ---- prep role: positions 2 tid and 2 tid + 1 of a stash vector: two adjacent rows of one (component, clip) ----
+    const int ppos = 2 * tid, pl_ = ppos & 63;
+    const int pq = pl_ >> 3, pi = pl_ & 7;
     const int pcomp = (pq >> 1) & 1, pclip = pq & 1;
-    const int prow0 = 16 * (tid >> 6) + 8 * (pq >> 2) + pi;
+    const int prow = 16 * (ppos >> 6) + 8 * (pq >> 2) + pi;      // even; the second position is row prow + 1
 
     // y of unit u (steps k_lo + 8 u ..) -> bf16 pieces + float32 rows, buffer u & 1.  Unclamped loads: see k_grad_wide.
     auto prep = [&](int u) {
         const int kb = k_lo + HU * u;
         unsigned char* pb = pcs + (size_t)(u & 1) * 3 * PIECE;
         float* yb = yf + (size_t)(u & 1) * FBUF;
+        const float2* src = reinterpret_cast<const float2*>(stash + wide_stash_vec<PD>(blockIdx.x, N, 0, 0) + (ptrdiff_t)kb * (8 * PD) + ppos);
+        float2 Y[HU];
 #pragma unroll
-        for (int hp = 0; hp < 2; ++hp) {
-            const int pos = tid + hp * NTHR, prow = prow0 + hp * (PD / 2);
-            const float* src = stash + wide_stash_vec<PD>(blockIdx.x, N, 0, 0) + (ptrdiff_t)kb * (8 * PD) + pos;
-            float Y[HU];
+        for (int j = 0; j < HU; ++j) Y[j] = src[(ptrdiff_t)j * (4 * PD)];
 #pragma unroll
-            for (int j = 0; j < HU; ++j) Y[j] = src[(ptrdiff_t)j * (8 * PD)];
-#pragma unroll
-            for (int j = 0; j < HU; ++j) {
-                const float v = kb + j < k_hi ? Y[j] : 0.f;
-                unsigned h, m, l;
-                split3(v, h, m, l);
-                const int rowi = (j * 2 + pclip) * 2 + pcomp;
-                unsigned short* d = reinterpret_cast<unsigned short*>(pb + rowi * PROW) + prow;
-                d[0] = (unsigned short)(h >> 16);
-                *reinterpret_cast<unsigned short*>(reinterpret_cast<unsigned char*>(d) + PIECE) = (unsigned short)(m >> 16);
-                *reinterpret_cast<unsigned short*>(reinterpret_cast<unsigned char*>(d) + 2 * PIECE) = (unsigned short)(l >> 16);
-                yb[rowi * FROW + prow] = v;
-            }
+        for (int j = 0; j < HU; ++j) {
+            const bool in = kb + j < k_hi;
+            const float v0 = in ? Y[j].x : 0.f, v1 = in ? Y[j].y : 0.f;
+            unsigned h0, m0, l0, h1, m1, l1;
+            split3(v0, h0, m0, l0);
+            split3(v1, h1, m1, l1);
+            const int rowi = (j * 2 + pclip) * 2 + pcomp;
+            unsigned char* d = pb + rowi * PROW + prow * 2;       // rows prow, prow + 1: one dword per piece
+            *reinterpret_cast<unsigned*>(d) = pack_hi16(h0, h1);
+            *reinterpret_cast<unsigned*>(d + PIECE) = pack_hi16(m0, m1);
+            *reinterpret_cast<unsigned*>(d + 2 * PIECE) = pack_hi16(l0, l1);
+            *reinterpret_cast<float2*>(&yb[rowi * FROW + prow]) = make_float2(v0, v1);
         }
     };
     // the tile of unit u, e partials, H y rows (float32) into hf
@@ -520,14 +519,11 @@ __global__ __launch_bounds__(2 * PD, 1) void k_hy_wide(Dev P) {
     auto writeout = [&](int u) {
         const int kb = k_lo + HU * u;
         const float* hb = hf + (size_t)(u & 1) * FBUF;
+        float2* dst = reinterpret_cast<float2*>(stash + wide_stash_vec<PD>(blockIdx.x, N, 0, 1) + (ptrdiff_t)kb * (8 * PD) + ppos);
 #pragma unroll
-        for (int hp = 0; hp < 2; ++hp) {
-            const int pos = tid + hp * NTHR, prow = prow0 + hp * (PD / 2);
-            float* dst = stash + wide_stash_vec<PD>(blockIdx.x, N, 0, 1) + (ptrdiff_t)kb * (8 * PD) + pos;
-#pragma unroll
-            for (int j = 0; j < HU; ++j)
-                if (kb + j < k_hi) dst[(ptrdiff_t)j * (8 * PD)] = hb[((j * 2 + pclip) * 2 + pcomp) * FROW + prow];
-        }
+        for (int j = 0; j < HU; ++j)
+            if (kb + j < k_hi)
+                dst[(ptrdiff_t)j * (4 * PD)] = *reinterpret_cast<const float2*>(&hb[((j * 2 + pclip) * 2 + pcomp) * FROW + prow]);
         if (tid < 16) {
             const int j = tid >> 1, cl = tid & 1, k = kb + j;
             float e = 0.f;
@@ -814,45 +810,52 @@ __global__ __launch_bounds__(2 * PD, 1) void k_grad_wide(Dev P, const float* __r
     // operands of unit u into buffer u & 1.  Loads are NOT clamped: rows one step below / up to four steps above the pair's
     // range lie inside the caller's workspace (other sections of it), and every value derived from them is discarded by a
     // select (never by a product with zero).
-    auto prep = [&](int u) {
+    // raw rows of a unit, fetched ONE ITERATION AHEAD into registers (the operand build then never waits for memory and can be
+    // spread between the MFMAs of the unit before it)
+    float rY[2][GU + 1], rYP[2][GU], rYB[2][GU];
+    float2 rRH[2][GU];
+    auto load_raw = [&](int u) {
+        const int kb = GU * u;
+#pragma unroll
+        for (int hp = 0; hp < 2; ++hp) {
+            const int pos = tid + hp * NTHR, prow = prow0 + hp * (PD / 2);
+            const float* ysrc = stf + wide_stash_vec<PD>(blockIdx.x, N, 0, 0) + (ptrdiff_t)(kb - 1) * (8 * PD) + pos;   // y_{kb-1}, own
+            const float* bsrc = ybs + wide_ybar_vec<PD>(blockIdx.x, N, 0) + (ptrdiff_t)kb * (4 * PD) + pos;             // ybar_kb
+            const float2* rsrc = P.rho + (ptrdiff_t)(kb - 1) * PD + prow;                                               // rho_{kb-1}
+#pragma unroll
+            for (int j = 0; j <= GU; ++j) {
+                rY[hp][j] = ysrc[(ptrdiff_t)j * (8 * PD)];
+                if (j < GU) {
+                    rYP[hp][j] = (ysrc - pos + (pos ^ 16))[(ptrdiff_t)j * (8 * PD)];
+                    rRH[hp][j] = rsrc[(ptrdiff_t)j * PD];
+                    rYB[hp][j] = bsrc[(ptrdiff_t)j * (4 * PD)];
+                }
+            }
+        }
+    };
+    auto prep = [&](int u) {                                       // from the rows load_raw(u) fetched
         const int kb = GU * u;
         u4w* dst = ops + (size_t)(u & 1) * NPC * OPS;
 #pragma unroll
         for (int hp = 0; hp < 2; ++hp) {
-            const int pos = tid + hp * NTHR, prow = prow0 + hp * (PD / 2);
+            const int prow = prow0 + hp * (PD / 2);
             const float2 ps = P.psi0[prow];
             const float ps0 = pcomp ? ps.y : ps.x;
-            const float* ysrc = stf + wide_stash_vec<PD>(blockIdx.x, N, 0, 0) + (ptrdiff_t)(kb - 1) * (8 * PD) + pos;   // y_{kb-1}, own
-            const float* bsrc = ybs + wide_ybar_vec<PD>(blockIdx.x, N, 0) + (ptrdiff_t)kb * (4 * PD) + pos;             // ybar_kb
-            const float2* rsrc = P.rho + (ptrdiff_t)(kb - 1) * PD + prow;                                               // rho_{kb-1}
             float TY[GU], SB[GU], YB[GU], YK[GU], UK[GU];
-            {
-                float Y[GU + 1], YP[GU];
-                float2 RH[GU];
 #pragma unroll
-                for (int j = 0; j <= GU; ++j) {
-                    Y[j] = ysrc[(ptrdiff_t)j * (8 * PD)];
-                    if (j < GU) {
-                        YP[j] = (ysrc - pos + (pos ^ 16))[(ptrdiff_t)j * (8 * PD)];
-                        RH[j] = rsrc[(ptrdiff_t)j * PD];
-                        YB[j] = bsrc[(ptrdiff_t)j * (4 * PD)];
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < GU; ++j) {
-                    const int k = kb + j;
-                    const bool in = k < N;
-                    const v4f sk = tab[(((k / WCH) & 1) * WCH + (k & (WCH - 1))) * 2 + pclip];
-                    const int km = k > 0 ? k - 1 : 0;
-                    const float invp = tab[(((km / WCH) & 1) * WCH + (km & (WCH - 1))) * 2 + pclip].y;
-                    const float yk = Y[j + 1], yb = YB[j];
-                    const float uk = k > 0 ? RH[j].x * (Y[j] * invp) + psgn * RH[j].y * (YP[j] * invp) : ps0;
-                    TY[j] = in ? pwq * (sk.w * yk) : 0.f;      // te y
-                    SB[j] = in ? pwq * (sk.x * yb) : 0.f;      // s ybar
-                    YB[j] = in ? pwq * yb : 0.f;               // ybar
-                    YK[j] = in ? yk : 0.f;                     // y
-                    UK[j] = in ? uk : 0.f;                     // u
-                }
+            for (int j = 0; j < GU; ++j) {
+                const int k = kb + j;
+                const bool in = k < N;
+                const v4f sk = tab[(((k / WCH) & 1) * WCH + (k & (WCH - 1))) * 2 + pclip];
+                const int km = k > 0 ? k - 1 : 0;
+                const float invp = tab[(((km / WCH) & 1) * WCH + (km & (WCH - 1))) * 2 + pclip].y;
+                const float yk = rY[hp][j + 1], yb = rYB[hp][j];
+                const float uk = k > 0 ? rRH[hp][j].x * (rY[hp][j] * invp) + psgn * rRH[hp][j].y * (rYP[hp][j] * invp) : ps0;
+                TY[j] = in ? pwq * (sk.w * yk) : 0.f;      // te y
+                SB[j] = in ? pwq * (sk.x * yb) : 0.f;      // s ybar
+                YB[j] = in ? pwq * yb : 0.f;               // ybar
+                YK[j] = in ? yk : 0.f;                     // y
+                UK[j] = in ? uk : 0.f;                     // u
             }
 #pragma unroll
             for (int o = 0; o < 5; ++o) {
@@ -913,16 +916,19 @@ __global__ __launch_bounds__(2 * PD, 1) void k_grad_wide(Dev P, const float* __r
     // chunk tables: chunk c + 1 is built at the second unit of chunk c (the chunk below c is no longer read by then) and is
     // first read fourteen units (barriers) later
     build_tab(0);
+    load_raw(0);
     __syncthreads();
     prep(0);
+    load_raw(1);
     __syncthreads();
     for (int u = 0; u < NU; ++u) {
         // mac first in program order: its LDS reads may alias prep's LDS writes as far as the compiler knows, so only this order
-        // lets prep's loads and arithmetic start under the MFMAs (21.4 -> 16.7 ms at configs[4]; forcing a finer interleave
-        // with sched_group_barrier made it slower: 26 ms).  prep is unconditional (one basic block); the unit behind the last one
-        // builds zeros from in-workspace rows (see prep) into the idle buffer.
+        // lets prep's arithmetic move up between the MFMAs (21.4 -> 16.7 ms at configs[4]; with the rows fetched a unit ahead 16.2;
+        // forcing a 1 MFMA : 4 VALU interleave with sched_group_barrier on top of that changed nothing: 16.8).  prep / load_raw are
+        // unconditional (one basic block); the units behind the last one build zeros from in-workspace rows into the idle buffer.
         mac(u);
         prep(u + 1);
+        load_raw(u + 2);
         if ((u & (WCH / GU - 1)) == 1) build_tab(u / (WCH / GU) + 1);
         __syncthreads();
     }
