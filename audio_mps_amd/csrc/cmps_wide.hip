@@ -278,6 +278,10 @@ __global__ __launch_bounds__(4 * PD) void k_fwd_wide(Dev P, const float* __restr
             sv1 = ((in1 ? xr1[idx + 1] : 0.f) - (in0 ? xr1[idx] : 0.f)) / A;
         }
         const float2 rho_k = rho_next;
+        // y_{k-1} goes out HERE, in front of the rho load: vector-memory operations retire in order, so waiting for rho_{k+1} at the
+        // top of the next step then only waits for operations a full step old (with the store behind the load, every step waited
+        // for its predecessor's store to be acknowledged)
+        if (SAVE && k >= 1) stash[wide_stash_vec<PD>(blockIdx.x, N, k - 1, 0) + pos] = yprev;
         if (k + 1 < N) rho_next = P.rho[(size_t)(k + 1) * PD + row];
         // |y_{k-1}|^2 of both clips (published before the barrier of the previous iteration)
         float n0 = 1.f, n1 = 1.f;
@@ -318,7 +322,6 @@ __global__ __launch_bounds__(4 * PD) void k_fwd_wide(Dev P, const float* __restr
             const float py = partner16(y, im_lane);
             ut = rho_k.x * y + (im_lane ? rho_k.y : -rho_k.y) * py;      // ut_{k+1} = rho_k y_k (un-normalised)
             reinterpret_cast<float*>(uvec + (p ^ 1) * VEC4)[own_f] = ut;
-            if (SAVE) stash[wide_stash_vec<PD>(blockIdx.x, N, k, 0) + pos] = y;
             if (lossmv) {
                 const float hy = reduce_slices(hRe0, hIm0, hRe1, hIm1, clip1);
                 const float ep = clip_wave_sum(yprev * hy);
