@@ -27,6 +27,32 @@ for it in range(40):                                   # pure-state wave / block
     cfg = (D, T, B, round(sigma, 5), round(rs, 3), variant)
     note("psi loss", float(np.max(np.abs(per - ref["loss_per_clip"]) / np.maximum(np.abs(ref["loss_per_clip"]), 1))), cfg)
     note("psi grad", max(rel_inf(g[k], gr[k]) for k in ("Rbar", "fbar", "psi0bar", "Abar")), cfg)
+for it in range(16):                                   # wide kernels (float32, 32 < D <= 128; AUTO) vs the C restatement
+    D = int(rng.integers(33, 129)); T = int(rng.integers(2, 500)); B = int(rng.integers(1, 8))
+    sigma = float(10 ** rng.uniform(-4, 0)); rs = float(10 ** rng.uniform(-1.5, -0.3)); inp = str(rng.choice(["damped_sine", "damped_sine_noise", "bandlimited"]))
+    from audio_mps_amd.data import synthetic_audio
+    hp = HParams(minibatch_size=B, bond_dim=D, sigma=sigma, A=float(10 ** rng.uniform(0.5, 2)))
+    audio = synthetic_audio(inp, B, T, hp.delta_t, 400 + it)
+    m = PsiCMPS(hp, data_iterator=audio, seed=it, backend=HipScan(D, rank1=int(rng.choice([1, 2]))))
+    assert m._get_backend().variant == 5
+    m.variables["Rx"] *= np.float32(rs); m.variables["Ry"] *= np.float32(rs)
+    per = m.loss_per_clip(); flat, _ = m.grad_sums(); g = unpack_grad(flat.cpu().numpy(), D)
+    ref = c_oracle_run(m, audio, "f32"); gr = C.unpack_grad(ref["grad"], D)
+    cfg = (D, T, B, round(sigma, 5), round(rs, 3), inp)
+    note("wide loss", float(np.max(np.abs(per - ref["loss_per_clip"]) / np.maximum(np.abs(ref["loss_per_clip"]), 1))), cfg)
+    note("wide grad", max(rel_inf(g[k], gr[k]) for k in ("Rbar", "fbar", "psi0bar", "Abar")), cfg)
+for it in range(8):                                    # device-resident optimiser step vs the host one, 10 steps
+    from audio_mps_amd.train import Trainer
+    D = int(rng.choice([3, 8, 16, 24, 32, 48])); T = int(rng.integers(20, 300)); B = int(rng.integers(1, 9))
+    hp = HParams(minibatch_size=B, bond_dim=D, learning_rate=float(10 ** rng.uniform(-3, -1.7)))
+    audio = make_audio(B, T, hp.delta_t, 500 + it)
+    ms = [PsiCMPS(hp, data_iterator=audio, seed=it, backend=HipScan(D)) for _ in range(2)]
+    if D > 32:
+        for mm in ms:
+            mm.variables["Rx"] *= np.float32(0.5); mm.variables["Ry"] *= np.float32(0.5)
+    td, th = Trainer(ms[0], hp, device_step=True), Trainer(ms[1], hp)
+    dev = np.array([td.step()["total_loss"] for _ in range(10)]); host = np.array([th.step()["total_loss"] for _ in range(10)])
+    note("device-step trajectory", float(np.max(np.abs(dev - host) / np.maximum(np.abs(host), 1))), (D, T, B, round(hp.learning_rate, 4)))
 for it in range(14):                                   # pair kernels vs the bf16 emulation
     D = int(rng.integers(33, 129)); T = int(rng.integers(2, 400)); B = int(rng.integers(1, 7))
     hp = HParams(minibatch_size=B, bond_dim=D)
@@ -38,6 +64,8 @@ for it in range(14):                                   # pair kernels vs the bf1
     note("pair grad", max(rel_inf(g[k], em[k]) for k in ("Rbar", "fbar", "psi0bar", "Abar")), (D, T, B))
 for it in range(14):                                   # RhoCMPS (column kernels for rank <= 8, GEMM kernels above, block kernels for D > 32)
     D = int(rng.integers(2, 41)); r = int(rng.integers(1, min(D, 32) + 1)); T = int(rng.integers(2, 150)); B = int(rng.integers(1, 6))
+    if it >= 11:                                       # the reference's default rank = D above the old LDS limit (workspace columns)
+        D = int(rng.integers(72, 129)); r = D; T = int(rng.integers(2, 12)); B = int(rng.integers(1, 3))
     hp = HParams(minibatch_size=B, bond_dim=D, initial_rank=r, sigma=float(10 ** rng.uniform(-4, -0.3)))
     audio = make_audio(B, T, hp.delta_t, 200 + it)
     m = RhoCMPS(hp, data_iterator=audio, seed=it)
