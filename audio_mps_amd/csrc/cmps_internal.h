@@ -19,9 +19,9 @@ namespace cmps {
 //   hst      : [B][N][64][2] float    wave variants' stash (same region as `stash`), 512 B per step: pairs (y_k, (R + R^dagger) y_k)
 //                                     per real component n = 2 i + {re, im} (32-row layout) or per lane (16-row layout)
 //   scal     : [B][NC][2][64] float   per 64-step chunk: |y_k|^2 and e_k, one step per lane (wave variant)
-//   gops     : [pairs][ceil(N/8)][5][2 clips][2 comps][DP] x 8 bf16   D > 32, TRAIN: operands of the gradient GEMM, written
-//                                     by the pair kernels' reverse scan (te y | ybar | s ybar | y | u), eight steps per 16 B;
-//                                     the wide kernels (cmps_wide.hip) keep ybar_k there: [pairs][N][4 DP] float
+//   gops     : [pairs][N][4 DP] float   D > 32, TRAIN: ybar_k of the reverse scan for the gradient GEMM, which builds its
+//                                     operands (te y | s ybar | ybar | y | u) itself: pair kernels [clip][re | im][DP], wide kernels
+//                                     [wave][lane] (round 2 kept the five operands here in bf16, 2.5 x the bytes)
 //   slabs    : [B][slab] float        per-clip gradient partials (TRAIN only)
 //   sums     : [slab] float           reduced partials, followed by [32][slab] double first-pass partial sums
 // DP = D rounded up to a multiple of 32 (components >= D are zero padding and stay exactly zero).
@@ -73,7 +73,7 @@ inline Layout make_layout(int D, int B, int T, int flags) {
         L.off_slabs = o; o = align256(o + (size_t)B * L.slab_floats * sizeof(float));
         L.off_sums = o;  o = align256(o + (L.slab_floats + 64) * sizeof(float) + 32 * L.slab_floats * sizeof(double));
         L.off_gops = o;
-        if (D > 32) o = align256(o + (size_t)((B + 1) / 2) * ((N + 7) / 8) * 20 * DP * 16);
+        if (D > 32) o = align256(o + ((size_t)((B + 1) / 2) * N + 8) * 4 * DP * sizeof(float));   // ybar rows (+ 8 rows the GEMM's unclamped prefetch may touch)
     }
     L.total = o;
     return L;
@@ -97,7 +97,7 @@ struct Dev {
                          // 2: pair rows (cmps_pair.hip)  3: hst rows of (y[n], (H y)[n]) pairs, n = 2 i + {re, im} (cmps_wave2.hip)
                          // 4: wide rows (cmps_wide.hip): [pair][step][y | H y][wave][lane] float
     float* scal;         // [B][NC][2][64]
-    void* gops;          // gradient-GEMM operands of the pair kernels (see the layout comment), D > 32 only
+    void* gops;          // ybar rows for the gradient GEMM (see the layout comment), D > 32 only
     float* slabs;        // [B][slab]
     float* sums;         // [slab]
     size_t slab_floats;

@@ -831,8 +831,10 @@ hipError_t launch_fwd_pair(const Dev& P, const float* audio, float* loss, bool s
 namespace cmps {
 
 // ------------------------------------------------------------------------------------------------
-// reverse scan: the cotangent recursion; the rank-1 gradient contractions over (clip, step) are a GEMM (k_grad_pair) whose
-// five operands this kernel writes in bf16, GEMM-ready (Dev::gops).
+// reverse scan: the cotangent recursion; the rank-1 gradient contractions over (clip, step) are a GEMM (k_grad_pair) that builds
+// its five bf16 operands itself from the float32 rows: this kernel only leaves ybar_k behind (Dev::gops: [pair][step][clip][re | im][D]
+// float32, one 8-byte store per lane and step, 128 contiguous bytes per (clip, component)).  Round 2 wrote the five operands here,
+// GEMM-ready in bf16 (ten 16-byte pieces per lane and eight steps: ~3 of the scan's 12.7 ms and 39 GB of traffic per step).
 //   yhat = y_k inv_k;  yhb = conj(rho_k) g;  ybar = (yhb - yhat rad_{k+1}) inv_k + te_k H y_k
 //   g    = ybar + Q ybar + s_k R^dagger ybar            (64 MFMAs, bf16 operands)
 //   fbar += dt_k Im(g conj(rho_k yhat));   Abar += zbar_k (-e_k x_k / A^2) + Re(d^dagger u_k) (-x_k / A^2)
@@ -914,12 +916,8 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
     const float* sc1 = P.scal + ((size_t)b1 * NC) * 128;
     const float* stf = reinterpret_cast<const float*>(P.stash);
     const int NBLK = (N + GB - 1) / GB;
-    // this lane's pieces: rows ia, ia + 1 (32 contiguous bytes) of component (c & 1), clip q
-    uint4* gbase = reinterpret_cast<uint4*>(P.gops) + gop_index<PD>(blockIdx.x, NBLK, 0, 0, q, odd ? 1 : 0, ia);
-    // after the piece exchange (see the flush below): lanes of row groups 0..3 store their own row ia and row ia + 16 (from the
-    // lane 16 above), lanes of row groups 4..7 store row ia - 15 (from the lane 16 below) and their own row ia + 1
-    const int goff1 = rg >= 4 ? -15 : 0, goff2 = rg >= 4 ? 1 : 16;
-    constexpr size_t GOP_STRIDE = (size_t)4 * PD, GBLK_STRIDE = (size_t)20 * PD;      // per operand / per block, in pieces
+    // ybar_k of this lane: rows ia, ia + 1 (8 contiguous bytes) of component (c & 1), clip q
+    float* ybar_base = reinterpret_cast<float*>(P.gops) + ((size_t)blockIdx.x * N * 4 + (q * 2 + (odd ? 1 : 0))) * PD + ia;
     const float A = dev_A(P);
     const float sgn = odd ? 1.f : -1.f;                                // (rho x)_own = rho_re x_own + sgn rho_im x_partner
 
@@ -1013,18 +1011,6 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
         c3a = S0.w * cur.z;                     // rad_N = 0
         c3b = S0.w * cur.w;
     }
-    // GEMM operand pieces being assembled: [operand][row a / b][dword = two steps]; zero = "no contribution"
-    unsigned E[5][2][4];
-    float hold[5][2];
-#pragma unroll
-    for (int o = 0; o < 5; ++o)
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            hold[o][r] = 0.f;
-#pragma unroll
-            for (int d = 0; d < 4; ++d) E[o][r][d] = 0u;
-        }
-
     const float2 psa = P.psi0[ia], psb = P.psi0[ib];
     const float ps0a = odd ? psa.y : psa.x, ps0b = odd ? psb.y : psb.x;        // u_0 = psi_0
 #if defined(CMPS_DIAG) && defined(PABL_TIMING)        // diagnostic builds only: where a step's cycles go (s_memtime stamps, consumed a step late)
@@ -1083,40 +1069,14 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
                 c3a = fmaf(SP0.w, PRV.z, -(ypa * radk));                                                                           \
                 c3b = fmaf(SP0.w, PRV.w, -(ypb * radk));                                                                           \
                 PAIR_PIN2(c3a, c3b);                                                                                               \
-            } else if constexpr (PI >= 5 && PI <= 9 && PAIR_EXPORT) {   /* GEMM operands of step k: te y | ybar | s ybar | y | u */ \
-                constexpr int o = PI - 5;                                                                                          \
-                const float va = o == 0 ? te * CUR.x : o == 1 ? yba : o == 2 ? s * yba : o == 3 ? CUR.x : uka;                     \
-                const float vb = o == 0 ? te * CUR.y : o == 1 ? ybb : o == 2 ? s * ybb : o == 3 ? CUR.y : ukb;                     \
-                if ((J) & 1) {                                                                                                     \
-                    hold[o][0] = va; hold[o][1] = vb;                                                                              \
-                    PAIR_PIN2(hold[o][0], hold[o][1]);                                                                             \
-                } else {                                                                                                           \
-                    E[o][0][(J) >> 1] = pk_bf16(va, hold[o][0]);                                                                   \
-                    E[o][1][(J) >> 1] = pk_bf16(vb, hold[o][1]);                                                                   \
-                    PAIR_PIN2(E[o][0][(J) >> 1], E[o][1][(J) >> 1]);                                                               \
-                }                                                                                                                  \
+            } else if constexpr (PI == 5 && PAIR_EXPORT && PAIR_EXPORT_STORES) {   /* ybar_k, float32, for the gradient GEMM */       \
+                *reinterpret_cast<float2*>(ybar_base + (size_t)k * (4 * PD)) = make_float2(yba, ybb);                              \
             } else if constexpr (PI == 10) {                                                                                       \
                 CUR = row_at(k - 8);                                  /* this slot's next row (row k is dead from here on) */      \
             } else if constexpr (PI == 16) {         /* scalars and rho row of step k - 2, behind the last MFMAs */                 \
                 nrh = rho_rows(km2);                                                                                               \
                 nS0 = tab_row(km2, 0);                                                                                             \
                 nS1 = tab_row(km2, 1);                                                                                             \
-            } else if constexpr (PI >= 11 && PI <= 15 && PAIR_EXPORT && PAIR_EXPORT_STORES) {                                      \
-                if ((J) == 0) {                                       /* a block of eight steps is complete */                     \
-                    /* Row groups rg and rg + 4 (lanes 16 apart) trade one piece each so that one store instruction writes the    \
-                       rows 16 (rg >> 2) .. + 15 of each of its four (clip, component) arrays COMPLETELY: 256 contiguous bytes     \
-                       per array instead of sixteen 16-byte pieces 32 bytes apart (the stores were ~240 cycles each: the L2's     \
-                       write path is limited by requests, and every 64-byte request carried 16 useful bytes). */                  \
-                    constexpr int o = PI - 11;                                                                                     \
-                    uint4* gp = gbase + (size_t)blk * GBLK_STRIDE + o * GOP_STRIDE;                                                \
-                    unsigned x_[4], y_[4];                                                                                         \
-                    _Pragma("unroll") for (int d = 0; d < 4; ++d) {                                                                \
-                        const auto r = __builtin_amdgcn_permlane16_swap(E[o][0][d], E[o][1][d], false, false);                     \
-                        x_[d] = r[0]; y_[d] = r[1];                                                                                \
-                    }                                                                                                              \
-                    gp[goff1] = make_uint4(x_[0], x_[1], x_[2], x_[3]);                                                            \
-                    gp[goff2] = make_uint4(y_[0], y_[1], y_[2], y_[3]);                                                            \
-                }                                                                                                                  \
             }                                                                                                                      \
         });                                                                                                                        \
         PAIR_BSTAMP_B();                                                                                                           \
@@ -1213,19 +1173,22 @@ namespace cmps {
 
 // ------------------------------------------------------------------------------------------------
 // gradient contraction: Rbar = sum_{clip,k} (te_k y_k) y_k^dagger + (s_k ybar_k) u_k^dagger,  Qbar = sum ybar_k u_k^dagger
-// as bf16 MFMA GEMMs (v_mfma_f32_32x32x16_bf16, fp32 accumulators resident for the whole pair) over the operands the
-// reverse scan left in Dev::gops.  A complex outer product  C += a b^dagger  is two real GEMMs over K = (step, {re, im}):
-//   Re C = [a_re | a_im] [b_re | b_im]^T,   Im C = [a_im | -a_re] [b_re | b_im]^T.
-// One MFMA covers K = 16 = 8 steps x {re, im} of one clip: the K half (lane >> 5) is the component, and a lane's eight K
-// values are ONE 16-byte piece of the operand array -- the kernel is loads and MFMAs only (no conversion, no VALU fill).
-// Wave w owns the row block 32w..32w+31 of all four outputs.
+// as bf16 MFMA GEMMs (v_mfma_f32_32x32x16_bf16, fp32 accumulators resident for the whole pair).  A complex outer product
+// C += a b^dagger  is two real GEMMs over K:  Re C = [a_re | a_im] [b_re | b_im]^T,   Im C = [a_im | -a_re] [b_re | b_im]^T.
+// One MFMA covers K = 16 = {re, im} x 2 clips x 4 steps: the K half (lane >> 5) is the component and a lane's eight K values are ONE
+// 16-byte piece [clip][step] of an operand array op[operand][component][row].  The five operands of a 4-step unit (te y | s ybar |
+// ybar | y | u, each rounded to bf16 once: the rounding points of oracle/cmps_oracle.py::psi_bf16_scan) are built here from the
+// float32 rows -- y from the forward's stash, ybar from the reverse scan, u_k = rho_{k-1} y_{k-1} / |y_{k-1}| recomputed -- by
+// the waves that run the MFMAs: rows fetched one unit ahead, MFMAs first in program order, operands double-buffered in LDS, one
+// barrier per unit (the structure of k_grad_wide, cmps_wide.hip).  Wave w owns the row block 32w..32w+31 of all four outputs.
 // ------------------------------------------------------------------------------------------------
 namespace {
 
 typedef short bf8 __attribute__((ext_vector_type(8)));
 typedef float f16v __attribute__((ext_vector_type(16)));
+constexpr int GU4 = 4;         // steps per unit
 
-__device__ __forceinline__ bf8 as_bf8(uint4 v, unsigned mask) {
+__device__ __forceinline__ bf8 as_bf8(u4 v, unsigned mask) {
     u4 t = {v.x ^ mask, v.y ^ mask, v.z ^ mask, v.w ^ mask};
     return __builtin_bit_cast(bf8, t);
 }
@@ -1233,81 +1196,141 @@ __device__ __forceinline__ bf8 as_bf8(uint4 v, unsigned mask) {
 }  // namespace
 
 template <int PD>
-__global__ __launch_bounds__(2 * PD, 1) void k_grad_pair(Dev P) {
-    constexpr int PWV = PD / 32, NP = 10 * PD;                      // 16-byte pieces per (block, clip): [operand][component][row]
-    // Every piece is needed by several waves (the B operands by all of them): it is fetched from HBM once, by one thread,
-    // and shared through LDS (two stages); the fetch runs three iterations ahead in registers (5 pieces per thread each).
-    __shared__ __attribute__((aligned(16))) uint4 stage[2][NP];
+__global__ __launch_bounds__(2 * PD, 1) void k_grad_pair(Dev P, const float* __restrict__ audio) {
+    constexpr int PWV = PD / 32, NTHR = 2 * PD;
+    constexpr int OPS = 5 * 2 * PD;                               // 16-byte pieces per buffer: [operand][component][row]
+    __shared__ __attribute__((aligned(16))) u4 ops[2][OPS];
+    __shared__ __attribute__((aligned(16))) f4 tab[2][PCH][2];    // (s, inv, ok, te) per (chunk parity, step, clip)
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int mr = lane & 31, mh = lane >> 5;                          // row / column, K half = component
-    const int N = P.N, NBLK = (N + GB - 1) / GB;
-    const bool two = 2 * blockIdx.x + 1 < P.B;
-    const int NIT = two ? 2 * NBLK : NBLK;                             // (block, clip) iterations; an odd batch has no second clip
-    const uint4* g = reinterpret_cast<const uint4*>(P.gops) + gop_index<PD>(blockIdx.x, NBLK, 0, 0, 0, 0, 0);
-    const unsigned nmask = mh ? 0x80008000u : 0u;
+    const int N = P.N, T = P.T, NC = (N + PCH - 1) / PCH, NU = (N + GU4 - 1) / GU4;
+    const int b0 = 2 * blockIdx.x, b1 = (b0 + 1 < P.B) ? b0 + 1 : b0;
+    const bool two = b1 != b0;
+    const float A = dev_A(P);
+    // prep role: this thread = row `prow` of clip `pclip`, both components (u_k needs both: every float32 row is read once)
+    const int pclip = tid / PD, prow = tid % PD;
+    const float* stf = reinterpret_cast<const float*>(P.stash);
+    const float* ybs = reinterpret_cast<const float*>(P.gops);
+    const float2 ps0 = P.psi0[prow];
+    const float wq = (pclip == 0 || two) ? 1.f : 0.f;             // the repeated clip of an odd batch contributes nothing
+    const int mr = lane & 31, mh = lane >> 5;
+    const unsigned imask = mh ? 0x80008000u : 0u;                 // Im form: K half 1 is -a_re
 
-    f16v Rre[PWV], Rim[PWV], Qre[PWV], Qim[PWV];                   // this wave's row block x PWV column blocks
+    f16v Rre[PWV], Rim[PWV], Qre[PWV], Qim[PWV];
 #pragma unroll
     for (int cb = 0; cb < PWV; ++cb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) Rre[cb][r] = Rim[cb][r] = Qre[cb][r] = Qim[cb][r] = 0.f;
 
-    // piece j of this thread: index e = tid + 2 PD j in [operand][component][row] order; its place in gops
-    // (five named values, not an array: arrays handed to lambdas by reference end up in scratch memory)
-    struct Five { uint4 v0, v1, v2, v3, v4; };
-    auto src_of = [&](const uint4* gb, int j) {
-        const int e = tid + 2 * PD * j;
-        const int op = e / (2 * PD), rest = e % (2 * PD);              // rest = component * PD + row
-        return gb[op * 4 * PD + rest];
-    };
-    auto fetch = [&](int it) {
-        const int itc = it < NIT ? it : NIT - 1;                       // clamped, unconditional loads
-        const int blk = two ? itc >> 1 : itc, clip = two ? itc & 1 : 0;
-        const uint4* gb = g + (size_t)blk * 20 * PD + clip * 2 * PD;
-        Five r;
-        r.v0 = src_of(gb, 0); r.v1 = src_of(gb, 1); r.v2 = src_of(gb, 2); r.v3 = src_of(gb, 3); r.v4 = src_of(gb, 4);
-        return r;
-    };
-    auto commit = [&](int buf, const Five& r) {
-        uint4* d = &stage[buf][tid];
-        d[0] = r.v0; d[2 * PD] = r.v1; d[4 * PD] = r.v2; d[6 * PD] = r.v3; d[8 * PD] = r.v4;
-    };
-    auto mac = [&](int buf) {
-        const uint4* S = stage[buf];
-        bf8 aRe[3], aIm[3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            aRe[a] = as_bf8(S[(2 * a + mh) * PD + 32 * w + mr], 0u);
-            aIm[a] = as_bf8(S[(2 * a + (mh ^ 1)) * PD + 32 * w + mr], nmask);
+    auto build_tab = [&](int cj) {                                // threads 0 .. 127: (step, clip) of chunk cj; the reverse scan's formulas
+        if (tid < 2 * PCH && cj < NC) {
+            const int st = tid >> 1, cl = tid & 1, idx = cj * PCH + st;
+            const bool in = idx < N;
+            const float* xr = audio + (size_t)(cl ? b1 : b0) * T;
+            const float* sc = P.scal + ((size_t)(cl ? b1 : b0) * NC + cj) * 128;
+            const float x0 = idx < T ? xr[idx] : 0.f, x1 = idx + 1 < T ? xr[idx + 1] : 0.f;
+            const float inc = x1 - x0;
+            const float nv = in ? sc[st] : 1.f, ev = in ? sc[64 + st] : 0.f;
+            const float z = (ev * inc) / A;                       // model.py:294 operation order
+            const float zbar = -1.0f / (1.0f + z);
+            tab[cj & 1][st][cl] = f4{inc / A, 1.0f / sqrtf(fmaxf(nv, 1e-12f)), nv > 1e-12f ? 1.f : 0.f, in ? 2.0f * (zbar * inc / A) : 0.f};
         }
+    };
+    // rows of a unit, fetched one iteration ahead.  Loads are NOT clamped: rows one step below / up to four steps above the pair's
+    // range lie inside the caller's workspace, and every value derived from them is discarded by a select.
+    // Three sets in rotation (set = unit mod 3, static through the three-fold unrolled loop below): a unit's rows are requested
+    // three iterations (~3 us) before they are used -- under load the stash stream's latency is several microseconds.
+    float rY[3][2][GU4 + 1], rYB[3][2][GU4];                       // [set][component][step]
+    float2 rRH[3][GU4];
+    auto load_raw = [&](int u, auto setc) {
+        constexpr int st = decltype(setc)::value;
+        const int kb = GU4 * u;
+#pragma unroll
+        for (int cp = 0; cp < 2; ++cp) {
+            const float* ysrc = stf + pair_stash_index<PD>(blockIdx.x, N, 0, 0, pclip, cp, prow) + (ptrdiff_t)(kb - 1) * (8 * PD);
+            const float* bsrc = ybs + ((size_t)blockIdx.x * N * 4 + (pclip * 2 + cp)) * PD + prow + (ptrdiff_t)kb * (4 * PD);
+#pragma unroll
+            for (int j = 0; j <= GU4; ++j) {
+                rY[st][cp][j] = ysrc[(ptrdiff_t)j * (8 * PD)];
+                if (j < GU4) rYB[st][cp][j] = bsrc[(ptrdiff_t)j * (4 * PD)];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < GU4; ++j) rRH[st][j] = P.rho[(ptrdiff_t)(kb - 1 + j) * PD + prow];
+    };
+    auto prep = [&](int u, auto setc) {
+        constexpr int st = decltype(setc)::value;
+        const int kb = GU4 * u;
+        u4* dst = ops[u & 1];
+        float V[5][2][GU4];                                        // [operand][component][step]
+#pragma unroll
+        for (int j = 0; j < GU4; ++j) {
+            const int k = kb + j;
+            const bool in = k < N;
+            const f4 sk = tab[(k / PCH) & 1][k & (PCH - 1)][pclip];
+            const int km = k > 0 ? k - 1 : 0;
+            const float invp = tab[(km / PCH) & 1][km & (PCH - 1)][pclip].y;
+            const float hre = rY[st][0][j] * invp, him = rY[st][1][j] * invp;          // yhat_{k-1}
+            const float ure = k > 0 ? rRH[st][j].x * hre - rRH[st][j].y * him : ps0.x; // u_k = rho_{k-1} yhat_{k-1}  (psi_0 at k = 0)
+            const float uim = k > 0 ? rRH[st][j].x * him + rRH[st][j].y * hre : ps0.y;
+#pragma unroll
+            for (int cp = 0; cp < 2; ++cp) {
+                const float yk = rY[st][cp][j + 1], yb = rYB[st][cp][j];
+                V[0][cp][j] = in ? wq * (sk.w * yk) : 0.f;         // te y
+                V[1][cp][j] = in ? wq * (sk.x * yb) : 0.f;         // s ybar
+                V[2][cp][j] = in ? wq * yb : 0.f;                  // ybar
+                V[3][cp][j] = in ? yk : 0.f;                       // y
+                V[4][cp][j] = in ? (cp ? uim : ure) : 0.f;         // u
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < 5; ++o)
+#pragma unroll
+            for (int cp = 0; cp < 2; ++cp) {
+                unsigned* d = reinterpret_cast<unsigned*>(dst + (o * 2 + cp) * PD + prow) + 2 * pclip;      // piece = [clip][4 steps]
+                *reinterpret_cast<uint2*>(d) = make_uint2(pk_bf16(V[o][cp][0], V[o][cp][1]), pk_bf16(V[o][cp][2], V[o][cp][3]));
+            }
+    };
+    auto mac = [&](int u) {
+        const u4* S = ops[u & 1];
+        const bf8 r1 = as_bf8(S[mh * PD + 32 * w + mr], 0u), r2 = as_bf8(S[(2 + mh) * PD + 32 * w + mr], 0u),
+                  r3 = as_bf8(S[(4 + mh) * PD + 32 * w + mr], 0u);
+        const bf8 i1 = as_bf8(S[(mh ^ 1) * PD + 32 * w + mr], imask), i2 = as_bf8(S[(2 + (mh ^ 1)) * PD + 32 * w + mr], imask),
+                  i3 = as_bf8(S[(4 + (mh ^ 1)) * PD + 32 * w + mr], imask);
 #pragma unroll
         for (int cb = 0; cb < PWV; ++cb) {
             const bf8 by = as_bf8(S[(6 + mh) * PD + 32 * cb + mr], 0u), bu = as_bf8(S[(8 + mh) * PD + 32 * cb + mr], 0u);
-            Rre[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aRe[0], by, Rre[cb], 0, 0, 0);
-            Rim[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aIm[0], by, Rim[cb], 0, 0, 0);
-            Qre[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aRe[1], bu, Qre[cb], 0, 0, 0);
-            Qim[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aIm[1], bu, Qim[cb], 0, 0, 0);
-            Rre[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aRe[2], bu, Rre[cb], 0, 0, 0);
-            Rim[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aIm[2], bu, Rim[cb], 0, 0, 0);
+            Rre[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r1, by, Rre[cb], 0, 0, 0);
+            Rim[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(i1, by, Rim[cb], 0, 0, 0);
+            Qre[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r3, bu, Qre[cb], 0, 0, 0);
+            Qim[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(i3, bu, Qim[cb], 0, 0, 0);
+            Rre[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r2, bu, Rre[cb], 0, 0, 0);
+            Rim[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(i2, bu, Rim[cb], 0, 0, 0);
         }
     };
-    Five r0 = fetch(0), r1 = fetch(1), r2 = fetch(2);
-    commit(0, r0);
-    r0 = fetch(3);
-    lds_barrier();
-    // iteration it: stage it & 1 holds its operands; the set fetched two iterations ago goes to the other stage
-#define GRAD_ITER(IT, RNEXT)                                         \
-    if ((IT) < NIT) {                                                \
-        commit(((IT) + 1) & 1, RNEXT);                               \
-        RNEXT = fetch((IT) + 4);                                     \
-        mac((IT) & 1);                                               \
-        lds_barrier();                                               \
+    // chunk tables: chunk c + 1 is built at the second unit of chunk c (the chunk below c is no longer read by then)
+    build_tab(0);
+    load_raw(0, ic<0>{});
+    load_raw(1, ic<1>{});
+    load_raw(2, ic<2>{});
+    __syncthreads();
+    prep(0, ic<0>{});
+    load_raw(3, ic<0>{});
+    __syncthreads();
+    // iteration u: MFMAs of unit u, operands of unit u + 1 (set (u + 1) % 3), rows of unit u + 4 into the set just freed.  The units
+    // behind the last one build zeros into the idle buffer.
+#define GRAD_ITER(U, SNEXT)                                                   \
+    if ((U) < NU) {                                                           \
+        mac(U);                                                               \
+        prep((U) + 1, ic<SNEXT>{});                                           \
+        load_raw((U) + 4, ic<SNEXT>{});                                       \
+        if (((U) & (PCH / GU4 - 1)) == 1) build_tab((U) / (PCH / GU4) + 1);   \
+        __syncthreads();                                                      \
     }
-    for (int it = 0; it < NIT; it += 3) {
-        GRAD_ITER(it, r1)
-        GRAD_ITER(it + 1, r2)
-        GRAD_ITER(it + 2, r0)
+    for (int u = 0; u < NU; u += 3) {
+        GRAD_ITER(u, 1)
+        GRAD_ITER(u + 1, 2)
+        GRAD_ITER(u + 2, 0)
     }
 #undef GRAD_ITER
     float* slab = P.slabs + (size_t)blockIdx.x * P.slab_floats;
@@ -1326,11 +1349,10 @@ __global__ __launch_bounds__(2 * PD, 1) void k_grad_pair(Dev P) {
 }
 
 hipError_t launch_grad_pair(const Dev& P, const float* audio, hipStream_t s) {
-    (void)audio;
     const unsigned nb = (unsigned)((P.B + 1) / 2);
-    if (P.DP == 128) hipLaunchKernelGGL(k_grad_pair<128>, dim3(nb), dim3(256), 0, s, P);
-    else if (P.DP == 96) hipLaunchKernelGGL(k_grad_pair<96>, dim3(nb), dim3(192), 0, s, P);
-    else if (P.DP == 64) hipLaunchKernelGGL(k_grad_pair<64>, dim3(nb), dim3(128), 0, s, P);
+    if (P.DP == 128) hipLaunchKernelGGL(k_grad_pair<128>, dim3(nb), dim3(256), 0, s, P, audio);
+    else if (P.DP == 96) hipLaunchKernelGGL(k_grad_pair<96>, dim3(nb), dim3(192), 0, s, P, audio);
+    else if (P.DP == 64) hipLaunchKernelGGL(k_grad_pair<64>, dim3(nb), dim3(128), 0, s, P, audio);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

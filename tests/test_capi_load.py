@@ -62,15 +62,15 @@ def test_workspace_bytes(hip_lib):
 
 
 def test_workspace_bytes_pair_variant(hip_lib):
-    """32 < D <= 128 with CMPS_WS_TRAIN: the pair stash (y and H y, float32) plus the gradient GEMM's bf16 operand pieces
-    (five operands, eight steps per 16-byte piece) -- include/cmps.h / cmps_internal.h::make_layout."""
+    """32 < D <= 128 with CMPS_WS_TRAIN: the stash of (y, H y) in float32 plus the reverse scan's ybar rows (float32), from which the
+    gradient GEMM builds its operands -- include/cmps.h / cmps_internal.h::make_layout (round 2: five bf16 operand arrays, 21 GB)."""
     from audio_mps_amd import _capi
     D, B, T = 128, 512, 16000
     N, pairs = T - 1, B // 2
     stash = pairs * N * 2 * 2 * 2 * D * 4                   # [pair][step][y | H y][clip][re | im][D] float32
-    gops = pairs * ((N + 7) // 8) * 5 * 2 * 2 * D * 16      # [pair][block][operand][clip][re | im][D] x 16 bytes
+    gops = pairs * N * 2 * 2 * D * 4                        # [pair][step][clip][re | im][D] float32
     trn = hip_lib.cmps_workspace_bytes(D, B, T, _capi.CMPS_WS_TRAIN)
-    assert stash + gops < trn < (stash + gops) * 1.02       # 16.8 GB + 21.0 GB at BASELINE configs[4]
+    assert stash + gops < trn < (stash + gops) * 1.02       # 16.8 GB + 8.4 GB at BASELINE configs[4]
     assert hip_lib.cmps_workspace_bytes(D, B, T, _capi.CMPS_WS_FWD_ONLY) < 64 * 1024 * 1024
 
 
