@@ -815,7 +815,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_grad_wide(Dev P, const float* __r
     // select (never by a product with zero).
     // raw rows of a unit, fetched ONE ITERATION AHEAD into registers (the operand build then never waits for memory and can be
     // spread between the MFMAs of the unit before it)
-    float rY[2][GU + 1], rYP[2][GU], rYB[2][GU];
+    float rY[2][GU + 1], rYB[2][GU];
     float2 rRH[2][GU];
     auto load_raw = [&](int u) {
         const int kb = GU * u;
@@ -829,7 +829,6 @@ __global__ __launch_bounds__(2 * PD, 1) void k_grad_wide(Dev P, const float* __r
             for (int j = 0; j <= GU; ++j) {
                 rY[hp][j] = ysrc[(ptrdiff_t)j * (8 * PD)];
                 if (j < GU) {
-                    rYP[hp][j] = (ysrc - pos + (pos ^ 16))[(ptrdiff_t)j * (8 * PD)];
                     rRH[hp][j] = rsrc[(ptrdiff_t)j * PD];
                     rYB[hp][j] = bsrc[(ptrdiff_t)j * (4 * PD)];
                 }
@@ -853,7 +852,8 @@ __global__ __launch_bounds__(2 * PD, 1) void k_grad_wide(Dev P, const float* __r
                 const int km = k > 0 ? k - 1 : 0;
                 const float invp = tab[(((km / WCH) & 1) * WCH + (km & (WCH - 1))) * 2 + pclip].y;
                 const float yk = rY[hp][j + 1], yb = rYB[hp][j];
-                const float uk = k > 0 ? rRH[hp][j].x * (rY[hp][j] * invp) + psgn * rRH[hp][j].y * (rYP[hp][j] * invp) : ps0;
+                const float ypar = partner16(rY[hp][j], pcomp != 0);          // the other component of y_{k-1}: position ^ 16 = lane ^ 16
+                const float uk = k > 0 ? rRH[hp][j].x * (rY[hp][j] * invp) + psgn * rRH[hp][j].y * (ypar * invp) : ps0;
                 TY[j] = in ? pwq * (sk.w * yk) : 0.f;      // te y
                 SB[j] = in ? pwq * (sk.x * yb) : 0.f;      // s ybar
                 YB[j] = in ? pwq * yb : 0.f;               // ybar
@@ -926,9 +926,11 @@ __global__ __launch_bounds__(2 * PD, 1) void k_grad_wide(Dev P, const float* __r
     __syncthreads();
     for (int u = 0; u < NU; ++u) {
         // mac first in program order: its LDS reads may alias prep's LDS writes as far as the compiler knows, so only this order
-        // lets prep's arithmetic move up between the MFMAs (21.4 -> 16.7 ms at configs[4]; with the rows fetched a unit ahead 16.2;
-        // forcing a 1 MFMA : 4 VALU interleave with sched_group_barrier on top of that changed nothing: 16.8).  prep / load_raw are
-        // unconditional (one basic block); the units behind the last one build zeros from in-workspace rows into the idle buffer.
+        // lets prep's arithmetic move up between the MFMAs (21.4 -> 16.7 ms at configs[4]; with the rows fetched a unit ahead 16.2).
+        // Tried on top of that and not kept: a 1 MFMA : 4 VALU interleave with sched_group_barrier (16.8 ms), a hand-made interleave
+        // of 60 slices of the build behind 24 groups of MFMAs pinned with sched_barrier (17.4 ms), rows two units ahead in a second
+        // register set (spills: 24.8 ms).  prep / load_raw are unconditional (one basic block); the units behind the last one build
+        // zeros from in-workspace rows into the idle buffer.
         mac(u);
         prep(u + 1);
         load_raw(u + 2);
