@@ -73,7 +73,9 @@ inline Layout make_layout(int D, int B, int T, int flags) {
         L.off_slabs = o; o = align256(o + (size_t)B * L.slab_floats * sizeof(float));
         L.off_sums = o;  o = align256(o + (L.slab_floats + 64) * sizeof(float) + 32 * L.slab_floats * sizeof(double));
         L.off_gops = o;
-        if (D > 32) o = align256(o + ((size_t)((B + 1) / 2) * N + 8) * 4 * DP * sizeof(float));   // ybar rows (+ 8 rows the GEMM's unclamped prefetch may touch)
+        // ybar rows; + 32 rows: the gradient GEMMs prefetch up to four 4-step units past a pair's last step without clamping (what they
+        // read there is discarded), and for the last pair that is past the section
+        if (D > 32) o = align256(o + ((size_t)((B + 1) / 2) * N + 32) * 4 * DP * sizeof(float));
     }
     L.total = o;
     return L;

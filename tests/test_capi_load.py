@@ -50,6 +50,24 @@ def test_host_only_entry_points(hip_lib):
     hip_lib.cmps_destroy(h64)
 
 
+def test_apply_step_argument_checks(hip_lib):
+    """cmps_psi_apply_step / cmps_set_params_dev / cmps_apply_step_scratch_bytes reject bad arguments before touching the device."""
+    from audio_mps_amd import _capi
+    assert hip_lib.cmps_apply_step_scratch_bytes(0) == 0 and hip_lib.cmps_apply_step_scratch_bytes(129) == 0
+    assert hip_lib.cmps_apply_step_scratch_bytes(32) == 2 * 32 * 8 + 2 * 32 * 32 * 4
+    h = ctypes.c_void_p()
+    assert hip_lib.cmps_create(8, ctypes.byref(h)) == _capi.CMPS_OK
+    z = [0.0] * 9
+    assert hip_lib.cmps_psi_apply_step(h, None, None, None, None, *z, 1, None, None, None, None) == _capi.CMPS_ERR_BAD_ARG
+    assert b"null variable" in hip_lib.cmps_last_error(h)
+    # an update (grad_sums given) needs the Adam slots, the loss outputs, the scratch buffer and a positive batch
+    assert hip_lib.cmps_psi_apply_step(h, 256, None, None, 256, 0.0, *z[1:], 1, 256, None, None, None) == _capi.CMPS_ERR_BAD_ARG
+    assert hip_lib.cmps_psi_apply_step(h, 256, 256, 256, 256, 4.0, *z[1:], 1, 256, 256, 260, None) == _capi.CMPS_ERR_BAD_ARG   # misaligned scratch
+    assert hip_lib.cmps_set_params_dev(h, None, 1e-4, 1 / 16000, 16, 1, 0, None, 0, None) == _capi.CMPS_ERR_BAD_ARG
+    assert hip_lib.cmps_set_params_dev(h, 256, 1e-4, 1 / 16000, 16, 1, 0, None, 0, None) == _capi.CMPS_ERR_WORKSPACE
+    hip_lib.cmps_destroy(h)
+
+
 def test_workspace_bytes(hip_lib):
     from audio_mps_amd import _capi
     assert hip_lib.cmps_workspace_bytes(0, 1, 16, 0) == 0
