@@ -927,9 +927,10 @@ __global__ __launch_bounds__(2 * PD, 1) void k_grad_wide(Dev P, const float* __r
     for (int u = 0; u < NU; ++u) {
         // mac first in program order: its LDS reads may alias prep's LDS writes as far as the compiler knows, so only this order
         // lets prep's arithmetic move up between the MFMAs (21.4 -> 16.7 ms at configs[4]; with the rows fetched a unit ahead 16.2).
-        // Tried on top of that and not kept: a 1 MFMA : 4 VALU interleave with sched_group_barrier (16.8 ms), a hand-made interleave
-        // of 60 slices of the build behind 24 groups of MFMAs pinned with sched_barrier (17.4 ms), rows two units ahead in a second
-        // register set (spills: 24.8 ms).  prep / load_raw are unconditional (one basic block); the units behind the last one build
+        // Measured: the MFMA stream alone (LDS reads, 144 MFMAs, barrier) is 10.4 ms, the operand build adds 5.7 ms on top WHEREVER it
+        // is placed -- tried and not kept: a 1 MFMA : 4 VALU interleave with sched_group_barrier (16.8 ms), hand-made interleaves of
+        // 60 slices of the build behind groups of three / behind single MFMAs pinned with sched_barrier (17.4 / 16.6 ms; counters
+        // unchanged: issue stalls 41 %, MFMA pipe busy 58 %), rows two units ahead in a second register set (spills: 24.8 ms).  prep / load_raw are unconditional (one basic block); the units behind the last one build
         // zeros from in-workspace rows into the idle buffer.
         mac(u);
         prep(u + 1);
