@@ -818,8 +818,8 @@ __global__ __launch_bounds__(2 * PD, 1) void k_grad_wide(Dev P, const float* __r
     // ---- build role: this thread = both components of one (row, clip): positions p and p + 16 of a stash vector ----
     const int prow = 8 * (tid >> 4) + (tid & 7), pclip = (tid >> 3) & 1;
     const int ppos = ((tid >> 4) << 5) | (tid & 15);
-    const float* stf = reinterpret_cast<const float*>(P.stash) + wide_stash_vec<PD>(blockIdx.x, N, 0, 0) + ppos;
-    const float* ybs = reinterpret_cast<const float*>(P.gops) + wide_ybar_vec<PD>(blockIdx.x, N, 0) + ppos;
+    const float* stf = reinterpret_cast<const float*>(P.stash) + wide_stash_vec<PD>(blockIdx.x, N, 0, 0);   // uniform bases: the loads
+    const float* ybs = reinterpret_cast<const float*>(P.gops) + wide_ybar_vec<PD>(blockIdx.x, N, 0);       // take SGPR base + lane offset
     const float2 ps0 = P.psi0[prow];
     // ---- MFMA role: wave w owns the 32-row block w of Re Rbar, Im Rbar, Re Qbar, Im Qbar ----
     const int mr = lane & 31, mh = lane >> 5;
@@ -852,17 +852,22 @@ __global__ __launch_bounds__(2 * PD, 1) void k_grad_wide(Dev P, const float* __r
     // values are discarded by a select.
     float rY[2][GU + 1], rYB[2][GU];                              // [component][step]
     float2 rRH[GU];
+    // buffer loads: descriptor base + SGPR row offset + a loop-invariant lane offset (no per-load address arithmetic on the VALU)
+    const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(stf - 8 * PD), 0, (N + 1) * (8 * PD * 4), 0x00020000);
+    const auto rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ybs), 0, N * (4 * PD * 4), 0x00020000);
+    const auto rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(P.rho - PD), 0, (N + 2) * (PD * 8), 0x00020000);
+    const int voff_y = ppos * 4, voff_r = prow * 8;
     auto load_y = [&](int kb, int c, int j) {
         const int row = (kb - 1 + j) < N ? (kb - 1 + j) : N - 1;
-        rY[c][j] = stf[(ptrdiff_t)row * (8 * PD) + 16 * c];
+        rY[c][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_y, voff_y + 64 * c, (row + 1) * (8 * PD * 4), 0));
     };
     auto load_yb = [&](int kb, int c, int j) {
         const int row = (kb + j) < N ? (kb + j) : N - 1;
-        rYB[c][j] = ybs[(ptrdiff_t)row * (4 * PD) + 16 * c];
+        rYB[c][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_b, voff_y + 64 * c, row * (4 * PD * 4), 0));
     };
     auto load_rho = [&](int kb, int j) {
         const int row = (kb - 1 + j) < N ? (kb - 1 + j) : N;
-        rRH[j] = P.rho[(ptrdiff_t)row * PD + prow];
+        rRH[j] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs_r, voff_r, (row + 1) * (PD * 8), 0));
     };
     auto load_one = [&](int kb, int l) {                          // the 22 loads of a unit, one by one
         if (l < 10) load_y(kb, l / 5, l % 5);
