@@ -20,6 +20,7 @@
 //   The identity part of y = ut + Q ut + s R ut stays float32; only the small correction goes through bf16.
 // Arithmetic restated (with the same rounding points) by oracle/cmps_oracle.py::psi_bf16_scan.
 #include "cmps_internal.h"
+#include "cmps_grad_gemm.h"
 
 namespace cmps {
 
@@ -831,7 +832,7 @@ hipError_t launch_fwd_pair(const Dev& P, const float* audio, float* loss, bool s
 namespace cmps {
 
 // ------------------------------------------------------------------------------------------------
-// reverse scan: the cotangent recursion; the rank-1 gradient contractions over (clip, step) are a GEMM (k_grad_pair) that builds
+// reverse scan: the cotangent recursion; the rank-1 gradient contractions over (clip, step) are a GEMM (k_grad_gemm, cmps_grad_gemm.h) that builds
 // its five bf16 operands itself from the float32 rows: this kernel only leaves ybar_k behind (Dev::gops: [pair][step][clip][re | im][D]
 // float32, one 8-byte store per lane and step, 128 contiguous bytes per (clip, component)).  Round 2 wrote the five operands here,
 // GEMM-ready in bf16 (ten 16-byte pieces per lane and eight steps: ~3 of the scan's 12.7 ms and 39 GB of traffic per step).
@@ -1123,7 +1124,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
 #undef PAIR_BSTAMP_A
 #undef PAIR_BSTAMP_B
 #undef PAIR_BSTAMP_C
-    // ---- the pair's slab: f | psi0bar_re | psi0bar_im | A (the R / Q sections are written by k_grad_pair) ----
+    // ---- the pair's slab: f | psi0bar_re | psi0bar_im | A (the R / Q sections are written by k_grad_gemm) ----
     float* slab = P.slabs + (size_t)blockIdx.x * P.slab_floats;
     const int DD = PD * PD;
     {
@@ -1172,187 +1173,22 @@ hipError_t launch_bwd_pair(const Dev& P, const float* audio, hipStream_t s) {
 namespace cmps {
 
 // ------------------------------------------------------------------------------------------------
-// gradient contraction: Rbar = sum_{clip,k} (te_k y_k) y_k^dagger + (s_k ybar_k) u_k^dagger,  Qbar = sum ybar_k u_k^dagger
-// as bf16 MFMA GEMMs (v_mfma_f32_32x32x16_bf16, fp32 accumulators resident for the whole pair).  A complex outer product
-// C += a b^dagger  is two real GEMMs over K:  Re C = [a_re | a_im] [b_re | b_im]^T,   Im C = [a_im | -a_re] [b_re | b_im]^T.
-// One MFMA covers K = 16 = {re, im} x 2 clips x 4 steps: the K half (lane >> 5) is the component and a lane's eight K values are ONE
-// 16-byte piece [clip][step] of an operand array op[operand][component][row].  The five operands of a 4-step unit (te y | s ybar |
-// ybar | y | u, each rounded to bf16 once: the rounding points of oracle/cmps_oracle.py::psi_bf16_scan) are built here from the
-// float32 rows -- y from the forward's stash, ybar from the reverse scan, u_k = rho_{k-1} y_{k-1} / |y_{k-1}| recomputed -- by
-// the waves that run the MFMAs: rows fetched one unit ahead, MFMAs first in program order, operands double-buffered in LDS, one
-// barrier per unit (the structure of k_grad_wide, cmps_wide.hip).  Wave w owns the row block 32w..32w+31 of all four outputs.
+// gradient contraction: k_grad_gemm (cmps_grad_gemm.h) with one bf16 piece per operand (each of te y | s ybar | ybar | y | u rounded
+// to bf16 once: the rounding points of oracle/cmps_oracle.py::psi_bf16_scan) on this family's rows -- [clip][component][row] inside a
+// step's y / ybar vector, 1 / sqrtf normalisation as in k_bwd_pair
 // ------------------------------------------------------------------------------------------------
-namespace {
-
-typedef short bf8 __attribute__((ext_vector_type(8)));
-typedef float f16v __attribute__((ext_vector_type(16)));
-constexpr int GU4 = 4;         // steps per unit
-
-__device__ __forceinline__ bf8 as_bf8(u4 v, unsigned mask) {
-    u4 t = {v.x ^ mask, v.y ^ mask, v.z ^ mask, v.w ^ mask};
-    return __builtin_bit_cast(bf8, t);
-}
-
-}  // namespace
-
 template <int PD>
-__global__ __launch_bounds__(2 * PD, 1) void k_grad_pair(Dev P, const float* __restrict__ audio) {
-    constexpr int PWV = PD / 32, NTHR = 2 * PD;
-    constexpr int OPS = 5 * 2 * PD;                               // 16-byte pieces per buffer: [operand][component][row]
-    __shared__ __attribute__((aligned(16))) u4 ops[2][OPS];
-    __shared__ __attribute__((aligned(16))) f4 tab[2][PCH][2];    // (s, inv, ok, te) per (chunk parity, step, clip)
-    const int tid = threadIdx.x;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int N = P.N, T = P.T, NC = (N + PCH - 1) / PCH, NU = (N + GU4 - 1) / GU4;
-    const int b0 = 2 * blockIdx.x, b1 = (b0 + 1 < P.B) ? b0 + 1 : b0;
-    const bool two = b1 != b0;
-    const float A = dev_A(P);
-    // prep role: this thread = row `prow` of clip `pclip`, both components (u_k needs both: every float32 row is read once)
-    const int pclip = tid / PD, prow = tid % PD;
-    const float* stf = reinterpret_cast<const float*>(P.stash);
-    const float* ybs = reinterpret_cast<const float*>(P.gops);
-    const float2 ps0 = P.psi0[prow];
-    const float wq = (pclip == 0 || two) ? 1.f : 0.f;             // the repeated clip of an odd batch contributes nothing
-    const int mr = lane & 31, mh = lane >> 5;
-    const unsigned imask = mh ? 0x80008000u : 0u;                 // Im form: K half 1 is -a_re
-
-    f16v Rre[PWV], Rim[PWV], Qre[PWV], Qim[PWV];
-#pragma unroll
-    for (int cb = 0; cb < PWV; ++cb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) Rre[cb][r] = Rim[cb][r] = Qre[cb][r] = Qim[cb][r] = 0.f;
-
-    auto build_tab = [&](int cj) {                                // threads 0 .. 127: (step, clip) of chunk cj; the reverse scan's formulas
-        if (tid < 2 * PCH && cj < NC) {
-            const int st = tid >> 1, cl = tid & 1, idx = cj * PCH + st;
-            const bool in = idx < N;
-            const float* xr = audio + (size_t)(cl ? b1 : b0) * T;
-            const float* sc = P.scal + ((size_t)(cl ? b1 : b0) * NC + cj) * 128;
-            const float x0 = idx < T ? xr[idx] : 0.f, x1 = idx + 1 < T ? xr[idx + 1] : 0.f;
-            const float inc = x1 - x0;
-            const float nv = in ? sc[st] : 1.f, ev = in ? sc[64 + st] : 0.f;
-            const float z = (ev * inc) / A;                       // model.py:294 operation order
-            const float zbar = -1.0f / (1.0f + z);
-            tab[cj & 1][st][cl] = f4{inc / A, 1.0f / sqrtf(fmaxf(nv, 1e-12f)), nv > 1e-12f ? 1.f : 0.f, in ? 2.0f * (zbar * inc / A) : 0.f};
-        }
-    };
-    // rows of a unit, fetched one iteration ahead.  Loads are NOT clamped: rows one step below / up to four steps above the pair's
-    // range lie inside the caller's workspace, and every value derived from them is discarded by a select.
-    // Three sets in rotation (set = unit mod 3, static through the three-fold unrolled loop below): a unit's rows are requested
-    // three iterations (~3 us) before they are used -- under load the stash stream's latency is several microseconds.
-    float rY[3][2][GU4 + 1], rYB[3][2][GU4];                       // [set][component][step]
-    float2 rRH[3][GU4];
-    auto load_raw = [&](int u, auto setc) {
-        constexpr int st = decltype(setc)::value;
-        const int kb = GU4 * u;
-#pragma unroll
-        for (int cp = 0; cp < 2; ++cp) {
-            const float* ysrc = stf + pair_stash_index<PD>(blockIdx.x, N, 0, 0, pclip, cp, prow) + (ptrdiff_t)(kb - 1) * (8 * PD);
-            const float* bsrc = ybs + ((size_t)blockIdx.x * N * 4 + (pclip * 2 + cp)) * PD + prow + (ptrdiff_t)kb * (4 * PD);
-#pragma unroll
-            for (int j = 0; j <= GU4; ++j) {
-                rY[st][cp][j] = ysrc[(ptrdiff_t)j * (8 * PD)];
-                if (j < GU4) rYB[st][cp][j] = bsrc[(ptrdiff_t)j * (4 * PD)];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < GU4; ++j) rRH[st][j] = P.rho[(ptrdiff_t)(kb - 1 + j) * PD + prow];
-    };
-    auto prep = [&](int u, auto setc) {
-        constexpr int st = decltype(setc)::value;
-        const int kb = GU4 * u;
-        u4* dst = ops[u & 1];
-        float V[5][2][GU4];                                        // [operand][component][step]
-#pragma unroll
-        for (int j = 0; j < GU4; ++j) {
-            const int k = kb + j;
-            const bool in = k < N;
-            const f4 sk = tab[(k / PCH) & 1][k & (PCH - 1)][pclip];
-            const int km = k > 0 ? k - 1 : 0;
-            const float invp = tab[(km / PCH) & 1][km & (PCH - 1)][pclip].y;
-            const float hre = rY[st][0][j] * invp, him = rY[st][1][j] * invp;          // yhat_{k-1}
-            const float ure = k > 0 ? rRH[st][j].x * hre - rRH[st][j].y * him : ps0.x; // u_k = rho_{k-1} yhat_{k-1}  (psi_0 at k = 0)
-            const float uim = k > 0 ? rRH[st][j].x * him + rRH[st][j].y * hre : ps0.y;
-#pragma unroll
-            for (int cp = 0; cp < 2; ++cp) {
-                const float yk = rY[st][cp][j + 1], yb = rYB[st][cp][j];
-                V[0][cp][j] = in ? wq * (sk.w * yk) : 0.f;         // te y
-                V[1][cp][j] = in ? wq * (sk.x * yb) : 0.f;         // s ybar
-                V[2][cp][j] = in ? wq * yb : 0.f;                  // ybar
-                V[3][cp][j] = in ? yk : 0.f;                       // y
-                V[4][cp][j] = in ? (cp ? uim : ure) : 0.f;         // u
-            }
-        }
-#pragma unroll
-        for (int o = 0; o < 5; ++o)
-#pragma unroll
-            for (int cp = 0; cp < 2; ++cp) {
-                unsigned* d = reinterpret_cast<unsigned*>(dst + (o * 2 + cp) * PD + prow) + 2 * pclip;      // piece = [clip][4 steps]
-                *reinterpret_cast<uint2*>(d) = make_uint2(pk_bf16(V[o][cp][0], V[o][cp][1]), pk_bf16(V[o][cp][2], V[o][cp][3]));
-            }
-    };
-    auto mac = [&](int u) {
-        const u4* S = ops[u & 1];
-        const bf8 r1 = as_bf8(S[mh * PD + 32 * w + mr], 0u), r2 = as_bf8(S[(2 + mh) * PD + 32 * w + mr], 0u),
-                  r3 = as_bf8(S[(4 + mh) * PD + 32 * w + mr], 0u);
-        const bf8 i1 = as_bf8(S[(mh ^ 1) * PD + 32 * w + mr], imask), i2 = as_bf8(S[(2 + (mh ^ 1)) * PD + 32 * w + mr], imask),
-                  i3 = as_bf8(S[(4 + (mh ^ 1)) * PD + 32 * w + mr], imask);
-#pragma unroll
-        for (int cb = 0; cb < PWV; ++cb) {
-            const bf8 by = as_bf8(S[(6 + mh) * PD + 32 * cb + mr], 0u), bu = as_bf8(S[(8 + mh) * PD + 32 * cb + mr], 0u);
-            Rre[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r1, by, Rre[cb], 0, 0, 0);
-            Rim[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(i1, by, Rim[cb], 0, 0, 0);
-            Qre[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r3, bu, Qre[cb], 0, 0, 0);
-            Qim[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(i3, bu, Qim[cb], 0, 0, 0);
-            Rre[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r2, bu, Rre[cb], 0, 0, 0);
-            Rim[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(i2, bu, Rim[cb], 0, 0, 0);
-        }
-    };
-    // chunk tables: chunk c + 1 is built at the second unit of chunk c (the chunk below c is no longer read by then)
-    build_tab(0);
-    load_raw(0, ic<0>{});
-    load_raw(1, ic<1>{});
-    load_raw(2, ic<2>{});
-    __syncthreads();
-    prep(0, ic<0>{});
-    load_raw(3, ic<0>{});
-    __syncthreads();
-    // iteration u: MFMAs of unit u, operands of unit u + 1 (set (u + 1) % 3), rows of unit u + 4 into the set just freed.  The units
-    // behind the last one build zeros into the idle buffer.
-#define GRAD_ITER(U, SNEXT)                                                   \
-    if ((U) < NU) {                                                           \
-        mac(U);                                                               \
-        prep((U) + 1, ic<SNEXT>{});                                           \
-        load_raw((U) + 4, ic<SNEXT>{});                                       \
-        if (((U) & (PCH / GU4 - 1)) == 1) build_tab((U) / (PCH / GU4) + 1);   \
-        __syncthreads();                                                      \
-    }
-    for (int u = 0; u < NU; u += 3) {
-        GRAD_ITER(u, 1)
-        GRAD_ITER(u + 1, 2)
-        GRAD_ITER(u + 2, 0)
-    }
-#undef GRAD_ITER
-    float* slab = P.slabs + (size_t)blockIdx.x * P.slab_floats;
-    constexpr int DD = PD * PD;
-#pragma unroll
-    for (int cb = 0; cb < PWV; ++cb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = 32 * w + (r & 3) + 8 * (r >> 2) + 4 * mh;   // C/D layout of the 32x32 MFMA: column = lane & 31
-            const int o = row * PD + 32 * cb + mr;
-            slab[o] = Rre[cb][r];
-            slab[DD + o] = Rim[cb][r];
-            slab[2 * DD + o] = Qre[cb][r];
-            slab[3 * DD + o] = Qim[cb][r];
-        }
-}
+struct PairRows {
+    static __device__ __forceinline__ int y_off(int tid, int c) { return ((((tid >> 3) & 1) * 2 + c) * PD) + 8 * (tid >> 4) + (tid & 7); }
+    static __device__ __forceinline__ int yb_off(int tid, int c) { return y_off(tid, c); }
+    static __device__ __forceinline__ float rsq(float m) { return 1.0f / sqrtf(m); }
+};
 
 hipError_t launch_grad_pair(const Dev& P, const float* audio, hipStream_t s) {
     const unsigned nb = (unsigned)((P.B + 1) / 2);
-    if (P.DP == 128) hipLaunchKernelGGL(k_grad_pair<128>, dim3(nb), dim3(256), 0, s, P, audio);
-    else if (P.DP == 96) hipLaunchKernelGGL(k_grad_pair<96>, dim3(nb), dim3(192), 0, s, P, audio);
-    else if (P.DP == 64) hipLaunchKernelGGL(k_grad_pair<64>, dim3(nb), dim3(128), 0, s, P, audio);
+    if (P.DP == 128) hipLaunchKernelGGL((k_grad_gemm<128, 1, PairRows<128>>), dim3(nb), dim3(256), 0, s, P, audio);
+    else if (P.DP == 96) hipLaunchKernelGGL((k_grad_gemm<96, 1, PairRows<96>>), dim3(nb), dim3(192), 0, s, P, audio);
+    else if (P.DP == 64) hipLaunchKernelGGL((k_grad_gemm<64, 1, PairRows<64>>), dim3(nb), dim3(128), 0, s, P, audio);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

@@ -21,7 +21,7 @@
 // Forward  (k_fwd_wide):  one LDS-only barrier per step; the loss product of step k - 1 shares step k's barrier interval.
 // Reverse  (k_bwd_wide):  the cotangent recursion g -> conj(rho) g -> ybar -> (Q + s R^dagger) ybar, analytic radial
 //                         derivative (see cmps_pair.hip); writes ybar_k (float32, lane order) for the gradient kernel.
-// Gradient (k_grad_wide): Rbar = sum (te y) y^dagger + (s ybar) u^dagger, Qbar = sum ybar u^dagger as
+// Gradient (k_grad_gemm, cmps_grad_gemm.h): Rbar = sum (te y) y^dagger + (s ybar) u^dagger, Qbar = sum ybar u^dagger as
 //                         v_mfma_f32_32x32x16_bf16 GEMMs over K = (clip, step, {re, im}); every operand is split EXACTLY into
 //                         three bf16 pieces (8 + 8 + 8 significand bits) on the fly and the six significant piece products
 //                         are accumulated in fp32 (24 operand bits: what is dropped is <= 2^-23 |a||b|), the same
@@ -30,7 +30,7 @@
 // Stash (Dev::stash, layout 4): [pair][step][y | H y][wave][lane] float32 (4 PD floats per vector: the lane order above);
 // ybar: the same vector shape per (pair, step) in Dev::gops.
 #include "cmps_internal.h"
-#include <type_traits>
+#include "cmps_grad_gemm.h"
 
 namespace cmps {
 
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_hy_wide(Dev P) {
     const int pcomp = (pq >> 1) & 1, pclip = pq & 1;
     const int prow = 16 * (ppos >> 6) + 8 * (pq >> 2) + pi;      // even; the second position is row prow + 1
 
-    // y of unit u (steps k_lo + 8 u ..) -> bf16 pieces + float32 rows, buffer u & 1.  Unclamped loads: see k_grad_wide.
+    // y of unit u (steps k_lo + 8 u ..) -> bf16 pieces + float32 rows, buffer u & 1.  Unclamped loads: rows one step below / a few steps above the pair's range lie inside the caller's workspace, and every value derived from them is discarded by a select.
     auto prep = [&](int u) {
         const int kb = k_lo + HU * u;
         unsigned char* pb = pcs + (size_t)(u & 1) * 3 * PIECE;
@@ -722,7 +722,7 @@ __global__ __launch_bounds__(4 * PD) void k_bwd_wide(Dev P, const float* __restr
         step(kb, ring0, ring3);
     }
 
-    // ---- the pair's slab: f | psi0bar_re | psi0bar_im | A (the R / Q sections are written by k_grad_wide) ----
+    // ---- the pair's slab: f | psi0bar_re | psi0bar_im | A (the R / Q sections are written by k_grad_gemm) ----
     float* slab = P.slabs + (size_t)blockIdx.x * P.slab_floats;
     constexpr int DD = PD * PD;
     {
@@ -755,291 +755,15 @@ __global__ __launch_bounds__(4 * PD) void k_bwd_wide(Dev P, const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-// gradient contraction (see the header).  A complex outer product  C += a b^dagger  is two real GEMMs over K:
-//   Re C = [a_re | a_im] [b_re | b_im]^T,   Im C = [a_im | -a_re] [b_re | b_im]^T.
-// One MFMA covers K = 16 = {re, im} x 2 clips x 4 steps: the K half (lane >> 5) is the component and a lane's eight K values
-// are ONE 16-byte piece [clip][step] of an operand array op[piece][operand][component][row].  A unit = 4 steps of both clips.
-// Wave w (one per SIMD, 512 registers: 256 of them accumulators) owns the 32-row block w of Re / Im Rbar and Re / Im Qbar; the
-// operands of the next unit are built (loads, scaling, rotation, bf16 splits: VALU) in the same instruction stream as this
-// unit's MFMAs (matrix pipe), double-buffered in LDS, one barrier per unit.
+// gradient contraction: k_grad_gemm (cmps_grad_gemm.h) on this family's rows -- a stash vector is in lane order (position p = 64 (row
+// / 16) + 8 q + (row % 8), q = (row half, component, clip)), and the reverse scan normalises with rsq_newton
 // ------------------------------------------------------------------------------------------------------------------------
-namespace {
-
-// slot t of a unit applies the sign of an Im piece (four v_xor): such slots get no slice of the build
-template <int PWV, int NG>
-constexpr bool grad_fix_slot(int t) {
-    const int g = t / (6 * PWV), ap = (t / PWV) % 6, cb = t % PWV;
-    return cb == PWV - 1 && ((g == 0 && ap < 2) || (g > 0 && ap == 0) || (g + 1 < NG && (ap == 2 || ap == 4)));
-}
-template <int PWV, int NG>
-constexpr int grad_free_slots(int t) {          // slots below t that take a slice
-    int n = 0;
-    for (int i = 0; i < t; ++i) n += grad_fix_slot<PWV, NG>(i) ? 0 : 1;
-    return n;
-}
-
-template <int I, int E, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < E) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, E>(f);
-    }
-}
-
-}  // namespace
-
-// The issue order of a unit is written out: slot t = MFMA t of the unit followed by one small slice of the next unit's operand
-// build (at most four VALU instructions, or one global load, or three LDS stores), MFMA and slice each closed by a sched_barrier.
-// Measured on this chip (scripts/ubench/mfma_valu_overlap*.hip, profiles/r3_ubench_mfma_valu_overlap.log): behind one
-// v_mfma_f32_32x32x16_bf16 of a lone wave, 1 ds_read_b128 + 3 VALU + 1/4 ds_write_b64 are free (17.9 against 16.9 ns per MFMA),
-// 5 VALU cost +40 %, back-to-back dependent VALU pairs +10-20 %, v_pk_fma_f32 never hides; left to itself hipcc issues the MFMAs in
-// runs of 20-30 and the build in runs of 40-150 VALU, which adds the two streams (MFMAs alone 11.0 ms, build alone 10.6 ms, together
-// 17.2 ms at configs[4]).
-// MFMA order inside a piece-pair group: A piece outermost (te y | y: Re, Im; ybar | u: Re, Im; s ybar | u: Re, Im), column block
-// innermost, so an A register is free after PD / 32 MFMAs and is refilled for the next group at once (single-buffered operands: 24 +
-// 2 PD / 4 registers), and consecutive MFMAs never share an accumulator.
-template <int PD, int NPC>       // NPC = bf16 pieces per operand: 3 (six products, 24 bits) or 2 (three products, 16 bits)
-__global__ __launch_bounds__(2 * PD, 1) void k_grad_wide(Dev P, const float* __restrict__ audio) {
-    constexpr int PWV = PD / 32;                                  // waves = 32-row blocks; one wave per SIMD, 512 registers
-    constexpr int OPS = 5 * 2 * PD;                               // 16-byte pieces per (buffer, piece): [operand][component][row]
-    constexpr int NG = NPC * (NPC + 1) / 2;                       // piece-pair groups (a, b), a + b <= NPC - 1
-    constexpr int NM = NG * 6 * PWV;                              // MFMAs per unit
-    // the two operand buffers are two distinct arrays (and the unit loop is unrolled by two): no aliasing between the build's
-    // stores and the reads of the unit being multiplied
-    __shared__ __attribute__((aligned(16))) u4w opsA[NPC * OPS];  // [NPC][OPS] each
-    __shared__ __attribute__((aligned(16))) u4w opsB[NPC * OPS];
-    __shared__ __attribute__((aligned(16))) v4f tab[2 * WCH * 2]; // [2][WCH][2]: (s w, inv, w, te w) per (chunk parity, step, clip)
-    const int tid = threadIdx.x;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int N = P.N, T = P.T, NC = (N + WCH - 1) / WCH, NU = (N + GU - 1) / GU;
-    const int b0 = 2 * blockIdx.x, b1 = (b0 + 1 < P.B) ? b0 + 1 : b0;
-    const bool two = b1 != b0;
-    const float A = dev_A(P);
-    // ---- build role: this thread = both components of one (row, clip): positions p and p + 16 of a stash vector ----
-    const int prow = 8 * (tid >> 4) + (tid & 7), pclip = (tid >> 3) & 1;
-    const int ppos = ((tid >> 4) << 5) | (tid & 15);
-    const float* stf = reinterpret_cast<const float*>(P.stash) + wide_stash_vec<PD>(blockIdx.x, N, 0, 0);   // uniform bases: the loads
-    const float* ybs = reinterpret_cast<const float*>(P.gops) + wide_ybar_vec<PD>(blockIdx.x, N, 0);       // take SGPR base + lane offset
-    const float2 ps0 = P.psi0[prow];
-    // ---- MFMA role: wave w owns the 32-row block w of Re Rbar, Im Rbar, Re Qbar, Im Qbar ----
-    const int mr = lane & 31, mh = lane >> 5;
-    const unsigned imask = mh ? 0x80008000u : 0u;                 // Im form: K half 1 is -a_re
-    const int a_re_off = mh * PD + 32 * w + mr, a_im_off = (mh ^ 1) * PD + 32 * w + mr, b_off = (6 + mh) * PD + mr;
-
-    f16w Rre[PWV], Rim[PWV], Qre[PWV], Qim[PWV];
-#pragma unroll
-    for (int cb = 0; cb < PWV; ++cb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) Rre[cb][r] = Rim[cb][r] = Qre[cb][r] = Qim[cb][r] = 0.f;
-
-    // per-step scalars of chunk cj, threads 0 .. 127 = (step, clip); steps behind the clip's last one (and the repeated clip of an
-    // odd batch) get weight 0 and finite scalars, so whatever the build forms from their (clamped) rows multiplies to zero
-    auto build_tab = [&](int cj) {
-        if (tid < 2 * WCH) {
-            const int st = tid >> 1, cl = tid & 1, idx = cj * WCH + st;
-            const bool in = idx < N;
-            const float* xr = audio + (size_t)(cl ? b1 : b0) * T;
-            const float* sc = P.scal + ((size_t)(cl ? b1 : b0) * NC + cj) * 128;
-            const float x0 = idx < T ? xr[idx] : 0.f, x1 = idx + 1 < T ? xr[idx + 1] : 0.f;
-            const float nv = in ? sc[st] : 1.f, ev = in ? sc[64 + st] : 0.f;
-            const StepScal r = step_scalars(x1 - x0, nv, ev, A);
-            const bool on = in && (cl == 0 || two);
-            tab[((cj & 1) * WCH + st) * 2 + cl] = v4f{on ? r.s : 0.f, r.inv, on ? 1.f : 0.f, on ? r.te : 0.f};
-        }
-    };
-    // raw rows of one unit: y_{kb-1 .. kb+3}, ybar_{kb .. kb+3} (both components), rho_{kb-1 .. kb+2}; fetched one unit ahead of
-    // their use.  Row numbers are clamped to the pair's range (scalar arithmetic); row -1 of unit 0 is an in-workspace row whose
-    // values are discarded by a select.
-    float rY[2][GU + 1], rYB[2][GU];                              // [component][step]
-    float2 rRH[GU];
-    // buffer loads: descriptor base + SGPR row offset + a loop-invariant lane offset (no per-load address arithmetic on the VALU)
-    const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(stf - 8 * PD), 0, (N + 1) * (8 * PD * 4), 0x00020000);
-    const auto rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ybs), 0, N * (4 * PD * 4), 0x00020000);
-    const auto rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(P.rho - PD), 0, (N + 2) * (PD * 8), 0x00020000);
-    const int voff_y = ppos * 4, voff_r = prow * 8;
-    auto load_y = [&](int kb, int c, int j) {
-        const int row = (kb - 1 + j) < N ? (kb - 1 + j) : N - 1;
-        rY[c][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_y, voff_y + 64 * c, (row + 1) * (8 * PD * 4), 0));
-    };
-    auto load_yb = [&](int kb, int c, int j) {
-        const int row = (kb + j) < N ? (kb + j) : N - 1;
-        rYB[c][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_b, voff_y + 64 * c, row * (4 * PD * 4), 0));
-    };
-    auto load_rho = [&](int kb, int j) {
-        const int row = (kb - 1 + j) < N ? (kb - 1 + j) : N;
-        rRH[j] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs_r, voff_r, (row + 1) * (PD * 8), 0));
-    };
-    auto load_one = [&](int kb, int l) {                          // the 22 loads of a unit, one by one
-        if (l < 10) load_y(kb, l / 5, l % 5);
-        else if (l < 18) load_yb(kb, (l - 10) / 4, (l - 10) % 4);
-        else load_rho(kb, l - 18);
-    };
-
-    // one unit: the MFMAs of unit u from RD (MAC), the operands of unit u + 1 into WR, the raw rows of unit u + 2
-    auto run_unit = [&](auto mac_c, const u4w* RD, u4w* WR, int u) {
-        constexpr bool MAC = decltype(mac_c)::value;
-        constexpr int S_M0 = 1, S_L0 = S_M0 + 16, S_X0 = S_L0 + 22, NS = S_X0 + 60;    // slices: table | math | loads | split, pack, store
-        const int kb = GU * (u + 1);                              // first step of the unit being built
-        const int kl = GU * (u + 2);                              // ... of the unit being fetched
-        v4f sk[GU];
-        float invp0 = 1.f;
-        float val[2][GU][5];                                      // te y, s ybar, ybar, y, u per (component, step)
-        float t1 = 0.f, t2 = 0.f;
-        float sv[2][3];                                           // (x, x - hi, x - hi - mid) of the two steps being packed
-        unsigned w0[3] = {0u, 0u, 0u};
-        bf8w Areg[6], By[PWV], Bu[PWV];
-        auto a_off = [&](int ap) { return (ap == 0 ? 0 : ap == 1 ? 0 : ap < 4 ? 4 * PD : 2 * PD) + ((ap & 1) ? a_im_off : a_re_off); };
-        auto read_a = [&](int ap, int apiece) { Areg[ap] = __builtin_bit_cast(bf8w, RD[(size_t)apiece * OPS + a_off(ap)]); };
-        auto fix_a = [&](int ap) { Areg[ap] = piece_bits(__builtin_bit_cast(u4w, Areg[ap]), imask); };
-        auto slice = [&](auto ic) {
-            constexpr int I = decltype(ic)::value;
-            if constexpr (I == 0) {                               // the unit's table rows (its four steps lie in one chunk)
-                const v4f* tb = tab + (((kb / WCH) & 1) * WCH + (kb & (WCH - 1))) * 2 + pclip;
-#pragma unroll
-                for (int j = 0; j < GU; ++j) sk[j] = tb[2 * j];
-                const int km = kb > 0 ? kb - 1 : 0;
-                invp0 = tab[(((km / WCH) & 1) * WCH + (km & (WCH - 1))) * 2 + pclip].y;
-            } else if constexpr (I < S_L0) {                      // math of step j, four parts
-                constexpr int m = I - S_M0, j = m / 4, part = m % 4;
-                if constexpr (part == 0) {                        // u = rho_{k-1} y_{k-1} / |y_{k-1}| (psi0 at k = 0)
-                    const float invp = j == 0 ? invp0 : sk[j > 0 ? j - 1 : 0].y;
-                    t1 = rY[0][j] * invp;
-                    t2 = rY[1][j] * invp;
-                    const float ur = rRH[j].x * t1 - rRH[j].y * t2;
-                    val[0][j][4] = (kb + j > 0) ? ur : ps0.x;
-                } else if constexpr (part == 1) {
-                    const float ui = rRH[j].x * t2 + rRH[j].y * t1;
-                    val[1][j][4] = (kb + j > 0) ? ui : ps0.y;
-                } else {
-                    constexpr int c = part - 2;
-                    val[c][j][0] = sk[j].w * rY[c][j + 1];
-                    val[c][j][1] = sk[j].x * rYB[c][j];
-                    val[c][j][2] = sk[j].z * rYB[c][j];
-                    val[c][j][3] = rY[c][j + 1];
-                }
-            } else if constexpr (I < S_X0) {                      // one global load of the unit after
-#if !(defined(CMPS_DIAG) && defined(WABL_GRAD_NO_LOADS))          // diagnostic builds only (results are wrong)
-                load_one(kl, I - S_L0);
-#endif
-            } else {                                              // split two steps of one operand, pack, store
-                constexpr int x = I - S_X0, c = x / 30, o = (x / 6) % 5, jp = (x / 3) % 2, part = x % 3;
-                if constexpr (part == 0) {                        // the two steps' chains interleaved: back-to-back dependent VALU
-                    const float v0 = val[c][2 * jp][o], v1 = val[c][2 * jp + 1][o];              // instructions do not hide behind an MFMA
-                    const unsigned h0 = __float_as_uint(v0) & 0xFFFF0000u, h1 = __float_as_uint(v1) & 0xFFFF0000u;
-                    sv[0][0] = v0; sv[1][0] = v1;
-                    sv[0][1] = v0 - __uint_as_float(h0);
-                    sv[1][1] = v1 - __uint_as_float(h1);
-                } else if constexpr (part == 1) {
-                    const unsigned m0 = __float_as_uint(sv[0][1]) & 0xFFFF0000u, m1 = __float_as_uint(sv[1][1]) & 0xFFFF0000u;
-                    sv[0][2] = sv[0][1] - __uint_as_float(m0);
-                    sv[1][2] = sv[1][1] - __uint_as_float(m1);
-                } else {
-                    unsigned pk[3];
-#pragma unroll
-                    for (int a = 0; a < 3; ++a) pk[a] = pack_hi16(__float_as_uint(sv[0][a]), __float_as_uint(sv[1][a]));
-                    if constexpr (jp == 0) {
-#pragma unroll
-                        for (int a = 0; a < 3; ++a) w0[a] = pk[a];
-                    } else {
-#pragma unroll
-                        for (int a = 0; a < NPC; ++a) {
-                            unsigned* d = reinterpret_cast<unsigned*>(WR + (size_t)a * OPS + (o * 2 + c) * PD + prow) + 2 * pclip;
-#if defined(CMPS_DIAG) && defined(WABL_GRAD_NO_STORE)
-                            if constexpr (MAC) { asm volatile("" : : "v"(w0[a]), "v"(pk[a])); continue; }
-#endif
-                            *reinterpret_cast<uint2*>(d) = make_uint2(w0[a], pk[a]);
-                        }
-                    }
-                }
-            }
-        };
-        if constexpr (MAC) {
-            // operands of the first group: A pieces of piece index 0, B pieces of index NPC - 1
-            read_a(0, 0);
-#pragma unroll
-            for (int cb = 0; cb < PWV; ++cb) By[cb] = __builtin_bit_cast(bf8w, RD[(size_t)(NPC - 1) * OPS + b_off + 32 * cb]);
-            read_a(1, 0);
-            read_a(2, 0);
-#pragma unroll
-            for (int cb = 0; cb < PWV; ++cb) Bu[cb] = __builtin_bit_cast(bf8w, RD[(size_t)(NPC - 1) * OPS + b_off + 2 * PD + 32 * cb]);
-            read_a(3, 0);
-            read_a(4, 0);
-            read_a(5, 0);
-            fix_a(1);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        static_for<0, (MAC ? NM : NS)>([&](auto tc) {
-            constexpr int t = decltype(tc)::value;
-            if constexpr (MAC) {
-                // group g = (a, b): b = NPC - 1 .. 0, a = NPC - 1 - b .. 0
-                constexpr int g = t / (6 * PWV), ap = (t / PWV) % 6, cb = t % PWV;
-                constexpr int ga = (NPC == 3) ? (g == 0 ? 0 : g == 1 ? 1 : g == 2 ? 0 : 5 - g) : (g == 0 ? 0 : 2 - g);
-                constexpr int ng = g + 1;
-                constexpr int nb = (NPC == 3) ? (ng < 3 ? 1 : 0) : 0;
-                constexpr int na = (NPC == 3) ? (ng == 1 ? 1 : ng == 2 ? 0 : 5 - ng) : (2 - ng);
-                if constexpr (ap == 0) Rre[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Areg[0], By[cb], Rre[cb], 0, 0, 0);
-                if constexpr (ap == 1) Rim[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Areg[1], By[cb], Rim[cb], 0, 0, 0);
-                if constexpr (ap == 2) Qre[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Areg[2], Bu[cb], Qre[cb], 0, 0, 0);
-                if constexpr (ap == 3) Qim[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Areg[3], Bu[cb], Qim[cb], 0, 0, 0);
-                if constexpr (ap == 4) Rre[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Areg[4], Bu[cb], Rre[cb], 0, 0, 0);
-                if constexpr (ap == 5) Rim[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Areg[5], Bu[cb], Rim[cb], 0, 0, 0);
-                if constexpr (cb == PWV - 1) {
-                    // the Im pieces carry the sign of their K half: applied a row of MFMAs after the read was issued
-                    if constexpr (g == 0 && ap == 0) fix_a(3);                                 // (first group: read before slot 0)
-                    if constexpr (g == 0 && ap == 1) fix_a(5);
-                    if constexpr (g > 0 && ap == 0) fix_a(5);                                  // refilled at the end of the group before
-                    if constexpr (ng < NG) {
-                        read_a(ap, na);                                                        // this A register is free: next group's piece
-                        if constexpr (ap == 2) fix_a(1);
-                        if constexpr (ap == 4) fix_a(3);
-                    }
-                }
-                if constexpr (ng < NG && ga == 0) {                                            // last group of this B piece: next one
-                    if constexpr (ap == 1) By[cb] = __builtin_bit_cast(bf8w, RD[(size_t)nb * OPS + b_off + 32 * cb]);
-                    if constexpr (ap == 5) Bu[cb] = __builtin_bit_cast(bf8w, RD[(size_t)nb * OPS + b_off + 2 * PD + 32 * cb]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#if !(defined(CMPS_DIAG) && defined(WABL_GRAD_NO_SLICES))          // diagnostic builds only (results are wrong): the MFMA stream alone
-                constexpr int NF = grad_free_slots<PWV, NG>(NM), f0 = grad_free_slots<PWV, NG>(t);
-                if constexpr (!grad_fix_slot<PWV, NG>(t)) static_for<(f0 * NS) / NF, ((f0 + 1) * NS) / NF>(slice);
-#endif
-            } else {
-                slice(tc);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        });
-    };
-
-    // chunk tables: chunk c + 1 is built at the second unit of chunk c (the chunk below c is no longer read by then) and is
-    // first read fourteen units (barriers) later
-    build_tab(0);
-#pragma unroll
-    for (int l = 0; l < 22; ++l) load_one(0, l);
-    __syncthreads();
-    run_unit(std::false_type{}, opsB, opsA, -1);                  // operands of unit 0, raw rows of unit 1
-    __syncthreads();
-    for (int u = 0; u < NU; u += 2) {                             // an odd count runs one unit of zero operands
-        run_unit(std::true_type{}, opsA, opsB, u);
-        __syncthreads();
-        run_unit(std::true_type{}, opsB, opsA, u + 1);
-        if (((u + 1) & (WCH / GU - 1)) == 1) build_tab((u + 1) / (WCH / GU) + 1);
-        __syncthreads();
-    }
-
-    float* slab = P.slabs + (size_t)blockIdx.x * P.slab_floats;
-    constexpr int DD = PD * PD;
-#pragma unroll
-    for (int cb = 0; cb < PWV; ++cb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = 32 * w + (r & 3) + 8 * (r >> 2) + 4 * mh;    // C/D layout of the 32x32 MFMA: column = lane & 31
-            const int o = row * PD + 32 * cb + mr;
-            slab[o] = Rre[cb][r];
-            slab[DD + o] = Rim[cb][r];
-            slab[2 * DD + o] = Qre[cb][r];
-            slab[3 * DD + o] = Qim[cb][r];
-        }
-}
+template <int PD>
+struct WideRows {
+    static __device__ __forceinline__ int y_off(int tid, int c) { return (((tid >> 4) << 5) | (tid & 15)) + 16 * c; }
+    static __device__ __forceinline__ int yb_off(int tid, int c) { return y_off(tid, c); }
+    static __device__ __forceinline__ float rsq(float m) { return rsq_newton(m); }
+};
 
 // ------------------------------------------------------------------------------------------------------------------------
 // launchers
@@ -1091,7 +815,7 @@ hipError_t launch_bwd_wide(const Dev& P, const float* audio, hipStream_t s) {
 template <int PD, int NPC>
 static hipError_t grad_wide_t(const Dev& P, const float* audio, hipStream_t s) {
     const unsigned nb = (unsigned)((P.B + 1) / 2);
-    hipLaunchKernelGGL((k_grad_wide<PD, NPC>), dim3(nb), dim3(2 * PD), 0, s, P, audio);   // static LDS: 2 x NPC x 160 PD + 4 KB
+    hipLaunchKernelGGL((k_grad_gemm<PD, NPC, WideRows<PD>>), dim3(nb), dim3(2 * PD), 0, s, P, audio);   // static LDS: 2 x NPC x 160 PD + 4 KB
     return hipGetLastError();
 }
 
