@@ -396,7 +396,7 @@ constexpr int HCHUNK = 512;                // steps per workgroup
 template <int PD>
 struct HyGeom {
     static constexpr int PROW = 2 * PD + 16;                      // bytes of one (step, clip, component) row of bf16 + bank-spread padding
-    static constexpr int PIECE = HU * 4 * PROW;                   // bytes of one piece of one unit: [step][clip][comp] rows
+    static constexpr int PIECE = HU * 6 * PROW;                   // bytes of one piece of one unit: [step][clip][y_re | y_im | -y_re] rows
     static constexpr int FROW = PD + 4;                           // floats of one float32 row + padding
     static constexpr int FBUF = HU * 4 * FROW;                    // floats of one float32 unit buffer
     static constexpr size_t LDS = (size_t)2 * 3 * PIECE + (size_t)4 * FBUF * 4 + 2 * (PD / 32) * 16 * 4;
@@ -459,14 +459,17 @@ __global__ __launch_bounds__(2 * PD, 1) void k_hy_wide(Dev P) {
     const int prow = 16 * (ppos >> 6) + 8 * (pq >> 2) + pi;      // even; the second position is row prow + 1
 
     // y of unit u (steps k_lo + 8 u ..) -> bf16 pieces + float32 rows, buffer u & 1.  Unclamped loads: rows one step below / a few steps above the pair's range lie inside the caller's workspace, and every value derived from them is discarded by a select.
+    float2 Y[HU];                                                  // the rows of the next unit, requested before this unit's MFMAs
+    auto fetch = [&](int u) {
+        const int kb = k_lo + HU * u;
+        const float2* src = reinterpret_cast<const float2*>(stash + wide_stash_vec<PD>(blockIdx.x, N, 0, 0) + (ptrdiff_t)kb * (8 * PD) + ppos);
+#pragma unroll
+        for (int j = 0; j < HU; ++j) Y[j] = src[(ptrdiff_t)j * (4 * PD)];
+    };
     auto prep = [&](int u) {
         const int kb = k_lo + HU * u;
         unsigned char* pb = pcs + (size_t)(u & 1) * 3 * PIECE;
         float* yb = yf + (size_t)(u & 1) * FBUF;
-        const float2* src = reinterpret_cast<const float2*>(stash + wide_stash_vec<PD>(blockIdx.x, N, 0, 0) + (ptrdiff_t)kb * (8 * PD) + ppos);
-        float2 Y[HU];
-#pragma unroll
-        for (int j = 0; j < HU; ++j) Y[j] = src[(ptrdiff_t)j * (4 * PD)];
 #pragma unroll
         for (int j = 0; j < HU; ++j) {
             const bool in = kb + j < k_hi;
@@ -475,35 +478,44 @@ __global__ __launch_bounds__(2 * PD, 1) void k_hy_wide(Dev P) {
             split3(v0, h0, m0, l0);
             split3(v1, h1, m1, l1);
             const int rowi = (j * 2 + pclip) * 2 + pcomp;
-            unsigned char* d = pb + rowi * PROW + prow * 2;       // rows prow, prow + 1: one dword per piece
-            *reinterpret_cast<unsigned*>(d) = pack_hi16(h0, h1);
-            *reinterpret_cast<unsigned*>(d + PIECE) = pack_hi16(m0, m1);
-            *reinterpret_cast<unsigned*>(d + 2 * PIECE) = pack_hi16(l0, l1);
+            unsigned char* d = pb + ((j * 2 + pclip) * 3 + pcomp) * PROW + prow * 2;       // rows prow, prow + 1: one dword per piece
+            const unsigned wh = pack_hi16(h0, h1), wm = pack_hi16(m0, m1), wl = pack_hi16(l0, l1);
+            *reinterpret_cast<unsigned*>(d) = wh;
+            *reinterpret_cast<unsigned*>(d + PIECE) = wm;
+            *reinterpret_cast<unsigned*>(d + 2 * PIECE) = wl;
+            // the Im form's second K half is -y_re: a negated copy (third row) instead of sign flips on every operand read
+            unsigned char* dn = d + 2 * PROW;
+            if (pcomp == 0) {
+                *reinterpret_cast<unsigned*>(dn) = wh ^ 0x80008000u;
+                *reinterpret_cast<unsigned*>(dn + PIECE) = wm ^ 0x80008000u;
+                *reinterpret_cast<unsigned*>(dn + 2 * PIECE) = wl ^ 0x80008000u;
+            }
             *reinterpret_cast<float2*>(&yb[rowi * FROW + prow]) = make_float2(v0, v1);
         }
     };
     // the tile of unit u, e partials, H y rows (float32) into hf
     auto mac = [&](int u) {
         const unsigned char* pb = pcs + (size_t)(u & 1) * 3 * PIECE;
-        f16w acc;
+        f16w acc, acc2;                                                // two chains: consecutive MFMAs never share an accumulator
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[r] = acc2[r] = 0.f;
 #pragma unroll
         for (int t = 0; t < KT; ++t) {
             const int part = (16 * t) / PD, j0 = (16 * t) % PD + 8 * mh;
-            const int comp = part == 0 ? cf : 1 - cf;                  // Re form: [y_re; y_im]; Im form: [y_im; -y_re]
-            const unsigned neg = (part == 1 && cf == 1) ? 0x80008000u : 0u;
-            const unsigned char* src = pb + ((cs * 2 + cc) * 2 + comp) * PROW + j0 * 2;
-            const bf8w bh = piece_bits(*reinterpret_cast<const u4w*>(src), neg);
-            const bf8w bm = piece_bits(*reinterpret_cast<const u4w*>(src + PIECE), neg);
-            const bf8w bl = piece_bits(*reinterpret_cast<const u4w*>(src + 2 * PIECE), neg);
+            const int comp = part == 0 ? cf : (cf == 0 ? 1 : 2);       // Re form: [y_re; y_im]; Im form: [y_im; -y_re]
+            const unsigned char* src = pb + ((cs * 2 + cc) * 3 + comp) * PROW + j0 * 2;
+            const bf8w bh = piece_bits(*reinterpret_cast<const u4w*>(src), 0u);
+            const bf8w bm = piece_bits(*reinterpret_cast<const u4w*>(src + PIECE), 0u);
+            const bf8w bl = piece_bits(*reinterpret_cast<const u4w*>(src + 2 * PIECE), 0u);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al[t], bh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[t], bl, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[t], bl, acc2, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am[t], bm, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am[t], bh, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am[t], bh, acc2, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[t], bm, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[t], bh, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[t], bh, acc2, 0, 0, 0);
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
         // C/D layout: column = lane & 31, rows (r & 3) + 8 (r >> 2) + 4 mh of this wave's 32
         const int rowi = (cs * 2 + cc) * 2 + cf;
         const float* yr = yf + (size_t)(u & 1) * FBUF + rowi * FROW + 32 * w + 4 * mh;
@@ -538,9 +550,11 @@ __global__ __launch_bounds__(2 * PD, 1) void k_hy_wide(Dev P) {
         }
     };
 
+    fetch(0);
     prep(0);
     __syncthreads();
     for (int u = 0; u < NU; ++u) {
+        fetch(u + 1);                   // in flight behind this unit's MFMAs (unclamped: see prep)
         mac(u);
         prep(u + 1);                    // (the unit behind the last one: zeros, into the idle buffer)
         __syncthreads();
