@@ -39,6 +39,7 @@ namespace {
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned u4w __attribute__((ext_vector_type(4)));
+typedef unsigned u2w __attribute__((ext_vector_type(2)));
 typedef short bf8w __attribute__((ext_vector_type(8)));
 typedef float f16w __attribute__((ext_vector_type(16)));
 
@@ -396,22 +397,29 @@ constexpr int HCHUNK = 512;                // steps per workgroup
 template <int PD>
 struct HyGeom {
     static constexpr int PROW = 2 * PD + 16;                      // bytes of one (step, clip, component) row of bf16 + bank-spread padding
-    static constexpr int PIECE = HU * 6 * PROW;                   // bytes of one piece of one unit: [step][clip][y_re | y_im | -y_re] rows
+    static constexpr int PIECE = HU * 4 * PROW;                   // bytes of one piece of one unit: [step][clip][comp] rows
     static constexpr int FROW = PD + 4;                           // floats of one float32 row + padding
     static constexpr int FBUF = HU * 4 * FROW;                    // floats of one float32 unit buffer
-    static constexpr size_t LDS = (size_t)2 * 3 * PIECE + (size_t)4 * FBUF * 4 + 2 * (PD / 32) * 16 * 4;
+    static constexpr size_t LDS = (size_t)2 * 3 * PIECE + (size_t)5 * FBUF * 4 + 2 * (PD / 32) * 16 * 4;   // pieces x2, y x3, H y x2, e
 };
 
 }  // namespace
 
+// Five units are in flight per workgroup, one barrier per unit:  rows of unit u + 2 requested | bf16 pieces and float32 rows of unit
+// u + 1 built | MFMAs of unit u | e partials and H y rows of unit u - 1 from the accumulators (two accumulator pairs, by unit parity)
+// | H y rows and e of unit u - 2 out to memory.  The issue order is written out as in k_grad_gemm (cmps_grad_gemm.h): slot t = MFMA t
+// + at most one small slice of the other four stages, fenced.  The sign of the Im form's second K half (-y_re) is applied to the
+// accumulator of that half (out = acc0 +- acc1 per column form), not to the operand reads.
 template <int PD>
 __global__ __launch_bounds__(2 * PD, 1) void k_hy_wide(Dev P) {
     using HG = HyGeom<PD>;
-    constexpr int PWV = PD / 32, NTHR = 2 * PD, KT = 2 * PD / 16, PROW = HG::PROW, PIECE = HG::PIECE, FROW = HG::FROW, FBUF = HG::FBUF;
+    using gg::static_for;
+    constexpr int PWV = PD / 32, KT = 2 * PD / 16, PROW = HG::PROW, PIECE = HG::PIECE, FROW = HG::FROW, FBUF = HG::FBUF;
+    constexpr int NM = 6 * KT;                                    // MFMAs per unit
     extern __shared__ __attribute__((aligned(16))) unsigned char wide_lds[];
     unsigned char* pcs = wide_lds;                                          // [2 buffers][3 pieces][PIECE]
-    float* yf = reinterpret_cast<float*>(wide_lds + 2 * 3 * PIECE);         // [2][FBUF]: y, float32
-    float* hf = yf + 2 * FBUF;                                              // [2][FBUF]: H y, float32
+    float* yf = reinterpret_cast<float*>(wide_lds + 2 * 3 * PIECE);         // [3][FBUF]: y, float32
+    float* hf = yf + 3 * FBUF;                                              // [2][FBUF]: H y, float32
     float* eacc = hf + 2 * FBUF;                                            // [2][PWV][16]
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -424,6 +432,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_hy_wide(Dev P) {
     const int mr = lane & 31, mh = lane >> 5;
     // this lane's column of a unit: (step, clip, form)
     const int cs = mr >> 2, cc = (mr >> 1) & 1, cf = mr & 1;
+    const float sgn = cf ? -1.f : 1.f;
 
     // ---- A operand: row 32 w + mr of [H_re | -H_im], K values 16 t + 8 mh .. + 7, three bf16 pieces ----
     bf8w Ah[KT], Am[KT], Al[KT];
@@ -452,113 +461,156 @@ __global__ __launch_bounds__(2 * PD, 1) void k_hy_wide(Dev P) {
             Al[t] = __builtin_bit_cast(bf8w, u4w{pl[0], pl[1], pl[2], pl[3]});
         }
     }
-    // ---- prep role: positions 2 tid and 2 tid + 1 of a stash vector: two adjacent rows of one (component, clip) ----
+    // ---- build / write-out role: positions 2 tid and 2 tid + 1 of a stash vector: two adjacent rows of one (component, clip) ----
     const int ppos = 2 * tid, pl_ = ppos & 63;
     const int pq = pl_ >> 3, pi = pl_ & 7;
     const int pcomp = (pq >> 1) & 1, pclip = pq & 1;
     const int prow = 16 * (ppos >> 6) + 8 * (pq >> 2) + pi;      // even; the second position is row prow + 1
+    // buffer descriptors (SGPR row offset + a loop-invariant lane offset; a store to be dropped gets a lane offset beyond the
+    // descriptor's range instead of a branch): the pair's stash rows, and the scalar stash
+    float* pair_rows = stash + wide_stash_vec<PD>(blockIdx.x, N, 0, 0);
+    const auto rs_st = __builtin_amdgcn_make_buffer_rsrc(pair_rows, 0, N * (8 * PD * 4), 0x00020000);
+    const auto rs_sc = __builtin_amdgcn_make_buffer_rsrc(P.scal, 0, (int)((size_t)P.B * NC * 128 * 4), 0x00020000);
+    const int voff_y = ppos * 4, voff_h = (4 * PD + ppos) * 4;
 
-    // y of unit u (steps k_lo + 8 u ..) -> bf16 pieces + float32 rows, buffer u & 1.  Unclamped loads: rows one step below / a few steps above the pair's range lie inside the caller's workspace, and every value derived from them is discarded by a select.
-    float2 Y[HU];                                                  // the rows of the next unit, requested before this unit's MFMAs
-    auto fetch = [&](int u) {
-        const int kb = k_lo + HU * u;
-        const float2* src = reinterpret_cast<const float2*>(stash + wide_stash_vec<PD>(blockIdx.x, N, 0, 0) + (ptrdiff_t)kb * (8 * PD) + ppos);
-#pragma unroll
-        for (int j = 0; j < HU; ++j) Y[j] = src[(ptrdiff_t)j * (4 * PD)];
+    // rows of a unit (steps k_lo + 8 u ..).  Unclamped loads: rows a few steps above the pair's range lie inside the caller's
+    // workspace, and every value derived from them is discarded by a select.
+    float2 Y[HU];
+    auto fetch_row = [&](int u, int j) {                          // (rows past the pair's last one read as zero: the descriptor's range)
+        Y[j] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs_st, voff_y, (k_lo + HU * u + j) * (8 * PD * 4), 0));
     };
-    auto prep = [&](int u) {
-        const int kb = k_lo + HU * u;
-        unsigned char* pb = pcs + (size_t)(u & 1) * 3 * PIECE;
-        float* yb = yf + (size_t)(u & 1) * FBUF;
-#pragma unroll
-        for (int j = 0; j < HU; ++j) {
-            const bool in = kb + j < k_hi;
-            const float v0 = in ? Y[j].x : 0.f, v1 = in ? Y[j].y : 0.f;
-            unsigned h0, m0, l0, h1, m1, l1;
-            split3(v0, h0, m0, l0);
-            split3(v1, h1, m1, l1);
+    // step j of unit u -> bf16 pieces (buffer u & 1) + float32 row (buffer u % 3); three parts
+    unsigned sh[3];
+    float sr0 = 0.f, sr1 = 0.f, sv0 = 0.f, sv1 = 0.f;
+    auto prep_part = [&](int u, int u3, int j, int part) {
+        if (part == 0) {
+            const bool in = k_lo + HU * u + j < k_hi;
+            sv0 = in ? Y[j].x : 0.f; sv1 = in ? Y[j].y : 0.f;
+            sr0 = sv0 - __uint_as_float(__float_as_uint(sv0) & 0xFFFF0000u);
+            sr1 = sv1 - __uint_as_float(__float_as_uint(sv1) & 0xFFFF0000u);
+        } else if (part == 1) {
+            const float q0 = sr0 - __uint_as_float(__float_as_uint(sr0) & 0xFFFF0000u);
+            const float q1 = sr1 - __uint_as_float(__float_as_uint(sr1) & 0xFFFF0000u);
+            sh[0] = pack_hi16(__float_as_uint(sv0), __float_as_uint(sv1));
+            sh[1] = pack_hi16(__float_as_uint(sr0), __float_as_uint(sr1));
+            sh[2] = pack_hi16(__float_as_uint(q0), __float_as_uint(q1));
+        } else {
             const int rowi = (j * 2 + pclip) * 2 + pcomp;
-            unsigned char* d = pb + ((j * 2 + pclip) * 3 + pcomp) * PROW + prow * 2;       // rows prow, prow + 1: one dword per piece
-            const unsigned wh = pack_hi16(h0, h1), wm = pack_hi16(m0, m1), wl = pack_hi16(l0, l1);
-            *reinterpret_cast<unsigned*>(d) = wh;
-            *reinterpret_cast<unsigned*>(d + PIECE) = wm;
-            *reinterpret_cast<unsigned*>(d + 2 * PIECE) = wl;
-            // the Im form's second K half is -y_re: a negated copy (third row) instead of sign flips on every operand read
-            unsigned char* dn = d + 2 * PROW;
-            if (pcomp == 0) {
-                *reinterpret_cast<unsigned*>(dn) = wh ^ 0x80008000u;
-                *reinterpret_cast<unsigned*>(dn + PIECE) = wm ^ 0x80008000u;
-                *reinterpret_cast<unsigned*>(dn + 2 * PIECE) = wl ^ 0x80008000u;
-            }
-            *reinterpret_cast<float2*>(&yb[rowi * FROW + prow]) = make_float2(v0, v1);
-        }
-    };
-    // the tile of unit u, e partials, H y rows (float32) into hf
-    auto mac = [&](int u) {
-        const unsigned char* pb = pcs + (size_t)(u & 1) * 3 * PIECE;
-        f16w acc, acc2;                                                // two chains: consecutive MFMAs never share an accumulator
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = acc2[r] = 0.f;
-#pragma unroll
-        for (int t = 0; t < KT; ++t) {
-            const int part = (16 * t) / PD, j0 = (16 * t) % PD + 8 * mh;
-            const int comp = part == 0 ? cf : (cf == 0 ? 1 : 2);       // Re form: [y_re; y_im]; Im form: [y_im; -y_re]
-            const unsigned char* src = pb + ((cs * 2 + cc) * 3 + comp) * PROW + j0 * 2;
-            const bf8w bh = piece_bits(*reinterpret_cast<const u4w*>(src), 0u);
-            const bf8w bm = piece_bits(*reinterpret_cast<const u4w*>(src + PIECE), 0u);
-            const bf8w bl = piece_bits(*reinterpret_cast<const u4w*>(src + 2 * PIECE), 0u);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al[t], bh, acc, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[t], bl, acc2, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am[t], bm, acc, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am[t], bh, acc2, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[t], bm, acc, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[t], bh, acc2, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
-        // C/D layout: column = lane & 31, rows (r & 3) + 8 (r >> 2) + 4 mh of this wave's 32
-        const int rowi = (cs * 2 + cc) * 2 + cf;
-        const float* yr = yf + (size_t)(u & 1) * FBUF + rowi * FROW + 32 * w + 4 * mh;
-        float* hr = hf + (size_t)(u & 1) * FBUF + rowi * FROW + 32 * w + 4 * mh;
-        float ep = 0.f;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const v4f yv = *reinterpret_cast<const v4f*>(yr + 8 * g);
-            ep += yv.x * acc[4 * g] + yv.y * acc[4 * g + 1] + yv.z * acc[4 * g + 2] + yv.w * acc[4 * g + 3];
-            *reinterpret_cast<v4f*>(hr + 8 * g) = v4f{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-        }
-        ep = swap32_add(ep, ep);                                   // + the other row half
-        ep += wdpp<0xB1>(ep);                                      // + the other component (column ^ 1)
-        if (mh == 0 && cf == 0) eacc[((u & 1) * PWV + w) * 16 + (mr >> 1)] = ep;
-    };
-    // H y rows and e of unit u out to the stash (lane order: coalesced) / the scalar stash
-    auto writeout = [&](int u) {
-        const int kb = k_lo + HU * u;
-        const float* hb = hf + (size_t)(u & 1) * FBUF;
-        float2* dst = reinterpret_cast<float2*>(stash + wide_stash_vec<PD>(blockIdx.x, N, 0, 1) + (ptrdiff_t)kb * (8 * PD) + ppos);
-#pragma unroll
-        for (int j = 0; j < HU; ++j)
-            if (kb + j < k_hi)
-                dst[(ptrdiff_t)j * (4 * PD)] = *reinterpret_cast<const float2*>(&hb[((j * 2 + pclip) * 2 + pcomp) * FROW + prow]);
-        if (tid < 16) {
-            const int j = tid >> 1, cl = tid & 1, k = kb + j;
-            float e = 0.f;
-#pragma unroll
-            for (int ww = 0; ww < PWV; ++ww) e += eacc[((u & 1) * PWV + ww) * 16 + tid];
-            if (k < k_hi && (cl == 0 || two))
-                P.scal[((size_t)(cl ? b1 : b0) * NC + k / WCH) * 128 + 64 + (k & (WCH - 1))] = e;
+            unsigned char* d = pcs + (size_t)(u & 1) * 3 * PIECE + rowi * PROW + prow * 2;     // rows prow, prow + 1: one dword per piece
+            *reinterpret_cast<unsigned*>(d) = sh[0];
+            *reinterpret_cast<unsigned*>(d + PIECE) = sh[1];
+            *reinterpret_cast<unsigned*>(d + 2 * PIECE) = sh[2];
+            *reinterpret_cast<float2*>(&yf[(size_t)u3 * FBUF + rowi * FROW + prow]) = make_float2(sv0, sv1);
         }
     };
 
-    fetch(0);
-    prep(0);
+    // one unit.  PAR = u & 1 (static: accumulator pair and LDS buffers of the stages), u3 = u % 3.
+    f16w acc0[2], acc1[2];                                         // [unit parity]: K half 0 (H_re), K half 1 (-H_im)
+    float ep_run = 0.f;
+    float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto run_unit = [&](auto par_c, auto mac_c, int u, int u3) {
+        constexpr int PAR = decltype(par_c)::value;
+        constexpr bool MAC = decltype(mac_c)::value;
+        constexpr int S_W0 = 0, S_E0 = S_W0 + 9, S_P0 = S_E0 + 9, S_F0 = S_P0 + 24, NS = S_F0 + 8;
+        const unsigned char* pb = pcs + (size_t)PAR * 3 * PIECE;
+        const int up3 = u3 == 0 ? 2 : u3 - 1, un3 = u3 == 2 ? 0 : u3 + 1;    // (u - 1) % 3, (u + 1) % 3
+        const int rowi = (cs * 2 + cc) * 2 + cf;
+        const float* yr = yf + (size_t)up3 * FBUF + rowi * FROW + 32 * w + 4 * mh;
+        float* hr = hf + (size_t)(1 - PAR) * FBUF + rowi * FROW + 32 * w + 4 * mh;
+        const int kw = k_lo + HU * (u - 2);                        // first step of the unit being written out
+        const float* hb = hf + (size_t)PAR * FBUF;
+        bf8w Bq[2][3];
+        auto read_b = [&](int t, int buf) {
+            const int part = (16 * t) / PD, j0 = (16 * t) % PD + 8 * mh;
+            const int comp = part == 0 ? cf : 1 - cf;              // Re form: [y_re; y_im]; Im form: [y_im; y_re] (sign: see the epilogue)
+            const unsigned char* src = pb + ((cs * 2 + cc) * 2 + comp) * PROW + j0 * 2;
+            Bq[buf][0] = __builtin_bit_cast(bf8w, *reinterpret_cast<const u4w*>(src));
+            Bq[buf][1] = __builtin_bit_cast(bf8w, *reinterpret_cast<const u4w*>(src + PIECE));
+            Bq[buf][2] = __builtin_bit_cast(bf8w, *reinterpret_cast<const u4w*>(src + 2 * PIECE));
+        };
+        auto slice = [&](auto ic) {
+            constexpr int I = decltype(ic)::value;
+            if constexpr (I < S_E0) {                             // unit u - 2: H y rows and e out (lane order: coalesced)
+                if constexpr (I < 8) {
+                    constexpr int j = I;
+                    const float2 v = *reinterpret_cast<const float2*>(&hb[((j * 2 + pclip) * 2 + pcomp) * FROW + prow]);
+                    const bool ok = u >= 2 && kw + j < k_hi;
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2w, v), rs_st, ok ? voff_h : 0x7fffffff,
+                                                          ok ? (kw + j) * (8 * PD * 4) : 0, 0);
+                } else {
+                    const int j = (tid >> 1) & 7, cl = tid & 1, k = kw + j;
+                    float e = 0.f;
+#pragma unroll
+                    for (int ww = 0; ww < PWV; ++ww) e += eacc[(PAR * PWV + ww) * 16 + (tid & 15)];
+                    const bool ok = tid < 16 && u >= 2 && k < k_hi && (cl == 0 || two);
+                    const int so = (int)((((size_t)(cl ? b1 : b0) * NC + (ok ? k / WCH : 0)) * 128 + 64 + (k & (WCH - 1))) * 4);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, e), rs_sc, ok ? so : 0x7fffffff, 0, 0);
+                }
+            } else if constexpr (I < S_P0) {                      // unit u - 1: H y = acc0 +- acc1, e partial, float32 rows into hf
+                constexpr int x = I - S_E0;                       // C/D layout: column = lane & 31, rows (r & 3) + 8 (r >> 2) + 4 mh
+                if constexpr (x < 8) {
+                    constexpr int g = x / 2;
+                    if constexpr ((x & 1) == 0) {
+                        hv = make_float4(acc0[1 - PAR][4 * g] + sgn * acc1[1 - PAR][4 * g], acc0[1 - PAR][4 * g + 1] + sgn * acc1[1 - PAR][4 * g + 1],
+                                         acc0[1 - PAR][4 * g + 2] + sgn * acc1[1 - PAR][4 * g + 2], acc0[1 - PAR][4 * g + 3] + sgn * acc1[1 - PAR][4 * g + 3]);
+                        if constexpr (g == 0) ep_run = 0.f;
+                    } else {
+                        const v4f yv = *reinterpret_cast<const v4f*>(yr + 8 * g);
+                        ep_run += yv.x * hv.x + yv.y * hv.y + yv.z * hv.z + yv.w * hv.w;
+                        *reinterpret_cast<v4f*>(hr + 8 * g) = v4f{hv.x, hv.y, hv.z, hv.w};
+                    }
+                } else {
+                    float ep = swap32_add(ep_run, ep_run);        // + the other row half
+                    ep += wdpp<0xB1>(ep);                         // + the other component (column ^ 1)
+                    if (mh == 0 && cf == 0) eacc[((1 - PAR) * PWV + w) * 16 + (mr >> 1)] = ep;
+                }
+            } else if constexpr (I < S_F0) {                      // unit u + 1: pieces and float32 rows from the fetched rows
+                constexpr int x = I - S_P0;
+                prep_part(u + 1, un3, x / 3, x % 3);
+            } else {                                              // unit u + 2: request its rows
+                fetch_row(u + 2, I - S_F0);
+            }
+        };
+        if constexpr (MAC) {
+            read_b(0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        static_for<0, (MAC ? NM : NS)>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            if constexpr (MAC) {
+                constexpr int kt = t / 6, pr = t % 6, buf = kt & 1;
+                if constexpr (pr == 0 && kt + 1 < KT) read_b(kt + 1, 1 - buf);
+                // piece products a + b <= 2: lo hi', hi lo', mid mid', mid hi', hi mid', hi hi'
+                const bf8w av = pr == 0 ? Al[kt] : (pr == 2 || pr == 3) ? Am[kt] : Ah[kt];
+                const bf8w bv = pr == 1 ? Bq[buf][2] : (pr == 2 || pr == 4) ? Bq[buf][1] : Bq[buf][0];
+                constexpr f16w zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if constexpr (kt < KT / 2) acc0[PAR] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, t == 0 ? zero : acc0[PAR], 0, 0, 0);
+                else acc1[PAR] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, t == 6 * (KT / 2) ? zero : acc1[PAR], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<(t * NS) / NM, ((t + 1) * NS) / NM>(slice);
+            } else {
+                slice(tc);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+
+#pragma unroll
+    for (int j = 0; j < HU; ++j) fetch_row(0, j);
+#pragma unroll
+    for (int x = 0; x < 24; ++x) prep_part(0, 0, x / 3, x % 3);
+#pragma unroll
+    for (int j = 0; j < HU; ++j) fetch_row(1, j);
     __syncthreads();
-    for (int u = 0; u < NU; ++u) {
-        fetch(u + 1);                   // in flight behind this unit's MFMAs (unclamped: see prep)
-        mac(u);
-        prep(u + 1);                    // (the unit behind the last one: zeros, into the idle buffer)
+    // units 0 .. NU + 1: the last two only drain the pipeline (their MFMAs run on zero columns)
+    int u3 = 0;
+    for (int u = 0; u < NU + 2; u += 2) {
+        run_unit(std::integral_constant<int, 0>{}, std::true_type{}, u, u3);
+        u3 = u3 == 2 ? 0 : u3 + 1;
         __syncthreads();
-        writeout(u);
+        run_unit(std::integral_constant<int, 1>{}, std::true_type{}, u + 1, u3);
+        u3 = u3 == 2 ? 0 : u3 + 1;
+        __syncthreads();
     }
 }
 
