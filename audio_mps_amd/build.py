@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libcmps.so")
-SOURCES = ["cmps_capi.hip", "cmps_prep.hip", "cmps_opt.hip", "cmps_block.hip", "cmps_wave.hip", "cmps_wave2.hip", "cmps_wave16.hip", "cmps_pair.hip", "cmps_wide.hip", "cmps_legacy.hip", "cmps_legacy_wave.hip", "cmps_rho.hip", "cmps_rho_wave.hip", "cmps_rho_mfma.hip"]
+SOURCES = ["cmps_capi.hip", "cmps_prep.hip", "cmps_opt.hip", "cmps_block.hip", "cmps_wave.hip", "cmps_wave2.hip", "cmps_wave16.hip", "cmps_pair.hip", "cmps_wide.hip", "cmps_legacy.hip", "cmps_rho.hip", "cmps_rho_wave.hip", "cmps_rho_mfma.hip"]
 HEADERS = ["cmps_internal.h", "cmps_wave_util.h", "cmps_grad_gemm.h", os.path.join("..", "..", "include", "cmps.h")]
 
 

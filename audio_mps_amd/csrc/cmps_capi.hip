@@ -370,8 +370,16 @@ int cmps_legacy_set_params(cmps_handle_t h, const float* R_dev, const float* Q_r
     P.sums = (flags & CMPS_WS_TRAIN) ? reinterpret_cast<float*>(ws + L.off_sums) : nullptr;
     P.slab_floats = L.slab_floats;
     P.dt = (float)delta_t;
+    // the tables of the pure-state wave kernels, which the D <= 32 legacy kernels share (cmps_wave2.hip / cmps_wave.hip, LEGACY):
+    // rotation rho = 1, psi_0 = e_0, no time table
+    P.psi0 = reinterpret_cast<float2*>(ws + L.off_psi0);
+    P.dtk = reinterpret_cast<float*>(ws + L.off_dtk);
+    P.rho = reinterpret_cast<float2*>(ws + L.off_rho);
+    P.A = 1.0f;
     hipError_t e = launch_pack_legacy(P, R_dev, Q_re_dev, Q_im_dev, const_cast<float2*>(P.R), const_cast<float2*>(P.RT),
                                       const_cast<float2*>(P.Q), const_cast<float2*>(P.QT), static_cast<hipStream_t>(stream));
+    if (e == hipSuccess) e = launch_legacy_tables(P, const_cast<float2*>(P.psi0), const_cast<float*>(P.dtk), const_cast<float2*>(P.rho),
+                                                  static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail_hip(h, e, "cmps_legacy_set_params");
     h->L = L; h->P = P; h->ws = ws;
     h->tt_ws = nullptr;               // the time table of the PsiCMPS mode is no longer valid for this workspace
@@ -392,7 +400,7 @@ int cmps_legacy_loss_fwd(cmps_handle_t h, const float* audio_dev, int B, int T, 
         return fail(h, CMPS_ERR_WORKSPACE, "cmps_legacy_loss_fwd: save_for_bwd needs a CMPS_WS_TRAIN workspace");
     Dev P = h->P;
     P.B = B;
-    const bool wave = h->D <= 32 && h->variant_req != CMPS_VARIANT_BLOCK;     // wave-per-clip kernels (cmps_legacy_wave.hip)
+    const bool wave = h->D <= 32 && h->variant_req != CMPS_VARIANT_BLOCK;     // the pure-state wave kernels in LEGACY mode (cmps_wave2.hip, cmps_wave.hip)
     hipError_t e = wave ? launch_fwd_legacy_wave(P, audio_dev, loss_dev, save_for_bwd != 0, static_cast<hipStream_t>(stream))
                         : launch_fwd_legacy(P, audio_dev, loss_dev, save_for_bwd != 0, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail_hip(h, e, "cmps_legacy_loss_fwd");
@@ -412,7 +420,7 @@ int cmps_legacy_loss_bwd(cmps_handle_t h, const float* audio_dev, int B, int T, 
     Dev P = h->P;
     P.B = B;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipError_t e = h->saved_variant == CMPS_VARIANT_WAVE ? launch_bwd_legacy_wave(P, audio_dev, s) : launch_bwd_legacy(P, audio_dev, s);
+    hipError_t e = h->saved_variant == CMPS_VARIANT_WAVE ? launch_bwd_legacy_wave(P, audio_dev, h->rank1_mode, s) : launch_bwd_legacy(P, audio_dev, s);
     if (e != hipSuccess) return fail_hip(h, e, "cmps_legacy_loss_bwd (scan)");
     e = launch_reduce_only(P, s);
     if (e == hipSuccess) e = launch_finalize_legacy(P, h->saved_loss, grad_dev, s);

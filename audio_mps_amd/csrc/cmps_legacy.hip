@@ -186,6 +186,19 @@ __global__ void k_finalize_legacy(Dev P, const float* __restrict__ sums, const f
     }
 }
 
+// rho = 1 ((N + 1) DP entries), psi_0 = e_0, dtk = 0 (N + 64): the tables the shared wave kernels read
+__global__ void k_legacy_tables(int DP, int N, float2* __restrict__ psi0, float* __restrict__ dtk, float2* __restrict__ rho) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+    for (int i = idx; i < (N + 1) * DP; i += nth) rho[i] = make_float2(1.f, 0.f);
+    for (int i = idx; i < N + 64; i += nth) dtk[i] = 0.f;
+    if (idx < DP) psi0[idx] = make_float2(idx == 0 ? 1.f : 0.f, 0.f);
+}
+
+hipError_t launch_legacy_tables(const Dev& P, float2* psi0, float* dtk, float2* rho, hipStream_t s) {
+    hipLaunchKernelGGL(k_legacy_tables, dim3(256), dim3(256), 0, s, P.DP, P.N, psi0, dtk, rho);
+    return hipGetLastError();
+}
+
 hipError_t launch_pack_legacy(const Dev& P, const float* Rr, const float* Qre, const float* Qim, float2* R,
                               float2* RT, float2* Q, float2* QT, hipStream_t s) {
     const int n = P.DP * P.DP;

@@ -59,7 +59,14 @@ struct Pre {
 
 // RANK1: how the three rank-1 gradient updates of a step are applied (cmps_set_option(CMPS_OPT_RANK1)):
 //   0 exact fp32 MFMA every step; 1 bf16 hi/lo split, 3 products; 2 bf16 hi/mid/lo split, 6 products (see below)
-template <int RANK1>
+// LEGACY: the reverse sweep of the previous-generation AudioMPS arithmetic (cmps_legacy.hip) on the same chain.  With rho = 1 in the
+// tables, g = cotangent of psi_{k+1} without its own loss term, and e_k = psi_k^dagger H psi_k (degree 0 in y_{k-1}):
+//   ybar_k = (g_{k+1} - yhat_k dot) inv_k + te_{k+1} inv_k^2 (H y_k),   dot = Re(yhat_k^dagger g_{k+1}) + te_{k+1} e_{k+1}
+//   (Re(yhat_k^dagger g_{k+1}) is 0 analytically -- everything downstream of psi_{k+1} but e_{k+1} is scale invariant -- and is
+//   taken exactly once per staged chunk);   g_k = ybar_k + (Q^dagger + dt x_k R^dagger) ybar_k;   te_k = 2 (e_k - x_k)
+//   Rbar += (te_k psi_k) psi_k^dagger + (dt x_k ybar_k) psi_k^dagger,   Qbar += ybar_k psi_k^dagger
+// so only the per-step scalar rows, Q^dagger instead of Q and the first rank-1 operand differ.
+template <int RANK1, bool LEGACY = false>
 __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* __restrict__ audio) {
     __shared__ __attribute__((aligned(16))) float4 stY[WAVES][CHB * 32];   // stashed (y, H y) rows of the staged chunk
     __shared__ __attribute__((aligned(16))) float4 stR[WAVES][CHB * 16];   // rho rows
@@ -80,7 +87,12 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
     for (int m = 0; m < 16; ++m) {
         const v2f rt = ld2(&P.RT[i * DPW + 16 * h + m]);   // R[16h+m][i]
         MRd[m] = mk2(rt.x, -rt.y);                          // R^dagger[i][16h+m]
-        MQ[m] = ld2(&P.Q[i * DPW + 16 * h + m]);
+        if constexpr (LEGACY) {
+            const v2f qt = ld2(&P.QT[i * DPW + 16 * h + m]);
+            MQ[m] = mk2(qt.x, -qt.y);                       // Q^dagger (the legacy Q is not Hermitian)
+        } else {
+            MQ[m] = ld2(&P.Q[i * DPW + 16 * h + m]);
+        }
     }
     v16f Rre = {}, Rim = {}, Qre = {}, Qim = {};
 
@@ -112,13 +124,24 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
         rnv = sc[(size_t)c * 128 + lane];
         rev = sc[(size_t)c * 128 + 64 + lane];
     };
+    float te_above = 0.f;             // LEGACY: te of the first step of the chunk above (no step N: 0)
     auto scal_commit = [&](int c) {
         const int idx = c * CH + lane;
         const float inc = ra1 - ra0;
-        const float sv = inc / A;
         const float nv = rnv, ev = rev;
         const float invv = rsq_nr(fmaxf(nv, 1e-12f));
         const float invokv = nv > 1e-12f ? invv : 0.f;
+        if constexpr (LEGACY) {
+            const float tev = idx < N ? 2.0f * (ev - inc) : 0.f;              // te_k = 2 ebar_k, ebar_k = e_k - x_k
+            float ten = __shfl_down(tev, 1, 64);                              // te_{k+1}
+            if (lane == 63) ten = te_above;
+            te_above = rdlane(tev, 0);
+            // row: (s, dtk, inv, te_k | te_{k+1} inv_k^2 (the coefficient of H y_k), invok, rad = te_k e_k, -)
+            scl[w][2 * lane] = make_float4(P.dt * inc, rdt, invv, tev);
+            scl[w][2 * lane + 1] = make_float4(ten * invv * invv, invokv, tev * ev, 0.f);
+            return;
+        }
+        const float sv = inc / A;
         const float ex = ev * inc;                      // model.py:294 operation order
         const float z = ex / A;
         const float zbar = -1.0f / (1.0f + z);
@@ -268,8 +291,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(piece(std::integral_constant<int, WA>{}, ia)),
                                                           frag(piece(std::integral_constant<int, WB>{}, ib)), acc, 0, 0, 0);
         };
-        if constexpr (PR == 0) mf(Rre, 0, 3);
-        if constexpr (PR == 1) mf(Rim, 0, 4);
+        if constexpr (PR == 0) mf(Rre, 0, LEGACY ? 5 : 3);
+        if constexpr (PR == 1) mf(Rim, 0, LEGACY ? 6 : 4);
         if constexpr (PR == 2) mf(Qre, 1, 5);
         if constexpr (PR == 3) mf(Qim, 1, 6);
         if constexpr (PR == 4) mf(Rre, 2, 5);
@@ -305,7 +328,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
         const v2f yhbp = cmul2_conj_b(mk2(g, go), S.rho);              // conj(rho_k) g
         const float yhb = yhbp.x;
         float dot = rad_next;
-        if (exact) dot = sum64(S.yhp * yhb);
+        if (exact) dot = LEGACY ? sum64(S.yhp * yhb) + rad_next : sum64(S.yhp * yhb);
         rad_next = S.rad;
         const float ybar = (yhb - dot * S.yhp) * S.inv + S.pre;
         bcast_issue(aBw, aBr, ybar, qc);                               // 9 ops
@@ -359,11 +382,11 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
         //   Rbar += 2 ebar y y^dagger + s ybar u^dagger ;  Qbar += ybar u^dagger
         //   Re(a b^dagger): A = a (split), B = b (split);  Im(a b^dagger): A = a (split), B = -b_osig
         //   (the sign of the Im tiles is applied once at the end)
-        const float a1 = S.ten * S.yh;           // 2 ebar n yhat  (y y^dagger = n yhat yhat^dagger)
+        const float a1 = LEGACY ? S.ten * uk : S.ten * S.yh;   // 2 ebar n yhat  (y y^dagger = n yhat yhat^dagger); legacy: te_k psi_k
         const float a2 = S.s * ybar;
         if constexpr (decltype(slot)::value < 0) {
-            Rre = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, S.yh, Rre, 0, 0, 0);
-            Rim = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, S.yho, Rim, 0, 0, 0);
+            Rre = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, LEGACY ? uk : S.yh, Rre, 0, 0, 0);
+            Rim = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, LEGACY ? uko : S.yho, Rim, 0, 0, 0);
             Qre = __builtin_amdgcn_mfma_f32_32x32x2f32(ybar, uk, Qre, 0, 0, 0);
             Qim = __builtin_amdgcn_mfma_f32_32x32x2f32(ybar, uko, Qim, 0, 0, 0);
             Rre = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, uk, Rre, 0, 0, 0);
@@ -510,6 +533,17 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_sample_wave(Dev P, const floa
 hipError_t launch_sample_wave(const Dev& P, const float* noise, int n, int length, float* out, hipStream_t s) {
     const unsigned nb = (unsigned)((n + WAVES - 1) / WAVES);
     hipLaunchKernelGGL(k_sample_wave, dim3(nb), dim3(64 * WAVES), 0, s, P, noise, n, length, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_bwd_legacy_wave(const Dev& P, const float* audio, int rank1_mode, hipStream_t s) {
+    const unsigned nb = (unsigned)((P.B + WAVES - 1) / WAVES);
+    if (rank1_mode == 0)
+        hipLaunchKernelGGL((k_bwd_wave<0, true>), dim3(nb), dim3(64 * WAVES), 0, s, P, audio);
+    else if (rank1_mode == 1)
+        hipLaunchKernelGGL((k_bwd_wave<1, true>), dim3(nb), dim3(64 * WAVES), 0, s, P, audio);
+    else
+        hipLaunchKernelGGL((k_bwd_wave<2, true>), dim3(nb), dim3(64 * WAVES), 0, s, P, audio);
     return hipGetLastError();
 }
 

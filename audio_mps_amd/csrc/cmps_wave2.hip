@@ -134,7 +134,12 @@ __device__ __forceinline__ float vmax_s(float s, float c) {     // one v_max_f32
 #define DIAG_NO_CHAIN 0
 #endif
 
-template <bool SAVE>
+// LEGACY: the arithmetic of the previous-generation AudioMPS (cmps_legacy.hip: the recurrence and its graph.pbtxt lines) on the same
+// machinery.  With rho = 1 and psi_0 = e_0 in the tables (cmps_legacy_set_params) the chain is the same linear step,
+// y_k = inv_{k-1} (y_{k-1} + M_k y_{k-1}), M_k = Q + dt x_k R; what differs is the loss wave: e_k = psi_k^dagger H psi_k is taken on the
+// normalised state BEFORE the update, i.e. e_k = (y_{k-1}^dagger H y_{k-1}) / max(|y_{k-1}|^2, 1e-12) (e_0 = H_00), and
+// loss += (x_k - e_k)^2 / 2.  The stash rows (y_k, H y_k) and the |y_k|^2 rows are the same; the e rows hold the legacy e_k.
+template <bool SAVE, bool LEGACY = false>
 __global__ __launch_bounds__(128 * WAVES, 1) void k_fwd_wave2(Dev P, const float* __restrict__ audio,
                                                               float* __restrict__ loss_out) {
     __shared__ __attribute__((aligned(16))) float4 stR[WAVES][CH2 * 16];   // rho rows of the chain wave's chunk
@@ -187,7 +192,7 @@ __global__ __launch_bounds__(128 * WAVES, 1) void k_fwd_wave2(Dev P, const float
         // reduction of |y_{k-1}|^2 rides inside the FMA blocks of step k instead of sitting on the serial chain.
         float xsq = lane == 0 ? 1.f : 0.f;      // "|y_{-1}|^2" = 1: psi_0 arrives normalised
         float nvec = 1.f;
-        float sv = (xa1 - xa0) / A;             // model.py:263, 303: s_k = x_k / A, one step per lane
+        float sv = LEGACY ? P.dt * (xa1 - xa0) : (xa1 - xa0) / A;   // model.py:263, 303: s_k = x_k / A, one step per lane (legacy: dt x_k)
         // M_k = Q + s_k R (model.py:308-313 with the two products merged): one packed FMA per complex entry
 #define FORM_M(S_)                                                                                            \
         {                                                                                                     \
@@ -272,7 +277,7 @@ __global__ __launch_bounds__(128 * WAVES, 1) void k_fwd_wave2(Dev P, const float
             flag_store(aProd, c + 1, lane);                            // publish (ordered behind the chunk's y rows)
             if (c + 1 < NC2) {
                 stage_commit<8>(stR[w], lane, sr);
-                sv = (xa1 - xa0) / A;                                  // the next chunk's s_k
+                sv = LEGACY ? P.dt * (xa1 - xa0) : (xa1 - xa0) / A;    // the next chunk's s_k
                 FORM_M(rdlane(sv, 0))                                  // the last in-loop FORM_M used the stale lane 0
                 bcast_issue_tab(aUw, aUr, u, aRho, qu, rho);
             }
@@ -332,6 +337,7 @@ __global__ __launch_bounds__(128 * WAVES, 1) void k_fwd_wave2(Dev P, const float
     float* pew = &pe[w][0];
     float2* st = SAVE ? reinterpret_cast<float2*>(P.hst + (size_t)b * N * 128) : nullptr;   // rows of 64 (y[n], (H y)[n]) pairs
     float loss = 0.f;
+    float f_below = 2.0f * P.R[0].x, n_below = 1.f;                    // LEGACY: y^dagger H y and |y|^2 of the step below the chunk (psi_0 = e_0)
     for (int c = 0; c < NC2; ++c) {
         const int kbeg = c * CH2;
         const int cnt = (N - kbeg) < CH2 ? (N - kbeg) : CH2;
@@ -372,6 +378,11 @@ __global__ __launch_bounds__(128 * WAVES, 1) void k_fwd_wave2(Dev P, const float
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) pr[r] = yc0[r] * acc0[r] + yc1[r] * acc1[r];
+        float pn[LEGACY ? 16 : 1];
+        if constexpr (LEGACY) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pn[r] = yc0[r] * yc0[r] + yc1[r] * yc1[r];
+        }
         if (SAVE) {
             // Stash row (kbeg + step) = 64 pairs (y[n], (H y)[n]) = 512 contiguous bytes.  Register r holds step s0 = (r & 3) +
             // 8 (r >> 2) in lanes 0-31 and step s0 + 4 in lanes 32-63, for n = 0..31 (tile 0) and n = 32..63 (tile 1): one
@@ -406,8 +417,33 @@ __global__ __launch_bounds__(128 * WAVES, 1) void k_fwd_wave2(Dev P, const float
         }
         __builtin_amdgcn_wave_barrier();
         const float incv = x1 - x0;
-        const float z = (evec * incv) / A;                             // model.py:294 operation order
-        const float lv = -logf(1.0f + z);
+        float lv;
+        if constexpr (LEGACY) {
+            // |y_k|^2 the same way, then the expectation on the normalised state of the step below
+            float nvec2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pew[((r & 3) + 8 * (r >> 2) + 4 * chk) * PE2_LD + crow] = pn[r];
+            __builtin_amdgcn_wave_barrier();
+            {
+                const float4* rowp = reinterpret_cast<const float4*>(pew + crow * PE2_LD + 16 * chk);
+                const float4 q0 = rowp[0], q1 = rowp[1], q2 = rowp[2], q3 = rowp[3];
+                const float part = ((q0.x + q0.y) + (q0.z + q0.w)) + ((q1.x + q1.y) + (q1.z + q1.w)) +
+                                   (((q2.x + q2.y) + (q2.z + q2.w)) + ((q3.x + q3.y) + (q3.z + q3.w)));
+                nvec2 = swapadd(part, part);
+            }
+            __builtin_amdgcn_wave_barrier();
+            float fb = __shfl_up(evec, 1, 64), nb = __shfl_up(nvec2, 1, 64);       // lanes k and k + 32 both hold step k
+            if (crow == 0) { fb = f_below; nb = n_below; }
+            f_below = rdlane(evec, CH2 - 1);
+            n_below = rdlane(nvec2, CH2 - 1);
+            const float invb = 1.0f / sqrtf(fmaxf(nb, 1e-12f));       // graph.pbtxt:14350-14594
+            evec = (fb * invb) * invb;                                 // e_k = psi_k^dagger (R + R^T) psi_k  (:11857-12661)
+            const float d = incv - evec;
+            lv = d * d / 2.0f;                                         // :12685-12819
+        } else {
+            const float z = (evec * incv) / A;                         // model.py:294 operation order
+            lv = -logf(1.0f + z);
+        }
         for (int j = 0; j < cnt; ++j) loss += rdlane(lv, j);           // model.py:279: sequential in time
         if (SAVE && lane < CH2) sc[(size_t)(c >> 1) * 128 + 64 + (c & 1) * CH2 + lane] = evec;
     }
@@ -420,6 +456,15 @@ hipError_t launch_fwd_wave2(const Dev& P, const float* audio, float* loss, bool 
         hipLaunchKernelGGL(k_fwd_wave2<true>, dim3(nb), dim3(128 * WAVES), 0, s, P, audio, loss);
     else
         hipLaunchKernelGGL(k_fwd_wave2<false>, dim3(nb), dim3(128 * WAVES), 0, s, P, audio, loss);
+    return hipGetLastError();
+}
+
+hipError_t launch_fwd_legacy_wave(const Dev& P, const float* audio, float* loss, bool save, hipStream_t s) {
+    const unsigned nb = (unsigned)((P.B + WAVES - 1) / WAVES);
+    if (save)
+        hipLaunchKernelGGL((k_fwd_wave2<true, true>), dim3(nb), dim3(128 * WAVES), 0, s, P, audio, loss);
+    else
+        hipLaunchKernelGGL((k_fwd_wave2<false, true>), dim3(nb), dim3(128 * WAVES), 0, s, P, audio, loss);
     return hipGetLastError();
 }
 

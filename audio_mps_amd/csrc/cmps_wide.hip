@@ -163,7 +163,6 @@ __device__ __forceinline__ size_t wide_ybar_vec(size_t pair, int N, int step) {
     return (pair * N + step) * (size_t)(4 * PD);
 }
 
-constexpr int GU = 4;       // steps per unit
 
 // x = hi + mid + lo exactly, each with 8 significant bits: returned as bf16 bit patterns in the upper halves
 __device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
@@ -587,7 +586,9 @@ __global__ __launch_bounds__(2 * PD, 1) void k_hy_wide(Dev P) {
                 if constexpr (kt < KT / 2) acc0[PAR] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, t == 0 ? zero : acc0[PAR], 0, 0, 0);
                 else acc1[PAR] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, t == 6 * (KT / 2) ? zero : acc1[PAR], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
+#if !(defined(CMPS_DIAG) && defined(WABL_HY_NO_SLICES))            // diagnostic builds only (results are wrong): the MFMA stream alone
                 static_for<(t * NS) / NM, ((t + 1) * NS) / NM>(slice);
+#endif
             } else {
                 slice(tc);
             }

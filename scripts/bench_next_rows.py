@@ -3,7 +3,7 @@
 
 For every row: device time of one call at a stated shape (HIP events around the launches, median of a few rounds, inputs
 resident in HBM), the throughput in audio samples/s, and the same arithmetic on the host CPU (the numpy oracle, one
-process, a bounded sample) for scale.  Prints one JSON object; scripts/.. -> profiles/r2_next_rows.json.
+process, a bounded sample) for scale.  Prints one JSON object; scripts/.. -> profiles/r3_next_rows.json.
 """
 import json
 import os
@@ -66,7 +66,7 @@ ms = dev_ms(lambda: (lb.legacy_forward(audio, save_for_bwd=True), lb.legacy_back
 t0 = time.perf_counter()
 O.legacy_loss_and_grads(lm.variables["H"], lm.variables["R"], lm.delta_t, audio[:8, :1000].cpu().numpy())
 cpu = 8 * 1000 / (time.perf_counter() - t0)
-res["legacy_audiomps"] = {"shape": f"D=32, T={T}, B={B}, fwd+bwd", "kernel": "k_fwd_legacy_wave + k_bwd_legacy_wave (wave per clip)", "ms": ms,
+res["legacy_audiomps"] = {"shape": f"D=32, T={T}, B={B}, fwd+bwd", "kernel": "k_fwd_wave2<LEGACY> + k_bwd_wave<LEGACY> (the pure-state wave kernels in legacy mode)", "ms": ms,
                           "samples_per_s": B * T / ms * 1e3, "cpu_numpy_samples_per_s": cpu, "bound": "straight-line wave-per-clip kernels: two wave reductions per forward step, three exact fp32 MFMAs per reverse step (latency)"}
 
 # ---- rank 3: RhoCMPS forward + backward (rank-r column kernels), D = 32, rank 4 and 32, T = 1000, 256 clips

@@ -425,7 +425,7 @@ def test_legacy_audiomps_matches_oracle(D, T, B, dt):
 
 @pytest.mark.parametrize("T", [65, 130, 400])
 def test_legacy_wave_and_block_kernels_agree(T):
-    """D <= 32 runs the wave-per-clip legacy kernels (cmps_legacy_wave.hip); CMPS_VARIANT_BLOCK forces the block kernels."""
+    """D <= 32 runs the wave-per-clip kernels in legacy mode (k_fwd_wave2<LEGACY>, k_bwd_wave<LEGACY>); CMPS_VARIANT_BLOCK forces the block kernels."""
     from audio_mps_amd import LegacyAudioMPS
     from audio_mps_amd.scan import HipScan
     audio = make_audio(6, T, 0.004, 3, noise=0.05)
