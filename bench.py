@@ -290,7 +290,7 @@ def executed_split(variant, D, rank1):
                         "what": "k_fwd_wide: merged (Q + s R) u, fp32 v_pk_fma (8 + 4 forming it); k_hy_wide: H y for all (clip, step) pairs "
                                 "as a bf16x3-split GEMM; k_loss_wide: the sequential float32 loss sums"},
                 "bwd": {"valu_fp32": 12, "mfma_fp32_equiv": 24, "mfma_products": prod, "eliminated": 20,
-                        "what": "k_bwd_wide: merged (Q + s R^dagger) ybar on the VALU; k_grad_wide: rank-1 sums as split-bf16 GEMMs"}}
+                        "what": "k_bwd_wide: merged (Q + s R^dagger) ybar on the VALU; k_grad_gemm (NPC = 3 or 2): rank-1 sums as split-bf16 GEMMs"}}
     if variant == V_PAIR:
         return {"fwd": {"valu_fp32": 0, "mfma_fp32_equiv": 24, "mfma_products": 1, "eliminated": 0, "what": "R u, Q u (4x4x4 bf16), H y (32x32x16 bf16)"},
                 "bwd": {"valu_fp32": 0, "mfma_fp32_equiv": 40, "mfma_products": 1, "eliminated": 16,
@@ -304,9 +304,9 @@ KERNEL_NAMES = {
     "wave16": ("k_fwd_wave16", "k_fwd_wave16 (forward scan, 16-row layout: chain wave + loss wave)", "k_bwd_wave16",
                "k_bwd_wave16 (reverse scan, 16-row layout: chain wave + gradient wave)"),
     "pair": ("k_fwd_pair", "k_fwd_pair (forward scan: 4x4x4 bf16 MFMA chain waves + 32x32x16 loss waves, eight steps per tile)", "k_bwd_pair",
-             "k_bwd_pair + k_grad_pair (reverse scan + streaming gradient GEMM)"),
+             "k_bwd_pair + k_grad_gemm<1 piece> (reverse scan + streaming gradient GEMM)"),
     "wide": ("k_fwd_wide", "k_fwd_wide + k_hy_wide + k_loss_wide (float32 forward chain, R / Q register resident; H y as a split-bf16 GEMM)", "k_bwd_wide",
-             "k_bwd_wide + k_grad_wide (float32 reverse scan + split-bf16 gradient GEMM)"),
+             "k_bwd_wide + k_grad_gemm<3 pieces> (float32 reverse scan + split-bf16 gradient GEMM)"),
     "block": ("k_fwd_block", "k_fwd_block", "k_bwd_block", "k_bwd_block"),
 }
 
@@ -634,7 +634,7 @@ def worker(ARGS):
                 ab[name].update({"ms_per_step": 1e3 * rr["elapsed"] / 5, "samples_per_s": B * T * 5 / rr["elapsed"],
                                  "bwd_ms": rr["t_bwd"] * 1e3, "fwd_ms": rr["t_fwd"] * 1e3})
             run.backend.set_rank1(RANK1_MODES[ARGS.rank1])
-            out["precision_ab"] = {"what": "rank-1 gradient sums (k_bwd_wave / k_grad_wide); everything else is identical fp32 code.  All "
+            out["precision_ab"] = {"what": "rank-1 gradient sums (k_bwd_wave / k_grad_gemm); everything else is identical fp32 code.  All "
                                            "modes sit in float32 reorder noise of the oracle: the label 'fp32-faithful' of bf16x3 rests on its "
                                            "operand-bit argument (24 bits kept), not on a difference this comparison can resolve",
                                    "headline_mode": ARGS.rank1, "modes": ab}
