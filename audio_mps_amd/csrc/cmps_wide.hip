@@ -586,9 +586,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_hy_wide(Dev P) {
                 if constexpr (kt < KT / 2) acc0[PAR] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, t == 0 ? zero : acc0[PAR], 0, 0, 0);
                 else acc1[PAR] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, t == 6 * (KT / 2) ? zero : acc1[PAR], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-#if !(defined(CMPS_DIAG) && defined(WABL_HY_NO_SLICES))            // diagnostic builds only (results are wrong): the MFMA stream alone
                 static_for<(t * NS) / NM, ((t + 1) * NS) / NM>(slice);
-#endif
             } else {
                 slice(tc);
             }

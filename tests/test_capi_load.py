@@ -116,7 +116,8 @@ def test_options_default_and_errors(hip_lib):
     ("cmps_wave2.hip", ["-DCMPS_DIAG_NO_LOSS"]), ("cmps_wave2.hip", ["-DCMPS_DIAG_NO_CHAIN"]),
     ("cmps_pair.hip", ["-DPABL_NO_MFMA"]), ("cmps_pair.hip", ["-DPABL_NO_REDUCE", "-DPABL_NO_BARRIER", "-DPABL_NO_EXPORT"]),
     ("cmps_pair.hip", ["-DPABL_NO_STASHREAD", "-DPABL_HALF_READS"]), ("cmps_pair.hip", ["-DPABL_TIMING", "-DPABL_NO_EXPORT_STORES"]),
-    ("cmps_wave16.hip", ["-DW16_TIMING"]), ("cmps_wide.hip", ["-DWABL_NO_LOSSMV"]),
+    ("cmps_wave16.hip", ["-DW16_TIMING"]), ("cmps_wide.hip", ["-DWABL_NO_LOSSMV", "-DWABL_GRAD_NO_LOADS", "-DWABL_GRAD_NO_STORE"]),
+    ("cmps_pair.hip", ["-DWABL_GRAD_NO_SLICES"]),
 ])
 def test_diagnostic_switches_compile(source, flags, tmp_path):
     """The timing-only switches of scripts/ablate.py live behind -DCMPS_DIAG; each must keep compiling for gfx950."""
