@@ -407,7 +407,8 @@ def test_more_clips_than_simds():
 # ---------------------------------------------------------------------------------------------------
 # next row: the legacy AudioMPS arithmetic
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("D,T,B,dt", [(5, 200, 8, 0.01), (10, 300, 4, 0.001), (32, 150, 3, 0.01), (40, 60, 2, 0.01)])
+@pytest.mark.parametrize("D,T,B,dt", [(5, 200, 8, 0.01), (10, 300, 4, 0.001), (32, 150, 3, 0.01), (40, 60, 2, 0.01),
+                                      (7, 2, 3, 0.01), (32, 34, 5, 0.004), (16, 1000, 9, 0.002)])      # one step; a one-step last chunk; many chunks
 def test_legacy_audiomps_matches_oracle(D, T, B, dt):
     from audio_mps_amd import AudioMPS, LegacyAudioMPS
     audio = make_audio(B, T, dt, D, noise=0.05)
