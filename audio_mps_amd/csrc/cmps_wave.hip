@@ -472,6 +472,49 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
 // One wavefront per sample path, same layout and mat-vec as the forward scan; here both wave reductions sit on
 // the serial chain (the increment feeds the update), so this kernel is latency-bound by construction.
 // ------------------------------------------------------------------------------------------------
+namespace {
+
+// Two mat-vec chains (this half's 16 columns of MA u and MB u) with the wave reduction of `x` threaded through them (one DPP
+// step every four packed FMAs, as mv1r_lo / mv1r_hi of cmps_wave2.hip); after the second block `tot` (SGPR) = sum of x over
+// the 64 lanes.
+#define SDPP(ctrl) "v_add_f32_dpp %[x], %[x], %[x] " ctrl " row_mask:0xf bank_mask:0xf\n\t"
+__device__ __forceinline__ void mv2r_lo(const v2f (&MA)[16], const v2f (&MB)[16], const v4f (&q)[8], v2f& accA, v2f& accB, float& x) {
+    asm(CM_FIRST([a], [a0], [q0]) CM_FIRST([b], [b0], [q0]) SDPP("quad_perm:[1,0,3,2]")
+        CM([a], [a1], [q1]) CM([b], [b1], [q1]) CM([a], [a2], [q2]) CM([b], [b2], [q2]) SDPP("quad_perm:[2,3,0,1]")
+        CM([a], [a3], [q3]) CM([b], [b3], [q3]) CM([a], [a4], [q4]) CM([b], [b4], [q4]) SDPP("row_half_mirror")
+        CM([a], [a5], [q5]) CM([b], [b5], [q5]) CM([a], [a6], [q6]) CM([b], [b6], [q6]) SDPP("row_mirror")
+        CM([a], [a7], [q7]) CM([b], [b7], [q7])
+        : [a] "=&v"(accA), [b] "=&v"(accB), [x] "+v"(x)
+        : [a0] "v"(MA[0]), [a1] "v"(MA[1]), [a2] "v"(MA[2]), [a3] "v"(MA[3]), [a4] "v"(MA[4]), [a5] "v"(MA[5]), [a6] "v"(MA[6]), [a7] "v"(MA[7]),
+          [b0] "v"(MB[0]), [b1] "v"(MB[1]), [b2] "v"(MB[2]), [b3] "v"(MB[3]), [b4] "v"(MB[4]), [b5] "v"(MB[5]), [b6] "v"(MB[6]), [b7] "v"(MB[7]),
+          [q0] "v"(lo2(q[0])), [q1] "v"(hi2(q[0])), [q2] "v"(lo2(q[1])), [q3] "v"(hi2(q[1])), [q4] "v"(lo2(q[2])), [q5] "v"(hi2(q[2])),
+          [q6] "v"(lo2(q[3])), [q7] "v"(hi2(q[3])));
+}
+__device__ __forceinline__ void mv2r_hi(const v2f (&MA)[16], const v2f (&MB)[16], const v4f (&q)[8], v2f& accA, v2f& accB, float& x,
+                                        float& tot) {
+    asm(CM([a], [a0], [q0]) CM([b], [b0], [q0]) CM([a], [a1], [q1]) CM([b], [b1], [q1])
+        "v_add_f32_dpp %[x], %[x], %[x] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        CM([a], [a2], [q2]) CM([b], [b2], [q2]) CM([a], [a3], [q3]) CM([b], [b3], [q3])
+        "v_add_f32_dpp %[x], %[x], %[x] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        CM([a], [a4], [q4]) CM([b], [b4], [q4]) CM([a], [a5], [q5]) CM([b], [b5], [q5])
+        "v_readlane_b32 %[t], %[x], 63\n\t"
+        CM([a], [a6], [q6]) CM([b], [b6], [q6]) CM([a], [a7], [q7]) CM([b], [b7], [q7])
+        : [a] "+v"(accA), [b] "+v"(accB), [x] "+v"(x), [t] "=s"(tot)
+        : [a0] "v"(MA[8]), [a1] "v"(MA[9]), [a2] "v"(MA[10]), [a3] "v"(MA[11]), [a4] "v"(MA[12]), [a5] "v"(MA[13]), [a6] "v"(MA[14]),
+          [a7] "v"(MA[15]),
+          [b0] "v"(MB[8]), [b1] "v"(MB[9]), [b2] "v"(MB[10]), [b3] "v"(MB[11]), [b4] "v"(MB[12]), [b5] "v"(MB[13]), [b6] "v"(MB[14]),
+          [b7] "v"(MB[15]),
+          [q0] "v"(lo2(q[4])), [q1] "v"(hi2(q[4])), [q2] "v"(lo2(q[5])), [q3] "v"(hi2(q[5])), [q4] "v"(lo2(q[6])), [q5] "v"(hi2(q[6])),
+          [q6] "v"(lo2(q[7])), [q7] "v"(hi2(q[7])));
+}
+#undef SDPP
+
+}  // namespace
+
+// Round 3: the normalisation is linear, so the wave carries ut = rho_{k-1} y_{k-1} UN-normalised and the reduction of |y_{k-1}|^2 rides
+// inside the FMA blocks of step k (as in the forward scan, cmps_wave2.hip): with inv = rsqrt(max(|y_{k-1}|^2, 1e-12)),
+//   e = 2 inv^2 Re(ut^dagger R ut),   y_k = inv (ut + Q ut + s R ut),
+// and only the expectation's reduction is left on the serial chain.
 __global__ __launch_bounds__(64 * WAVES, 1) void k_sample_wave(Dev P, const float* __restrict__ noise, int n_paths,
                                                                int length, float* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) float4 stR[WAVES][CH * 16];
@@ -496,6 +539,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_sample_wave(Dev P, const floa
     const float A = dev_A(P), dt = P.dt;
     const float2 p0 = P.psi0[i];
     float u = hb ? p0.y : p0.x;
+    float xsq = lane == 0 ? 1.f : 0.f;                   // "|y_{-1}|^2" = 1: psi_0 arrives normalised
     float samp = 0.f;                                    // model.py:244 batch_zeros
     v4f sr[16], qu[8];
     v2f rho;
@@ -510,21 +554,22 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_sample_wave(Dev P, const floa
             bcast_issue_tab(aUw, aUr, u, aRho + kk * 256, qu, rho);
             lds_wait_lo<5>(qu);
             v2f av, aq;
-            mv2_lo(MR, MQ, qu, av, aq);
+            float nprev;
+            mv2r_lo(MR, MQ, qu, av, aq, xsq);
             lds_wait_hi_t<0>(qu, rho);
-            mv2_hi(MR, MQ, qu, av, aq);
+            mv2r_hi(MR, MQ, qu, av, aq, xsq, nprev);                 // nprev = |y_{k-1}|^2
             const float vs = swapadd(av.x, av.y), qs = swapadd(aq.x, aq.y);
-            const float e = 2.0f * sum64(u * vs);                    // _expectation (model.py:319-325)
+            const float inv = rsq_nr(fmaxf(nprev, 1e-12f));          // :289 of the step before
+            const float e = 2.0f * (sum64(u * vs) * inv) * inv;      // _expectation on the normalised state (model.py:319-325)
             const float inc = e * dt + rdlane(nz, kk);               // model.py:286
             samp += inc;                                             // :287
             svec = (lane == kk) ? samp : svec;
             const float s = inc / A;                                 // :288 -> :303
-            const float y = u + (qs + s * vs);
-            const float n = sum64(y * y);
-            const float inv = rsq_nr(fmaxf(n, 1e-12f));              // :289
+            const float y = inv * (u + (qs + s * vs));
             const float yo = osig_of(y, hb);
-            const v2f un = cmul2(inv * mk2(y, yo), rho);
+            const v2f un = cmul2(mk2(y, yo), rho);                   // rho_k y_k, normalised in the next step
             u = un.x;
+            xsq = y * y;
         }
         if (lane < cnt) orow[kbeg + lane] = A * svec;                // model.py:251
     }
