@@ -1046,7 +1046,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
         float uka, ukb, yha, yhb, ypa, ypb, una, unb;                                                                              \
         matvec2p<PD>(FQ, FD, lds_addr_of(L.vec[p][0]) + rd_off, cQ, cD, [&](auto pc) {                                             \
             constexpr int PI = decltype(pc)::value;                                                                                \
-            const float s = S0.x, inv = S0.y, te = S0.w, dt = S1.z, invp = SP0.y;                                                  \
+            const float inv = S0.y, dt = S1.z, invp = SP0.y;                                                                       \
             if constexpr (PI == 0) {                                                                                               \
                 yha = CUR.x * inv; yhb = CUR.y * inv;                                                                              \
                 ypa = PRV.x * invp; ypb = PRV.y * invp;                                                                            \
