@@ -52,6 +52,27 @@ def test_long_clip():
     _check_against_oracle(m, audio, nthreads=16)
 
 
+def test_config5_float32_full_size_properties():
+    """BASELINE configs[4] in float32 at full size (D=128, T=16000, 512 clips; 25 GB of workspace): finite results, the loss
+    sum the reverse path reports equals the sum of the forward's per-clip losses, and the clip order does not matter (clips are
+    processed in pairs: permuting the batch must permute the per-clip losses exactly and leave the gradient sums unchanged up
+    to float32 summation order)."""
+    from audio_mps_amd.scan import unpack_grad
+    m, audio = _wide_model(128, 16000, 512, seed=4)
+    per = m.loss_per_clip()
+    flat, _ = m.grad_sums()
+    g = unpack_grad(flat.cpu().numpy(), 128)
+    assert np.all(np.isfinite(per)) and np.all(np.isfinite(flat.cpu().numpy()))
+    assert abs(g["loss_sum"] - float(np.sum(per, dtype=np.float64))) <= 1e-5 * max(abs(g["loss_sum"]), 1.0)
+    perm = np.random.default_rng(0).permutation(512)
+    per2 = m.loss_per_clip(audio[perm])
+    np.testing.assert_array_equal(per2, per[perm])
+    flat2, _ = m.grad_sums(audio[perm])
+    g2 = unpack_grad(flat2.cpu().numpy(), 128)
+    for k in ("Rbar", "fbar", "psi0bar", "Abar"):
+        assert rel_inf(g2[k], g[k]) <= 1e-5, k
+
+
 @pytest.mark.parametrize("D", [64, 96, 128])
 def test_wide_matches_block(D):
     """The wide kernels against the block-per-clip kernels (plain fp32 FMA code throughout): same arithmetic up to float32
