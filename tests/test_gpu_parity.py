@@ -440,6 +440,26 @@ def test_legacy_wave_and_block_kernels_agree(T):
         assert rel_inf(ga[k], gb[k]) <= GRAD_RTOL, k
 
 
+def test_legacy_full_size_properties():
+    """The legacy arithmetic at the shape of scripts/bench_next_rows.py (D=32, T=4000, 1024 clips = one clip per SIMD): finite
+    results, the reported loss is the mean of the per-clip losses, and the clip order does not matter (per-clip losses permute
+    exactly, gradients agree up to float32 summation order)."""
+    from audio_mps_amd import LegacyAudioMPS
+    B, T, dt = 1024, 4000, 0.001
+    audio = make_audio(B, T, dt, 11, noise=0.05)
+    m = LegacyAudioMPS(32, dt, B, data_iterator=audio, seed=7)
+    per = m.loss_per_clip()
+    loss, grads = m.loss_and_grads()
+    assert np.all(np.isfinite(per)) and all(np.all(np.isfinite(v)) for v in grads.values())
+    assert abs(float(loss) - float(np.mean(per, dtype=np.float64))) <= 1e-5 * max(abs(float(loss)), 1.0)
+    perm = np.random.default_rng(1).permutation(B)
+    m2 = LegacyAudioMPS(32, dt, B, data_iterator=audio[perm], seed=7)
+    np.testing.assert_array_equal(m2.loss_per_clip(), per[perm])
+    _, grads2 = m2.loss_and_grads()
+    for k in grads:
+        assert rel_inf(grads2[k], grads[k]) <= 1e-5, k
+
+
 def test_reference_default_clip_length():
     """T = 2**16, the reference's default --sample_duration (train.py:27): four times the benchmark length.  The loss stays
     inside the 1e-5 bar; the gradient bar is doubled here (observed 5e-5 ... 9e-5: the float32 restatement's own distance
