@@ -2,21 +2,27 @@
 // clips, instantiated for the padded bond dimensions 64, 96 and 128 (components >= D are zero padding).
 //
 // At D = 128 and B = 512 there are two clips per CU and a matrix is 128 KB in complex64: nothing like the wave-per-clip
-// layout fits.  What does fit is the batched 4x4x4 bf16 MFMA (v_mfma_f32_4x4x4_16b_bf16: 16 independent 4x4 blocks per
-// instruction, D_b += A_b B_b).  A complex mat-vec y = M u is the real product  [M_re | M_im] (128 x 256)  times a
-// 256-vector, once with  c0 = [u_re; -u_im]  (-> Re y) and once with  c1 = [u_im; u_re]  (-> Im y).  With TWO clips the
-// four B columns of every block are {clip0 c0, clip0 c1, clip1 c0, clip1 c1}: all of the MFMA is useful work and the
-// matrix is stored once, in registers, as bf16 A fragments (64 VGPRs per matrix and wave).
+// layout fits, and a GEMM tile over clips would be two columns wide.  A complex mat-vec y = M u is the real product
+// [M_re | M_im] (D x 2D)  times a 2D-vector, once with the form  c0 = [u_re; -u_im]  (-> Re y) and once with
+// c1 = [u_im; u_re]  (-> Im y): with TWO clips there are FOUR such forms.  Round 4 runs it on v_mfma_f32_16x16x32_bf16 with
+// the roles turned round (rounds 1-3 used the batched 4x4x4 MFMA: twice the instructions, a K split over the lane halves
+// that had to be summed with permlane swaps, and a lone wave issues it every 12 cycles instead of its 8):
 //
-//   workgroup = 4 waves; wave w owns rows 32w..32w+31 of every matrix.
-//   lane l: block b = l >> 2 = (rg = b & 7, kh = b >> 3), position p = l & 3.
-//     A operand of instruction t (0..31): rows 32w + 4rg + p, columns 4t..4t+3 of M_re (kh = 0) or M_im (kh = 1).
-//     B operand: column c = p, entries 4t..4t+3 of  [u_re | u_im] (kh = 0)  or  [-u_im | u_re] (kh = 1)  of clip c >> 1,
-//       read from LDS (every lane reads 256 contiguous bytes per vector: 16 ds_read_b128, shared by all matrices).
-//     D: 4 registers = rows 4rg..4rg+3, column c, partial over this lane half's K range; one v_permlane32_swap + add per
-//       register pair sums the halves: lane (rg, kh, c) ends up owning rows 32w + 4rg + kh and +2 of component
-//       (c & 1 ? Im : Re) of clip c >> 1 -- every (row, component, clip) lives in exactly one lane.
-//   Per step: 64 MFMAs on the chain (R ut, Q ut), 32 off it (H y of the previous step), ONE workgroup barrier.
+//   D (16 x 16) = A (16 x 32) B (32 x 16):   A rows = vector forms, B columns = sixteen ROWS of the matrix, K = 32 entries of
+//   the real form.  Only A rows {0, 4, 8, 12} carry the four forms: row 4 f lands in accumulator register 0 of the lanes
+//   16 f .. 16 f + 15, so after the K loop register 0 of lane l IS  (M u)[row (l & 15)], form (l >> 4)  -- one useful value
+//   in every lane, K summed by the matrix pipe, no cross-lane reduction, no compaction (scripts/ubench/mfma16_matvec.hip
+//   checks the layout with integer data and times the instruction: 16 cycles back to back from a lone wave).
+//
+//   workgroup = D / 32 chain waves (+ as many loss waves in the forward); wave w owns rows 32 w .. 32 w + 31 as TWO tiles
+//   (tile 0 = the even rows, tile 1 = the odd rows: a lane's two values are adjacent rows, one packed 4-byte LDS store).
+//   lane l = (j = l & 15, f = l >> 4): rows ia = 32 w + 2 j and ia + 1, component (f & 1 ? Im : Re) of clip f >> 1 -- every
+//     (row, component, clip) lives in exactly one lane; its Re <-> Im partner sits 16 lanes away (v_permlane16_swap).
+//   B operand (resident, AGPRs): 8 bf16 = columns 32 t + 8 (l >> 4) .. + 7 of  [M_re | M_im]  in row 32 w + 2 (l & 15) + tile,
+//     D / 16 K-steps t, two tiles: D / 2 registers per matrix and lane.
+//   A operand: lane l reads 16 bytes of form (l >> 2) & 3 (all four lanes of a quad read the same address: only A rows 0, 4,
+//     8, 12 matter) at K = 32 t + 8 (l >> 4): D / 16 ds_read_b128 per broadcast vector and lane, shared by both matrices.
+//   Per step: 4 D / 16 MFMAs on the chain (R ut, Q ut; 512 matrix-pipe cycles at D = 128), ONE workgroup barrier.
 //   The identity part of y = ut + Q ut + s R ut stays float32; only the small correction goes through bf16.
 // Arithmetic restated (with the same rounding points) by oracle/cmps_oracle.py::psi_bf16_scan.
 #include "cmps_internal.h"
@@ -27,13 +33,11 @@ namespace cmps {
 namespace {
 
 constexpr int PCH = 64;      // steps per chunk of per-step scalars
-// Everything below is templated on the padded bond dimension D (64, 96 or 128): D / 32 waves own 32 rows each, a mat-vec is D / 4
-// MFMA instructions per matrix and wave, a broadcast vector is D / 8 16-byte reads per lane.
+// Everything below is templated on the padded bond dimension D (64, 96 or 128): D / 32 waves own 32 rows each, a mat-vec pair is
+// 4 D / 16 MFMA instructions per wave, a broadcast vector is D / 16 16-byte reads per lane.
 
-typedef short bf4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
-typedef unsigned u2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ unsigned short bf16_rne(float f) {
     unsigned u = __float_as_uint(f);
@@ -58,7 +62,7 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
 }
-// sum over the two lane halves: lower lanes get a0 + a0', upper lanes get a1 + a1'  (see cmps_wave_util.h::swapadd)
+// sum over the two lane halves, both operands (see cmps_wave_util.h::swapadd); the loss waves' row halves
 __device__ __forceinline__ float half_add(float a0, float a1) {
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a0), __float_as_uint(a1), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
@@ -67,36 +71,36 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
 }
-// sum over the 32 lanes that carry the same clip (c >> 1); every lane receives its clip's total
+// the value the lane 16 away holds (the Re <-> Im partner of the same row and clip): v_permlane16_swap of x with itself leaves
+// the even rows' values in r[0] and the odd rows' values in r[1], in both rows of a pair
+__device__ __forceinline__ float partner16(float x, bool odd) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(odd ? r[0] : r[1]);
+}
+// sum over the 32 lanes that carry the same clip (l >> 5); every lane receives its clip's total
 __device__ __forceinline__ float clip_sum(float x) {
-#if defined(CMPS_DIAG) && defined(PABL_NO_REDUCE)     // diagnostic builds only (scripts/ablate.py)
-    return x;
-#endif
-    x += dpp_mov<0xB1>(x);        // quad_perm [1,0,3,2]: re + im partner
-    x += dpp_mov<0x124>(x);       // row_ror:4
-    x += dpp_mov<0x128>(x);       // row_ror:8   -> total of this 16-lane row for this clip
     {
         const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-        x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        x = __uint_as_float(r[0]) + __uint_as_float(r[1]);      // Re row + Im row
     }
-    {
-        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-        x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    }
+    x += dpp_mov<0x128>(x);       // row_ror:8
+    x += dpp_mov<0x124>(x);       // row_ror:4
+    x += dpp_mov<0x122>(x);       // row_ror:2
+    x += dpp_mov<0x121>(x);       // row_ror:1   -> total of the clip's 16 lanes x 2 components
     return x;
 }
+// sum over the two clips (lanes l and l ^ 32), in every lane
+__device__ __forceinline__ float both_clips(float x) { return half_add(x, x); }
 
-// LDS image of one broadcast vector for both clips: arrays re | im | -im, each [2 clips][128] bf16, + a dummy row
-// Rows are padded by 16 B: the eight lane groups (kh, c) of a wave read eight DIFFERENT rows at the same offset in the same
-// instruction, and unpadded 256-byte rows would all start in the same LDS bank (measured: 73 % of the LDS cycles were bank
-// conflicts before the padding).
+// LDS image of one broadcast vector for both clips: arrays re | im | -im | dummy, each [2 clips][D] bf16.
+// Rows are padded by 32 B: the sixteen distinct 16-byte pieces a ds_read_b128 of the A operand touches -- four forms (four
+// different rows at the same offset) x four K groups (16 bytes apart) -- then fall into sixteen different 4-bank groups
+// (row r starts 8 r banks in; with the 16-byte padding of rounds 1-3 form f + 1 at K group g met form f at K group g + 1).
 template <int D>
 struct PairLds {
-    static constexpr int VROW = D * 2 + 16;                           // bytes per (array, clip) row
-    static constexpr int VEC_BYTES = 8 * VROW;    // re, im, -im (x 2 clips) + 2 dummy rows (the even lanes' second write)
+    static constexpr int VROW = D * 2 + 32;                           // bytes per (array, clip) row
+    static constexpr int VEC_BYTES = 8 * VROW;    // re, im, -im (x 2 clips) + 2 dummy rows (the Re lanes' second write)
     __attribute__((aligned(16))) unsigned char vec[2][2][VEC_BYTES];   // [parity][0: ut, 1: y]
-    __attribute__((aligned(16))) float nrm[2][2][4];                   // [parity][clip][wave]
-    __attribute__((aligned(16))) float ee[2][2][4];
 };
 template <int W>
 __device__ __forceinline__ float sum_waves(const float* p) {          // p[0..W-1], 16-byte aligned
@@ -112,362 +116,141 @@ __device__ __forceinline__ float sum_waves(const float* p) {          // p[0..W-
     }
 }
 
-__device__ __forceinline__ bf4 frag_of(unsigned lo, unsigned hi) {
-    const u2 t = {lo, hi};
-    return __builtin_bit_cast(bf4, t);
-}
-
-// eight consecutive 16-byte reads issued back to back (the compiler's own schedule waits for each read right before its
-// first use, one read ahead: ~70 exposed cycles per read); completion is awaited with counted lgkmcnt waits
 __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
     return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
 }
-__device__ __forceinline__ void rd8(unsigned addr, u4 (&o)[8]) {
-    asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\t"
-                 "ds_read_b128 %2, %8 offset:32\n\tds_read_b128 %3, %8 offset:48\n\t"
-                 "ds_read_b128 %4, %8 offset:64\n\tds_read_b128 %5, %8 offset:80\n\t"
-                 "ds_read_b128 %6, %8 offset:96\n\tds_read_b128 %7, %8 offset:112"
-                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
-                 : "v"(addr) : "memory");
+
+// ---- the lane geometry of a chain wave ----
+struct ChainLane {
+    int j, f, q, ia, ib;          // B column / D lane, form, clip, the two adjacent rows
+    bool odd;                     // this lane's component: Im (odd) or Re
+    int rd_lo, rd_hi;             // byte offsets of the A operand inside a vector image: K < D (array re / im) and K >= D (-im / re)
+    int wr1, wr2;                 // byte offsets of the rows this lane writes: own array; -im (Im lanes) or the dummy row (Re lanes)
+};
+template <int PD>
+__device__ __forceinline__ ChainLane chain_lane(int w, int lane) {
+    constexpr int VROW = PairLds<PD>::VROW;
+    ChainLane g;
+    g.j = lane & 15; g.f = lane >> 4; g.q = g.f >> 1; g.odd = (g.f & 1) != 0;
+    g.ia = 32 * w + 2 * g.j; g.ib = g.ia + 1;
+    const int af = (lane >> 2) & 3, aq = af >> 1, kg = lane >> 4;      // the form this lane's A operand belongs to, its K group
+    const bool ac1 = (af & 1) != 0;                                   // c1 = [u_im; u_re], c0 = [u_re; -u_im]
+    g.rd_lo = ((ac1 ? 1 : 0) * 2 + aq) * VROW + 16 * kg;
+    g.rd_hi = ((ac1 ? 0 : 2) * 2 + aq) * VROW + 16 * kg;
+    g.wr1 = ((g.odd ? 1 : 0) * 2 + g.q) * VROW + g.ia * 2;
+    g.wr2 = ((g.odd ? 2 : 3) * 2 + g.q) * VROW + g.ia * 2;
+    return g;
 }
-__device__ __forceinline__ void rd4(unsigned addr, u4 (&o)[8]) {        // first four elements only (D = 96: 8 + 4 reads)
-    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\t"
-                 "ds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48"
-                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]) : "v"(addr) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void rd_wait(u4 (&o)[8]) {
-    asm volatile("s_waitcnt lgkmcnt(%8)"
-                 : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(o[4]), "+v"(o[5]), "+v"(o[6]), "+v"(o[7])
-                 : "n"(N) : "memory");
-}
-#if defined(CMPS_DIAG) && defined(PABL_NO_MFMA)       // diagnostic builds only (scripts/ablate.py)
-#define MFMA4(A, B, C) (C)
-#else
-#define MFMA4(A, B, C) __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(bf4, A), B, C, 0, 0, 0)
-#endif
-// two matrices against eight 16-byte pieces of one vector (instructions t = 2 * (T0 + i), 2 * (T0 + i) + 1); two
-// accumulators per matrix keep dependent MFMAs four instructions apart (no wait states)
-struct Acc2 { f4 a, b; };
-template <int T0, int NT, int NP = 8>
-__device__ __forceinline__ void mm2(const u2 (&FA)[NT], const u2 (&FB)[NT], const u4 (&v)[8], Acc2& x, Acc2& y) {
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-        const bf4 lo = frag_of(v[i].x, v[i].y), hi = frag_of(v[i].z, v[i].w);
-        x.a = MFMA4(FA[2 * (T0 + i)], lo, x.a);
-        y.a = MFMA4(FB[2 * (T0 + i)], lo, y.a);
-        x.b = MFMA4(FA[2 * (T0 + i) + 1], hi, x.b);
-        y.b = MFMA4(FB[2 * (T0 + i) + 1], hi, y.b);
-    }
-}
-// one matrix, four accumulators
-struct Acc4 { f4 a, b, c, d; };
-template <int T0, int NT, int NP = 8>
-__device__ __forceinline__ void mm1(const u2 (&FA)[NT], const u4 (&v)[8], Acc4& x) {
-#pragma unroll
-    for (int i = 0; i < NP; i += 2) {
-        x.a = MFMA4(FA[2 * (T0 + i)], frag_of(v[i].x, v[i].y), x.a);
-        x.b = MFMA4(FA[2 * (T0 + i) + 1], frag_of(v[i].z, v[i].w), x.b);
-        x.c = MFMA4(FA[2 * (T0 + i) + 2], frag_of(v[i + 1].x, v[i + 1].y), x.c);
-        x.d = MFMA4(FA[2 * (T0 + i) + 3], frag_of(v[i + 1].z, v[i + 1].w), x.d);
-    }
-}
-// the two rows a lane owns after the K halves are summed: registers (0, 2) -> row 2 kh, registers (1, 3) -> row 2 kh + 1
-__device__ __forceinline__ void rows_of(const f4& t, float& ra, float& rb) {
-    ra = half_add(t[0], t[2]);
-    rb = half_add(t[1], t[3]);
+// rows ia, ia + 1 are adjacent: one packed 4-byte store per array
+__device__ __forceinline__ void write_vec(unsigned char* base, const ChainLane& g, float xa, float xb) {
+    const unsigned pk = pk_bf16(xa, xb);
+    *reinterpret_cast<unsigned*>(base + g.wr1) = pk;
+    *reinterpret_cast<unsigned*>(base + g.wr2) = pk ^ 0x80008000u;
 }
 
-// ---- a mat-vec pair with the vector streamed through three 4-read buffers (48 VGPRs instead of 64 .. 128: with the whole
-// vector in registers next to two matrices' fragments the compiler parks fragments in AGPRs and copies two of them back
-// in front of every MFMA -- measured 57 v_accvgpr_read per step in the reverse scan) ----
-__device__ __forceinline__ void rd4g(unsigned addr, u4 (&o)[4]) {
-    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\t"
-                 "ds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48"
-                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]) : "v"(addr) : "memory");
+// B fragments of one matrix for this lane: frag[tile * KS + t] = 8 bf16 = real-form columns 32 t + 8 kg .. + 7 of row ia + tile;
+// elem(tile, kappa) is the float32 entry, kappa in [0, 2 PD): [M_re | M_im]
+template <int PD, typename F>
+__device__ __forceinline__ void load_frags(u4 (&frag)[PD / 8], int kg, F&& elem) {
+    constexpr int KS = PD / 16;
+#pragma unroll
+    for (int tile = 0; tile < 2; ++tile)
+#pragma unroll
+        for (int t = 0; t < KS; ++t) {
+            unsigned v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int kp = 32 * t + 8 * kg + 2 * e;
+                v[e] = (unsigned)bf16_rne(elem(tile, kp)) | ((unsigned)bf16_rne(elem(tile, kp + 1)) << 16);
+            }
+            frag[tile * KS + t] = u4{v[0], v[1], v[2], v[3]};
+            asm volatile("" : "+a"(frag[tile * KS + t]));       // into its AGPRs now: the loads of all fragments in flight at once
+        }                                                      // would be the kernel's register peak
 }
-template <int N>
-__device__ __forceinline__ void rd_wait4(u4 (&o)[4]) {
-    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]) : "n"(N) : "memory");
-}
-// Sixteen (two matrices) or eight (one matrix) MFMAs as ONE asm statement: the A fragments are read straight from AGPRs
-// (constraint "a": they stay there for the whole kernel, no copies), the accumulators live in VGPRs where the VALU tail
-// reads them, and the instruction order is fixed -- four accumulators in rotation keep dependent MFMAs four instructions
-// apart, which is what the 2-pass 4x4x4 needs; the compiler cannot see inside, so the wait states between the last MFMA
-// and the first VALU read of an accumulator (s_nop 7) are part of the LAST group's text.
+
 #if defined(CMPS_DIAG) && defined(PABL_NO_MFMA)       // diagnostic builds only (scripts/ablate.py)
 #define PAIR_ASM(TEXT) "s_nop 0"
 #else
 #define PAIR_ASM(TEXT) TEXT
 #endif
-#define PAIR_G2_OPS(FA, FB, g, v)                                                                                              \
-    "a"(FA[8 * (g)]), "a"(FA[8 * (g) + 1]), "a"(FA[8 * (g) + 2]), "a"(FA[8 * (g) + 3]), "a"(FA[8 * (g) + 4]),                    \
-    "a"(FA[8 * (g) + 5]), "a"(FA[8 * (g) + 6]), "a"(FA[8 * (g) + 7]),                                                            \
-    "a"(FB[8 * (g)]), "a"(FB[8 * (g) + 1]), "a"(FB[8 * (g) + 2]), "a"(FB[8 * (g) + 3]), "a"(FB[8 * (g) + 4]),                    \
-    "a"(FB[8 * (g) + 5]), "a"(FB[8 * (g) + 6]), "a"(FB[8 * (g) + 7]),                                                            \
-    "v"(u2{v[0].x, v[0].y}), "v"(u2{v[0].z, v[0].w}), "v"(u2{v[1].x, v[1].y}), "v"(u2{v[1].z, v[1].w}),                          \
-    "v"(u2{v[2].x, v[2].y}), "v"(u2{v[2].z, v[2].w}), "v"(u2{v[3].x, v[3].y}), "v"(u2{v[3].z, v[3].w})
-template <int G, bool FIRST, bool LAST, int NT>
-__device__ __forceinline__ void mm2g(const u2 (&FA)[NT], const u2 (&FB)[NT], const u4 (&v)[4], Acc2& x, Acc2& y) {
-    if constexpr (FIRST && LAST) {
-        asm volatile(PAIR_ASM(
-                     "v_mfma_f32_4x4x4_16b_bf16 %0, %4, %20, 0\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %1, %12, %20, 0\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %2, %5, %21, 0\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %3, %13, %21, 0\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %0, %6, %22, %0\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %1, %14, %22, %1\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %2, %7, %23, %2\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %3, %15, %23, %3\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %0, %8, %24, %0\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %1, %16, %24, %1\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %2, %9, %25, %2\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %3, %17, %25, %3\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %0, %10, %26, %0\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %1, %18, %26, %1\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %2, %11, %27, %2\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %3, %19, %27, %3\n\t"
-                     "s_nop 7")
-                     : "=&v"(x.a), "=&v"(y.a), "=&v"(x.b), "=&v"(y.b) : PAIR_G2_OPS(FA, FB, G, v));
-    } else if constexpr (FIRST) {
-        asm volatile(PAIR_ASM(
-                     "v_mfma_f32_4x4x4_16b_bf16 %0, %4, %20, 0\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %1, %12, %20, 0\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %2, %5, %21, 0\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %3, %13, %21, 0\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %0, %6, %22, %0\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %1, %14, %22, %1\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %2, %7, %23, %2\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %3, %15, %23, %3\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %0, %8, %24, %0\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %1, %16, %24, %1\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %2, %9, %25, %2\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %3, %17, %25, %3\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %0, %10, %26, %0\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %1, %18, %26, %1\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %2, %11, %27, %2\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %3, %19, %27, %3")
-                     : "=&v"(x.a), "=&v"(y.a), "=&v"(x.b), "=&v"(y.b) : PAIR_G2_OPS(FA, FB, G, v));
-    } else if constexpr (LAST) {
-        asm volatile(PAIR_ASM(
-                     "v_mfma_f32_4x4x4_16b_bf16 %0, %4, %20, %0\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %1, %12, %20, %1\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %2, %5, %21, %2\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %3, %13, %21, %3\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %0, %6, %22, %0\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %1, %14, %22, %1\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %2, %7, %23, %2\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %3, %15, %23, %3\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %0, %8, %24, %0\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %1, %16, %24, %1\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %2, %9, %25, %2\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %3, %17, %25, %3\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %0, %10, %26, %0\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %1, %18, %26, %1\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %2, %11, %27, %2\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %3, %19, %27, %3\n\t"
-                     "s_nop 7")
-                     : "+v"(x.a), "+v"(y.a), "+v"(x.b), "+v"(y.b) : PAIR_G2_OPS(FA, FB, G, v));
-    } else {
-        asm volatile(PAIR_ASM(
-                     "v_mfma_f32_4x4x4_16b_bf16 %0, %4, %20, %0\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %1, %12, %20, %1\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %2, %5, %21, %2\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %3, %13, %21, %3\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %0, %6, %22, %0\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %1, %14, %22, %1\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %2, %7, %23, %2\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %3, %15, %23, %3\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %0, %8, %24, %0\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %1, %16, %24, %1\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %2, %9, %25, %2\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %3, %17, %25, %3\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %0, %10, %26, %0\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %1, %18, %26, %1\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %2, %11, %27, %2\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %3, %19, %27, %3")
-                     : "+v"(x.a), "+v"(y.a), "+v"(x.b), "+v"(y.b) : PAIR_G2_OPS(FA, FB, G, v));
-    }
+// the D / 16 reads of one broadcast vector, issued back to back; completion is awaited K-step by K-step with counted lgkmcnt
+// waits (LDS operations of a wave complete in order, so whatever else is in flight only makes a counted wait stricter)
+template <int KS>
+__device__ __forceinline__ void rd_vec(unsigned lo, unsigned hi, u4 (&v)[KS]) {
+    if constexpr (KS == 8)
+        asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:64\n\tds_read_b128 %2, %8 offset:128\n\t"
+                     "ds_read_b128 %3, %8 offset:192\n\tds_read_b128 %4, %9\n\tds_read_b128 %5, %9 offset:64\n\t"
+                     "ds_read_b128 %6, %9 offset:128\n\tds_read_b128 %7, %9 offset:192"
+                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                     : "v"(lo), "v"(hi) : "memory");
+    else if constexpr (KS == 6)
+        asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:64\n\tds_read_b128 %2, %6 offset:128\n\t"
+                     "ds_read_b128 %3, %7\n\tds_read_b128 %4, %7 offset:64\n\tds_read_b128 %5, %7 offset:128"
+                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]) : "v"(lo), "v"(hi) : "memory");
+    else
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\t"
+                     "ds_read_b128 %2, %5\n\tds_read_b128 %3, %5 offset:64"
+                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(lo), "v"(hi) : "memory");
 }
-#define PAIR_G1_OPS(FA, g, v)                                                                                                  \
-    "a"(FA[8 * (g)]), "a"(FA[8 * (g) + 1]), "a"(FA[8 * (g) + 2]), "a"(FA[8 * (g) + 3]), "a"(FA[8 * (g) + 4]),                    \
-    "a"(FA[8 * (g) + 5]), "a"(FA[8 * (g) + 6]), "a"(FA[8 * (g) + 7]),                                                            \
-    "v"(u2{v[0].x, v[0].y}), "v"(u2{v[0].z, v[0].w}), "v"(u2{v[1].x, v[1].y}), "v"(u2{v[1].z, v[1].w}),                          \
-    "v"(u2{v[2].x, v[2].y}), "v"(u2{v[2].z, v[2].w}), "v"(u2{v[3].x, v[3].y}), "v"(u2{v[3].z, v[3].w})
-template <int G, bool FIRST, bool LAST, int NT>
-__device__ __forceinline__ void mm1g(const u2 (&FA)[NT], const u4 (&v)[4], Acc4& x) {
+// One K-step: the A operand v against the fragments of two matrices x two tiles, as ONE asm statement -- the fragments are read
+// straight from AGPRs (constraint "a": they stay there for the whole kernel, no copies), the accumulators live in VGPRs where
+// the VALU tail reads them, four accumulators in rotation.  The compiler cannot see inside, so the wait for the operand's LDS
+// read opens the statement and the wait states between the last MFMA and the first VALU read of an accumulator (gfx950: passes
+// + 4 states; twelve cover the 8-pass case) close the last one.
+template <int W, bool FIRST, bool LAST>
+__device__ __forceinline__ void kstep(const u4& fa0, const u4& fa1, const u4& fb0, const u4& fb1, u4& v, f4& a0, f4& a1, f4& b0, f4& b1) {
     if constexpr (FIRST) {
-        asm volatile(PAIR_ASM(
-                     "v_mfma_f32_4x4x4_16b_bf16 %0, %4, %12, 0\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %1, %5, %13, 0\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %2, %6, %14, 0\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %3, %7, %15, 0\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %0, %8, %16, %0\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %1, %9, %17, %1\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %2, %10, %18, %2\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %3, %11, %19, %3")
-                     : "=&v"(x.a), "=&v"(x.b), "=&v"(x.c), "=&v"(x.d) : PAIR_G1_OPS(FA, G, v));
+        asm volatile("s_waitcnt lgkmcnt(%9)\n\t"
+                     PAIR_ASM("v_mfma_f32_16x16x32_bf16 %0, %8, %4, 0\n\t"
+                              "v_mfma_f32_16x16x32_bf16 %1, %8, %5, 0\n\t"
+                              "v_mfma_f32_16x16x32_bf16 %2, %8, %6, 0\n\t"
+                              "v_mfma_f32_16x16x32_bf16 %3, %8, %7, 0")
+                     : "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1) : "a"(fa0), "a"(fa1), "a"(fb0), "a"(fb1), "v"(v), "n"(W) : "memory");
     } else if constexpr (LAST) {
-        asm volatile(PAIR_ASM(
-                     "v_mfma_f32_4x4x4_16b_bf16 %0, %4, %12, %0\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %1, %5, %13, %1\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %2, %6, %14, %2\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %3, %7, %15, %3\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %0, %8, %16, %0\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %1, %9, %17, %1\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %2, %10, %18, %2\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %3, %11, %19, %3\n\t"
-                     "s_nop 7")
-                     : "+v"(x.a), "+v"(x.b), "+v"(x.c), "+v"(x.d) : PAIR_G1_OPS(FA, G, v));
+        asm volatile("s_waitcnt lgkmcnt(%9)\n\t"
+                     PAIR_ASM("v_mfma_f32_16x16x32_bf16 %0, %8, %4, %0\n\t"
+                              "v_mfma_f32_16x16x32_bf16 %1, %8, %5, %1\n\t"
+                              "v_mfma_f32_16x16x32_bf16 %2, %8, %6, %2\n\t"
+                              "v_mfma_f32_16x16x32_bf16 %3, %8, %7, %3\n\t"
+                              "s_nop 11")
+                     : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1) : "a"(fa0), "a"(fa1), "a"(fb0), "a"(fb1), "v"(v), "n"(W) : "memory");
     } else {
-        asm volatile(PAIR_ASM(
-                     "v_mfma_f32_4x4x4_16b_bf16 %0, %4, %12, %0\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %1, %5, %13, %1\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %2, %6, %14, %2\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %3, %7, %15, %3\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %0, %8, %16, %0\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %1, %9, %17, %1\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %2, %10, %18, %2\n\t"
-                     "v_mfma_f32_4x4x4_16b_bf16 %3, %11, %19, %3")
-                     : "+v"(x.a), "+v"(x.b), "+v"(x.c), "+v"(x.d) : PAIR_G1_OPS(FA, G, v));
+        asm volatile("s_waitcnt lgkmcnt(%9)\n\t"
+                     PAIR_ASM("v_mfma_f32_16x16x32_bf16 %0, %8, %4, %0\n\t"
+                              "v_mfma_f32_16x16x32_bf16 %1, %8, %5, %1\n\t"
+                              "v_mfma_f32_16x16x32_bf16 %2, %8, %6, %2\n\t"
+                              "v_mfma_f32_16x16x32_bf16 %3, %8, %7, %3")
+                     : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1) : "a"(fa0), "a"(fa1), "a"(fb0), "a"(fb1), "v"(v), "n"(W) : "memory");
     }
 }
-// the vector at LDS address `addr` (PD / 32 groups of four 16-byte reads) against two matrices / one matrix.
-// SHADOW runs after the first reads are issued (work nothing on the chain waits for).
-template <int PD, typename Shadow>
-__device__ __forceinline__ void matvec2(const u2 (&FA)[PD / 4], const u2 (&FB)[PD / 4], unsigned addr, Acc2& x, Acc2& y, Shadow&& shadow) {
-    constexpr int NG = PD / 32;
-    u4 b0[4], b1[4], b2[4];
-    rd4g(addr, b0);
-    rd4g(addr + 64, b1);
-#if !(defined(CMPS_DIAG) && defined(PABL_HALF_READS))
-    if constexpr (NG > 2) rd4g(addr + 128, b2);
-#endif
-    shadow();
-    if constexpr (NG == 2) {
-        rd_wait4<4>(b0); mm2g<0, true, false>(FA, FB, b0, x, y);
-        rd_wait4<0>(b1); mm2g<1, false, true>(FA, FB, b1, x, y);
-    } else if constexpr (NG == 3) {
-        rd_wait4<8>(b0); mm2g<0, true, false>(FA, FB, b0, x, y);
-        rd_wait4<4>(b1); mm2g<1, false, false>(FA, FB, b1, x, y);
-        rd_wait4<0>(b2); mm2g<2, false, true>(FA, FB, b2, x, y);
-    } else {
-#if defined(CMPS_DIAG) && defined(PABL_HALF_READS)    // diagnostic builds only: half of the vector is read, and used twice
-        rd_wait4<4>(b0); mm2g<0, true, false>(FA, FB, b0, x, y);
-        rd_wait4<0>(b1); mm2g<1, false, false>(FA, FB, b1, x, y);
-        mm2g<2, false, false>(FA, FB, b0, x, y);
-        mm2g<3, false, true>(FA, FB, b1, x, y);
-#else
-        rd_wait4<8>(b0); mm2g<0, true, false>(FA, FB, b0, x, y);
-        rd4g(addr + 192, b0);
-        rd_wait4<8>(b1); mm2g<1, false, false>(FA, FB, b1, x, y);
-        rd_wait4<4>(b2); mm2g<2, false, false>(FA, FB, b2, x, y);
-        rd_wait4<0>(b0); mm2g<3, false, true>(FA, FB, b0, x, y);
-#endif
-    }
-}
-template <int PD, typename Shadow>
-__device__ __forceinline__ void matvec1(const u2 (&FA)[PD / 4], unsigned addr, Acc4& x, Shadow&& shadow) {
-    constexpr int NG = PD / 32;
-    u4 b0[4], b1[4], b2[4];
-    rd4g(addr, b0);
-    rd4g(addr + 64, b1);
-    if constexpr (NG > 2) rd4g(addr + 128, b2);
-    shadow();
-    if constexpr (NG == 2) {
-        rd_wait4<4>(b0); mm1g<0, true, false>(FA, b0, x);
-        rd_wait4<0>(b1); mm1g<1, false, true>(FA, b1, x);
-    } else if constexpr (NG == 3) {
-        rd_wait4<8>(b0); mm1g<0, true, false>(FA, b0, x);
-        rd_wait4<4>(b1); mm1g<1, false, false>(FA, b1, x);
-        rd_wait4<0>(b2); mm1g<2, false, true>(FA, b2, x);
-    } else {
-        rd_wait4<8>(b0); mm1g<0, true, false>(FA, b0, x);
-        rd4g(addr + 192, b0);
-        rd_wait4<8>(b1); mm1g<1, false, false>(FA, b1, x);
-        rd_wait4<4>(b2); mm1g<2, false, false>(FA, b2, x);
-        rd_wait4<0>(b0); mm1g<3, false, true>(FA, b0, x);
-    }
-}
-
-// ---- the same mat-vec pair in statements of FOUR MFMAs with a caller-supplied piece of independent work after each (piece
-// 0 runs while the first LDS reads are in flight, pieces 1 .. 16 behind the MFMA quads): a 4x4x4 MFMA holds the matrix pipe
-// for 8 cycles but issues in 4, so a quad leaves room for four VALU instructions that cost nothing.  The compiler does not
-// know what the asm statements cost and would sink the work below all of them: every piece must end by pinning its results
-// (PAIR_PIN) so that it stays where it is called.
+// The vector image at LDS address `img` against matrices A and B: a0 / a1 = (A v) rows ia / ia + 1, b0 / b1 = (B v), in register 0.
+// piece(ic<0>) runs while the reads are in flight, piece(ic<t + 1>) behind the four MFMAs of K-step t (64 matrix-pipe cycles of
+// which the MFMAs' own issue takes 32: room for about eight independent VALU instructions that cost nothing), ic<KS + 1 .. 8> after
+// the last one.  The compiler does not know what the asm statements cost and would sink the work below all of them: every piece
+// must end by pinning its results (PAIR_PIN) so that it stays where it is called.
 template <int I> struct ic { static constexpr int value = I; };
 #define PAIR_PIN1(a) asm volatile("" : "+v"(a))
 #define PAIR_PIN2(a, b) asm volatile("" : "+v"(a), "+v"(b))
 #define PAIR_PIN4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
-template <bool FIRST, bool LAST>
-__device__ __forceinline__ void quad2(const u2& fa0, const u2& fb0, const u2& fa1, const u2& fb1, const u4& v, Acc2& x, Acc2& y) {
-    const u2 lo = {v.x, v.y}, hi = {v.z, v.w};
-    if constexpr (FIRST) {
-        asm volatile(PAIR_ASM("v_mfma_f32_4x4x4_16b_bf16 %0, %4, %8, 0\n\t"
-                              "v_mfma_f32_4x4x4_16b_bf16 %1, %5, %8, 0\n\t"
-                              "v_mfma_f32_4x4x4_16b_bf16 %2, %6, %9, 0\n\t"
-                              "v_mfma_f32_4x4x4_16b_bf16 %3, %7, %9, 0")
-                     : "=&v"(x.a), "=&v"(y.a), "=&v"(x.b), "=&v"(y.b) : "a"(fa0), "a"(fb0), "a"(fa1), "a"(fb1), "v"(lo), "v"(hi));
-    } else if constexpr (LAST) {
-        asm volatile(PAIR_ASM("v_mfma_f32_4x4x4_16b_bf16 %0, %4, %8, %0\n\t"
-                              "v_mfma_f32_4x4x4_16b_bf16 %1, %5, %8, %1\n\t"
-                              "v_mfma_f32_4x4x4_16b_bf16 %2, %6, %9, %2\n\t"
-                              "v_mfma_f32_4x4x4_16b_bf16 %3, %7, %9, %3\n\t"
-                              "s_nop 7")
-                     : "+v"(x.a), "+v"(y.a), "+v"(x.b), "+v"(y.b) : "a"(fa0), "a"(fb0), "a"(fa1), "a"(fb1), "v"(lo), "v"(hi));
-    } else {
-        asm volatile(PAIR_ASM("v_mfma_f32_4x4x4_16b_bf16 %0, %4, %8, %0\n\t"
-                              "v_mfma_f32_4x4x4_16b_bf16 %1, %5, %8, %1\n\t"
-                              "v_mfma_f32_4x4x4_16b_bf16 %2, %6, %9, %2\n\t"
-                              "v_mfma_f32_4x4x4_16b_bf16 %3, %7, %9, %3")
-                     : "+v"(x.a), "+v"(y.a), "+v"(x.b), "+v"(y.b) : "a"(fa0), "a"(fb0), "a"(fa1), "a"(fb1), "v"(lo), "v"(hi));
+template <int PD, int T, typename Piece>
+__device__ __forceinline__ void ksteps(const u4 (&FA)[PD / 8], const u4 (&FB)[PD / 8], u4 (&v)[PD / 16], f4& a0, f4& a1, f4& b0, f4& b1, Piece&& piece) {
+    constexpr int KS = PD / 16;
+    if constexpr (T < KS) {
+        kstep<KS - 1 - T, T == 0, T == KS - 1>(FA[T], FA[KS + T], FB[T], FB[KS + T], v[T], a0, a1, b0, b1);
+        piece(ic<T + 1>{});
+        ksteps<PD, T + 1>(FA, FB, v, a0, a1, b0, b1, piece);
+    } else if constexpr (T < 8) {
+        piece(ic<T + 1>{});
+        ksteps<PD, T + 1>(FA, FB, v, a0, a1, b0, b1, piece);
     }
-}
-template <int G, int NG, int NT, typename Piece>
-__device__ __forceinline__ void quads_of_group(const u2 (&FA)[NT], const u2 (&FB)[NT], const u4 (&v)[4], Acc2& x, Acc2& y, Piece&& piece) {
-    quad2<G == 0, false>(FA[8 * G], FB[8 * G], FA[8 * G + 1], FB[8 * G + 1], v[0], x, y);
-    piece(ic<4 * G + 1>{});
-    quad2<false, false>(FA[8 * G + 2], FB[8 * G + 2], FA[8 * G + 3], FB[8 * G + 3], v[1], x, y);
-    piece(ic<4 * G + 2>{});
-    quad2<false, false>(FA[8 * G + 4], FB[8 * G + 4], FA[8 * G + 5], FB[8 * G + 5], v[2], x, y);
-    piece(ic<4 * G + 3>{});
-    quad2<false, G == NG - 1>(FA[8 * G + 6], FB[8 * G + 6], FA[8 * G + 7], FB[8 * G + 7], v[3], x, y);
-    piece(ic<4 * G + 4>{});
 }
 template <int PD, typename Piece>
-__device__ __forceinline__ void matvec2p(const u2 (&FA)[PD / 4], const u2 (&FB)[PD / 4], unsigned addr, Acc2& x, Acc2& y, Piece&& piece) {
-    constexpr int NG = PD / 32;
-    u4 b0[4], b1[4], b2[4];
-    rd4g(addr, b0);
-    rd4g(addr + 64, b1);
-#if !(defined(CMPS_DIAG) && defined(PABL_HALF_READS))
-    if constexpr (NG > 2) rd4g(addr + 128, b2);
-#endif
+__device__ __forceinline__ void matvec2(const u4 (&FA)[PD / 8], const u4 (&FB)[PD / 8], unsigned img, const ChainLane& g,
+                                        f4& a0, f4& a1, f4& b0, f4& b1, Piece&& piece) {
+    u4 v[PD / 16];
+    rd_vec<PD / 16>(img + g.rd_lo, img + g.rd_hi, v);
     piece(ic<0>{});
-    if constexpr (NG == 2) {
-        rd_wait4<4>(b0); quads_of_group<0, NG>(FA, FB, b0, x, y, piece);
-        rd_wait4<0>(b1); quads_of_group<1, NG>(FA, FB, b1, x, y, piece);
-        piece(ic<9>{}); piece(ic<10>{}); piece(ic<11>{}); piece(ic<12>{});
-        piece(ic<13>{}); piece(ic<14>{}); piece(ic<15>{}); piece(ic<16>{});
-    } else if constexpr (NG == 3) {
-        rd_wait4<8>(b0); quads_of_group<0, NG>(FA, FB, b0, x, y, piece);
-        rd_wait4<4>(b1); quads_of_group<1, NG>(FA, FB, b1, x, y, piece);
-        rd_wait4<0>(b2); quads_of_group<2, NG>(FA, FB, b2, x, y, piece);
-        piece(ic<13>{}); piece(ic<14>{}); piece(ic<15>{}); piece(ic<16>{});
-    } else {
-#if defined(CMPS_DIAG) && defined(PABL_HALF_READS)    // diagnostic builds only: half of the vector is read, and used twice
-        rd_wait4<4>(b0); quads_of_group<0, NG>(FA, FB, b0, x, y, piece);
-        rd_wait4<0>(b1); quads_of_group<1, NG>(FA, FB, b1, x, y, piece);
-        quads_of_group<2, NG>(FA, FB, b0, x, y, piece);
-        quads_of_group<3, NG>(FA, FB, b1, x, y, piece);
-#else
-        rd_wait4<8>(b0); quads_of_group<0, NG>(FA, FB, b0, x, y, piece);
-        rd4g(addr + 192, b0);
-        rd_wait4<8>(b1); quads_of_group<1, NG>(FA, FB, b1, x, y, piece);
-        rd_wait4<4>(b2); quads_of_group<2, NG>(FA, FB, b2, x, y, piece);
-        rd_wait4<0>(b0); quads_of_group<3, NG>(FA, FB, b0, x, y, piece);
-#endif
-    }
+    ksteps<PD, 0>(FA, FB, v, a0, a1, b0, b1, piece);
 }
 
 // rho rows are staged through LDS one 32-step chunk at a time (a row per step straight from L2 / HBM costs its full
@@ -497,30 +280,16 @@ __device__ __forceinline__ void rho_stage(const Dev& P, RhoStage<D>& S, int chun
     dst[tid + 8 * D] = r4;     dst[tid + 10 * D] = r5;     dst[tid + 12 * D] = r6;     dst[tid + 14 * D] = r7;
 }
 
-// A fragments of one matrix for this lane: frag[t] = 4 bf16 = M_part[row][4t..4t+3]
-// (kept as two packed dwords: a <4 x i16> array makes hipcc re-assemble every fragment with two v_perm_b32 per MFMA)
-template <int NT, typename F>
-__device__ __forceinline__ void load_frags(u2 (&frag)[NT], F&& elem) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        u2 v;
-        v.x = (unsigned)bf16_rne(elem(4 * t)) | ((unsigned)bf16_rne(elem(4 * t + 1)) << 16);
-        v.y = (unsigned)bf16_rne(elem(4 * t + 2)) | ((unsigned)bf16_rne(elem(4 * t + 3)) << 16);
-        frag[t] = v;
-    }
-}
-
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
-// forward: 8 waves per workgroup.  Waves 0-3 ("chain") carry the recurrence u -> y -> u' with the R and Q fragments and meet
-// at ONE LDS-only barrier per step.  Waves 4-7 ("loss") do everything nothing waits for -- H y, e = Re(y^dagger H y), the
+// forward: 2 D / 32 waves per workgroup.  The first D / 32 ("chain") carry the recurrence u -> y -> u' with the R and Q fragments
+// and meet at ONE LDS-only barrier per step.  The others ("loss") do everything nothing waits for -- H y, e = Re(y^dagger H y), the
 // stash rows, the per-step scalars and the loss -- and do it EIGHT STEPS AT A TIME: the chain leaves every y_k in an LDS
 // ring (bf16 images for the matrix cores, float32 for the dot product), and  H [y_k .. y_{k+7}]  of both clips is one
 // 32 x 32 tile of v_mfma_f32_32x32x16_bf16 per loss wave (columns = (component, step, clip); 2 D / 16 MFMAs per batch, spread
 // two per step over the following batch so that no step's barrier waits for them).  Per step a loss wave issues about a
-// dozen instructions instead of ~160 (32 4x4x4 MFMAs, 16 LDS reads and the VALU tail per step before), and both kinds share
-// a SIMD's issue slots, so this is what the chain gets back.
+// dozen instructions, and both kinds share a SIMD's issue slots and matrix pipe.
 // Stash (Dev::stash, pair layout): per pair and step  [y | H y][clip][re | im][D] float32.
 // ------------------------------------------------------------------------------------------------
 namespace {
@@ -528,14 +297,13 @@ namespace {
 constexpr int FB = 8;                                   // steps per loss-wave batch
 template <int D>
 struct FwdRing {
-    static constexpr int BROW = D * 2 + 16, FROW = D * 4 + 16;         // padded rows (bank spread, see PairLds)
+    static constexpr int BROW = D * 2 + 16, FROW = D * 4 + 16;         // padded rows (bank spread for the loss waves' reads)
     __attribute__((aligned(16))) unsigned char b[2 * FB][2][4][BROW];  // [slot][clip][re | im | -im | dummy] bf16
     __attribute__((aligned(16))) unsigned char f[2 * FB][2][2][FROW];  // [slot][clip][re | im] float32
     __attribute__((aligned(16))) float nrm[2 * FB][2][4];              // [slot][clip][chain wave]: partial |y|^2
     __attribute__((aligned(16))) float ee[2][2 * FB][4];               // [batch parity][step in batch * 2 + clip][loss wave]
 };
 
-typedef short bf8v __attribute__((ext_vector_type(8)));
 typedef float f16t __attribute__((ext_vector_type(16)));
 
 // float index of (pair, step, y / H y, clip, component, row) in the pair stash
@@ -549,7 +317,7 @@ __device__ __forceinline__ size_t pair_stash_index(size_t pair, int N, int step,
 template <int PD, bool SAVE>
 __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __restrict__ audio,
                                                         float* __restrict__ loss_out) {
-    constexpr int PWV = PD / 32, NT = PD / 4, VROW = PairLds<PD>::VROW;
+    constexpr int PWV = PD / 32;
     constexpr int BROW = FwdRing<PD>::BROW, FROW = FwdRing<PD>::FROW;
     __shared__ PairLds<PD> L;
     __shared__ RhoStage<PD> RS;
@@ -570,34 +338,22 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
 
     if (!loss_wave) {
         // ================================================================== chain waves
-        const int c = lane & 3, q = c >> 1, rg = (lane >> 2) & 7, kh = lane >> 5;
-        const bool odd = (c & 1) != 0;
-        const int ia = 32 * w + 4 * rg + 2 * kh, ib = ia + 1;          // the two (adjacent) rows this lane owns after rows_of
-        const int arow = 32 * w + 4 * rg + c;                          // the row of this lane's A operand
-        // LDS addressing (see PairLds): read 256 B of array  kh == 0 ? (odd ? im : re) : (odd ? re : -im)  of clip q
-        const int rd_arr = kh == 0 ? (odd ? 1 : 0) : (odd ? 0 : 2);
-        const int rd_off = (rd_arr * 2 + q) * VROW;
         __builtin_amdgcn_s_setprio(3);      // both kinds share a SIMD's matrix pipe: the serial chain goes first
-        u2 FR[NT], FQ[NT];
+        u4 FR[PD / 8], FQ[PD / 8];
         {
-            const float2* Rrow = P.R + (size_t)arow * PD;
-            const float2* Qrow = P.Q + (size_t)arow * PD;
-            if (kh == 0) {
-                load_frags(FR, [&](int j) { return Rrow[j].x; });
-                load_frags(FQ, [&](int j) { return Qrow[j].x; });
-            } else {
-                load_frags(FR, [&](int j) { return Rrow[j].y; });
-                load_frags(FQ, [&](int j) { return Qrow[j].y; });
-            }
+            const int row0 = 32 * w + 2 * (lane & 15);                 // rows ia (tile 0) and ia + 1 (tile 1)
+            const float2* Rrow = P.R + (size_t)row0 * PD;
+            const float2* Qrow = P.Q + (size_t)row0 * PD;
+            load_frags<PD>(FR, lane >> 4, [&](int tile, int kp) { return kp < PD ? Rrow[tile * PD + kp].x : Rrow[tile * PD + kp - PD].y; });
+            load_frags<PD>(FQ, lane >> 4, [&](int tile, int kp) { return kp < PD ? Qrow[tile * PD + kp].x : Qrow[tile * PD + kp - PD].y; });
         }
-        // write: even lanes own Re rows -> array re (second write to a dummy row); odd lanes own Im rows -> im and -im
-        const int wr1 = ((odd ? 1 : 0) * 2 + q) * VROW;
-        const int wr2 = (odd ? 2 * 2 + q : 3 * 2 + q) * VROW;
-        auto write_vec = [&](unsigned char* base, float xa, float xb) {
-            const unsigned pk = pk_bf16(xa, xb);                       // rows ia, ia + 1 are adjacent: one 4-byte store each
-            *reinterpret_cast<unsigned*>(base + wr1 + ia * 2) = pk;
-            *reinterpret_cast<unsigned*>(base + wr2 + ia * 2) = pk ^ 0x80008000u;
-        };
+        // (everything below is derived from a laundered copy of the lane number: addresses computed before the fragment loads would
+        // be live across their register peak, and the allocator then keeps them in scratch memory for the whole kernel)
+        int lane_c = lane;
+        asm volatile("" : "+v"(lane_c));
+        const ChainLane g = chain_lane<PD>(w, lane_c);
+        const int q = g.q, ia = g.ia, ib = g.ib;
+        const bool odd = g.odd;
         // the ring rows of this lane within a slot: bf16 (own array, and -im / dummy), float32
         const int rb1 = (q * 4 + (odd ? 1 : 0)) * BROW + ia * 2, rb2 = (q * 4 + (odd ? 2 : 3)) * BROW + ia * 2;
         const int rf = (q * 2 + (odd ? 1 : 0)) * FROW + ia * 4;
@@ -605,8 +361,8 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
         float uta = odd ? pa.y : pa.x, utb = odd ? pb.y : pb.x;      // ut_0 = psi_0 (both clips)
         float inv = 1.f;                                              // 1/sqrt(max(|y_{k-1}|^2, eps)) of this lane's clip
         float sv0 = 0.f, sv1 = 0.f;                                   // s = x / A of the current 64 steps, lane <-> step
-        write_vec(L.vec[0][0], uta, utb);
-        rho_stage<PD>(P, RS, 0, 0, tid);
+        write_vec(L.vec[0][0], g, uta, utb);
+        rho_stage<PD>(P, RS, 0, 0, 64 * w + lane_c);
         __syncthreads();
 #if defined(CMPS_DIAG) && defined(PABL_TIMING)        // diagnostic builds only: where a chain step's cycles go (s_memtime stamps, consumed a step late)
         unsigned long long fA = 0, fB = 0, fC = 0, fA1 = 0, fB1 = 0, fC1 = 0, fC2 = 0, fPre = 0, fMv = 0, fTail = 0, fN = 0;
@@ -618,47 +374,42 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
 #define PAIR_FSTAMP_B()
 #define PAIR_FSTAMP_C(x)
 #endif
-        // Eight steps per block with the step-in-block J static: the LDS parities and ring slots are immediates, the chunk
-        // boundaries (increments every 64 steps, rho staging every 32) can only fall on J = 0, and in blocks that lie entirely
-        // below N no step is conditional (about 15 scalar instructions per step less than the plain loop).
-#define PAIR_FWD_STEP(J, LIVE)                                                                                             \
+        // Eight steps per block with the step-in-block J static: the LDS parities and ring slots are immediates and the chunk
+        // boundaries (increments every 64 steps, rho staging every 32) can only fall on J = 0.
+#define PAIR_FWD_STEP(J)                                                                                                   \
         {                                                                                                                  \
             constexpr int p = (J) & 1;                                                                                     \
-            if (LIVE) {                                                                                                    \
+            {                                                                                                              \
                 const int k = FB * bt + (J);                                                                               \
                 if ((J) == 0 && (bt & (PCH / FB - 1)) == 0) {          /* increments of the next 64 steps, one per lane */  \
-                    const int idx = k + lane;                                                                              \
+                    const int idx = k + lane_c;                                                                             \
                     const bool in0 = idx < T, in1 = idx + 1 < T;                                                           \
                     sv0 = ((in1 ? xr0[idx + 1] : 0.f) - (in0 ? xr0[idx] : 0.f)) / A;     /* model.py:263, 303 */            \
                     sv1 = ((in1 ? xr1[idx + 1] : 0.f) - (in0 ? xr1[idx] : 0.f)) / A;                                       \
                 }                                                                                                          \
                 if ((J) == 0 && (bt & (RCH / FB - 1)) == 0)            /* next chunk of rho into the other buffer */        \
-                    rho_stage<PD>(P, RS, k / RCH + 1, (k / RCH + 1) & 1, tid);                                             \
+                    rho_stage<PD>(P, RS, k / RCH + 1, (k / RCH + 1) & 1, 64 * w + lane_c);                                            \
                 const float2* rrow = &RS.row[(bt / (RCH / FB)) & 1][(bt & (RCH / FB - 1)) * FB + (J)][0];                  \
-                const float2 rha = rrow[ia], rhb = rrow[ib];           /* rho_k of this lane's rows */                     \
+                const float4 rh = *reinterpret_cast<const float4*>(rrow + ia);     /* rho_k of this lane's rows */         \
                 const int hb_ = bt & 1;                                /* the ring half of this block */                   \
                 if ((J) > 0 || bt > 0) {                               /* |y_{k-1}|^2, published by the previous iteration */ \
                     const float* np_ = (J) > 0 ? &RG.nrm[hb_ * FB + (J) - 1][q][0] : &RG.nrm[(hb_ ^ 1) * FB + FB - 1][q][0]; \
                     inv = __builtin_amdgcn_rsqf(fmaxf(sum_waves<PWV>(np_), 1e-12f));     /* model.py:332 */                \
                 }                                                                                                          \
-                const unsigned aU = lds_addr_of(L.vec[p][0]) + rd_off;                                                     \
-                Acc2 cR, cQ;                                                                                               \
+                f4 cR0, cR1, cQ0, cQ1;                                                                                     \
                 PAIR_FSTAMP_A();                                                                                           \
-                matvec2<PD>(FR, FQ, aU, cR, cQ, [] {});                                                                    \
+                matvec2<PD>(FR, FQ, lds_addr_of(L.vec[p][0]), g, cR0, cR1, cQ0, cQ1, [](auto) {});                         \
                 PAIR_FSTAMP_B();                                                                                           \
                 const int kl = (bt & (PCH / FB - 1)) * FB + (J);                                                           \
                 const float s0 = rdl(sv0, kl), s1 = rdl(sv1, kl);      /* (both read: a readlane inside a select becomes a branch) */ \
                 const float s = q ? s1 : s0;                                                                               \
-                float ra, rb, qa, qb;                                                                                      \
-                rows_of(cR.a + cR.b, ra, rb);                                                                              \
-                rows_of(cQ.a + cQ.b, qa, qb);                                                                              \
-                const float yna = inv * (uta + (qa + s * ra));         /* y_k, rows ia / ib */                             \
-                const float ynb = inv * (utb + (qb + s * rb));                                                             \
-                /* the chain first: ut_{k+1} = rho_k y_k (un-normalised), own component with the partner's (re <-> im) through DPP */ \
-                const float pya = dpp_mov<0xB1>(yna), pyb = dpp_mov<0xB1>(ynb);                                            \
-                uta = rha.x * yna + (odd ? rha.y : -rha.y) * pya;                                                          \
-                utb = rhb.x * ynb + (odd ? rhb.y : -rhb.y) * pyb;                                                          \
-                write_vec(L.vec[p ^ 1][0], uta, utb);                                                                      \
+                const float yna = inv * (uta + (cQ0[0] + s * cR0[0])); /* y_k, rows ia / ib */                             \
+                const float ynb = inv * (utb + (cQ1[0] + s * cR1[0]));                                                     \
+                /* the chain first: ut_{k+1} = rho_k y_k (un-normalised), own component with the partner's (re <-> im) */   \
+                const float pya = partner16(yna, odd), pyb = partner16(ynb, odd);                                          \
+                uta = rh.x * yna + (odd ? rh.y : -rh.y) * pya;                                                             \
+                utb = rh.z * ynb + (odd ? rh.w : -rh.w) * pyb;                                                             \
+                write_vec(L.vec[p ^ 1][0], g, uta, utb);                                                                   \
                 asm volatile("" ::: "memory");                         /* (keeps the stores above ahead of what follows) */ \
                 {   /* y_k for the loss waves: bf16 images and float32 */                                                  \
                     unsigned char* rbase = &RG.b[hb_ * FB + (J)][0][0][0];                                                 \
@@ -668,20 +419,18 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
                     *reinterpret_cast<float2*>(&RG.f[hb_ * FB + (J)][0][0][0] + rf) = make_float2(yna, ynb);               \
                 }                                                                                                          \
                 const float nn = clip_sum(yna * yna + ynb * ynb);                                                          \
-                if (lane == 0 || lane == 2) RG.nrm[hb_ * FB + (J)][q][w] = nn;                                             \
+                if (lane_c == 0 || lane_c == 32) RG.nrm[hb_ * FB + (J)][q][w] = nn;                                            \
                 PAIR_FSTAMP_C(nn);                                                                                         \
             }                                                                                                              \
             lds_barrier();                                                                                                 \
         }
-        int bt = 0;
-        for (; FB * bt + FB <= N; ++bt) {                                  // whole blocks
-            PAIR_FWD_STEP(0, true) PAIR_FWD_STEP(1, true) PAIR_FWD_STEP(2, true) PAIR_FWD_STEP(3, true)
-            PAIR_FWD_STEP(4, true) PAIR_FWD_STEP(5, true) PAIR_FWD_STEP(6, true) PAIR_FWD_STEP(7, true)
-        }
-        for (; bt < NBT; ++bt) {                                           // the last steps and the loss waves' run-out
-            PAIR_FWD_STEP(0, FB * bt + 0 < N) PAIR_FWD_STEP(1, FB * bt + 1 < N) PAIR_FWD_STEP(2, FB * bt + 2 < N)
-            PAIR_FWD_STEP(3, FB * bt + 3 < N) PAIR_FWD_STEP(4, FB * bt + 4 < N) PAIR_FWD_STEP(5, FB * bt + 5 < N)
-            PAIR_FWD_STEP(6, FB * bt + 6 < N) PAIR_FWD_STEP(7, FB * bt + 7 < N)
+        // ONE straight-line copy of the eight steps, run for every iteration: the steps behind the clip's end (at most 7, and the
+        // 16 of the loss waves' run-out) compute on whatever is there and write ring slots the loss waves never look at (they check
+        // every step against N themselves).  A second, conditional copy of the block gave the fragments' "a" operands a second
+        // register assignment and the allocator moved them through scratch memory and sixteen v_accvgpr copies per K-step.
+        for (int bt = 0; bt < NBT; ++bt) {
+            PAIR_FWD_STEP(0) PAIR_FWD_STEP(1) PAIR_FWD_STEP(2) PAIR_FWD_STEP(3)
+            PAIR_FWD_STEP(4) PAIR_FWD_STEP(5) PAIR_FWD_STEP(6) PAIR_FWD_STEP(7)
         }
 #undef PAIR_FWD_STEP
 #if defined(CMPS_DIAG) && defined(PABL_TIMING)
@@ -828,7 +577,6 @@ hipError_t launch_fwd_pair(const Dev& P, const float* audio, float* loss, bool s
 }
 
 }  // namespace cmps
-
 namespace cmps {
 
 // ------------------------------------------------------------------------------------------------
@@ -837,13 +585,13 @@ namespace cmps {
 // float32, one 8-byte store per lane and step, 128 contiguous bytes per (clip, component)).  Round 2 wrote the five operands here,
 // GEMM-ready in bf16 (ten 16-byte pieces per lane and eight steps: ~3 of the scan's 12.7 ms and 39 GB of traffic per step).
 //   yhat = y_k inv_k;  yhb = conj(rho_k) g;  ybar = (yhb - yhat rad_{k+1}) inv_k + te_k H y_k
-//   g    = ybar + Q ybar + s_k R^dagger ybar            (64 MFMAs, bf16 operands)
+//   g    = ybar + Q ybar + s_k R^dagger ybar            (4 D / 16 16x16x32 MFMAs, bf16 operands)
 //   fbar += dt_k Im(g conj(rho_k yhat));   Abar += zbar_k (-e_k x_k / A^2) + Re(d^dagger u_k) (-x_k / A^2)
 // rad_{k+1} = Re(u_{k+1}^dagger g_{k+1}) = 2 ebar_{k+1} e_{k+1} (Euler's theorem: everything downstream of u_{k+1} is
 // scale invariant except the loss term of step k+1, which is homogeneous of degree 2), 0 behind the last step.
 // Only  g -> conj(rho) g -> ybar -> bf16 -> LDS -> barrier -> mat-vec -> g  is on the chain: the part of ybar that does
-// not depend on g (c3 = te H y - ok yhat rad inv), u_k, the scalars and rho row of the next step and the GEMM operands are
-// computed / fetched in the shadow of the LDS reads and MFMAs of the step before.
+// not depend on g (c3 = te H y - ok yhat rad inv), u_k, the scalars and rho row of the next step are computed / fetched in
+// the shadow of the LDS reads and MFMAs of the step before (the pieces of matvec2).
 // ------------------------------------------------------------------------------------------------
 namespace {
 
@@ -853,64 +601,37 @@ struct StepTab {
     __attribute__((aligned(16))) f4 row[W][2][PCH][2][2];              // [wave][chunk parity][step][clip][half]
 };
 
-constexpr int GB = 8;          // steps per 16-byte piece of a GEMM operand
-#if defined(CMPS_DIAG) && defined(PABL_NO_EXPORT)     // diagnostic builds only (scripts/ablate.py): no GEMM operands written
-constexpr bool PAIR_EXPORT = false;
-#else
-constexpr bool PAIR_EXPORT = true;
-#endif
-#if defined(CMPS_DIAG) && defined(PABL_NO_EXPORT_STORES)   // diagnostic builds only: operands packed but never stored
-constexpr bool PAIR_EXPORT_STORES = false;
-#else
-constexpr bool PAIR_EXPORT_STORES = true;
-#endif
-
-// gops index of the piece (pair, block, operand, clip, component, row): units of 16 bytes
-template <int PD>
-__device__ __forceinline__ size_t gop_index(size_t pair, int nblk, int blk, int op, int clip, int comp, int row) {
-    return ((((pair * nblk + blk) * 5 + op) * 2 + clip) * 2 + comp) * PD + row;
-}
+constexpr int GB = 8;          // steps per block of the unrolled sweep
 
 }  // namespace
 
 template <int PD>
 __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __restrict__ audio) {
-    constexpr int PWV = PD / 32, NT = PD / 4, VROW = PairLds<PD>::VROW;
+    constexpr int PWV = PD / 32;
     __shared__ PairLds<PD> L;
     __shared__ StepTab<PWV> TB;
     __shared__ RhoStage<PD> RS;
     __shared__ float redA[PWV];
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int c = lane & 3, q = c >> 1, rg = (lane >> 2) & 7, kh = lane >> 5;
-    const bool odd = (c & 1) != 0;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane0 = threadIdx.x & 63;
     const int N = P.N, T = P.T, NC = (N + PCH - 1) / PCH;
     const int b0 = 2 * blockIdx.x, b1 = (b0 + 1 < P.B) ? b0 + 1 : b0;
     const bool two = b1 != b0;
-    const float wq = (q == 0 || two) ? 1.f : 0.f;                      // weight of this lane's clip (0: the repeated clip)
-    const int ia = 32 * w + 4 * rg + 2 * kh, ib = ia + 1;
-    const int arow = 32 * w + 4 * rg + c;
 
-    u2 FQ[NT], FD[NT];                                                // Q (Hermitian) and R^dagger
+    u4 FQ[PD / 8], FD[PD / 8];                                        // Q (Hermitian) and R^dagger
     {
-        const float2* Qrow = P.Q + (size_t)arow * PD;
-        const float2* RTrow = P.RT + (size_t)arow * PD;                // R^dagger[i][j] = conj(R[j][i]) = conj(RT[i][j])
-        if (kh == 0) {
-            load_frags(FQ, [&](int j) { return Qrow[j].x; });
-            load_frags(FD, [&](int j) { return RTrow[j].x; });
-        } else {
-            load_frags(FQ, [&](int j) { return Qrow[j].y; });
-            load_frags(FD, [&](int j) { return -RTrow[j].y; });
-        }
+        const int row0 = 32 * w + 2 * (lane0 & 15);                    // rows ia (tile 0) and ia + 1 (tile 1)
+        const float2* Qrow = P.Q + (size_t)row0 * PD;
+        const float2* RTrow = P.RT + (size_t)row0 * PD;                // R^dagger[i][j] = conj(R[j][i]) = conj(RT[i][j])
+        load_frags<PD>(FQ, lane0 >> 4, [&](int tile, int kp) { return kp < PD ? Qrow[tile * PD + kp].x : Qrow[tile * PD + kp - PD].y; });
+        load_frags<PD>(FD, lane0 >> 4, [&](int tile, int kp) { return kp < PD ? RTrow[tile * PD + kp].x : -RTrow[tile * PD + kp - PD].y; });
     }
-    const int rd_arr = kh == 0 ? (odd ? 1 : 0) : (odd ? 0 : 2);
-    const int rd_off = (rd_arr * 2 + q) * VROW;
-    const int wr1 = ((odd ? 1 : 0) * 2 + q) * VROW;
-    const int wr2 = (odd ? 2 * 2 + q : 3 * 2 + q) * VROW;
-    auto write_vec = [&](unsigned char* base, float xa, float xb) {
-        const unsigned pk = pk_bf16(xa, xb);                           // rows ia, ia + 1 are adjacent: one 4-byte store each
-        *reinterpret_cast<unsigned*>(base + wr1 + ia * 2) = pk;
-        *reinterpret_cast<unsigned*>(base + wr2 + ia * 2) = pk ^ 0x80008000u;
-    };
+    // (everything below is derived from a laundered copy of the lane number: see k_fwd_pair)
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const ChainLane g = chain_lane<PD>(w, lane);
+    const int q = g.q, ia = g.ia, ib = g.ib;
+    const bool odd = g.odd;
+    const float wq = (q == 0 || two) ? 1.f : 0.f;                      // weight of this lane's clip (0: the repeated clip)
     const float* xr0 = audio + (size_t)b0 * T;
     const float* xr1 = audio + (size_t)b1 * T;
     const float* sc0 = P.scal + ((size_t)b0 * NC) * 128;
@@ -961,8 +682,8 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
     // chunk j + 1 (rows k and k - 1 of a step can straddle two chunks, so two are always resident)
     {
         const int cl = (N - 1) / RCH;
-        rho_stage<PD>(P, RS, cl, cl & 1, threadIdx.x);
-        if (cl > 0) rho_stage<PD>(P, RS, cl - 1, (cl - 1) & 1, threadIdx.x);
+        rho_stage<PD>(P, RS, cl, cl & 1, 64 * w + lane);
+        if (cl > 0) rho_stage<PD>(P, RS, cl - 1, (cl - 1) & 1, 64 * w + lane);
     }
     __syncthreads();
 
@@ -978,11 +699,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
     // unconditional (clamped) loads: a select on the loaded value would force the wait right behind the load
     // row k of the stash for this lane: (y_k a, y_k b) and ((H y_k) a, (H y_k) b), rows ia | ia + 1 of component (c & 1), clip q
     auto row_at = [&](int k) {
-#if defined(CMPS_DIAG) && defined(PABL_NO_STASHREAD)  // diagnostic builds only: every fetch hits the same (cached) rows
-        const int kc = k > 0 ? k & 7 : 0;
-#else
         const int kc = k > 0 ? k : 0;
-#endif
         const float2 y = *reinterpret_cast<const float2*>(stf + pair_stash_index<PD>(blockIdx.x, N, kc, 0, q, odd ? 1 : 0, ia));
         const float2 h = *reinterpret_cast<const float2*>(stf + pair_stash_index<PD>(blockIdx.x, N, kc, 1, q, odd ? 1 : 0, ia));
         return make_float4(y.x, y.y, h.x, h.y);
@@ -1031,20 +748,20 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
         const int km2 = k > 1 ? k - 2 : 0;                                                                                         \
         if ((k & (PCH - 1)) == 1 && k > 1) chunk_rows(k / PCH - 1);                 /* step k - 2: the chunk below */               \
         if ((k & (RCH - 1)) == RCH - 1 && k != N - 1 && k >= RCH)                   /* entering rho chunk k / RCH: fetch the one below */ \
-            rho_stage<PD>(P, RS, k / RCH - 1, (k / RCH - 1) & 1, threadIdx.x);                                                     \
+            rho_stage<PD>(P, RS, k / RCH - 1, (k / RCH - 1) & 1, 64 * w + lane);                                                     \
         float4 nrh;                                                                                                                \
         f4 nS0, nS1;                                                                                                               \
         /* ---- the chain ---- */                                                                                                  \
-        const float pga = dpp_mov<0xB1>(ga), pgb = dpp_mov<0xB1>(gb);                                                              \
+        const float pga = partner16(ga, odd), pgb = partner16(gb, odd);                                                              \
         const float hba = rh.x * ga - sgn * rh.y * pga;              /* conj(rho_k) g */                                           \
         const float hbb = rh.z * gb - sgn * rh.w * pgb;                                                                            \
         float yba = fmaf(hba, S0.y, c3a), ybb = fmaf(hbb, S0.y, c3b);                                                              \
-        write_vec(L.vec[p][0], yba, ybb);                                                                                          \
+        write_vec(L.vec[p][0], g, yba, ybb);                                                                                          \
         lds_barrier();                                                                                                             \
         PAIR_BSTAMP_A();                                                                                                           \
-        Acc2 cQ, cD;                                                                                                               \
+        f4 cQ0, cQ1, cD0, cD1;                                                                                                             \
         float uka, ukb, yha, yhb, ypa, ypb, una, unb;                                                                              \
-        matvec2p<PD>(FQ, FD, lds_addr_of(L.vec[p][0]) + rd_off, cQ, cD, [&](auto pc) {                                             \
+        matvec2<PD>(FQ, FD, lds_addr_of(L.vec[p][0]), g, cQ0, cQ1, cD0, cD1, [&](auto pc) {                                        \
             constexpr int PI = decltype(pc)::value;                                                                                \
             const float inv = S0.y, dt = S1.z, invp = SP0.y;                                                                       \
             if constexpr (PI == 0) {                                                                                               \
@@ -1052,16 +769,16 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
                 ypa = PRV.x * invp; ypb = PRV.y * invp;                                                                            \
                 PAIR_PIN4(yha, yhb, ypa, ypb);                                                                                     \
             } else if constexpr (PI == 1) {          /* u_{k+1} = rho_k yhat */                                                    \
-                una = rh.x * yha + sgn * rh.y * dpp_mov<0xB1>(yha);                                                                \
-                unb = rh.z * yhb + sgn * rh.w * dpp_mov<0xB1>(yhb);                                                                \
+                una = rh.x * yha + sgn * rh.y * partner16(yha, odd);                                                               \
+                unb = rh.z * yhb + sgn * rh.w * partner16(yhb, odd);                                                               \
                 PAIR_PIN2(una, unb);                                                                                               \
             } else if constexpr (PI == 2) {          /* the frequency gradient (meaningful in the Re lanes) */                     \
-                facca += dt * (pga * una - ga * dpp_mov<0xB1>(una));                                                               \
-                faccb += dt * (pgb * unb - gb * dpp_mov<0xB1>(unb));                                                               \
+                facca += dt * (pga * una - ga * partner16(una, odd));                                                              \
+                faccb += dt * (pgb * unb - gb * partner16(unb, odd));                                                              \
                 PAIR_PIN2(facca, faccb);                                                                                           \
             } else if constexpr (PI == 3) {          /* u_k = rho_{k-1} y_{k-1} inv_{k-1}  (psi_0 at k = 0) */                     \
-                const float ra = rhp.x * ypa + sgn * rhp.y * dpp_mov<0xB1>(ypa);                                                   \
-                const float rb = rhp.z * ypb + sgn * rhp.w * dpp_mov<0xB1>(ypb);                                                   \
+                const float ra = rhp.x * ypa + sgn * rhp.y * partner16(ypa, odd);                                                  \
+                const float rb = rhp.z * ypb + sgn * rhp.w * partner16(ypb, odd);                                                  \
                 uka = k > 0 ? ra : ps0a;                                                                                           \
                 ukb = k > 0 ? rb : ps0b;                                                                                           \
                 PAIR_PIN2(uka, ukb);                                                                                               \
@@ -1070,20 +787,18 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
                 c3a = fmaf(SP0.w, PRV.z, -(ypa * radk));                                                                           \
                 c3b = fmaf(SP0.w, PRV.w, -(ypb * radk));                                                                           \
                 PAIR_PIN2(c3a, c3b);                                                                                               \
-            } else if constexpr (PI == 5 && PAIR_EXPORT && PAIR_EXPORT_STORES) {   /* ybar_k, float32, for the gradient GEMM */       \
+            } else if constexpr (PI == 5) {          /* ybar_k, float32, for the gradient GEMM */                                 \
                 *reinterpret_cast<float2*>(ybar_base + (size_t)k * (4 * PD)) = make_float2(yba, ybb);                              \
-            } else if constexpr (PI == 10) {                                                                                       \
+            } else if constexpr (PI == 6) {                                                                                        \
                 CUR = row_at(k - 8);                                  /* this slot's next row (row k is dead from here on) */      \
-            } else if constexpr (PI == 16) {         /* scalars and rho row of step k - 2, behind the last MFMAs */                 \
+            } else if constexpr (PI == 8) {          /* scalars and rho row of step k - 2, behind the last MFMAs */                 \
                 nrh = rho_rows(km2);                                                                                               \
                 nS0 = tab_row(km2, 0);                                                                                             \
                 nS1 = tab_row(km2, 1);                                                                                             \
             }                                                                                                                      \
         });                                                                                                                        \
         PAIR_BSTAMP_B();                                                                                                           \
-        float qa, qb, da, db;                                                                                                      \
-        rows_of(cQ.a + cQ.b, qa, qb);                                                                                              \
-        rows_of(cD.a + cD.b, da, db);                                                                                              \
+        const float qa = cQ0[0], qb = cQ1[0], da = cD0[0], db = cD1[0];                                                            \
         accS += (da * uka + db * ukb) * S1.y;                                                                                      \
         ga = yba + qa + S0.x * da;                                                                                                 \
         gb = ybb + qb + S0.x * db;                                                                                                 \
@@ -1129,15 +844,15 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
     const int DD = PD * PD;
     {
         const float fa = facca * wq, fb = faccb * wq;
-        const float fta = fa + dpp_mov<0x4E>(fa), ftb = fb + dpp_mov<0x4E>(fb);      // quad_perm [2,3,0,1]: the other clip
+        const float fta = both_clips(fa), ftb = both_clips(fb);
         const float g0a = ga * wq, g0b = gb * wq;
-        const float gta = g0a + dpp_mov<0x4E>(g0a), gtb = g0b + dpp_mov<0x4E>(g0b);
-        if (c == 0) {
+        const float gta = both_clips(g0a), gtb = both_clips(g0b);
+        if (g.f == 0) {                                                    // Re lanes of clip 0
             slab[4 * DD + ia] = fta;
             slab[4 * DD + ib] = ftb;
             slab[4 * DD + PD + ia] = gta;
             slab[4 * DD + PD + ib] = gtb;
-        } else if (c == 1) {
+        } else if (g.f == 1) {                                             // Im lanes of clip 0
             slab[4 * DD + 2 * PD + ia] = gta;
             slab[4 * DD + 2 * PD + ib] = gtb;
         }
@@ -1169,7 +884,6 @@ hipError_t launch_bwd_pair(const Dev& P, const float* audio, hipStream_t s) {
 }
 
 }  // namespace cmps
-
 namespace cmps {
 
 // ------------------------------------------------------------------------------------------------

@@ -114,8 +114,7 @@ def test_options_default_and_errors(hip_lib):
 
 @pytest.mark.parametrize("source,flags", [
     ("cmps_wave2.hip", ["-DCMPS_DIAG_NO_LOSS"]), ("cmps_wave2.hip", ["-DCMPS_DIAG_NO_CHAIN"]),
-    ("cmps_pair.hip", ["-DPABL_NO_MFMA"]), ("cmps_pair.hip", ["-DPABL_NO_REDUCE", "-DPABL_NO_BARRIER", "-DPABL_NO_EXPORT"]),
-    ("cmps_pair.hip", ["-DPABL_NO_STASHREAD", "-DPABL_HALF_READS"]), ("cmps_pair.hip", ["-DPABL_TIMING", "-DPABL_NO_EXPORT_STORES"]),
+    ("cmps_pair.hip", ["-DPABL_NO_MFMA", "-DPABL_NO_BARRIER"]), ("cmps_pair.hip", ["-DPABL_TIMING"]),
     ("cmps_wave16.hip", ["-DW16_TIMING"]), ("cmps_wide.hip", ["-DWABL_NO_LOSSMV", "-DWABL_GRAD_NO_LOADS", "-DWABL_GRAD_NO_STORE"]),
     ("cmps_pair.hip", ["-DWABL_GRAD_NO_SLICES"]),
 ])
