@@ -89,6 +89,20 @@ __device__ __forceinline__ float clip_sum(float x) {
     x += dpp_mov<0x121>(x);       // row_ror:1   -> total of the clip's 16 lanes x 2 components
     return x;
 }
+// sum over the 16 lanes of a row (one clip, one component); every lane receives the total
+__device__ __forceinline__ float row_sum16(float x) {
+    x += dpp_mov<0x128>(x);       // row_ror:8
+    x += dpp_mov<0x124>(x);       // row_ror:4
+    x += dpp_mov<0x122>(x);       // row_ror:2
+    x += dpp_mov<0x121>(x);       // row_ror:1
+    return x;
+}
+template <int W>
+__device__ __forceinline__ float sum4(const float __attribute__((ext_vector_type(4))) & t) {   // the first W entries
+    if constexpr (W == 4) return (t.x + t.y) + (t.z + t.w);
+    else if constexpr (W == 3) return (t.x + t.y) + t.z;
+    else return t.x + t.y;
+}
 // sum over the two clips (lanes l and l ^ 32), in every lane
 __device__ __forceinline__ float both_clips(float x) { return half_add(x, x); }
 
@@ -100,7 +114,7 @@ template <int D>
 struct PairLds {
     static constexpr int VROW = D * 2 + 32;                           // bytes per (array, clip) row
     static constexpr int VEC_BYTES = 8 * VROW;    // re, im, -im (x 2 clips) + 2 dummy rows (the Re lanes' second write)
-    __attribute__((aligned(16))) unsigned char vec[2][2][VEC_BYTES];   // [parity][0: ut, 1: y]
+    __attribute__((aligned(16))) unsigned char vec[2][VEC_BYTES];      // [parity]: the un-normalised ut (forward) / ybar (reverse)
 };
 template <int W>
 __device__ __forceinline__ float sum_waves(const float* p) {          // p[0..W-1], 16-byte aligned
@@ -121,48 +135,61 @@ __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
 }
 
 // ---- the lane geometry of a chain wave ----
+// Wave w reads the K-steps in ITS OWN order: local step tau = 0 is the K range this wave itself produced (rows 32 w .. 32 w + 31 of
+// the vector: global K-step w of the M_re half, KH + w of the M_im half), tau = 1 .. KH - 1 follow cyclically.  The fragments are
+// loaded in that order, so the step code is the same for all waves, and the two own K-steps need no barrier: they are read back
+// right behind the wave's own stores and their eight MFMAs start the moment the barrier opens, while the reads of the other waves'
+// ranges are still in flight (rounds 1-3 and the first 16x16x32 version: ~110 cycles of LDS latency with an idle matrix pipe).
+template <int KH>
 struct ChainLane {
     int j, f, q, ia, ib;          // B column / D lane, form, clip, the two adjacent rows
     bool odd;                     // this lane's component: Im (odd) or Re
-    int rd_lo, rd_hi;             // byte offsets of the A operand inside a vector image: K < D (array re / im) and K >= D (-im / re)
+    unsigned lo[KH], hi[KH];      // LDS byte addresses (parity 0 image) of the A operand of local K-step tau: K < D (array re / im) and K >= D (-im / re)
     int wr1, wr2;                 // byte offsets of the rows this lane writes: own array; -im (Im lanes) or the dummy row (Re lanes)
 };
 template <int PD>
-__device__ __forceinline__ ChainLane chain_lane(int w, int lane) {
-    constexpr int VROW = PairLds<PD>::VROW;
-    ChainLane g;
+__device__ __forceinline__ ChainLane<PD / 32> chain_lane(int w, int lane, unsigned img0) {
+    constexpr int VROW = PairLds<PD>::VROW, KH = PD / 32;
+    ChainLane<KH> g;
     g.j = lane & 15; g.f = lane >> 4; g.q = g.f >> 1; g.odd = (g.f & 1) != 0;
     g.ia = 32 * w + 2 * g.j; g.ib = g.ia + 1;
-    const int af = (lane >> 2) & 3, aq = af >> 1, kg = lane >> 4;      // the form this lane's A operand belongs to, its K group
+    // A rows 4 f (register 0 of the result: this lane's own form) and 4 f + 1 (register 1: the Re <-> Im PARTNER's form, so that no
+    // lane ever has to fetch its partner's value from 16 lanes away); the other rows repeat row 4 f (their results are not used)
+    const int af = ((lane >> 2) & 3) ^ ((lane & 3) == 1 ? 1 : 0), aq = af >> 1, kg = lane >> 4;
     const bool ac1 = (af & 1) != 0;                                   // c1 = [u_im; u_re], c0 = [u_re; -u_im]
-    g.rd_lo = ((ac1 ? 1 : 0) * 2 + aq) * VROW + 16 * kg;
-    g.rd_hi = ((ac1 ? 0 : 2) * 2 + aq) * VROW + 16 * kg;
+    const unsigned rd_lo = img0 + ((ac1 ? 1 : 0) * 2 + aq) * VROW + 16 * kg;
+    const unsigned rd_hi = img0 + ((ac1 ? 0 : 2) * 2 + aq) * VROW + 16 * kg;
+#pragma unroll
+    for (int t = 0; t < KH; ++t) {
+        g.lo[t] = rd_lo + 64 * ((t + w) % KH);
+        g.hi[t] = rd_hi + 64 * ((t + w) % KH);
+    }
     g.wr1 = ((g.odd ? 1 : 0) * 2 + g.q) * VROW + g.ia * 2;
     g.wr2 = ((g.odd ? 2 : 3) * 2 + g.q) * VROW + g.ia * 2;
     return g;
 }
 // rows ia, ia + 1 are adjacent: one packed 4-byte store per array
-__device__ __forceinline__ void write_vec(unsigned char* base, const ChainLane& g, float xa, float xb) {
+template <int KH>
+__device__ __forceinline__ void write_vec(unsigned char* base, const ChainLane<KH>& g, float xa, float xb) {
     const unsigned pk = pk_bf16(xa, xb);
     *reinterpret_cast<unsigned*>(base + g.wr1) = pk;
     *reinterpret_cast<unsigned*>(base + g.wr2) = pk ^ 0x80008000u;
 }
 
-// B fragments of one matrix for this lane: frag[tile * KS + t] = 8 bf16 = real-form columns 32 t + 8 kg .. + 7 of row ia + tile;
-// elem(tile, kappa) is the float32 entry, kappa in [0, 2 PD): [M_re | M_im]
+// B fragments of one matrix for this lane in the wave's K-step order: frag[tile * KS + tau] (M_re half) and frag[tile * KS + KH + tau]
+// (M_im half) = 8 bf16 = columns 32 ((tau + w) % KH) + 8 kg .. + 7 of that half in row ia + tile; elem(tile, half, col) is the float32 entry
 template <int PD, typename F>
-__device__ __forceinline__ void load_frags(u4 (&frag)[PD / 8], int kg, F&& elem) {
-    constexpr int KS = PD / 16;
+__device__ __forceinline__ void load_frags(u4 (&frag)[PD / 8], int w, int kg, F&& elem) {
+    constexpr int KS = PD / 16, KH = PD / 32;
 #pragma unroll
     for (int tile = 0; tile < 2; ++tile)
 #pragma unroll
         for (int t = 0; t < KS; ++t) {
             unsigned v[4];
+            const int half = t / KH, col0 = 32 * ((t % KH + w) % KH) + 8 * kg;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int kp = 32 * t + 8 * kg + 2 * e;
-                v[e] = (unsigned)bf16_rne(elem(tile, kp)) | ((unsigned)bf16_rne(elem(tile, kp + 1)) << 16);
-            }
+            for (int e = 0; e < 4; ++e)
+                v[e] = (unsigned)bf16_rne(elem(tile, half, col0 + 2 * e)) | ((unsigned)bf16_rne(elem(tile, half, col0 + 2 * e + 1)) << 16);
             frag[tile * KS + t] = u4{v[0], v[1], v[2], v[3]};
             asm volatile("" : "+a"(frag[tile * KS + t]));       // into its AGPRs now: the loads of all fragments in flight at once
         }                                                      // would be the kernel's register peak
@@ -173,24 +200,41 @@ __device__ __forceinline__ void load_frags(u4 (&frag)[PD / 8], int kg, F&& elem)
 #else
 #define PAIR_ASM(TEXT) TEXT
 #endif
-// the D / 16 reads of one broadcast vector, issued back to back; completion is awaited K-step by K-step with counted lgkmcnt
-// waits (LDS operations of a wave complete in order, so whatever else is in flight only makes a counted wait stricter)
-template <int KS>
-__device__ __forceinline__ void rd_vec(unsigned lo, unsigned hi, u4 (&v)[KS]) {
-    if constexpr (KS == 8)
-        asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:64\n\tds_read_b128 %2, %8 offset:128\n\t"
-                     "ds_read_b128 %3, %8 offset:192\n\tds_read_b128 %4, %9\n\tds_read_b128 %5, %9 offset:64\n\t"
-                     "ds_read_b128 %6, %9 offset:128\n\tds_read_b128 %7, %9 offset:192"
-                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
-                     : "v"(lo), "v"(hi) : "memory");
-    else if constexpr (KS == 6)
-        asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:64\n\tds_read_b128 %2, %6 offset:128\n\t"
-                     "ds_read_b128 %3, %7\n\tds_read_b128 %4, %7 offset:64\n\tds_read_b128 %5, %7 offset:128"
-                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]) : "v"(lo), "v"(hi) : "memory");
+// ---- LDS reads of the A operands, all in asm: issued back to back, awaited K-step by K-step with counted lgkmcnt waits (LDS
+// operations of a wave complete in order, so whatever else is in flight only makes a counted wait stricter) ----
+// the wave's own K-steps (tau = 0), read back right behind its own stores of image parity `POFF / stride`
+template <int POFF>
+__device__ __forceinline__ void rd_own(unsigned lo0, unsigned hi0, u4& vlo, u4& vhi) {
+    asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b128 %1, %3 offset:%4"
+                 : "=&v"(vlo), "=&v"(vhi) : "v"(lo0), "v"(hi0), "n"(POFF) : "memory");
+}
+// two 16-byte table rows (x0, x1: per-step scalars, rho rows, norm partials) and then the K-steps tau = 1 .. KH - 1 of both halves:
+// 2 + 2 (KH - 1) reads; v[tau - 1] / v[KH - 1 + tau - 1]
+template <int KH, int POFF>
+__device__ __forceinline__ void rd_rest(unsigned ax0, unsigned ax1, const unsigned (&lo)[KH], const unsigned (&hi)[KH], f4& x0, f4& x1,
+                                        u4 (&v)[2 * KH - 2]) {
+    if constexpr (KH == 4)
+        asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\t"
+                     "ds_read_b128 %2, %10 offset:%16\n\tds_read_b128 %3, %11 offset:%16\n\tds_read_b128 %4, %12 offset:%16\n\t"
+                     "ds_read_b128 %5, %13 offset:%16\n\tds_read_b128 %6, %14 offset:%16\n\tds_read_b128 %7, %15 offset:%16"
+                     : "=&v"(x0), "=&v"(x1), "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5])
+                     : "v"(ax0), "v"(ax1), "v"(lo[1]), "v"(lo[2]), "v"(lo[3]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]), "n"(POFF) : "memory");
+    else if constexpr (KH == 3)
+        asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %7\n\t"
+                     "ds_read_b128 %2, %8 offset:%12\n\tds_read_b128 %3, %9 offset:%12\n\t"
+                     "ds_read_b128 %4, %10 offset:%12\n\tds_read_b128 %5, %11 offset:%12"
+                     : "=&v"(x0), "=&v"(x1), "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+                     : "v"(ax0), "v"(ax1), "v"(lo[1]), "v"(lo[2]), "v"(hi[1]), "v"(hi[2]), "n"(POFF) : "memory");
     else
-        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\t"
-                     "ds_read_b128 %2, %5\n\tds_read_b128 %3, %5 offset:64"
-                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(lo), "v"(hi) : "memory");
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\t"
+                     "ds_read_b128 %2, %6 offset:%8\n\tds_read_b128 %3, %7 offset:%8"
+                     : "=&v"(x0), "=&v"(x1), "=&v"(v[0]), "=&v"(v[1])
+                     : "v"(ax0), "v"(ax1), "v"(lo[1]), "v"(hi[1]), "n"(POFF) : "memory");
+}
+// wait until at most W LDS operations are outstanding; the named registers are the reads this makes available
+template <int W>
+__device__ __forceinline__ void lds_wait2(f4& a, f4& b) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(W) : "memory");
 }
 // One K-step: the A operand v against the fragments of two matrices x two tiles, as ONE asm statement -- the fragments are read
 // straight from AGPRs (constraint "a": they stay there for the whole kernel, no copies), the accumulators live in VGPRs where
@@ -223,34 +267,42 @@ __device__ __forceinline__ void kstep(const u4& fa0, const u4& fa1, const u4& fb
                      : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1) : "a"(fa0), "a"(fa1), "a"(fb0), "a"(fb1), "v"(v), "n"(W) : "memory");
     }
 }
-// The vector image at LDS address `img` against matrices A and B: a0 / a1 = (A v) rows ia / ia + 1, b0 / b1 = (B v), in register 0.
-// piece(ic<0>) runs while the reads are in flight, piece(ic<t + 1>) behind the four MFMAs of K-step t (64 matrix-pipe cycles of
-// which the MFMAs' own issue takes 32: room for about eight independent VALU instructions that cost nothing), ic<KS + 1 .. 8> after
-// the last one.  The compiler does not know what the asm statements cost and would sink the work below all of them: every piece
-// must end by pinning its results (PAIR_PIN) so that it stays where it is called.
+// A mat-vec pair after the barrier: a0 / a1 = (A v) rows ia / ia + 1, b0 / b1 = (B v); register 0 = this lane's own form, register 1
+// = its partner's.  Order: the table rows and the other waves' K ranges are requested (rd_rest), the two OWN K-steps (already in
+// registers: vlo, vhi) go to the matrix pipe at once, piece(ic<0>) with the two table rows, then K-step i = 1 .. 2 KH - 2 of the
+// rest with piece(ic<i>) behind it (64 matrix-pipe cycles each, of which the four MFMAs' own issue takes 32: room for about eight
+// independent VALU instructions), ic<2 KH - 1 .. 7> behind the last.  The compiler does not know what the asm statements cost and
+// schedules plain code around them freely: a piece that must stay where it is called pins its inputs when it starts and its
+// results when it ends (PAIR_PIN).
 template <int I> struct ic { static constexpr int value = I; };
 #define PAIR_PIN1(a) asm volatile("" : "+v"(a))
 #define PAIR_PIN2(a, b) asm volatile("" : "+v"(a), "+v"(b))
 #define PAIR_PIN4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
-template <int PD, int T, typename Piece>
-__device__ __forceinline__ void ksteps(const u4 (&FA)[PD / 8], const u4 (&FB)[PD / 8], u4 (&v)[PD / 16], f4& a0, f4& a1, f4& b0, f4& b1, Piece&& piece) {
-    constexpr int KS = PD / 16;
-    if constexpr (T < KS) {
-        kstep<KS - 1 - T, T == 0, T == KS - 1>(FA[T], FA[KS + T], FB[T], FB[KS + T], v[T], a0, a1, b0, b1);
-        piece(ic<T + 1>{});
-        ksteps<PD, T + 1>(FA, FB, v, a0, a1, b0, b1, piece);
-    } else if constexpr (T < 8) {
-        piece(ic<T + 1>{});
-        ksteps<PD, T + 1>(FA, FB, v, a0, a1, b0, b1, piece);
+template <int PD, int I, typename Piece>
+__device__ __forceinline__ void ksteps_rest(const u4 (&FA)[PD / 8], const u4 (&FB)[PD / 8], u4 (&v)[PD / 16 - 2], f4& a0, f4& a1, f4& b0, f4& b1,
+                                            Piece&& piece) {
+    constexpr int KS = PD / 16, KH = PD / 32, NR = KS - 2;     // NR reads of the rest: lo tau = 1 .. KH - 1, then hi tau = 1 .. KH - 1
+    if constexpr (I < NR) {
+        constexpr int T = I < KH - 1 ? 1 + I : KH + 1 + (I - (KH - 1));   // index into the wave's fragment order
+        kstep<NR - 1 - I, false, I == NR - 1>(FA[T], FA[KS + T], FB[T], FB[KS + T], v[I], a0, a1, b0, b1);
+        piece(ic<I + 1>{});
+        ksteps_rest<PD, I + 1>(FA, FB, v, a0, a1, b0, b1, piece);
+    } else if constexpr (I < 7) {
+        piece(ic<I + 1>{});
+        ksteps_rest<PD, I + 1>(FA, FB, v, a0, a1, b0, b1, piece);
     }
 }
-template <int PD, typename Piece>
-__device__ __forceinline__ void matvec2(const u4 (&FA)[PD / 8], const u4 (&FB)[PD / 8], unsigned img, const ChainLane& g,
-                                        f4& a0, f4& a1, f4& b0, f4& b1, Piece&& piece) {
-    u4 v[PD / 16];
-    rd_vec<PD / 16>(img + g.rd_lo, img + g.rd_hi, v);
+template <int PD, int POFF, typename Piece>
+__device__ __forceinline__ void matvec2(const u4 (&FA)[PD / 8], const u4 (&FB)[PD / 8], const ChainLane<PD / 32>& g, unsigned ax0, unsigned ax1,
+                                        u4& vlo, u4& vhi, f4& x0, f4& x1, f4& a0, f4& a1, f4& b0, f4& b1, Piece&& piece) {
+    constexpr int KS = PD / 16, KH = PD / 32;
+    u4 v[KS - 2];
+    rd_rest<KH, POFF>(ax0, ax1, g.lo, g.hi, x0, x1, v);
+    kstep<KS, true, false>(FA[0], FA[KS], FB[0], FB[KS], vlo, a0, a1, b0, b1);          // (the counts are no-ops: vlo, vhi arrived
+    kstep<KS, false, false>(FA[KH], FA[KS + KH], FB[KH], FB[KS + KH], vhi, a0, a1, b0, b1);   // before the barrier)
+    lds_wait2<KS - 2>(x0, x1);
     piece(ic<0>{});
-    ksteps<PD, 0>(FA, FB, v, a0, a1, b0, b1, piece);
+    ksteps_rest<PD, 0>(FA, FB, v, a0, a1, b0, b1, piece);
 }
 
 // rho rows are staged through LDS one 32-step chunk at a time (a row per step straight from L2 / HBM costs its full
@@ -339,29 +391,35 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
     if (!loss_wave) {
         // ================================================================== chain waves
         __builtin_amdgcn_s_setprio(3);      // both kinds share a SIMD's matrix pipe: the serial chain goes first
+        constexpr int KH = PD / 32, VEC = PairLds<PD>::VEC_BYTES;
         u4 FR[PD / 8], FQ[PD / 8];
         {
             const int row0 = 32 * w + 2 * (lane & 15);                 // rows ia (tile 0) and ia + 1 (tile 1)
             const float2* Rrow = P.R + (size_t)row0 * PD;
             const float2* Qrow = P.Q + (size_t)row0 * PD;
-            load_frags<PD>(FR, lane >> 4, [&](int tile, int kp) { return kp < PD ? Rrow[tile * PD + kp].x : Rrow[tile * PD + kp - PD].y; });
-            load_frags<PD>(FQ, lane >> 4, [&](int tile, int kp) { return kp < PD ? Qrow[tile * PD + kp].x : Qrow[tile * PD + kp - PD].y; });
+            load_frags<PD>(FR, w, lane >> 4, [&](int tile, int half, int c) { return half ? Rrow[tile * PD + c].y : Rrow[tile * PD + c].x; });
+            load_frags<PD>(FQ, w, lane >> 4, [&](int tile, int half, int c) { return half ? Qrow[tile * PD + c].y : Qrow[tile * PD + c].x; });
         }
         // (everything below is derived from a laundered copy of the lane number: addresses computed before the fragment loads would
         // be live across their register peak, and the allocator then keeps them in scratch memory for the whole kernel)
         int lane_c = lane;
         asm volatile("" : "+v"(lane_c));
-        const ChainLane g = chain_lane<PD>(w, lane_c);
+        const ChainLane<KH> g = chain_lane<PD>(w, lane_c, lds_addr_of(&L.vec[0][0]));
         const int q = g.q, ia = g.ia, ib = g.ib;
         const bool odd = g.odd;
+        const float sg = odd ? 1.f : -1.f;                             // (rho y)_own = rho_re y_own + sg rho_im y_partner
         // the ring rows of this lane within a slot: bf16 (own array, and -im / dummy), float32
         const int rb1 = (q * 4 + (odd ? 1 : 0)) * BROW + ia * 2, rb2 = (q * 4 + (odd ? 2 : 3)) * BROW + ia * 2;
         const int rf = (q * 2 + (odd ? 1 : 0)) * FROW + ia * 4;
+        const unsigned a_nrm = lds_addr_of(&RG.nrm[0][q][0]);        // + 32 slot
+        const unsigned a_rho = lds_addr_of(&RS.row[0][0][ia]);        // + 8 PD (32 buffer + row)
         const float2 pa = P.psi0[ia], pb = P.psi0[ib];
-        float uta = odd ? pa.y : pa.x, utb = odd ? pb.y : pb.x;      // ut_0 = psi_0 (both clips)
-        float inv = 1.f;                                              // 1/sqrt(max(|y_{k-1}|^2, eps)) of this lane's clip
+        float uta = odd ? pa.y : pa.x, utb = odd ? pb.y : pb.x;      // ut_0 = psi_0 (both clips): own component ..
+        float puta = odd ? pa.x : pa.y, putb = odd ? pb.x : pb.y;    // .. and a copy of the partner's (kept in step by the MFMAs' register 1)
         float sv0 = 0.f, sv1 = 0.f;                                   // s = x / A of the current 64 steps, lane <-> step
-        write_vec(L.vec[0][0], g, uta, utb);
+        u4 vlo, vhi;                                                  // the wave's own K-steps of the image the next step multiplies
+        write_vec(L.vec[0], g, uta, utb);
+        rd_own<0>(g.lo[0], g.hi[0], vlo, vhi);
         rho_stage<PD>(P, RS, 0, 0, 64 * w + lane_c);
         __syncthreads();
 #if defined(CMPS_DIAG) && defined(PABL_TIMING)        // diagnostic builds only: where a chain step's cycles go (s_memtime stamps, consumed a step late)
@@ -376,52 +434,58 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
 #endif
         // Eight steps per block with the step-in-block J static: the LDS parities and ring slots are immediates and the chunk
         // boundaries (increments every 64 steps, rho staging every 32) can only fall on J = 0.
+        // A step: [barrier] -> table rows + the other waves' K ranges requested, own K-steps to the matrix pipe, the rest as it arrives
+        // -> y_k (own and partner copy, packed float32) -> ut_{k+1} -> bf16 image, own K ranges read back -> ring rows, |y|^2 -> [barrier]
 #define PAIR_FWD_STEP(J)                                                                                                   \
         {                                                                                                                  \
             constexpr int p = (J) & 1;                                                                                     \
-            {                                                                                                              \
-                const int k = FB * bt + (J);                                                                               \
-                if ((J) == 0 && (bt & (PCH / FB - 1)) == 0) {          /* increments of the next 64 steps, one per lane */  \
-                    const int idx = k + lane_c;                                                                             \
-                    const bool in0 = idx < T, in1 = idx + 1 < T;                                                           \
-                    sv0 = ((in1 ? xr0[idx + 1] : 0.f) - (in0 ? xr0[idx] : 0.f)) / A;     /* model.py:263, 303 */            \
-                    sv1 = ((in1 ? xr1[idx + 1] : 0.f) - (in0 ? xr1[idx] : 0.f)) / A;                                       \
-                }                                                                                                          \
-                if ((J) == 0 && (bt & (RCH / FB - 1)) == 0)            /* next chunk of rho into the other buffer */        \
-                    rho_stage<PD>(P, RS, k / RCH + 1, (k / RCH + 1) & 1, 64 * w + lane_c);                                            \
-                const float2* rrow = &RS.row[(bt / (RCH / FB)) & 1][(bt & (RCH / FB - 1)) * FB + (J)][0];                  \
-                const float4 rh = *reinterpret_cast<const float4*>(rrow + ia);     /* rho_k of this lane's rows */         \
-                const int hb_ = bt & 1;                                /* the ring half of this block */                   \
-                if ((J) > 0 || bt > 0) {                               /* |y_{k-1}|^2, published by the previous iteration */ \
-                    const float* np_ = (J) > 0 ? &RG.nrm[hb_ * FB + (J) - 1][q][0] : &RG.nrm[(hb_ ^ 1) * FB + FB - 1][q][0]; \
-                    inv = __builtin_amdgcn_rsqf(fmaxf(sum_waves<PWV>(np_), 1e-12f));     /* model.py:332 */                \
-                }                                                                                                          \
-                f4 cR0, cR1, cQ0, cQ1;                                                                                     \
-                PAIR_FSTAMP_A();                                                                                           \
-                matvec2<PD>(FR, FQ, lds_addr_of(L.vec[p][0]), g, cR0, cR1, cQ0, cQ1, [](auto) {});                         \
-                PAIR_FSTAMP_B();                                                                                           \
-                const int kl = (bt & (PCH / FB - 1)) * FB + (J);                                                           \
-                const float s0 = rdl(sv0, kl), s1 = rdl(sv1, kl);      /* (both read: a readlane inside a select becomes a branch) */ \
-                const float s = q ? s1 : s0;                                                                               \
-                const float yna = inv * (uta + (cQ0[0] + s * cR0[0])); /* y_k, rows ia / ib */                             \
-                const float ynb = inv * (utb + (cQ1[0] + s * cR1[0]));                                                     \
-                /* the chain first: ut_{k+1} = rho_k y_k (un-normalised), own component with the partner's (re <-> im) */   \
-                const float pya = partner16(yna, odd), pyb = partner16(ynb, odd);                                          \
-                uta = rh.x * yna + (odd ? rh.y : -rh.y) * pya;                                                             \
-                utb = rh.z * ynb + (odd ? rh.w : -rh.w) * pyb;                                                             \
-                write_vec(L.vec[p ^ 1][0], g, uta, utb);                                                                   \
-                asm volatile("" ::: "memory");                         /* (keeps the stores above ahead of what follows) */ \
-                {   /* y_k for the loss waves: bf16 images and float32 */                                                  \
-                    unsigned char* rbase = &RG.b[hb_ * FB + (J)][0][0][0];                                                 \
-                    const unsigned pk = pk_bf16(yna, ynb);                                                                 \
-                    *reinterpret_cast<unsigned*>(rbase + rb1) = pk;                                                        \
-                    *reinterpret_cast<unsigned*>(rbase + rb2) = pk ^ 0x80008000u;                                          \
-                    *reinterpret_cast<float2*>(&RG.f[hb_ * FB + (J)][0][0][0] + rf) = make_float2(yna, ynb);               \
-                }                                                                                                          \
-                const float nn = clip_sum(yna * yna + ynb * ynb);                                                          \
-                if (lane_c == 0 || lane_c == 32) RG.nrm[hb_ * FB + (J)][q][w] = nn;                                            \
-                PAIR_FSTAMP_C(nn);                                                                                         \
+            const int k = FB * bt + (J);                                                                                   \
+            if ((J) == 0 && (bt & (PCH / FB - 1)) == 0) {              /* increments of the next 64 steps, one per lane */  \
+                const int idx = k + lane_c;                                                                                \
+                const bool in0 = idx < T, in1 = idx + 1 < T;                                                               \
+                sv0 = ((in1 ? xr0[idx + 1] : 0.f) - (in0 ? xr0[idx] : 0.f)) / A;         /* model.py:263, 303 */            \
+                sv1 = ((in1 ? xr1[idx + 1] : 0.f) - (in0 ? xr1[idx] : 0.f)) / A;                                           \
             }                                                                                                              \
+            if ((J) == 0 && (bt & (RCH / FB - 1)) == 0)                /* next chunk of rho into the other buffer */        \
+                rho_stage<PD>(P, RS, k / RCH + 1, (k / RCH + 1) & 1, 64 * w + lane_c);                                     \
+            const int hb_ = bt & 1;                                    /* the ring half of this block */                   \
+            /* |y_{k-1}|^2 partials (published by the previous step; nothing at k = 0) and rho_k of this lane's rows */     \
+            const int nslot = (J) > 0 ? hb_ * FB + (J) - 1 : (hb_ ^ 1) * FB + FB - 1;                                      \
+            const unsigned ax0 = a_nrm + 32 * nslot;                                                                       \
+            const unsigned ax1 = a_rho + 8 * PD * (((bt / (RCH / FB)) & 1) * RCH + (bt & (RCH / FB - 1)) * FB + (J));       \
+            f4 xn, rh, cR0, cR1, cQ0, cQ1;                                                                                 \
+            float inv, s;                                                                                                  \
+            PAIR_FSTAMP_A();                                                                                               \
+            matvec2<PD, p * VEC>(FR, FQ, g, ax0, ax1, vlo, vhi, xn, rh, cR0, cR1, cQ0, cQ1, [&](auto pc) {                 \
+                if constexpr (decltype(pc)::value == 0) {                                                                  \
+                    inv = __builtin_amdgcn_rsqf(fmaxf(sum4<PWV>(xn), 1e-12f));           /* model.py:332 */                \
+                    if ((J) == 0 && bt == 0) inv = 1.f;                                                                    \
+                    const int kl = (bt & (PCH / FB - 1)) * FB + (J);                                                       \
+                    const float s0 = rdl(sv0, kl), s1 = rdl(sv1, kl);  /* (both read: a readlane inside a select becomes a branch) */ \
+                    s = q ? s1 : s0;                                                                                       \
+                    PAIR_PIN2(inv, s);                                                                                     \
+                }                                                                                                          \
+            });                                                                                                            \
+            PAIR_FSTAMP_B();                                                                                               \
+            /* y_k, rows ia / ib: own component (register 0) and the partner's (register 1) */                              \
+            const float yna = inv * (uta + (cQ0[0] + s * cR0[0])), ypna = inv * (puta + (cQ0[1] + s * cR0[1]));             \
+            const float ynb = inv * (utb + (cQ1[0] + s * cR1[0])), ypnb = inv * (putb + (cQ1[1] + s * cR1[1]));             \
+            /* the chain first: ut_{k+1} = rho_k y_k (un-normalised) */                                                    \
+            const float ria = sg * rh.y, rib = sg * rh.w;                                                                  \
+            uta = rh.x * yna + ria * ypna;   puta = rh.x * ypna - ria * yna;                                                \
+            utb = rh.z * ynb + rib * ypnb;   putb = rh.z * ypnb - rib * ynb;                                                \
+            write_vec(L.vec[p ^ 1], g, uta, utb);                                                                          \
+            rd_own<(p ^ 1) * VEC>(g.lo[0], g.hi[0], vlo, vhi);         /* (same wave, in order: no wait between store and read) */ \
+            {   /* y_k for the loss waves: bf16 images and float32 */                                                      \
+                unsigned char* rbase = &RG.b[hb_ * FB + (J)][0][0][0];                                                     \
+                const unsigned pk = pk_bf16(yna, ynb);                                                                     \
+                *reinterpret_cast<unsigned*>(rbase + rb1) = pk;                                                            \
+                *reinterpret_cast<unsigned*>(rbase + rb2) = pk ^ 0x80008000u;                                              \
+                *reinterpret_cast<float2*>(&RG.f[hb_ * FB + (J)][0][0][0] + rf) = make_float2(yna, ynb);                   \
+            }                                                                                                              \
+            const float nn = row_sum16((yna * yna + ypna * ypna) + (ynb * ynb + ypnb * ypnb));                             \
+            if (lane_c == 0 || lane_c == 32) RG.nrm[hb_ * FB + (J)][q][w] = nn;                                           \
+            PAIR_FSTAMP_C(nn);                                                                                             \
             lds_barrier();                                                                                                 \
         }
         // ONE straight-line copy of the eight steps, run for every iteration: the steps behind the clip's end (at most 7, and the
@@ -435,7 +499,7 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
 #undef PAIR_FWD_STEP
 #if defined(CMPS_DIAG) && defined(PABL_TIMING)
         if (blockIdx.x == 0 && threadIdx.x == 0)
-            printf("forward chain wave, cycles per step: tail end -> first read issue (barrier) %.1f, reads + MFMAs %.1f, tail %.1f\n",
+            printf("forward chain wave, cycles per step: tail end -> barrier exit %.1f, reads + MFMAs %.1f, tail %.1f\n",
                    (double)fPre / fN, (double)fMv / fN, (double)fTail / fN);
 #endif
 #undef PAIR_FSTAMP_A
@@ -483,6 +547,10 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
     // (step 4); finishes batch pe = bt - 2 from the tile copied at the end of the iteration before: H y stores (step 0),
     // e partial -> LDS (step 1), e, loss and the scalar rows (step 5).  Nothing is left for one step to do alone.
     for (int bt = 0; bt < NBT; ++bt) {
+#if defined(CMPS_DIAG) && defined(PABL_NO_LOSS)       // diagnostic builds only (scripts/ablate.py): the loss waves only keep the barriers
+        for (int jj = 0; jj < FB; ++jj) lds_barrier();
+        continue;
+#endif
         const int pb = bt - 1, pe = bt - 2;
         const bool mul = pb >= 0 && FB * pb < N;
         const bool fin = pe >= 0 && FB * pe < N;
@@ -622,13 +690,14 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
         const int row0 = 32 * w + 2 * (lane0 & 15);                    // rows ia (tile 0) and ia + 1 (tile 1)
         const float2* Qrow = P.Q + (size_t)row0 * PD;
         const float2* RTrow = P.RT + (size_t)row0 * PD;                // R^dagger[i][j] = conj(R[j][i]) = conj(RT[i][j])
-        load_frags<PD>(FQ, lane0 >> 4, [&](int tile, int kp) { return kp < PD ? Qrow[tile * PD + kp].x : Qrow[tile * PD + kp - PD].y; });
-        load_frags<PD>(FD, lane0 >> 4, [&](int tile, int kp) { return kp < PD ? RTrow[tile * PD + kp].x : -RTrow[tile * PD + kp - PD].y; });
+        load_frags<PD>(FQ, w, lane0 >> 4, [&](int tile, int half, int c) { return half ? Qrow[tile * PD + c].y : Qrow[tile * PD + c].x; });
+        load_frags<PD>(FD, w, lane0 >> 4, [&](int tile, int half, int c) { return half ? -RTrow[tile * PD + c].y : RTrow[tile * PD + c].x; });
     }
     // (everything below is derived from a laundered copy of the lane number: see k_fwd_pair)
     int lane = lane0;
     asm volatile("" : "+v"(lane));
-    const ChainLane g = chain_lane<PD>(w, lane);
+    constexpr int KH = PD / 32, VEC = PairLds<PD>::VEC_BYTES;
+    const ChainLane<KH> g = chain_lane<PD>(w, lane, lds_addr_of(&L.vec[0][0]));
     const int q = g.q, ia = g.ia, ib = g.ib;
     const bool odd = g.odd;
     const float wq = (q == 0 || two) ? 1.f : 0.f;                      // weight of this lane's clip (0: the repeated clip)
@@ -688,12 +757,13 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
     __syncthreads();
 
     // ---- state of the step about to run (k): everything the chain needs before the barrier is in registers ----
-    float ga = 0.f, gb = 0.f;                   // g: cotangent of u_{k+1}
+    float ga = 0.f, gb = 0.f, pga = 0.f, pgb = 0.f;     // g: cotangent of u_{k+1}, own component and a copy of the partner's (MFMA register 1)
+    float una = 0.f, unb = 0.f, puna = 0.f, punb = 0.f; // u_{k+1} = rho_k yhat_k, own and partner component (carried: it is u_k of the step before)
     float facca = 0.f, faccb = 0.f, accS = 0.f;
+    u4 vlo, vhi;                                        // the wave's own K-steps of ybar_k, read back before the barrier
     float4 rh, rhp;                             // rho_k and rho_{k-1}, rows ia | ib
     f4 S0, S1, SP0, SP1;                        // scalar rows of steps k and k - 1 (fetched two steps ahead, behind the MFMAs)
     float c3a, c3b;                             // te_k (H y_k) - ok_k yhat_k rad_{k+1} inv_k
-    int p = 0;
     auto rho_rows = [&](int k) { return *reinterpret_cast<const float4*>(&RS.row[(k / RCH) & 1][k & (RCH - 1)][ia]); };
     auto tab_row = [&](int k, int half) { return TB.row[w][(k / PCH) & 1][k & (PCH - 1)][q][half]; };
     // unconditional (clamped) loads: a select on the loaded value would force the wait right behind the load
@@ -730,7 +800,9 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
         c3b = S0.w * cur.w;
     }
     const float2 psa = P.psi0[ia], psb = P.psi0[ib];
-    const float ps0a = odd ? psa.y : psa.x, ps0b = odd ? psb.y : psb.x;        // u_0 = psi_0
+    const float ps0a = odd ? psa.y : psa.x, ps0b = odd ? psb.y : psb.x;        // u_0 = psi_0: own component ..
+    const float pps0a = odd ? psa.x : psa.y, pps0b = odd ? psb.x : psb.y;      // .. and the partner's
+    const unsigned a_tab = lds_addr_of(&TB.row[w][0][0][q][0]);                 // + 64 (64 chunk parity + step in chunk)
 #if defined(CMPS_DIAG) && defined(PABL_TIMING)        // diagnostic builds only: where a step's cycles go (s_memtime stamps, consumed a step late)
     unsigned long long tA = 0, tB = 0, tC = 0, tA1 = 0, tB1 = 0, tC1 = 0, tC2 = 0, accPre = 0, accMv = 0, accTail = 0, accN = 0;
 #define PAIR_BSTAMP_A() { if (tC2) { accPre += tA1 - tC2; accMv += tB1 - tA1; accTail += tC1 - tB1; ++accN; } tC2 = tC1; tA = __builtin_readcyclecounter(); }
@@ -741,70 +813,74 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
 #define PAIR_BSTAMP_B()
 #define PAIR_BSTAMP_C()
 #endif
-    // one step; J = k & 7 (static: selects ring slots and the operand dword).  COND: `true` in full blocks.
+    // one step; J = k & 7 (static: selects ring slots and the image parity).  COND: `true` in full blocks.
+    // Chain: g -> conj(rho) g -> ybar -> bf16 image (own K ranges read back) -> [barrier] -> mat-vecs -> g.  Everything else sits in
+    // the pieces behind the K-steps: the partner copy of ybar, yhat_{k-1} and its partner (the only two lane exchanges of a step),
+    // u_k (= the u_{k+1} of the next step: carried, not recomputed), the frequency gradient, the g-independent part of ybar_{k-1},
+    // the ybar store, the stash ring's next row, the rho row of step k - 2 (its scalar rows come with the operand reads).
 #define PAIR_BWD_STEP(J, CUR, PRV, COND)                                                                                            \
     if (COND) {                                                                                                                    \
+        constexpr int p = (J) & 1;                                                                                                 \
         const int k = 8 * blk + (J);                                                                                               \
         const int km2 = k > 1 ? k - 2 : 0;                                                                                         \
         if ((k & (PCH - 1)) == 1 && k > 1) chunk_rows(k / PCH - 1);                 /* step k - 2: the chunk below */               \
         if ((k & (RCH - 1)) == RCH - 1 && k != N - 1 && k >= RCH)                   /* entering rho chunk k / RCH: fetch the one below */ \
-            rho_stage<PD>(P, RS, k / RCH - 1, (k / RCH - 1) & 1, 64 * w + lane);                                                     \
+            rho_stage<PD>(P, RS, k / RCH - 1, (k / RCH - 1) & 1, 64 * w + lane);                                                   \
         float4 nrh;                                                                                                                \
         f4 nS0, nS1;                                                                                                               \
         /* ---- the chain ---- */                                                                                                  \
-        const float pga = partner16(ga, odd), pgb = partner16(gb, odd);                                                              \
         const float hba = rh.x * ga - sgn * rh.y * pga;              /* conj(rho_k) g */                                           \
         const float hbb = rh.z * gb - sgn * rh.w * pgb;                                                                            \
         float yba = fmaf(hba, S0.y, c3a), ybb = fmaf(hbb, S0.y, c3b);                                                              \
-        write_vec(L.vec[p][0], g, yba, ybb);                                                                                          \
+        write_vec(L.vec[p], g, yba, ybb);                                                                                          \
+        rd_own<p * VEC>(g.lo[0], g.hi[0], vlo, vhi);                                                                               \
         lds_barrier();                                                                                                             \
         PAIR_BSTAMP_A();                                                                                                           \
-        f4 cQ0, cQ1, cD0, cD1;                                                                                                             \
-        float uka, ukb, yha, yhb, ypa, ypb, una, unb;                                                                              \
-        matvec2<PD>(FQ, FD, lds_addr_of(L.vec[p][0]), g, cQ0, cQ1, cD0, cD1, [&](auto pc) {                                        \
+        f4 cQ0, cQ1, cD0, cD1;                                                                                                     \
+        float uka, ukb, puka, pukb, ypa, ypb, pypa, pypb, pyba, pybb;                                                              \
+        const unsigned ax0 = a_tab + 64 * (((km2 / PCH) & 1) * PCH + (km2 & (PCH - 1)));                                           \
+        matvec2<PD, p * VEC>(FQ, FD, g, ax0, ax0 + 16, vlo, vhi, nS0, nS1, cQ0, cQ1, cD0, cD1, [&](auto pc) {                      \
             constexpr int PI = decltype(pc)::value;                                                                                \
-            const float inv = S0.y, dt = S1.z, invp = SP0.y;                                                                       \
-            if constexpr (PI == 0) {                                                                                               \
-                yha = CUR.x * inv; yhb = CUR.y * inv;                                                                              \
+            const float dt = S1.z, invp = SP0.y;                                                                                   \
+            if constexpr (PI == 0) {                 /* the partner's ybar_k (for its g); yhat_{k-1} */                            \
+                pyba = partner16(yba, odd); pybb = partner16(ybb, odd);                                                            \
                 ypa = PRV.x * invp; ypb = PRV.y * invp;                                                                            \
-                PAIR_PIN4(yha, yhb, ypa, ypb);                                                                                     \
-            } else if constexpr (PI == 1) {          /* u_{k+1} = rho_k yhat */                                                    \
-                una = rh.x * yha + sgn * rh.y * partner16(yha, odd);                                                               \
-                unb = rh.z * yhb + sgn * rh.w * partner16(yhb, odd);                                                               \
-                PAIR_PIN2(una, unb);                                                                                               \
-            } else if constexpr (PI == 2) {          /* the frequency gradient (meaningful in the Re lanes) */                     \
-                facca += dt * (pga * una - ga * partner16(una, odd));                                                              \
-                faccb += dt * (pgb * unb - gb * partner16(unb, odd));                                                              \
+                PAIR_PIN4(pyba, pybb, ypa, ypb);                                                                                   \
+            } else if constexpr (PI == 1) {                                                                                        \
+                pypa = partner16(ypa, odd); pypb = partner16(ypb, odd);                                                            \
+                PAIR_PIN2(pypa, pypb);                                                                                             \
+            } else if constexpr (PI == 2) {          /* u_k = rho_{k-1} yhat_{k-1}  (psi_0 at k = 0), both components */           \
+                PAIR_PIN2(pypa, pypb);                                                                                             \
+                const float ria = sgn * rhp.y, rib = sgn * rhp.w;                                                                  \
+                const float ra = rhp.x * ypa + ria * pypa, pra = rhp.x * pypa - ria * ypa;                                         \
+                const float rb = rhp.z * ypb + rib * pypb, prb = rhp.z * pypb - rib * ypb;                                         \
+                uka = k > 0 ? ra : ps0a;   puka = k > 0 ? pra : pps0a;                                                             \
+                ukb = k > 0 ? rb : ps0b;   pukb = k > 0 ? prb : pps0b;                                                             \
+                PAIR_PIN4(uka, ukb, puka, pukb);                                                                                   \
+            } else if constexpr (PI == 3) {          /* the frequency gradient (meaningful in the Re lanes) */                     \
                 PAIR_PIN2(facca, faccb);                                                                                           \
-            } else if constexpr (PI == 3) {          /* u_k = rho_{k-1} y_{k-1} inv_{k-1}  (psi_0 at k = 0) */                     \
-                const float ra = rhp.x * ypa + sgn * rhp.y * partner16(ypa, odd);                                                  \
-                const float rb = rhp.z * ypb + sgn * rhp.w * partner16(ypb, odd);                                                  \
-                uka = k > 0 ? ra : ps0a;                                                                                           \
-                ukb = k > 0 ? rb : ps0b;                                                                                           \
-                PAIR_PIN2(uka, ukb);                                                                                               \
-            } else if constexpr (PI == 4) {          /* the g-independent part of ybar_{k-1} */                                    \
+                facca += dt * (pga * una - ga * puna);                                                                             \
+                faccb += dt * (pgb * unb - gb * punb);                                                                             \
+                PAIR_PIN2(facca, faccb);                                                                                           \
+            } else if constexpr (PI == 4) {          /* the g-independent part of ybar_{k-1}; ybar_k, float32, for the gradient GEMM */ \
+                PAIR_PIN2(ypa, ypb);                                                                                               \
                 const float radk = S1.x * SP0.z * invp;                /* rad_k ok_{k-1} inv_{k-1} */                              \
                 c3a = fmaf(SP0.w, PRV.z, -(ypa * radk));                                                                           \
                 c3b = fmaf(SP0.w, PRV.w, -(ypb * radk));                                                                           \
-                PAIR_PIN2(c3a, c3b);                                                                                               \
-            } else if constexpr (PI == 5) {          /* ybar_k, float32, for the gradient GEMM */                                 \
                 *reinterpret_cast<float2*>(ybar_base + (size_t)k * (4 * PD)) = make_float2(yba, ybb);                              \
-            } else if constexpr (PI == 6) {                                                                                        \
+                PAIR_PIN2(c3a, c3b);                                                                                               \
+            } else if constexpr (PI == 5) {                                                                                        \
                 CUR = row_at(k - 8);                                  /* this slot's next row (row k is dead from here on) */      \
-            } else if constexpr (PI == 8) {          /* scalars and rho row of step k - 2, behind the last MFMAs */                 \
-                nrh = rho_rows(km2);                                                                                               \
-                nS0 = tab_row(km2, 0);                                                                                             \
-                nS1 = tab_row(km2, 1);                                                                                             \
+                nrh = rho_rows(km2);                                  /* rho row of step k - 2 */                                  \
             }                                                                                                                      \
         });                                                                                                                        \
         PAIR_BSTAMP_B();                                                                                                           \
-        const float qa = cQ0[0], qb = cQ1[0], da = cD0[0], db = cD1[0];                                                            \
-        accS += (da * uka + db * ukb) * S1.y;                                                                                      \
-        ga = yba + qa + S0.x * da;                                                                                                 \
-        gb = ybb + qb + S0.x * db;                                                                                                 \
+        accS += (cD0[0] * uka + cD1[0] * ukb) * S1.y;                                                                              \
+        ga = yba + cQ0[0] + S0.x * cD0[0];   pga = pyba + cQ0[1] + S0.x * cD0[1];                                                   \
+        gb = ybb + cQ1[0] + S0.x * cD1[0];   pgb = pybb + cQ1[1] + S0.x * cD1[1];                                                   \
+        una = uka; unb = ukb; puna = puka; punb = pukb;                                                                            \
         rh = rhp; S0 = SP0; S1 = SP1;                                                                                              \
         rhp = nrh; SP0 = nS0; SP1 = nS1;                                                                                           \
-        p ^= 1;                                                                                                                    \
         PAIR_BSTAMP_C();                                                                                                           \
     }
 

@@ -62,6 +62,56 @@ __global__ __launch_bounds__(NT, 1) void k_rate(float* out, int iters) {
     out[blockIdx.x * NT + threadIdx.x] = c0[0] + c1[0] + c2[0] + c3[0] + x0 + x3;
 }
 
+
+// B operands (eight distinct fragments) resident in AGPRs ("a"), A from VGPRs, accumulators in VGPRs -- the pair kernels' operand mix.
+// VIN VALU instructions are written INSIDE the statement behind each MFMA (no hipcc s_nop pad between them).
+template <int NT, int VIN>
+__global__ __launch_bounds__(NT, 1) void k_rate_a(float* out, int iters) {
+    u4 bf[8];
+    for (int i = 0; i < 8; ++i) { bf[i] = u4{0x3f803f80u, 0x3f803f80u + i, 0x3f803f80u, threadIdx.x}; asm volatile("" : "+a"(bf[i])); }
+    u4 a0 = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, threadIdx.x};
+    f4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+    float x0 = threadIdx.x, x1 = 1.0001f, x2 = 0.5f, x3 = 2.f;
+    for (int it = 0; it < iters; ++it) {
+#define V1 "v_fma_f32 %9, %9, %10, %11\n\t"
+#define V2 "v_fma_f32 %9, %9, %10, %11\n\tv_mul_f32 %12, %12, %10\n\t"
+#define V3 "v_fma_f32 %9, %9, %10, %11\n\tv_mul_f32 %12, %12, %10\n\tv_fma_f32 %9, %9, %10, %11\n\t"
+#define KST(F0, F1, F2, F3, VV)                                                                                  \
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %4, %5, %0\n\t" VV "v_mfma_f32_16x16x32_bf16 %1, %4, %6, %1\n\t" VV \
+                     "v_mfma_f32_16x16x32_bf16 %2, %4, %7, %2\n\t" VV "v_mfma_f32_16x16x32_bf16 %3, %4, %8, %3\n\t" VV \
+                     : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(a0), "a"(F0), "a"(F1), "a"(F2), "a"(F3), "v"(x0), "v"(x1), "v"(x2), "v"(x3));
+        if (VIN == 0) { for (int r = 0; r < 4; ++r) { KST(bf[0], bf[1], bf[2], bf[3], "") KST(bf[4], bf[5], bf[6], bf[7], "") } }
+        else if (VIN == 1) { for (int r = 0; r < 4; ++r) { KST(bf[0], bf[1], bf[2], bf[3], V1) KST(bf[4], bf[5], bf[6], bf[7], V1) } }
+        else if (VIN == 2) { for (int r = 0; r < 4; ++r) { KST(bf[0], bf[1], bf[2], bf[3], V2) KST(bf[4], bf[5], bf[6], bf[7], V2) } }
+        else { for (int r = 0; r < 4; ++r) { KST(bf[0], bf[1], bf[2], bf[3], V3) KST(bf[4], bf[5], bf[6], bf[7], V3) } }
+#undef KST
+    }
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+    out[blockIdx.x * NT + threadIdx.x] = c0[0] + c1[0] + c2[0] + c3[0] + x0 + x3;
+}
+// the same 32 MFMAs + 64 VALU per iteration with the VALU in blocks of eight BEHIND each K-step of four MFMAs (what compiler-placed
+// "pieces" behind an asm K-step amount to)
+template <int NT>
+__global__ __launch_bounds__(NT, 1) void k_rate_blocks(float* out, int iters) {
+    u4 bf[8];
+    for (int i = 0; i < 8; ++i) { bf[i] = u4{0x3f803f80u, 0x3f803f80u + i, 0x3f803f80u, threadIdx.x}; asm volatile("" : "+a"(bf[i])); }
+    u4 a0 = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, threadIdx.x};
+    f4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+    float x0 = threadIdx.x, x1 = 1.0001f, x2 = 0.5f, x3 = 2.f;
+    for (int it = 0; it < iters; ++it) {
+#define KSB(F0, F1, F2, F3)                                                                                      \
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %4, %5, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %4, %6, %1\n\t"      \
+                     "v_mfma_f32_16x16x32_bf16 %2, %4, %7, %2\n\tv_mfma_f32_16x16x32_bf16 %3, %4, %8, %3\n\t"      \
+                     "v_fma_f32 %9, %9, %10, %11\n\tv_mul_f32 %12, %12, %10\n\tv_fma_f32 %9, %9, %10, %11\n\tv_mul_f32 %12, %12, %10\n\t" \
+                     "v_fma_f32 %9, %9, %10, %11\n\tv_mul_f32 %12, %12, %10\n\tv_fma_f32 %9, %9, %10, %11\n\tv_mul_f32 %12, %12, %10\n\t" \
+                     : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(a0), "a"(F0), "a"(F1), "a"(F2), "a"(F3), "v"(x0), "v"(x1), "v"(x2), "v"(x3));
+        for (int r = 0; r < 4; ++r) { KSB(bf[0], bf[1], bf[2], bf[3]) KSB(bf[4], bf[5], bf[6], bf[7]) }
+#undef KSB
+    }
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+    out[blockIdx.x * NT + threadIdx.x] = c0[0] + c1[0] + c2[0] + c3[0] + x0 + x3;
+}
+
 template <typename K> void run(const char* name, K kern, int nt) {
     float* out; (void)hipMalloc(&out, 256 * 512 * 4);
     const int iters = 20000;
@@ -107,5 +157,12 @@ int main() {
     run("16x16x32 bf16 + reads + 3 VALU per MFMA, one wave per SIMD", k_rate<256, 2, 2>, 256);
     run("16x16x32 bf16 + reads + 4 VALU per MFMA, one wave per SIMD", k_rate<256, 2, 3>, 256);
     run("16x16x32 bf16 + reads + 2 VALU per MFMA, two waves per SIMD", k_rate<512, 2, 1>, 512);
+    run("16x16x32, B in AGPRs, bare, one wave per SIMD", k_rate_a<256, 0>, 256);
+    run("16x16x32, B in AGPRs, 1 VALU inside behind each MFMA, one wave", k_rate_a<256, 1>, 256);
+    run("16x16x32, B in AGPRs, 2 VALU inside behind each MFMA, one wave", k_rate_a<256, 2>, 256);
+    run("16x16x32, B in AGPRs, 3 VALU inside behind each MFMA, one wave", k_rate_a<256, 3>, 256);
+    run("16x16x32, B in AGPRs, 8 VALU behind each block of 4 MFMAs, one wave", k_rate_blocks<256>, 256);
+    run("16x16x32, B in AGPRs, 2 VALU inside behind each MFMA, two waves", k_rate_a<512, 2>, 512);
+    run("16x16x32, B in AGPRs, 8 VALU behind each block of 4 MFMAs, two waves", k_rate_blocks<512>, 512);
     return 0;
 }
