@@ -37,6 +37,7 @@ constexpr int PCH = 64;      // steps per chunk of per-step scalars
 // 4 D / 16 MFMA instructions per wave, a broadcast vector is D / 16 16-byte reads per lane.
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ unsigned short bf16_rne(float f) {
@@ -178,7 +179,7 @@ __device__ __forceinline__ void write_vec(unsigned char* base, const ChainLane<K
 
 // B fragments of one matrix for this lane in the wave's K-step order: frag[tile * KS + tau] (M_re half) and frag[tile * KS + KH + tau]
 // (M_im half) = 8 bf16 = columns 32 ((tau + w) % KH) + 8 kg .. + 7 of that half in row ia + tile; elem(tile, half, col) is the float32 entry
-template <int PD, typename F>
+template <int PD, bool AGPR, typename F>
 __device__ __forceinline__ void load_frags(u4 (&frag)[PD / 8], int w, int kg, F&& elem) {
     constexpr int KS = PD / 16, KH = PD / 32;
 #pragma unroll
@@ -191,8 +192,10 @@ __device__ __forceinline__ void load_frags(u4 (&frag)[PD / 8], int w, int kg, F&
             for (int e = 0; e < 4; ++e)
                 v[e] = (unsigned)bf16_rne(elem(tile, half, col0 + 2 * e)) | ((unsigned)bf16_rne(elem(tile, half, col0 + 2 * e + 1)) << 16);
             frag[tile * KS + t] = u4{v[0], v[1], v[2], v[3]};
-            asm volatile("" : "+a"(frag[tile * KS + t]));       // into its AGPRs now: the loads of all fragments in flight at once
-        }                                                      // would be the kernel's register peak
+            // into its registers now: the loads of all fragments in flight at once would be the kernel's register peak
+            if constexpr (AGPR) asm volatile("" : "+a"(frag[tile * KS + t]));
+            else asm volatile("" : "+v"(frag[tile * KS + t]));
+        }
 }
 
 #if defined(CMPS_DIAG) && defined(PABL_NO_MFMA)       // diagnostic builds only (scripts/ablate.py)
@@ -213,6 +216,12 @@ __device__ __forceinline__ void rd_own(unsigned lo0, unsigned hi0, u4& vlo, u4& 
 template <int KH, int POFF>
 __device__ __forceinline__ void rd_rest(unsigned ax0, unsigned ax1, const unsigned (&lo)[KH], const unsigned (&hi)[KH], f4& x0, f4& x1,
                                         u4 (&v)[2 * KH - 2]) {
+#if defined(CMPS_DIAG) && defined(PABL_NO_READS)      // diagnostic builds only (scripts/ablate.py): the table rows only
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3" : "=&v"(x0), "=&v"(x1) : "v"(ax0), "v"(ax1) : "memory");
+    for (int i = 0; i < 2 * KH - 2; ++i) { v[i] = u4{lo[0], hi[0], ax0, ax1}; asm volatile("" : "+v"(v[i])); }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    return;
+#endif
     if constexpr (KH == 4)
         asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\t"
                      "ds_read_b128 %2, %10 offset:%16\n\tds_read_b128 %3, %11 offset:%16\n\tds_read_b128 %4, %12 offset:%16\n\t"
@@ -236,36 +245,35 @@ template <int W>
 __device__ __forceinline__ void lds_wait2(f4& a, f4& b) {
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(W) : "memory");
 }
-// One K-step: the A operand v against the fragments of two matrices x two tiles, as ONE asm statement -- the fragments are read
-// straight from AGPRs (constraint "a": they stay there for the whole kernel, no copies), the accumulators live in VGPRs where
-// the VALU tail reads them, four accumulators in rotation.  The compiler cannot see inside, so the wait for the operand's LDS
-// read opens the statement and the wait states between the last MFMA and the first VALU read of an accumulator (gfx950: passes
-// + 4 states; twelve cover the 8-pass case) close the last one.
-template <int W, bool FIRST, bool LAST>
+// One K-step: the A operand v against the fragments of two matrices x two tiles.  The MFMAs are compiler builtins: hipcc then places
+// the independent VALU work of a step BETWEEN them (about two instructions behind each: what a lone wave can hide -- eight in a
+// block behind four MFMAs cost it 46 % more, scripts/ubench/mfma16_matvec.hip) and pads the accumulator hazards itself (rounds 1-3
+// and the first 16x16x32 version wrote them as asm statements, which the scheduler treats as opaque blocks).  What the compiler
+// cannot see is when the operand's LDS read (issued in asm) has landed: the counted wait is an asm statement that "modifies" the
+// operand, and a scheduling barrier behind every K-step keeps the waits from being gathered in front of the first MFMA.
+// Where the fragments live is the kernel's choice: the forward (two waves per SIMD, 256 registers each) has no AGPR operand
+// anywhere, so hipcc selects the VGPR form of the MFMA and all 256 registers are one file (with "a" operands in the kernel it
+// selects the AGPR form, whose accumulators the tail has to read back with v_accvgpr_read, and the fixed 128 / 128 split spilled);
+// the reverse scan (one wave per SIMD, 512 registers) pins them in AGPRs (load_frags<.., true>: gfx950 MFMAs read A / B operands
+// from either file) and reads the eight accumulator values it needs back once per step.
+typedef short bf8 __attribute__((ext_vector_type(8)));
+template <int W, bool FIRST>
 __device__ __forceinline__ void kstep(const u4& fa0, const u4& fa1, const u4& fb0, const u4& fb1, u4& v, f4& a0, f4& a1, f4& b0, f4& b1) {
-    if constexpr (FIRST) {
-        asm volatile("s_waitcnt lgkmcnt(%9)\n\t"
-                     PAIR_ASM("v_mfma_f32_16x16x32_bf16 %0, %8, %4, 0\n\t"
-                              "v_mfma_f32_16x16x32_bf16 %1, %8, %5, 0\n\t"
-                              "v_mfma_f32_16x16x32_bf16 %2, %8, %6, 0\n\t"
-                              "v_mfma_f32_16x16x32_bf16 %3, %8, %7, 0")
-                     : "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1) : "a"(fa0), "a"(fa1), "a"(fb0), "a"(fb1), "v"(v), "n"(W) : "memory");
-    } else if constexpr (LAST) {
-        asm volatile("s_waitcnt lgkmcnt(%9)\n\t"
-                     PAIR_ASM("v_mfma_f32_16x16x32_bf16 %0, %8, %4, %0\n\t"
-                              "v_mfma_f32_16x16x32_bf16 %1, %8, %5, %1\n\t"
-                              "v_mfma_f32_16x16x32_bf16 %2, %8, %6, %2\n\t"
-                              "v_mfma_f32_16x16x32_bf16 %3, %8, %7, %3\n\t"
-                              "s_nop 11")
-                     : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1) : "a"(fa0), "a"(fa1), "a"(fb0), "a"(fb1), "v"(v), "n"(W) : "memory");
-    } else {
-        asm volatile("s_waitcnt lgkmcnt(%9)\n\t"
-                     PAIR_ASM("v_mfma_f32_16x16x32_bf16 %0, %8, %4, %0\n\t"
-                              "v_mfma_f32_16x16x32_bf16 %1, %8, %5, %1\n\t"
-                              "v_mfma_f32_16x16x32_bf16 %2, %8, %6, %2\n\t"
-                              "v_mfma_f32_16x16x32_bf16 %3, %8, %7, %3")
-                     : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1) : "a"(fa0), "a"(fa1), "a"(fb0), "a"(fb1), "v"(v), "n"(W) : "memory");
-    }
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(W) : "memory");
+    if constexpr (FIRST) { a0 = f4{0.f, 0.f, 0.f, 0.f}; a1 = a0; b0 = a0; b1 = a0; }
+    const bf8 av = __builtin_bit_cast(bf8, v);
+#if defined(CMPS_DIAG) && defined(PABL_NO_MFMA)       // diagnostic builds only (scripts/ablate.py)
+    a0[0] += __uint_as_float(v.x); a1[0] += __uint_as_float(fa1.x); b0[0] += __uint_as_float(fb0.x); b1[0] += __uint_as_float(fb1.x + fa0.x);
+#else
+    a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf8, fa0), a0, 0, 0, 0);
+    b0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf8, fb0), b0, 0, 0, 0);
+#if defined(CMPS_DIAG) && defined(PABL_HALF_MFMA)     // diagnostic builds only: tile 0 alone (what an MFMA costs in place: the difference, / 16)
+    a1[0] += __uint_as_float(fa1.x); b1[0] += __uint_as_float(fb1.x);
+#else
+    a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf8, fa1), a1, 0, 0, 0);
+    b1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf8, fb1), b1, 0, 0, 0);
+#endif
+#endif
 }
 // A mat-vec pair after the barrier: a0 / a1 = (A v) rows ia / ia + 1, b0 / b1 = (B v); register 0 = this lane's own form, register 1
 // = its partner's.  Order: the table rows and the other waves' K ranges are requested (rd_rest), the two OWN K-steps (already in
@@ -278,14 +286,28 @@ template <int I> struct ic { static constexpr int value = I; };
 #define PAIR_PIN1(a) asm volatile("" : "+v"(a))
 #define PAIR_PIN2(a, b) asm volatile("" : "+v"(a), "+v"(b))
 #define PAIR_PIN4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+// the issue order inside a K-step region: MFMA, two VALU, MFMA, two VALU ... -- what a lone wave hides behind a 16x16x32 MFMA
+// (scripts/ubench/mfma16_matvec.hip: one or two plain VALU behind each MFMA are free, a block of eight behind four costs 46 % more);
+// left alone the scheduler put a piece in front of its region's MFMAs with the matrix pipe idle.  The file is compiled with
+// -fno-slp-vectorize: packed-f32 VALU is expensive beside MFMAs, and the scheduler's packing added a v_mov shuffle per operand.
+template <int N>
+__device__ __forceinline__ void mfma_valu_pipeline() {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);     // two VALU
+    }
+}
 template <int PD, int I, typename Piece>
 __device__ __forceinline__ void ksteps_rest(const u4 (&FA)[PD / 8], const u4 (&FB)[PD / 8], u4 (&v)[PD / 16 - 2], f4& a0, f4& a1, f4& b0, f4& b1,
                                             Piece&& piece) {
     constexpr int KS = PD / 16, KH = PD / 32, NR = KS - 2;     // NR reads of the rest: lo tau = 1 .. KH - 1, then hi tau = 1 .. KH - 1
     if constexpr (I < NR) {
         constexpr int T = I < KH - 1 ? 1 + I : KH + 1 + (I - (KH - 1));   // index into the wave's fragment order
-        kstep<NR - 1 - I, false, I == NR - 1>(FA[T], FA[KS + T], FB[T], FB[KS + T], v[I], a0, a1, b0, b1);
+        kstep<NR - 1 - I, false>(FA[T], FA[KS + T], FB[T], FB[KS + T], v[I], a0, a1, b0, b1);
         piece(ic<I + 1>{});
+        mfma_valu_pipeline<4>();
+        __builtin_amdgcn_sched_barrier(0);
         ksteps_rest<PD, I + 1>(FA, FB, v, a0, a1, b0, b1, piece);
     } else if constexpr (I < 7) {
         piece(ic<I + 1>{});
@@ -298,10 +320,13 @@ __device__ __forceinline__ void matvec2(const u4 (&FA)[PD / 8], const u4 (&FB)[P
     constexpr int KS = PD / 16, KH = PD / 32;
     u4 v[KS - 2];
     rd_rest<KH, POFF>(ax0, ax1, g.lo, g.hi, x0, x1, v);
-    kstep<KS, true, false>(FA[0], FA[KS], FB[0], FB[KS], vlo, a0, a1, b0, b1);          // (the counts are no-ops: vlo, vhi arrived
-    kstep<KS, false, false>(FA[KH], FA[KS + KH], FB[KH], FB[KS + KH], vhi, a0, a1, b0, b1);   // before the barrier)
+    __builtin_amdgcn_sched_barrier(0);
+    kstep<KS, true>(FA[0], FA[KS], FB[0], FB[KS], vlo, a0, a1, b0, b1);          // (the counts are no-ops: vlo, vhi arrived
+    kstep<KS, false>(FA[KH], FA[KS + KH], FB[KH], FB[KS + KH], vhi, a0, a1, b0, b1);   // before the barrier)
     lds_wait2<KS - 2>(x0, x1);
     piece(ic<0>{});
+    mfma_valu_pipeline<8>();
+    __builtin_amdgcn_sched_barrier(0);
     ksteps_rest<PD, 0>(FA, FB, v, a0, a1, b0, b1, piece);
 }
 
@@ -347,6 +372,13 @@ __device__ __forceinline__ void rho_stage(const Dev& P, RhoStage<D>& S, int chun
 namespace {
 
 constexpr int FB = 8;                                   // steps per loss-wave batch
+// Diagnostic knob (-DPAIR_LOSS_SLEEP=n): a loss wave sleeps ~64 n cycles behind every barrier, which moves its LDS reads behind the chain
+// waves' operand burst and its two MFMAs into the chain's tail.  Measured at C5: 0 / 3 / 6 / 9 -> 9.67 / 9.91 / 10.17 / 10.46 ms per
+// forward scan (profiles/r4_c5_ablations.log): what matters is that the loss waves reach the next barrier early, so the default is 0.
+#ifndef PAIR_LOSS_SLEEP
+#define PAIR_LOSS_SLEEP 0
+#endif
+constexpr int LOSS_SLEEP = PAIR_LOSS_SLEEP;
 template <int D>
 struct FwdRing {
     static constexpr int BROW = D * 2 + 16, FROW = D * 4 + 16;         // padded rows (bank spread for the loss waves' reads)
@@ -397,8 +429,8 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
             const int row0 = 32 * w + 2 * (lane & 15);                 // rows ia (tile 0) and ia + 1 (tile 1)
             const float2* Rrow = P.R + (size_t)row0 * PD;
             const float2* Qrow = P.Q + (size_t)row0 * PD;
-            load_frags<PD>(FR, w, lane >> 4, [&](int tile, int half, int c) { return half ? Rrow[tile * PD + c].y : Rrow[tile * PD + c].x; });
-            load_frags<PD>(FQ, w, lane >> 4, [&](int tile, int half, int c) { return half ? Qrow[tile * PD + c].y : Qrow[tile * PD + c].x; });
+            load_frags<PD, false>(FR, w, lane >> 4, [&](int tile, int half, int c) { return half ? Rrow[tile * PD + c].y : Rrow[tile * PD + c].x; });
+            load_frags<PD, false>(FQ, w, lane >> 4, [&](int tile, int half, int c) { return half ? Qrow[tile * PD + c].y : Qrow[tile * PD + c].x; });
         }
         // (everything below is derived from a laundered copy of the lane number: addresses computed before the fragment loads would
         // be live across their register peak, and the allocator then keeps them in scratch memory for the whole kernel)
@@ -414,11 +446,11 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
         const unsigned a_nrm = lds_addr_of(&RG.nrm[0][q][0]);        // + 32 slot
         const unsigned a_rho = lds_addr_of(&RS.row[0][0][ia]);        // + 8 PD (32 buffer + row)
         const float2 pa = P.psi0[ia], pb = P.psi0[ib];
-        float uta = odd ? pa.y : pa.x, utb = odd ? pb.y : pb.x;      // ut_0 = psi_0 (both clips): own component ..
-        float puta = odd ? pa.x : pa.y, putb = odd ? pb.x : pb.y;    // .. and a copy of the partner's (kept in step by the MFMAs' register 1)
+        // ut_0 = psi_0 (both clips): (own component, a copy of the partner's -- kept in step by the MFMAs' register 1)
+        f2 ua = odd ? f2{pa.y, pa.x} : f2{pa.x, pa.y}, ub = odd ? f2{pb.y, pb.x} : f2{pb.x, pb.y};
         float sv0 = 0.f, sv1 = 0.f;                                   // s = x / A of the current 64 steps, lane <-> step
         u4 vlo, vhi;                                                  // the wave's own K-steps of the image the next step multiplies
-        write_vec(L.vec[0], g, uta, utb);
+        write_vec(L.vec[0], g, ua.x, ub.x);
         rd_own<0>(g.lo[0], g.hi[0], vlo, vhi);
         rho_stage<PD>(P, RS, 0, 0, 64 * w + lane_c);
         __syncthreads();
@@ -467,24 +499,40 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
                 }                                                                                                          \
             });                                                                                                            \
             PAIR_FSTAMP_B();                                                                                               \
-            /* y_k, rows ia / ib: own component (register 0) and the partner's (register 1) */                              \
-            const float yna = inv * (uta + (cQ0[0] + s * cR0[0])), ypna = inv * (puta + (cQ0[1] + s * cR0[1]));             \
-            const float ynb = inv * (utb + (cQ1[0] + s * cR1[0])), ypnb = inv * (putb + (cQ1[1] + s * cR1[1]));             \
-            /* the chain first: ut_{k+1} = rho_k y_k (un-normalised) */                                                    \
-            const float ria = sg * rh.y, rib = sg * rh.w;                                                                  \
-            uta = rh.x * yna + ria * ypna;   puta = rh.x * ypna - ria * yna;                                                \
-            utb = rh.z * ynb + rib * ypnb;   putb = rh.z * ypnb - rib * ynb;                                                \
-            write_vec(L.vec[p ^ 1], g, uta, utb);                                                                          \
+            /* y_k, rows ia / ib: own component (register 0) and the partner's (register 1), as explicit (own, partner) pairs: the tail  \
+               runs when the matrix pipe is idle, where packed float32 VALU halves its instruction count */                        \
+            const f2 ya = inv * (ua + (f2{cQ0[0], cQ0[1]} + s * f2{cR0[0], cR0[1]}));                                       \
+            const f2 yb = inv * (ub + (f2{cQ1[0], cQ1[1]} + s * f2{cR1[0], cR1[1]}));                                       \
+            const float yna = ya.x, ynb = yb.x;                                                                            \
+            /* Two chains start at y and both end in an LDS store the barrier waits for: ut_{k+1} = rho_k y_k -> bf16 image, and    \
+               |y_k|^2 -> four dependent DPP adds -> norm partial.  Written out turn by turn (scheduling barriers), the second      \
+               runs in the first one's dependency gaps; left to the scheduler it came behind it. */                                \
+            const f2 n2 = ya * ya + yb * yb;                                                                               \
+            float nn = n2.x + n2.y;                                                                                        \
+            const f2 ta = f2{sg * rh.y, -(sg * rh.y)} * __builtin_shufflevector(ya, ya, 1, 0);                              \
+            const f2 tb = f2{sg * rh.w, -(sg * rh.w)} * __builtin_shufflevector(yb, yb, 1, 0);                              \
+            __builtin_amdgcn_sched_barrier(0);                                                                             \
+            nn += dpp_mov<0x128>(nn);                                  /* row_ror:8 */                                     \
+            ua = rh.x * ya + ta;   ub = rh.z * yb + tb;               /* ut_{k+1} = rho_k y_k (un-normalised), own and partner */ \
+            __builtin_amdgcn_sched_barrier(0);                                                                             \
+            nn += dpp_mov<0x124>(nn);                                  /* row_ror:4 */                                     \
+            const unsigned pku = pk_bf16(ua.x, ub.x);                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                                             \
+            nn += dpp_mov<0x122>(nn);                                  /* row_ror:2 */                                     \
+            *reinterpret_cast<unsigned*>(L.vec[p ^ 1] + g.wr1) = pku;                                                      \
+            *reinterpret_cast<unsigned*>(L.vec[p ^ 1] + g.wr2) = pku ^ 0x80008000u;                                        \
             rd_own<(p ^ 1) * VEC>(g.lo[0], g.hi[0], vlo, vhi);         /* (same wave, in order: no wait between store and read) */ \
+            __builtin_amdgcn_sched_barrier(0);                                                                             \
+            nn += dpp_mov<0x121>(nn);                                  /* row_ror:1: the clip's total over this wave's rows */ \
+            const unsigned pky = pk_bf16(yna, ynb);                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                                             \
+            if (lane_c == 0 || lane_c == 32) RG.nrm[hb_ * FB + (J)][q][w] = nn;                                           \
             {   /* y_k for the loss waves: bf16 images and float32 */                                                      \
                 unsigned char* rbase = &RG.b[hb_ * FB + (J)][0][0][0];                                                     \
-                const unsigned pk = pk_bf16(yna, ynb);                                                                     \
-                *reinterpret_cast<unsigned*>(rbase + rb1) = pk;                                                            \
-                *reinterpret_cast<unsigned*>(rbase + rb2) = pk ^ 0x80008000u;                                              \
+                *reinterpret_cast<unsigned*>(rbase + rb1) = pky;                                                           \
+                *reinterpret_cast<unsigned*>(rbase + rb2) = pky ^ 0x80008000u;                                             \
                 *reinterpret_cast<float2*>(&RG.f[hb_ * FB + (J)][0][0][0] + rf) = make_float2(yna, ynb);                   \
             }                                                                                                              \
-            const float nn = row_sum16((yna * yna + ypna * ypna) + (ynb * ynb + ypnb * ypnb));                             \
-            if (lane_c == 0 || lane_c == 32) RG.nrm[hb_ * FB + (J)][q][w] = nn;                                           \
             PAIR_FSTAMP_C(nn);                                                                                             \
             lds_barrier();                                                                                                 \
         }
@@ -559,6 +607,7 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
         const int step_b = FB * pb + sb, step_e = FB * pe + sb;       // this lane's step in either batch
 #define PAIR_LOSS_STEP(J)                                                                                                  \
         {                                                                                                                  \
+            if constexpr (LOSS_SLEEP > 0) __builtin_amdgcn_s_sleep(LOSS_SLEEP);                                            \
             if (fin) {                                                                                                     \
                 if ((J) == 0 && SAVE && step_e < N) {                /* H y of batch pe */                                 \
                     float* hp = stash + pair_stash_index<PD>(blockIdx.x, N, step_e, 1, clip, comp, 32 * w + 4 * hk);       \
@@ -596,16 +645,16 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
                 _Pragma("unroll") for (int t = (J) * KT / FB; t < ((J) + 1) * KT / FB; ++t) {                              \
                     const int tt = t < KS ? t : t - KS;                                                                    \
                     const u4 bv = *reinterpret_cast<const u4*>(bslot + (t < KS ? ob1 : ob2) + 32 * tt);                    \
-                    /* asm, fragments straight from AGPRs (the chain waves' 128 fragment AGPRs leave this kernel 128 VGPRs) */ \
+                    /* asm (fixed issue points); no AGPR operand anywhere in this kernel: see kstep */                           \
                     if (t == 0)                                                                                            \
-                        asm volatile(PAIR_ASM("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0") : "=&v"(acc) : "a"(FHre[0]), "v"(bv));     \
+                        asm volatile(PAIR_ASM("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0") : "=&v"(acc) : "v"(FHre[0]), "v"(bv));     \
                     else if (t == KT - 1)       /* + the wait states before the VALU reads the tile (8 passes) */          \
                         asm volatile(PAIR_ASM("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 7")          \
-                                     : "+v"(acc) : "a"(FHim[KS - 1]), "v"(bv));                                            \
+                                     : "+v"(acc) : "v"(FHim[KS - 1]), "v"(bv));                                            \
                     else if (t < KS)                                                                                       \
-                        asm volatile(PAIR_ASM("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0") : "+v"(acc) : "a"(FHre[tt]), "v"(bv));   \
+                        asm volatile(PAIR_ASM("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0") : "+v"(acc) : "v"(FHre[tt]), "v"(bv));   \
                     else                                                                                                   \
-                        asm volatile(PAIR_ASM("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0") : "+v"(acc) : "a"(FHim[tt]), "v"(bv));   \
+                        asm volatile(PAIR_ASM("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0") : "+v"(acc) : "v"(FHim[tt]), "v"(bv));   \
                 }                                                                                                          \
                 if ((J) == FB - 1) {                                 /* the tile is complete: e partial, hand the tile over */ \
                     float ep = 0.f;                                                                                        \
@@ -670,6 +719,11 @@ struct StepTab {
 };
 
 constexpr int GB = 8;          // steps per block of the unrolled sweep
+#if defined(CMPS_DIAG) && defined(PABL_NO_PIECES)     // diagnostic builds only (scripts/ablate.py): the reverse scan without its off-chain work
+constexpr bool PAIR_NO_PIECES = true;
+#else
+constexpr bool PAIR_NO_PIECES = false;
+#endif
 
 }  // namespace
 
@@ -690,8 +744,8 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
         const int row0 = 32 * w + 2 * (lane0 & 15);                    // rows ia (tile 0) and ia + 1 (tile 1)
         const float2* Qrow = P.Q + (size_t)row0 * PD;
         const float2* RTrow = P.RT + (size_t)row0 * PD;                // R^dagger[i][j] = conj(R[j][i]) = conj(RT[i][j])
-        load_frags<PD>(FQ, w, lane0 >> 4, [&](int tile, int half, int c) { return half ? Qrow[tile * PD + c].y : Qrow[tile * PD + c].x; });
-        load_frags<PD>(FD, w, lane0 >> 4, [&](int tile, int half, int c) { return half ? -RTrow[tile * PD + c].y : RTrow[tile * PD + c].x; });
+        load_frags<PD, true>(FQ, w, lane0 >> 4, [&](int tile, int half, int c) { return half ? Qrow[tile * PD + c].y : Qrow[tile * PD + c].x; });
+        load_frags<PD, true>(FD, w, lane0 >> 4, [&](int tile, int half, int c) { return half ? -RTrow[tile * PD + c].y : RTrow[tile * PD + c].x; });
     }
     // (everything below is derived from a laundered copy of the lane number: see k_fwd_pair)
     int lane = lane0;
@@ -760,6 +814,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
     float ga = 0.f, gb = 0.f, pga = 0.f, pgb = 0.f;     // g: cotangent of u_{k+1}, own component and a copy of the partner's (MFMA register 1)
     float una = 0.f, unb = 0.f, puna = 0.f, punb = 0.f; // u_{k+1} = rho_k yhat_k, own and partner component (carried: it is u_k of the step before)
     float facca = 0.f, faccb = 0.f, accS = 0.f;
+    float sda = 0.f, sdb = 0.f, ssy = 0.f;              // (R^dagger ybar) rows and the -x / A^2 factor of the step before: its Abar term is added a step late
     u4 vlo, vhi;                                        // the wave's own K-steps of ybar_k, read back before the barrier
     float4 rh, rhp;                             // rho_k and rho_{k-1}, rows ia | ib
     f4 S0, S1, SP0, SP1;                        // scalar rows of steps k and k - 1 (fetched two steps ahead, behind the MFMAs)
@@ -803,21 +858,32 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
     const float ps0a = odd ? psa.y : psa.x, ps0b = odd ? psb.y : psb.x;        // u_0 = psi_0: own component ..
     const float pps0a = odd ? psa.x : psa.y, pps0b = odd ? psb.x : psb.y;      // .. and the partner's
     const unsigned a_tab = lds_addr_of(&TB.row[w][0][0][q][0]);                 // + 64 (64 chunk parity + step in chunk)
-#if defined(CMPS_DIAG) && defined(PABL_TIMING)        // diagnostic builds only: where a step's cycles go (s_memtime stamps, consumed a step late)
-    unsigned long long tA = 0, tB = 0, tC = 0, tA1 = 0, tB1 = 0, tC1 = 0, tC2 = 0, accPre = 0, accMv = 0, accTail = 0, accN = 0;
-#define PAIR_BSTAMP_A() { if (tC2) { accPre += tA1 - tC2; accMv += tB1 - tA1; accTail += tC1 - tB1; ++accN; } tC2 = tC1; tA = __builtin_readcyclecounter(); }
-#define PAIR_BSTAMP_B() tB = __builtin_readcyclecounter()
-#define PAIR_BSTAMP_C() { asm volatile("" : "+v"(ga), "+v"(gb)); tC = __builtin_readcyclecounter(); tA1 = tA; tB1 = tB; tC1 = tC; }
+#if defined(CMPS_DIAG) && defined(PABL_TIMING)        // diagnostic builds only: where a step's cycles go.  Fourteen s_memtime stamps per step into
+    // SGPR pairs, consumed behind one wait at the end of the step.  (SMEM answers count in lgkmcnt and return out of order: the counted
+    // LDS waits of such a build can let an operand through early -- its results are not to be used, its timings are representative.)
+    constexpr int NST = 14;
+    unsigned long long st[NST], sacc[NST] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stprev = 0;
+    int stn = 0;
+#define PAIR_STAMP(i) asm volatile("s_memtime %0" : "=s"(st[i]))
+#define PAIR_STAMPS_END()                                                                                                          \
+    {                                                                                                                              \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(st[0]), "+s"(st[1]), "+s"(st[2]), "+s"(st[3]), "+s"(st[4]), "+s"(st[5]), "+s"(st[6]), \
+                     "+s"(st[7]), "+s"(st[8]), "+s"(st[9]), "+s"(st[10]), "+s"(st[11]), "+s"(st[12]), "+s"(st[13]) :: "memory");      \
+        if (stprev) { sacc[0] += st[0] - stprev; for (int i_ = 1; i_ < NST; ++i_) sacc[i_] += st[i_] - st[i_ - 1]; ++stn; }          \
+        stprev = st[NST - 1];                                                                                                      \
+    }
 #else
-#define PAIR_BSTAMP_A()
-#define PAIR_BSTAMP_B()
-#define PAIR_BSTAMP_C()
+#define PAIR_STAMP(i)
+#define PAIR_STAMPS_END()
 #endif
     // one step; J = k & 7 (static: selects ring slots and the image parity).  COND: `true` in full blocks.
-    // Chain: g -> conj(rho) g -> ybar -> bf16 image (own K ranges read back) -> [barrier] -> mat-vecs -> g.  Everything else sits in
-    // the pieces behind the K-steps: the partner copy of ybar, yhat_{k-1} and its partner (the only two lane exchanges of a step),
-    // u_k (= the u_{k+1} of the next step: carried, not recomputed), the frequency gradient, the g-independent part of ybar_{k-1},
-    // the ybar store, the stash ring's next row, the rho row of step k - 2 (its scalar rows come with the operand reads).
+    // Chain: g -> conj(rho) g -> ybar -> bf16 image (own K ranges read back) -> [barrier] -> mat-vecs -> g.  Everything else is placed
+    // where the chain wave would otherwise idle or where the matrix pipe covers it:
+    //   * behind the image stores, while they complete (the barrier's lgkmcnt(0)): the ybar store, the partner copy of ybar, the
+    //     frequency gradient and the Abar term of the step before (~20 instructions against ~100 cycles of LDS store latency);
+    //   * behind the K-steps (about two instructions per MFMA are free for a lone wave): yhat_{k-1} and its partner (with ybar's the
+    //     only two lane exchanges of a step), u_k (= the u_{k+1} of the next step: carried, not recomputed), the g-independent part
+    //     of ybar_{k-1}, the stash ring's next row, the rho row of step k - 2 (its scalar rows come with the operand reads).
 #define PAIR_BWD_STEP(J, CUR, PRV, COND)                                                                                            \
     if (COND) {                                                                                                                    \
         constexpr int p = (J) & 1;                                                                                                 \
@@ -828,60 +894,74 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
             rho_stage<PD>(P, RS, k / RCH - 1, (k / RCH - 1) & 1, 64 * w + lane);                                                   \
         float4 nrh;                                                                                                                \
         f4 nS0, nS1;                                                                                                               \
+        PAIR_STAMP(0);                                                                                                             \
         /* ---- the chain ---- */                                                                                                  \
         const float hba = rh.x * ga - sgn * rh.y * pga;              /* conj(rho_k) g */                                           \
         const float hbb = rh.z * gb - sgn * rh.w * pgb;                                                                            \
         float yba = fmaf(hba, S0.y, c3a), ybb = fmaf(hbb, S0.y, c3b);                                                              \
+        PAIR_PIN2(yba, ybb);                                                                                                       \
+        PAIR_STAMP(1);                                                                                                             \
         write_vec(L.vec[p], g, yba, ybb);                                                                                          \
         rd_own<p * VEC>(g.lo[0], g.hi[0], vlo, vhi);                                                                               \
+        PAIR_STAMP(2);                                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                                         \
+        /* ---- behind the stores ---- */                                                                                          \
+        float pyba, pybb;                                                                                                          \
+        if constexpr (!PAIR_NO_PIECES) {                                                                                           \
+            *reinterpret_cast<float2*>(ybar_base + (size_t)k * (4 * PD)) = make_float2(yba, ybb);    /* for the gradient GEMM */   \
+            pyba = partner16(yba, odd); pybb = partner16(ybb, odd);                                                                \
+            facca += S1.z * (pga * una - ga * puna);                  /* the frequency gradient (meaningful in the Re lanes) */    \
+            faccb += S1.z * (pgb * unb - gb * punb);                                                                               \
+            accS += (sda * una + sdb * unb) * ssy;                    /* Re(d^dagger u) of the step before: its u_k is this step's u_{k+1} */ \
+        } else { pyba = yba; pybb = ybb; }                                                                                         \
+        PAIR_PIN2(facca, accS);                                                                                                    \
+        PAIR_STAMP(3);                                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                                         \
         lds_barrier();                                                                                                             \
-        PAIR_BSTAMP_A();                                                                                                           \
+        PAIR_STAMP(4);                                                                                                             \
         f4 cQ0, cQ1, cD0, cD1;                                                                                                     \
-        float uka, ukb, puka, pukb, ypa, ypb, pypa, pypb, pyba, pybb;                                                              \
+        float uka, ukb, puka, pukb, ypa, ypb, pypa, pypb;                                                                          \
         const unsigned ax0 = a_tab + 64 * (((km2 / PCH) & 1) * PCH + (km2 & (PCH - 1)));                                           \
         matvec2<PD, p * VEC>(FQ, FD, g, ax0, ax0 + 16, vlo, vhi, nS0, nS1, cQ0, cQ1, cD0, cD1, [&](auto pc) {                      \
             constexpr int PI = decltype(pc)::value;                                                                                \
-            const float dt = S1.z, invp = SP0.y;                                                                                   \
-            if constexpr (PI == 0) {                 /* the partner's ybar_k (for its g); yhat_{k-1} */                            \
-                pyba = partner16(yba, odd); pybb = partner16(ybb, odd);                                                            \
+            const float invp = SP0.y;                                                                                              \
+            if constexpr (PI < 7) { PAIR_STAMP(5 + PI); }                                                                          \
+            if constexpr (PAIR_NO_PIECES) {          /* diagnostic builds only */                                                  \
+                if constexpr (PI == 0) { ypa = PRV.x; ypb = PRV.y; pypa = ypa; pypb = ypb; uka = ypa; ukb = ypb; puka = ypa; pukb = ypb; nrh = rhp; } \
+            } else if constexpr (PI == 0) {          /* yhat_{k-1}, own and partner component (behind the eight own-range MFMAs) */ \
                 ypa = PRV.x * invp; ypb = PRV.y * invp;                                                                            \
-                PAIR_PIN4(pyba, pybb, ypa, ypb);                                                                                   \
-            } else if constexpr (PI == 1) {                                                                                        \
                 pypa = partner16(ypa, odd); pypb = partner16(ypb, odd);                                                            \
-                PAIR_PIN2(pypa, pypb);                                                                                             \
-            } else if constexpr (PI == 2) {          /* u_k = rho_{k-1} yhat_{k-1}  (psi_0 at k = 0), both components */           \
-                PAIR_PIN2(pypa, pypb);                                                                                             \
+                PAIR_PIN4(ypa, ypb, pypa, pypb);                                                                                   \
+            } else if constexpr (PI == 1) {          /* u_k = rho_{k-1} yhat_{k-1}, both components */                             \
                 const float ria = sgn * rhp.y, rib = sgn * rhp.w;                                                                  \
-                const float ra = rhp.x * ypa + ria * pypa, pra = rhp.x * pypa - ria * ypa;                                         \
-                const float rb = rhp.z * ypb + rib * pypb, prb = rhp.z * pypb - rib * ypb;                                         \
-                uka = k > 0 ? ra : ps0a;   puka = k > 0 ? pra : pps0a;                                                             \
-                ukb = k > 0 ? rb : ps0b;   pukb = k > 0 ? prb : pps0b;                                                             \
+                uka = rhp.x * ypa + ria * pypa;   puka = rhp.x * pypa - ria * ypa;                                                 \
+                ukb = rhp.z * ypb + rib * pypb;   pukb = rhp.z * pypb - rib * ypb;                                                 \
                 PAIR_PIN4(uka, ukb, puka, pukb);                                                                                   \
-            } else if constexpr (PI == 3) {          /* the frequency gradient (meaningful in the Re lanes) */                     \
-                PAIR_PIN2(facca, faccb);                                                                                           \
-                facca += dt * (pga * una - ga * puna);                                                                             \
-                faccb += dt * (pgb * unb - gb * punb);                                                                             \
-                PAIR_PIN2(facca, faccb);                                                                                           \
-            } else if constexpr (PI == 4) {          /* the g-independent part of ybar_{k-1}; ybar_k, float32, for the gradient GEMM */ \
-                PAIR_PIN2(ypa, ypb);                                                                                               \
+            } else if constexpr (PI == 2) {          /* the g-independent part of ybar_{k-1} */                                    \
                 const float radk = S1.x * SP0.z * invp;                /* rad_k ok_{k-1} inv_{k-1} */                              \
                 c3a = fmaf(SP0.w, PRV.z, -(ypa * radk));                                                                           \
                 c3b = fmaf(SP0.w, PRV.w, -(ypb * radk));                                                                           \
-                *reinterpret_cast<float2*>(ybar_base + (size_t)k * (4 * PD)) = make_float2(yba, ybb);                              \
                 PAIR_PIN2(c3a, c3b);                                                                                               \
-            } else if constexpr (PI == 5) {                                                                                        \
+            } else if constexpr (PI == 3) {                                                                                        \
                 CUR = row_at(k - 8);                                  /* this slot's next row (row k is dead from here on) */      \
+            } else if constexpr (PI == 4) {                                                                                        \
                 nrh = rho_rows(km2);                                  /* rho row of step k - 2 */                                  \
             }                                                                                                                      \
         });                                                                                                                        \
-        PAIR_BSTAMP_B();                                                                                                           \
-        accS += (cD0[0] * uka + cD1[0] * ukb) * S1.y;                                                                              \
-        ga = yba + cQ0[0] + S0.x * cD0[0];   pga = pyba + cQ0[1] + S0.x * cD0[1];                                                   \
-        gb = ybb + cQ1[0] + S0.x * cD1[0];   pgb = pybb + cQ1[1] + S0.x * cD1[1];                                                   \
+        PAIR_STAMP(12);                                                                                                            \
+        if (k == 0) { uka = ps0a; ukb = ps0b; puka = pps0a; pukb = pps0b; }         /* u_0 = psi_0 */                              \
+        {   /* g = ybar + Q ybar + s R^dagger ybar, (own, partner) pairs: packed float32 (the matrix pipe is idle here) */          \
+            const f2 Ga = (f2{yba, pyba} + f2{cQ0[0], cQ0[1]}) + S0.x * f2{cD0[0], cD0[1]};                                        \
+            const f2 Gb = (f2{ybb, pybb} + f2{cQ1[0], cQ1[1]}) + S0.x * f2{cD1[0], cD1[1]};                                        \
+            ga = Ga.x; pga = Ga.y; gb = Gb.x; pgb = Gb.y;                                                                          \
+        }                                                                                                                          \
+        sda = cD0[0]; sdb = cD1[0]; ssy = S1.y;                                                                                    \
         una = uka; unb = ukb; puna = puka; punb = pukb;                                                                            \
         rh = rhp; S0 = SP0; S1 = SP1;                                                                                              \
         rhp = nrh; SP0 = nS0; SP1 = nS1;                                                                                           \
-        PAIR_BSTAMP_C();                                                                                                           \
+        PAIR_PIN4(ga, gb, pga, pgb);                                                                                               \
+        PAIR_STAMP(13);                                                                                                            \
+        PAIR_STAMPS_END();                                                                                                         \
     }
 
     int blk = NBLK - 1;
@@ -908,13 +988,17 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
     }
 #undef PAIR_BWD_STEP
 #if defined(CMPS_DIAG) && defined(PABL_TIMING)
-    if (blockIdx.x == 0 && threadIdx.x == 0)
-        printf("reverse scan, cycles per step: tail end -> barrier exit %.1f, reads + MFMAs + pieces %.1f, tail %.1f\n",
-               (double)accPre / accN, (double)accMv / accN, (double)accTail / accN);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        printf("reverse scan, cycles per step by phase (0 loop overhead | 1 chain VALU | 2 image stores + own reads issued | 3 behind-the-stores work | "
+               "4 wait + barrier | 5 operand reads issued + own K-steps issued | 6..11 pieces / K-steps 1.. | 12 last K-steps | 13 tail):\n  cycles per step:");
+        double tot = 0;
+        for (int i_ = 0; i_ < NST; ++i_) { printf(" %.0f", (double)sacc[i_] / stn); tot += (double)sacc[i_] / stn; }
+        printf("   total %.0f\n", tot);
+    }
 #endif
-#undef PAIR_BSTAMP_A
-#undef PAIR_BSTAMP_B
-#undef PAIR_BSTAMP_C
+#undef PAIR_STAMP
+#undef PAIR_STAMPS_END
+    accS += (sda * una + sdb * unb) * ssy;                             // the Abar term of step 0
     // ---- the pair's slab: f | psi0bar_re | psi0bar_im | A (the R / Q sections are written by k_grad_gemm) ----
     float* slab = P.slabs + (size_t)blockIdx.x * P.slab_floats;
     const int DD = PD * PD;

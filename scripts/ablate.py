@@ -46,7 +46,7 @@ for name, flags in variants.items():
             o = os.path.join(build.OBJ_DIR, s.replace(".hip", ".o"))
             if s in only:
                 o = os.path.join(ROOT, "gpurun_out", f"{name}_{s}.o")
-                subprocess.run(common + ["-c", os.path.join(build.CSRC, s), "-o", o], check=True)
+                subprocess.run(common + build.EXTRA_FLAGS.get(s, []) + ["-c", os.path.join(build.CSRC, s), "-o", o], check=True)
             objs.append(o)
         subprocess.run([build._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs, check=True)
     else:
