@@ -545,13 +545,16 @@ int cmps_rho_sample(cmps_handle_t h, const float* noise_dev, int n, int length, 
         return fail(h, CMPS_ERR_STATE, "cmps_rho_sample: call cmps_set_params and cmps_rho_set_state first");
     if (!noise_dev || !out_dev || n < 1 || length < 1) return fail(h, CMPS_ERR_BAD_ARG, "cmps_rho_sample: bad argument");
     if (length > h->L.N) return fail(h, CMPS_ERR_BAD_ARG, "cmps_rho_sample: length exceeds T - 1 of cmps_set_params");
-    if (h->W.cols && n > h->rho_B)
+    // (only when the SAMPLER's three column arrays exceed the LDS: the workspace section exists from a smaller rank * D on, for the
+    // reverse scan's four -- ADVICE r3)
+    const bool mfma_sampler = h->D <= 32 && h->W.rank <= 32 && h->variant_req != CMPS_VARIANT_BLOCK;
+    if (!mfma_sampler && rho_cols_spill(3, h->W.rank, h->P.D) && n > h->rho_B)
         return fail(h, CMPS_ERR_WORKSPACE, "cmps_rho_sample: at this rank * D the columns live in the workspace: n must not exceed B_max");
     if (save_states && (!(h->rho_flags & CMPS_WS_TRAIN) || (size_t)n * length > (size_t)h->rho_B * (h->rho_T - 1)))
         return fail(h, CMPS_ERR_WORKSPACE, "cmps_rho_sample: save_states needs a CMPS_WS_TRAIN rho workspace with B_max*(T-1) >= n*length");
     // D <= 32 (rank <= 32): the row-array GEMM sampler, one wavefront per path (cmps_rho_mfma.hip); CMPS_VARIANT_BLOCK keeps the
     // general workgroup-per-path kernel (cross-check; 93 us per step at rank 32 against 2 us)
-    const bool mfma = h->D <= 32 && h->W.rank <= 32 && h->variant_req != CMPS_VARIANT_BLOCK;
+    const bool mfma = mfma_sampler;
     hipError_t e = mfma ? launch_sample_rho_mfma(h->P, h->W, noise_dev, n, length, out_dev, save_states != 0, static_cast<hipStream_t>(stream))
                         : launch_sample_rho(h->P, h->W, noise_dev, n, length, out_dev, save_states != 0, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail_hip(h, e, "cmps_rho_sample");

@@ -73,9 +73,9 @@ inline Layout make_layout(int D, int B, int T, int flags) {
         L.off_slabs = o; o = align256(o + (size_t)B * L.slab_floats * sizeof(float));
         L.off_sums = o;  o = align256(o + (L.slab_floats + 64) * sizeof(float) + 32 * L.slab_floats * sizeof(double));
         L.off_gops = o;
-        // ybar rows; + 32 rows: the gradient GEMMs prefetch up to four 4-step units past a pair's last step without clamping (what they
-        // read there is discarded), and for the last pair that is past the section
-        if (D > 32) o = align256(o + ((size_t)((B + 1) / 2) * N + 32) * 4 * DP * sizeof(float));
+        // ybar rows: exactly [pairs][N][4 DP] floats (k_grad_gemm clamps every row it requests to the pair's range and its buffer
+        // descriptors end at the last row; round 3's 32 rows of slack behind the section had no reader left -- ADVICE r3)
+        if (D > 32) o = align256(o + (size_t)((B + 1) / 2) * N * 4 * DP * sizeof(float));
     }
     L.total = o;
     return L;
@@ -126,6 +126,12 @@ struct RhoLayout {
 // rank * D above which the block kernels' column arrays (4 rank D complex numbers in the reverse scan) no longer fit into 160 KB of
 // LDS and live in the workspace instead (RhoDev::cols): the reference's default rank = D (model.py:62-65) from D = 72 upwards
 constexpr size_t RHO_LDS_COLS_MAX = 5000;
+// LDS a workgroup of the block rho kernels may use for its column arrays, and the ONE predicate both the launchers (cmps_rho.hip:
+// cols_if_needed) and the argument checks (cmps_capi.hip) use for "this kernel's `arrays` column arrays go to the workspace"
+// (forward 2, reverse scan 4, sampler 3 arrays of rank * D complex numbers): the workspace section is provided from
+// RHO_LDS_COLS_MAX upwards (sized for the reverse scan), but a kernel spills only when ITS request exceeds the LDS
+constexpr size_t RHO_LDS_MAX = 160 * 1024;
+inline bool rho_cols_spill(int arrays, int rank, int D) { return (size_t)arrays * rank * D * sizeof(float2) + 128 > RHO_LDS_MAX; }
 
 inline RhoLayout make_rho_layout(int D, int rank, int B, int T, int flags) {
     RhoLayout L{};

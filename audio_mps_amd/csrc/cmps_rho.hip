@@ -57,7 +57,7 @@ __global__ __launch_bounds__(NT) void k_fwd_rho(Dev P, RhoDev W, const float* __
     float loss = 0.f;
     for (int k = 0; k < N; ++k) {
         const float x = xrow[k + 1] - xrow[k];     // model.py:138
-        const float s = x / P.A;                   // :175
+        const float s = x / dev_A(P);                   // :175
         __syncthreads();
         if (act) {
             for (int a = 0; a < r; ++a) {
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(NT) void k_fwd_rho(Dev P, RhoDev W, const float* __
         }
         const float e = rblock_sum<NT>(pe, red);                  // Re tr(x rho'), :195-196
         const float n = rblock_sum<NT>(pn, red);                  // tr rho', :200
-        loss += -logf(1.0f + (e * x) / P.A);                      // :166, 155
+        loss += -logf(1.0f + (e * x) / dev_A(P));                      // :166, 155
         const float sc = sqrtf(1.0f / fmaxf(n, 1e-12f));          // :201 (columns scale with the square root)
         if (act) {
             const float2 rho = P.rho[(size_t)k * DP + t];
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(NT) void k_bwd_rho(Dev P, RhoDev W, const float* __
 
     for (int k = N - 1; k >= 0; --k) {
         const float x = xrow[k + 1] - xrow[k];
-        const float s = x / P.A;
+        const float s = x / dev_A(P);
         const float2 rho = act ? P.rho[(size_t)k * DP + t] : make_float2(1.f, 0.f);
         float pn = 0.f;
         if (act) {
@@ -174,10 +174,10 @@ __global__ __launch_bounds__(NT) void k_bwd_rho(Dev P, RhoDev W, const float* __
         }
         const float e = rblock_sum<NT>(pe, red);
         const float ex = e * x;
-        const float z = ex / P.A;
+        const float z = ex / dev_A(P);
         const float zbar = -1.0f / (1.0f + z);
-        const float ebar = zbar * x / P.A;
-        Abar += zbar * (-ex / (P.A * P.A));
+        const float ebar = zbar * x / dev_A(P);
+        Abar += zbar * (-ex / (dev_A(P) * dev_A(P)));
         const float te = 2.0f * ebar;
         float pnp = 0.f;
         if (act) {
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(NT) void k_bwd_rho(Dev P, RhoDev W, const float* __
             }
         }
         const float sbar = rblock_sum<NT>(ps, red);
-        Abar += sbar * (-x / (P.A * P.A));
+        Abar += sbar * (-x / (dev_A(P) * dev_A(P)));
 #pragma unroll
         for (int m = 0; m < EPT; ++m) {
             const int idx = t + m * NT;
@@ -359,7 +359,7 @@ __global__ void k_update_ancilla_rho(Dev P, const float* __restrict__ rho_in, co
     float2* Ti = sh + 2 * D;    // row i of U rho
     const int b = blockIdx.x / D, i = blockIdx.x % D, t = threadIdx.x;
     const bool act = t < D;
-    const float s = signal[b] / P.A;
+    const float s = signal[b] / dev_A(P);
     if (act) {
         const float th = __fmul_rn(P.freqs[t], tt);
         float sn, cs;
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(NT) void k_sample_rho(Dev P, RhoDev W, const float*
         const float e = 2.0f * rblock_sum<NT>(pe, red);                            // Re tr((Rt + Rt^dagger) rho), :189-196
         const float inc = e * P.dt + noise[(size_t)b * length + k];                // :162
         samp += inc;                                                               // :163
-        const float s = inc / P.A;                                                 // :164, 175
+        const float s = inc / dev_A(P);                                                 // :164, 175
         float pn = 0.f;
         if (act) {
             for (int a = 0; a < r; ++a) {
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(NT) void k_sample_rho(Dev P, RhoDev W, const float*
             const float2 rho = P.rho[(size_t)k * DP + t];
             for (int a = 0; a < r; ++a) S[a * D + t] = cmul(rho, cscale(sc, Wb[a * D + t]));
         }
-        if (t == 0) out[(size_t)b * length + k] = P.A * samp;                      // :116
+        if (t == 0) out[(size_t)b * length + k] = dev_A(P) * samp;                      // :116
     }
 }
 
@@ -484,8 +484,7 @@ hipError_t launch_pack_phi(const Dev& P, const RhoDev& W, const float* re, const
     return hipGetLastError();
 }
 
-// LDS a workgroup may use for the column arrays; beyond it they go to RhoDev::cols (the workspace)
-constexpr size_t RHO_LDS_MAX = 160 * 1024;
+// beyond RHO_LDS_MAX (cmps_internal.h: rho_cols_spill) the column arrays go to RhoDev::cols (the workspace)
 static float2* cols_if_needed(const RhoDev& W, size_t want_lds_bytes, size_t& shm, int blocks) {
     if (want_lds_bytes <= RHO_LDS_MAX) { shm = want_lds_bytes; return nullptr; }
     shm = 1024;                                   // reduction scratch (and the phases of k_states_rho) only

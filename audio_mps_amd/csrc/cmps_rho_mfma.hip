@@ -104,7 +104,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_fwd_rho_mfma(Dev P, RhoDev W,
     const float* xrow = audio + (size_t)b * T;
     float2* st = SAVE ? reinterpret_cast<float2*>(W.stash) + (size_t)b * N * r * 64 : nullptr;
     float* sc = SAVE ? W.scal + (size_t)b * NC * 128 : nullptr;
-    const float A = P.A;
+    const float A = dev_A(P);
     const float sgn = (col & 1) ? 1.f : -1.f;                  // Im lanes add rho_y * partner, Re lanes subtract it
     // the part of the gradient that needs no cotangent: P1 = sum_k 2 ebar_k Y^T Y (real form of sum_k 2 ebar_k sum_a y_a y_a^dagger),
     // a GEMM over the rows whose operands are the C/D tiles themselves (see k_bwd_rho_mfma)
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_rho_mfma(Dev P, RhoDev W,
     const float* xrow = audio + (size_t)b * T;
     const float2* st = reinterpret_cast<const float2*>(W.stash) + (size_t)b * N * r * 64;
     const float* sc = W.scal + (size_t)b * NC * 128;
-    const float A = P.A;
+    const float A = dev_A(P);
     const float sgn = (col & 1) ? 1.f : -1.f;        // rotation by rho: own*rho_x + sgn*partner*rho_y (conj: -sgn)
     // rows of this lane: a(q) = (q & 3) + 8 (q >> 2) + 4 hk
     // SEL 0: y_a(k) (.x of the stash pairs), SEL 1: (H y)_a(k); separate loads so that neither is held longer than it is used
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_sample_rho_mfma(Dev P, RhoDev
     const float* nrow = noise + (size_t)b * length;
     float* orow = out + (size_t)b * length;
     float2* st = SAVE ? reinterpret_cast<float2*>(W.stash) + (size_t)b * length * r * 64 : nullptr;
-    const float A = P.A;
+    const float A = dev_A(P);
     const float sgn = (col & 1) ? 1.f : -1.f;                        // Im lanes add rho_y * partner, Re lanes subtract it
     float samp = 0.f;
     for (int kbeg = 0; kbeg < length; kbeg += CH) {

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_fwd_rho_wave(Dev P, RhoDev W,
     const float* xrow = audio + (size_t)b * T;
     float2* st = SAVE ? reinterpret_cast<float2*>(W.stash) + (size_t)b * N * r * 64 + lane : nullptr;
     float* sc = SAVE ? W.scal + (size_t)b * NC * 128 : nullptr;
-    const float A = P.A;
+    const float A = dev_A(P);
     for (int a = 0; a < r; ++a) {
         const float2 p = W.phi0[a * DPW + i];
         S[w][a][lane] = hb ? p.y : p.x;
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_rho_wave(Dev P, RhoDev W,
     // (layout 2, k_fwd_rho_mfma)
     const float2* st = reinterpret_cast<const float2*>(W.stash) + (size_t)b * N * r * 64 + (W.stash_layout == 2 ? 2 * i + h : lane);
     const float* sc = W.scal + (size_t)b * NC * 128;
-    const float A = P.A;
+    const float A = dev_A(P);
     for (int a = 0; a < r; ++a) G[w][a][lane] = 0.f;
     v16f Rre = {}, Rim = {}, Qre = {}, Qim = {};
     float facc = 0.f, accA = 0.f, accS = 0.f;

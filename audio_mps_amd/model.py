@@ -96,7 +96,8 @@ class CMPS:
         self.data_iterator = data_iterator
         D = self.bond_d
         rng = np.random.default_rng(seed)
-        self.variables: Dict[str, np.ndarray] = {}
+        self._variables: Dict[str, np.ndarray] = {}
+        self._device_owner = None      # a Trainer whose device-resident optimiser state is newer than self._variables (see `variables`)
         self.variables["A"] = np.asarray(np.float32(hparams.A))   # model.py:19
         # --- R (model.py:31-42)
         if R_in is not None:
@@ -121,6 +122,17 @@ class CMPS:
             self.variables["freqs"] = rng.standard_normal(D).astype(np.float32)
             self._c_h = _rsqrt32(self.h_reg)
         self._rng = rng
+
+    @property
+    def variables(self) -> Dict[str, np.ndarray]:
+        """The raw trainable variables (host copies).  While a Trainer runs the device-resident optimiser step the current values
+        live on the GPU; reading this attribute then brings them back first (Trainer._lazy_sync: one device -> host copy, only after
+        steps that changed them), so loss / sample / effective_params / summaries never see stale parameters.
+        Values written here while a device-resident state is live are not pushed to it: restore() / a new Trainer rebuild it."""
+        owner = self._device_owner
+        if owner is not None:
+            owner._lazy_sync()
+        return self._variables
 
     # effective parameters, recomputed from the current variables ---------------------------------
     @property
@@ -246,6 +258,11 @@ class PsiCMPS(CMPS):
         be = self._get_backend()
         be.set_params(self.effective_params(), B, T, train=False)
         return be.forward(audio, save_for_bwd=False).detach().cpu().numpy()
+
+    def flat_size(self) -> int:
+        """Length of the buffer grad_sums() returns (cmps_psi_loss_bwd's layout): what an empty shard adds to the all-reduce as zeros."""
+        from .scan import grad_size
+        return grad_size(self.bond_d)
 
     def grad_sums(self, data=None):
         """Forward + reverse scan on this process's clips.  Returns (flat device/host buffer of SUMS over
@@ -399,6 +416,12 @@ class RhoCMPS(CMPS):
         be = self._prepare(B, T, train=False)
         return be.rho_forward(audio, save_for_bwd=False).detach().cpu().numpy()
 
+    def flat_size(self) -> int:
+        """Length of the buffer grad_sums() returns: the pure-state layout followed by the 2 rank D column cotangents
+        (include/cmps.h: cmps_rho_loss_bwd)."""
+        from .scan import grad_size
+        return grad_size(self.bond_d) + 2 * self.rank_rho_0 * self.bond_d
+
     def grad_sums(self, data=None):
         """(flat buffer of SUMS over this process's clips as laid out by cmps_rho_loss_bwd, number of clips)."""
         audio = self._to_device(self._batch(data))
@@ -536,6 +559,10 @@ class LegacyAudioMPS:
     @property
     def loss(self) -> np.float32:
         return np.float32(np.mean(self.loss_per_clip(), dtype=np.float32))
+
+    def flat_size(self) -> int:
+        """Length of the buffer grad_sums() returns (cmps_legacy_loss_bwd's layout)."""
+        return 3 * self.bond_d * self.bond_d + 1
 
     def grad_sums(self, data=None):
         audio = self._audio(data)

@@ -95,9 +95,10 @@ class Trainer:
         D = self.model.bond_d
         if data is not None and not callable(data) and len(data) == 0:
             import torch
-            nflat = len(self.model._last) if getattr(self.model, "_last", None) is not None else None
+            # sized from the MODEL (RhoCMPS appends its column cotangents: a shorter buffer here would be a size mismatch in the
+            # all-reduce -- ADVICE r3), not from what an earlier call happened to leave behind
             dev = getattr(self.model._get_backend(), "device", None)
-            flat = torch.zeros(nflat or (2 * D * D + 3 * D + 2), dtype=torch.float32, device=dev if dev is not None else "cpu")
+            flat = torch.zeros(self.model.flat_size(), dtype=torch.float32, device=dev if dev is not None else "cpu")
             b_local = 0
         else:
             flat, b_local = self.model.grad_sums(data)
@@ -131,8 +132,19 @@ class Trainer:
             st["params"] = torch.empty(V, dtype=torch.float32, device=be.device)
             st["losses"] = torch.zeros(2, dtype=torch.float32, device=be.device)
             self._dev = st
+            self._dirty = False
+            self.model._device_owner = self                        # model.variables now syncs lazily from the device state
             self._apply(None, 1)                                   # effective parameters of the current variables
         return self._dev
+
+    def _lazy_sync(self):
+        """Called by model.variables: device state -> host copies if a device step has run since the last sync."""
+        if self._dev is not None and getattr(self, "_dirty", False) and not getattr(self, "_syncing", False):
+            self._syncing = True
+            try:
+                self.sync_to_host()
+            finally:
+                self._syncing = False
 
     def _apply(self, grad_sums, global_batch):
         st, m, o = self._dev, self.model, self.opt
@@ -159,6 +171,7 @@ class Trainer:
         self.dp.allreduce_device(flat)
         self.opt.t += 1
         self._apply(flat, global_batch)
+        self._dirty = True                                          # the host copies (model.variables, Adam slots) are stale now
         self.global_step += 1
         out = {"global_step": self.global_step, "global_batch": int(global_batch), "losses_dev": st["losses"]}
         if sync:
@@ -174,7 +187,8 @@ class Trainer:
             return
         D = self.model.bond_d
         shapes = {"A": (), "Rx": (D, D), "Ry": (D, D), "freqs": (D,), "psi_x": (D,), "psi_y": (D,)}
-        for name, dst in (("vars", self.model.variables), ("m", self.opt.m), ("v", self.opt.v)):
+        self._dirty = False
+        for name, dst in (("vars", self.model._variables), ("m", self.opt.m), ("v", self.opt.v)):
             flat = self._dev[name].cpu().numpy()
             o = 0
             for k in VAR_ORDER:
@@ -202,11 +216,14 @@ class Trainer:
             self.opt.load_state_dict({k[5:]: z[k] for k in z.files if k.startswith("adam/")})
             self.global_step = int(z["global_step"])
         self._dev = None                                            # the device-resident copy is rebuilt from the restored state
+        self._dirty = False
         return True
 
 
 def build_parser():
     p = argparse.ArgumentParser(description="Train PsiCMPS on MI355X (mirror of audio-mps train.py)")
+    p.add_argument("--log_every", type=int, default=1, help="print the losses every n-th step (the device-resident step copies them "
+                   "to the host only then)")
     p.add_argument("--mps_model", default="psi_mps", choices=["rho_mps", "psi_mps"])           # train.py:18-20
     p.add_argument("--dataset", default="damped_sine",
                    choices=["damped_sine", "guitar", "organ", "nsynth"])                       # train.py:23-25
@@ -265,9 +282,12 @@ def main(argv=None, backend=None):
             full = get_audio(args.datadir, args.dataset, hp, args.sample_duration, seed=args.seed + trainer.global_step)
         # every rank reads the same global batch and keeps its shard (a short final batch of an epoch is sharded as it is)
         s0, c0 = dp.shard(full.shape[0]) if full.shape[0] != hp.minibatch_size else (start, count)
-        out = trainer.step(full[s0:s0 + c0], global_batch=int(full.shape[0]))
+        # the losses come to the host only on logging steps (the device-resident step needs no device -> host copy otherwise)
+        log_now = (it % max(args.log_every, 1) == 0) or it == args.max_steps - 1
+        out = trainer.step(full[s0:s0 + c0], sync=log_now, global_batch=int(full.shape[0]))
         if dp.rank == 0:
-            print(f"step {out['global_step']}: model_loss {out['model_loss']:.6f} total_loss {out['total_loss']:.6f}")
+            if log_now:
+                print(f"step {out['global_step']}: model_loss {out['model_loss']:.6f} total_loss {out['total_loss']:.6f}")
             if time.time() - last_save > args.save_checkpoint_secs or it == args.max_steps - 1:
                 trainer.save(ckpt)
                 last_save = time.time()

@@ -135,3 +135,42 @@ def test_gather_and_measured_world_size(tmp_path):
         z = np.load(os.path.join(tmp_path, f"c{r}.npz"))
         np.testing.assert_array_equal(z["got"], [10.0, 11.0])
         assert int(z["n"]) == 2 and float(z["mx"]) == 1.0 and float(z["us"]) == -1.0
+
+
+def _rho_empty_shard_worker(rank, world, port, T, D, r, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from audio_mps_amd import HParams, RhoCMPS
+    from audio_mps_amd.parallel import DataParallel
+    from audio_mps_amd.train import Trainer
+    from _util import OracleBackend, make_audio
+    B = 1                                   # a short final batch: fewer clips than ranks -> rank 1's shard is empty
+    hp = HParams(minibatch_size=B, bond_dim=D, learning_rate=0.01, initial_rank=r)
+    dp = DataParallel(backend="gloo")
+    full = make_audio(B, T, hp.delta_t, 5)
+    start, count = dp.shard(B)
+    assert count == (1 if rank == 0 else 0)
+    model = RhoCMPS(hp, seed=0, backend=OracleBackend(D))
+    assert model.flat_size() == 2 * D * D + 3 * D + 2 + 2 * r * D
+    tr = Trainer(model, hp, dp, device_step=False)
+    logs = [tr.step(full[start:start + count]) for _ in range(2)]
+    np.savez(os.path.join(out_dir, f"rho{rank}.npz"), total=np.array([l["total_loss"] for l in logs]),
+             gb=np.array([l["global_batch"] for l in logs]), **{k: v for k, v in model.variables.items()})
+    dp.barrier()
+    dp.close()
+
+
+@pytest.mark.timeout(300)
+def test_rho_empty_shard_two_ranks(tmp_path):
+    """the empty rank's zero buffer must have the MODEL's length (RhoCMPS appends 2 rank D column cotangents to the
+    pure-state layout); with the pure-state length the two ranks would all-reduce tensors of different sizes."""
+    T, D, r, world = 40, 4, 3, 2
+    mp.spawn(_rho_empty_shard_worker, args=(world, _free_port(), T, D, r, str(tmp_path)), nprocs=world, join=True)
+    r0 = np.load(os.path.join(tmp_path, "rho0.npz"))
+    r1 = np.load(os.path.join(tmp_path, "rho1.npz"))
+    assert list(r0["gb"]) == [1, 1] and np.all(np.isfinite(r0["total"]))
+    for k in ("A", "Rx", "Ry", "freqs", "Wx", "Wy", "total"):
+        np.testing.assert_array_equal(r0[k], r1[k])         # replicas stay bit-identical

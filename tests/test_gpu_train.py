@@ -198,3 +198,31 @@ def test_bench_runs_at_small_shapes(args):
         assert key in line["cpu_baseline"], key
     assert line["steps"] == 2 and line["n_gpus"] == 1 and line["value"] > 0
     assert line["parity_in_bench"]["ok"], line["parity_in_bench"]
+
+
+def test_model_accessors_follow_the_device_resident_state():
+    """with the device-resident optimiser step the current variables live on the GPU; anything that reads the model between
+    steps (variables, R, freqs, psi_0, loss) must see them, not the values of step 0.  The host copies are refreshed lazily: once per
+    read after a step, not per step."""
+    from audio_mps_amd import HParams, PsiCMPS
+    from audio_mps_amd.scan import HipScan
+    from audio_mps_amd.train import Trainer
+    D = 8
+    hp = HParams(minibatch_size=4, bond_dim=D, learning_rate=0.01)
+    data = make_audio(4, 120, hp.delta_t, 3)
+    m_dev = PsiCMPS(hp, data_iterator=data, seed=0, backend=HipScan(D))
+    m_host = PsiCMPS(hp, data_iterator=data, seed=0, backend=HipScan(D))
+    t_dev, t_host = Trainer(m_dev, hp, device_step=True), Trainer(m_host, hp)
+    R0 = m_dev.R.copy()
+    for _ in range(3):
+        t_dev.step(sync=False)
+        t_host.step()
+    assert t_dev._dirty                                             # nothing has come back yet
+    R3 = m_dev.R                                                    # first read: one sync
+    assert not t_dev._dirty and np.max(np.abs(R3 - R0)) > 1e-4
+    np.testing.assert_allclose(R3, m_host.R, rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(m_dev.freqs, m_host.freqs, rtol=2e-5, atol=1e-4)
+    np.testing.assert_allclose(m_dev.psi_0, m_host.psi_0, rtol=2e-5, atol=2e-6)
+    assert float(m_dev.loss) == pytest.approx(float(m_host.loss), rel=1e-5, abs=1e-6)
+    t_dev.step(sync=False)
+    assert t_dev._dirty
