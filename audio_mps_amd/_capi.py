@@ -28,6 +28,7 @@ CMPS_VARIANT_WAVE32 = 4
 CMPS_VARIANT_WIDE = 5
 
 CMPS_OPT_RANK1 = 1
+CMPS_OPT_KERNEL_EVENTS = 2
 CMPS_RANK1_EXACT_F32 = 0
 CMPS_RANK1_BF16X2 = 1
 CMPS_RANK1_BF16X3 = 2
@@ -36,7 +37,7 @@ RANK1_NAMES = {0: "exact_f32", 1: "bf16x2", 2: "bf16x3"}
 # every symbol include/cmps.h declares
 SYMBOLS = (
     "cmps_version", "cmps_create", "cmps_destroy", "cmps_last_error", "cmps_set_variant",
-    "cmps_get_variant", "cmps_set_option", "cmps_get_option", "cmps_workspace_bytes", "cmps_set_params", "cmps_set_params_dev",
+    "cmps_get_variant", "cmps_set_option", "cmps_get_option", "cmps_kernel_times", "cmps_workspace_bytes", "cmps_set_params", "cmps_set_params_dev",
     "cmps_apply_step_scratch_bytes", "cmps_psi_apply_step", "cmps_psi_loss_fwd",
     "cmps_psi_loss_bwd", "cmps_psi_update_ancilla", "cmps_psi_states", "cmps_psi_sample",
     "cmps_legacy_set_params", "cmps_legacy_loss_fwd", "cmps_legacy_loss_bwd",
@@ -70,6 +71,8 @@ def _declare(lib):
     lib.cmps_set_option.restype = c_int
     lib.cmps_get_option.argtypes = [vp, c_int]
     lib.cmps_get_option.restype = c_int
+    lib.cmps_kernel_times.argtypes = [vp, ctypes.c_char_p, c_size_t, ctypes.POINTER(c_float), ctypes.POINTER(c_int), c_int]
+    lib.cmps_kernel_times.restype = c_int
     lib.cmps_workspace_bytes.argtypes = [c_int, c_int, c_int, c_int]
     lib.cmps_workspace_bytes.restype = c_size_t
     lib.cmps_set_params.argtypes = [vp, vp, vp, vp, vp, vp, c_float, c_double, c_double, c_int, c_int,

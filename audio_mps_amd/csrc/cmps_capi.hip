@@ -11,6 +11,8 @@
 
 using namespace cmps;
 
+namespace cmps { thread_local KTimer* g_ktimer = nullptr; }
+
 struct cmps_handle_s {
     int D = 0;
     int variant_req = CMPS_VARIANT_AUTO;
@@ -35,6 +37,7 @@ struct cmps_handle_s {
     int rho_B = 0, rho_T = 0, rho_flags = 0, rho_saved_B = 0, rho_saved_steps = 0;
     RhoLayout RL{};
     RhoDev W{};
+    cmps::KTimer* ktimer = nullptr;   // non-null: CMPS_OPT_KERNEL_EVENTS is on
     std::string err;
 };
 
@@ -44,6 +47,17 @@ int fail(cmps_handle_t h, int code, const char* msg) {
     if (h) h->err = msg;
     return code;
 }
+
+void ktimer_free(cmps::KTimer* t) {
+    for (auto& r : t->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto e : t->pool) (void)hipEventDestroy(e);
+    delete t;
+}
+// sets the thread-local timer for the duration of one C ABI call
+struct KBind {
+    explicit KBind(cmps_handle_t h) { cmps::g_ktimer = h ? h->ktimer : nullptr; }
+    ~KBind() { cmps::g_ktimer = nullptr; }
+};
 
 int fail_hip(cmps_handle_t h, hipError_t e, const char* where) {
     if (h) {
@@ -81,6 +95,7 @@ int cmps_create(int D, cmps_handle_t* out) {
 }
 
 int cmps_destroy(cmps_handle_t h) {
+    if (h && h->ktimer) ktimer_free(h->ktimer);
     delete h;
     return CMPS_OK;
 }
@@ -109,12 +124,19 @@ int cmps_set_option(cmps_handle_t h, int option, int value) {
         h->rank1_mode = value;
         return CMPS_OK;
     }
+    if (option == CMPS_OPT_KERNEL_EVENTS) {
+        if (value != 0 && value != 1) return fail(h, CMPS_ERR_BAD_ARG, "cmps_set_option: CMPS_OPT_KERNEL_EVENTS takes 0 or 1");
+        if (value && !h->ktimer) h->ktimer = new cmps::KTimer();
+        if (!value && h->ktimer) { ktimer_free(h->ktimer); h->ktimer = nullptr; }
+        return CMPS_OK;
+    }
     return fail(h, CMPS_ERR_BAD_ARG, "cmps_set_option: unknown option");
 }
 
 int cmps_get_option(cmps_handle_t h, int option) {
     if (!h) return -1;
     if (option == CMPS_OPT_RANK1) return h->rank1_mode;
+    if (option == CMPS_OPT_KERNEL_EVENTS) return h->ktimer ? 1 : 0;
     return -1;
 }
 
@@ -236,17 +258,23 @@ int cmps_psi_loss_fwd(cmps_handle_t h, const float* audio_dev, int B, int T, flo
     P.B = B;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int variant = resolve_variant(h);
+    KBind kb(h);
     hipError_t e;
-    if (variant == CMPS_VARIANT_WAVE && h->D <= 16)
+    if (variant == CMPS_VARIANT_WAVE && h->D <= 16) {
+        KScope ks("k_fwd_wave16", s);
         e = launch_fwd_wave16(P, audio_dev, loss_dev, save_for_bwd != 0, s);
-    else if (variant == CMPS_VARIANT_WAVE || variant == CMPS_VARIANT_WAVE32)
+    } else if (variant == CMPS_VARIANT_WAVE || variant == CMPS_VARIANT_WAVE32) {
+        KScope ks("k_fwd_wave2", s);
         e = launch_fwd_wave2(P, audio_dev, loss_dev, save_for_bwd != 0, s);
-    else if (variant == CMPS_VARIANT_PAIR)
+    } else if (variant == CMPS_VARIANT_PAIR) {
+        KScope ks("k_fwd_pair", s);
         e = launch_fwd_pair(P, audio_dev, loss_dev, save_for_bwd != 0, s);
-    else if (variant == CMPS_VARIANT_WIDE)
-        e = launch_fwd_wide(P, audio_dev, loss_dev, save_for_bwd != 0, s);
-    else
+    } else if (variant == CMPS_VARIANT_WIDE) {
+        e = launch_fwd_wide(P, audio_dev, loss_dev, save_for_bwd != 0, s);      // k_fwd_wide, k_hy_wide, k_loss_wide: scopes inside
+    } else {
+        KScope ks("k_fwd_block", s);
         e = launch_fwd_block(P, audio_dev, loss_dev, save_for_bwd != 0, s);
+    }
     if (e != hipSuccess) return fail_hip(h, e, "cmps_psi_loss_fwd");
     h->fwd_saved = save_for_bwd != 0;
     h->saved_B = B; h->saved_T = T; h->saved_audio = audio_dev; h->saved_loss = loss_dev;
@@ -268,13 +296,16 @@ int cmps_psi_loss_bwd(cmps_handle_t h, const float* audio_dev, int B, int T, flo
     P.B = B;
     hipStream_t s = static_cast<hipStream_t>(stream);
     // the stash layout belongs to the variant that wrote it
+    KBind kb(h);
     if (h->saved_variant == CMPS_VARIANT_PAIR) {
         // reverse scan, then the gradient GEMM over the rows both scans left behind; one slab per PAIR of clips
-        hipError_t e = launch_bwd_pair(P, audio_dev, s);
-        if (e == hipSuccess) e = launch_grad_pair(P, audio_dev, s);
+        hipError_t e;
+        { KScope ks("k_bwd_pair", s); e = launch_bwd_pair(P, audio_dev, s); }
+        if (e == hipSuccess) { KScope ks("k_grad_gemm<1>", s); e = launch_grad_pair(P, audio_dev, s); }
         if (e != hipSuccess) return fail_hip(h, e, "cmps_psi_loss_bwd (pair scan)");
         Dev Pp = P;
         Pp.B = (B + 1) / 2;
+        KScope ks("reduce + finalize", s);
         e = launch_reduce_only(Pp, s);
         if (e == hipSuccess) e = launch_finalize_only(P, h->saved_loss, grad_dev, s);
         if (e != hipSuccess) return fail_hip(h, e, "cmps_psi_loss_bwd (pair reduce)");
@@ -282,11 +313,16 @@ int cmps_psi_loss_bwd(cmps_handle_t h, const float* audio_dev, int B, int T, flo
     }
     if (h->saved_variant == CMPS_VARIANT_WIDE) {
         // float32 reverse scan, then the gradient GEMM (operands split into bf16 pieces on the fly); one slab per PAIR of clips
-        hipError_t e = launch_bwd_wide(P, audio_dev, s);
-        if (e == hipSuccess) e = launch_grad_wide(P, audio_dev, h->rank1_mode == CMPS_RANK1_BF16X2 ? 2 : 3, s);
+        hipError_t e;
+        { KScope ks("k_bwd_wide", s); e = launch_bwd_wide(P, audio_dev, s); }
+        if (e == hipSuccess) {
+            KScope ks(h->rank1_mode == CMPS_RANK1_BF16X2 ? "k_grad_gemm<2>" : "k_grad_gemm<3>", s);
+            e = launch_grad_wide(P, audio_dev, h->rank1_mode == CMPS_RANK1_BF16X2 ? 2 : 3, s);
+        }
         if (e != hipSuccess) return fail_hip(h, e, "cmps_psi_loss_bwd (wide scan)");
         Dev Pp = P;
         Pp.B = (B + 1) / 2;
+        KScope ks("reduce + finalize", s);
         e = launch_reduce_only(Pp, s);
         P.abar_fix = 1;              // the merged mat-vec: k_finalize removes the Q part of sum Re(u^dagger (Q + s R^dagger) ybar)
         if (e == hipSuccess) e = launch_finalize_only(P, h->saved_loss, grad_dev, s);
@@ -294,11 +330,15 @@ int cmps_psi_loss_bwd(cmps_handle_t h, const float* audio_dev, int B, int T, flo
         return CMPS_OK;
     }
     const bool wave = h->saved_variant == CMPS_VARIANT_WAVE || h->saved_variant == CMPS_VARIANT_WAVE32;
-    hipError_t e = !wave ? launch_bwd_block(P, audio_dev, s)
-                 : (h->saved_variant == CMPS_VARIANT_WAVE && h->D <= 16) ? launch_bwd_wave16(P, audio_dev, s)
-                                                                         : launch_bwd_wave(P, audio_dev, h->rank1_mode, s);
+    const bool w16 = h->saved_variant == CMPS_VARIANT_WAVE && h->D <= 16;
+    hipError_t e;
+    {
+        KScope ks(!wave ? "k_bwd_block" : w16 ? "k_bwd_wave16" : "k_bwd_wave", s);
+        e = !wave ? launch_bwd_block(P, audio_dev, s) : w16 ? launch_bwd_wave16(P, audio_dev, s) : launch_bwd_wave(P, audio_dev, h->rank1_mode, s);
+    }
     if (e != hipSuccess) return fail_hip(h, e, "cmps_psi_loss_bwd (scan)");
     P.abar_fix = wave ? 1 : 0;
+    KScope ks("reduce + finalize", s);
     e = launch_reduce_finalize(P, h->saved_loss, grad_dev, s);
     if (e != hipSuccess) return fail_hip(h, e, "cmps_psi_loss_bwd (reduce)");
     return CMPS_OK;
@@ -574,6 +614,41 @@ int cmps_rho_states(cmps_handle_t h, int B, int steps, float* rho_out_dev, float
     hipError_t e = launch_states_rho(h->P, h->W, B, steps, rho_out_dev, purity_out_dev, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail_hip(h, e, "cmps_rho_states");
     return CMPS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// per-kernel durations recorded while CMPS_OPT_KERNEL_EVENTS is on
+// ---------------------------------------------------------------------------------------------------
+int cmps_kernel_times(cmps_handle_t h, char* names, size_t names_bytes, float* ms_sum, int* calls, int cap) {
+    if (!h) return -1;
+    if (!h->ktimer) { fail(h, CMPS_ERR_STATE, "cmps_kernel_times: CMPS_OPT_KERNEL_EVENTS is off"); return -1; }
+    if (!names || !ms_sum || !calls || cap < 1 || names_bytes < 1) { fail(h, CMPS_ERR_BAD_ARG, "cmps_kernel_times: bad argument"); return -1; }
+    KTimer* t = h->ktimer;
+    std::vector<const char*> order;
+    std::vector<double> sum;
+    std::vector<int> cnt;
+    for (auto& r : t->recs) {
+        if (hipEventSynchronize(r.b) != hipSuccess) { fail(h, CMPS_ERR_HIP, "cmps_kernel_times: hipEventSynchronize"); return -1; }
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, r.a, r.b);
+        size_t i = 0;
+        for (; i < order.size(); ++i) if (!strcmp(order[i], r.name)) break;
+        if (i == order.size()) { order.push_back(r.name); sum.push_back(0.0); cnt.push_back(0); }
+        sum[i] += ms; cnt[i] += 1;
+        t->pool.push_back(r.a); t->pool.push_back(r.b);
+    }
+    t->recs.clear();
+    std::string joined;
+    int n = 0;
+    for (size_t i = 0; i < order.size() && n < cap; ++i, ++n) {
+        if (i) joined += '\n';
+        joined += order[i];
+        ms_sum[n] = (float)sum[i];
+        calls[n] = cnt[i];
+    }
+    if (joined.size() + 1 > names_bytes) { fail(h, CMPS_ERR_BAD_ARG, "cmps_kernel_times: names buffer too small"); return -1; }
+    memcpy(names, joined.c_str(), joined.size() + 1);
+    return n;
 }
 
 // ---------------------------------------------------------------------------------------------------

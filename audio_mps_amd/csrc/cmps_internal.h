@@ -4,7 +4,37 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <vector>
+
 namespace cmps {
+
+// ---------------------------------------------------------------------------------------------
+// Per-kernel durations (cmps_set_option(CMPS_OPT_KERNEL_EVENTS, 1); cmps_kernel_times): while the option is on, every kernel the
+// scan entry points launch is bracketed by two HIP events on the caller's stream.  Off (the default) nothing is recorded and a
+// KScope is two pointer tests.  The C ABI functions set the thread-local pointer for the duration of a call.
+// ---------------------------------------------------------------------------------------------
+struct KTimer {
+    struct Rec { const char* name; hipEvent_t a, b; };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t get() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+};
+extern thread_local KTimer* g_ktimer;
+struct KScope {
+    KTimer* t; hipStream_t s; const char* name; hipEvent_t a;
+    KScope(const char* name_, hipStream_t s_) : t(g_ktimer), s(s_), name(name_), a(nullptr) {
+        if (t) { a = t->get(); (void)hipEventRecord(a, s); }
+    }
+    ~KScope() {
+        if (t) { hipEvent_t b = t->get(); (void)hipEventRecord(b, s); t->recs.push_back({name, a, b}); }
+    }
+};
+
 
 // ---------------------------------------------------------------------------------------------
 // Workspace layout (all offsets in bytes from the workspace base, every section 256-B aligned).

@@ -849,13 +849,14 @@ static hipError_t fwd_wide_t(const Dev& P, const float* audio, float* loss, bool
         e = wide_lds_attr(k_fwd_wide<PD, true>, shm);
         if (e == hipSuccess) e = wide_lds_attr(k_hy_wide<PD>, shm_hy);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_fwd_wide<PD, true>), dim3(nb), dim3(4 * PD), shm, s, P, audio, loss);
-        hipLaunchKernelGGL((k_hy_wide<PD>), dim3(nb, (unsigned)((P.N + HCHUNK - 1) / HCHUNK)), dim3(2 * PD), shm_hy, s, P);
-        hipLaunchKernelGGL(k_loss_wide, dim3((unsigned)P.B), dim3(64), 0, s, P, audio, loss);
+        { KScope ks("k_fwd_wide", s); hipLaunchKernelGGL((k_fwd_wide<PD, true>), dim3(nb), dim3(4 * PD), shm, s, P, audio, loss); }
+        { KScope ks("k_hy_wide", s); hipLaunchKernelGGL((k_hy_wide<PD>), dim3(nb, (unsigned)((P.N + HCHUNK - 1) / HCHUNK)), dim3(2 * PD), shm_hy, s, P); }
+        { KScope ks("k_loss_wide", s); hipLaunchKernelGGL(k_loss_wide, dim3((unsigned)P.B), dim3(64), 0, s, P, audio, loss); }
     } else {
         const size_t shm = WideGeom<PD>::FWD_LDS;
         e = wide_lds_attr(k_fwd_wide<PD, false>, shm);
         if (e != hipSuccess) return e;
+        KScope ks("k_fwd_wide", s);
         hipLaunchKernelGGL((k_fwd_wide<PD, false>), dim3(nb), dim3(4 * PD), shm, s, P, audio, loss);
     }
     return hipGetLastError();

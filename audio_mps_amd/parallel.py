@@ -18,6 +18,21 @@ import torch
 import torch.distributed as dist
 
 
+# The one collective is 2 D^2 + 3 D + 2 floats (8.6 KB at D = 32, 133 KB at D = 128) against a step of >= 10 ms: latency-bound.  On a
+# fully connected 8-GPU xGMI node a ring pays 2 (N - 1) = 14 hops whatever the size, and what a hop costs at this size is the
+# protocol's synchronisation, not the bytes: RCCL's LL protocol (8-byte {data, flag} granules, no separate fence per chunk) is the
+# low-latency one; LL128 / Simple only win from ~100s of KB.  RCCL's tuner picks LL at this size by itself; setting it makes the
+# choice explicit and keeps a tuner change from moving the step.  NCCL_ALGO is left to RCCL: inside
+# one node Tree degenerates to a chain of the same hop count, and the one-shot all-to-all form SURVEY describes is not an RCCL
+# algorithm one can select by name.  Both are only DEFAULTS: a value in the environment wins.
+LOW_LATENCY_ENV = {"NCCL_PROTO": "LL"}
+
+
+def collective_settings() -> dict:
+    """What is in force for the collective (for the bench line)."""
+    return {k: os.environ.get(k) for k in ("NCCL_PROTO", "NCCL_ALGO", "RCCL_MSCCL_ENABLE", "RCCL_MSCCLPP_ENABLE", "NCCL_MIN_NCHANNELS")}
+
+
 class DataParallel:
     time_collective = False       # bench.py sets it: HIP events around the all-reduce (SURVEY 8e: "print the all-reduce us")
     collective_ms = None          # list of timed collectives (ms), created on first use
@@ -40,6 +55,9 @@ class DataParallel:
                 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
                 os.environ.setdefault("MASTER_PORT", "29500")
                 kwargs = {}
+                if backend == "nccl":
+                    for k, v in LOW_LATENCY_ENV.items():          # before the communicator exists
+                        os.environ.setdefault(k, v)
                 if backend == "nccl" and device is not None:
                     kwargs["device_id"] = torch.device(device)
                 dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world_size, **kwargs)
@@ -152,6 +170,19 @@ class DataParallel:
         t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
+
+    def replicas_identical(self, t: torch.Tensor) -> bool:
+        """True when every rank holds bit-for-bit the same tensor (MAX and MIN over ranks of its int32 view coincide): the
+        data-parallel invariant after an optimiser step (same all-reduced sums -> same Adam update on every rank)."""
+        if not self._collective():
+            return True
+        bits = t.detach().contiguous().view(torch.int32)
+        if self.backend != "nccl":
+            bits = bits.cpu()
+        hi, lo = bits.clone(), bits.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        return bool(torch.equal(hi, lo))
 
     def close(self):
         if self._own_group and dist.is_initialized():

@@ -96,6 +96,24 @@ class HipScan:
     def rank1(self) -> int:
         return int(self._lib.cmps_get_option(self._h, _capi.CMPS_OPT_RANK1))
 
+    def kernel_events(self, on: bool):
+        """cmps_set_option(CMPS_OPT_KERNEL_EVENTS): bracket every kernel of forward() / backward() with HIP events (a measurement aid,
+        used by bench.py outside its timed region)."""
+        _capi.check(self._h, self._lib.cmps_set_option(self._h, _capi.CMPS_OPT_KERNEL_EVENTS, 1 if on else 0))
+
+    def kernel_times(self) -> dict:
+        """cmps_kernel_times: {kernel name: (summed ms, launches)} since the last call, in first-launch order (synchronises)."""
+        import ctypes
+        cap = 32
+        names = ctypes.create_string_buffer(2048)
+        ms = (ctypes.c_float * cap)()
+        calls = (ctypes.c_int * cap)()
+        n = self._lib.cmps_kernel_times(self._h, names, 2048, ms, calls, cap)
+        if n < 0:
+            raise _capi.CmpsError(n, self._lib.cmps_last_error(self._h).decode())
+        keys = names.value.decode().split("\n") if n else []
+        return {k: (float(ms[i]), int(calls[i])) for i, k in enumerate(keys)}
+
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 

@@ -292,9 +292,9 @@ def executed_split(variant, D, rank1):
                 "bwd": {"valu_fp32": 12, "mfma_fp32_equiv": 24, "mfma_products": prod, "eliminated": 20,
                         "what": "k_bwd_wide: merged (Q + s R^dagger) ybar on the VALU; k_grad_gemm (NPC = 3 or 2): rank-1 sums as split-bf16 GEMMs"}}
     if variant == V_PAIR:
-        return {"fwd": {"valu_fp32": 0, "mfma_fp32_equiv": 24, "mfma_products": 1, "eliminated": 0, "what": "R u, Q u (4x4x4 bf16), H y (32x32x16 bf16)"},
+        return {"fwd": {"valu_fp32": 0, "mfma_fp32_equiv": 24, "mfma_products": 1, "eliminated": 0, "what": "R u, Q u (16x16x32 bf16), H y (32x32x16 bf16)"},
                 "bwd": {"valu_fp32": 0, "mfma_fp32_equiv": 40, "mfma_products": 1, "eliminated": 16,
-                        "what": "Q ybar, R^dagger ybar (4x4x4 bf16) + the gradient GEMM; H y from the stash"}}
+                        "what": "Q ybar, R^dagger ybar (16x16x32 bf16) + the gradient GEMM; H y from the stash"}}
     return {"fwd": {"valu_fp32": 24, "mfma_fp32_equiv": 0, "mfma_products": 0, "eliminated": 0, "what": "three fp32 mat-vecs"},
             "bwd": {"valu_fp32": 56, "mfma_fp32_equiv": 0, "mfma_products": 0, "eliminated": 0, "what": "four fp32 mat-vecs + three rank-1 updates"}}
 
@@ -303,7 +303,7 @@ KERNEL_NAMES = {
     "wave": ("k_fwd_wave2", "k_fwd_wave2 (forward scan: chain wave + loss wave on the matrix cores)", "k_bwd_wave", "k_bwd_wave (reverse scan)"),
     "wave16": ("k_fwd_wave16", "k_fwd_wave16 (forward scan, 16-row layout: chain wave + loss wave)", "k_bwd_wave16",
                "k_bwd_wave16 (reverse scan, 16-row layout: chain wave + gradient wave)"),
-    "pair": ("k_fwd_pair", "k_fwd_pair (forward scan: 4x4x4 bf16 MFMA chain waves + 32x32x16 loss waves, eight steps per tile)", "k_bwd_pair",
+    "pair": ("k_fwd_pair", "k_fwd_pair (forward scan: 16x16x32 bf16 MFMA chain waves + 32x32x16 loss waves, eight steps per tile)", "k_bwd_pair",
              "k_bwd_pair + k_grad_gemm<1 piece> (reverse scan + streaming gradient GEMM)"),
     "wide": ("k_fwd_wide", "k_fwd_wide + k_hy_wide + k_loss_wide (float32 forward chain, R / Q register resident; H y as a split-bf16 GEMM)", "k_bwd_wide",
              "k_bwd_wide + k_grad_gemm<3 pieces> (float32 reverse scan + split-bf16 gradient GEMM)"),
@@ -317,7 +317,71 @@ def family_of(variant, D):
     return {V_WAVE: "wave", V_WAVE32: "wave", V_PAIR: "pair", V_WIDE: "wide", V_BLOCK: "block"}[variant]
 
 
-def roofline_record(D, T, B, variant, rank1, t_fwd, t_bwd, ms_per_step):
+# ---------------------------------------------------------------------------------------------------
+# one record per kernel and pipe: what the kernel EXECUTES on that pipe (per (clip, sample), in units of D^2 flop, or bytes), its
+# live duration (HIP events around each launch: cmps_set_option(CMPS_OPT_KERNEL_EVENTS), outside the timed region) and the peak of
+# THAT pipe -- so no fraction can exceed 1 (56 D^2 over the fp32 vector peak gave 1.32 for a pair of kernels that runs
+# most of it on the matrix pipe).  Products = bf16 piece products issued per float32 product (x6 / x3 split, x1 plain bf16).
+# ---------------------------------------------------------------------------------------------------
+PIPE_PEAK = {"valu_fp32": (FP32_PEAK_TFLOPS, "TFLOP/s"), "mfma_f32": (FP32_PEAK_TFLOPS, "TFLOP/s"),
+             "mfma_bf16": (BF16_PEAK_TFLOPS, "TFLOP/s"), "hbm": (HBM_PEAK_GBS, "GB/s")}
+
+
+def kernel_work_model(fam, D, DP, rank1):
+    """{kernel name as cmps_kernel_times reports it: [(pipe, D^2-flop per (clip, sample) | bytes per (clip, sample), what)]}"""
+    prod = {0: 1, 1: 3, 2: 6}[rank1]
+    rp = "mfma_f32" if rank1 == 0 else "mfma_bf16"
+    if fam == "wave":
+        return {"k_fwd_wave2": [("valu_fp32", 12 * D * D, "merged (Q + s R) u mat-vec 8 + forming it 4"),
+                                ("mfma_bf16", 8 * 6 * D * D, "H y as a bf16x3-split GEMM over 32-step chunks: 6 piece products"),
+                                ("hbm", 512.0, "stash rows written: 512 B per (clip, step)")],
+                "k_bwd_wave": [("valu_fp32", 12 * D * D, "merged (Q + s R^dagger) ybar mat-vec 8 + forming it 4"),
+                               (rp, 24 * prod * D * D, f"three rank-1 sums, {prod} product(s) per float32 product"),
+                               ("hbm", 512.0, "stash rows read")]}
+    if fam == "wave16":
+        return {"k_fwd_wave16": [("valu_fp32", 20 * D * D, "chain wave 12 + loss wave 8"), ("hbm", 512.0, "stash rows written")],
+                "k_bwd_wave16": [("valu_fp32", 12 * D * D, "merged mat-vec"), ("mfma_f32", 24 * D * D, "rank-1 sums, exact fp32 16x16x4 MFMAs"),
+                                 ("hbm", 512.0, "stash rows read")]}
+    if fam == "wide":
+        gp = 3 if rank1 == 1 else 6
+        return {"k_fwd_wide": [("valu_fp32", 12 * D * D, "merged (Q + s R) u, v_pk_fma_f32"), ("hbm", 8.0 * DP, "y rows written: 16 DP B per pair-step")],
+                "k_hy_wide": [("mfma_bf16", 8 * 6 * D * D, "H y for all (clip, step) pairs, bf16x3 split: 6 piece products"),
+                              ("hbm", 16.0 * DP, "y rows read + H y rows written")],
+                "k_loss_wide": [("hbm", 8.0, "e_k, |y_k|^2 scalars")],
+                "k_bwd_wide": [("valu_fp32", 12 * D * D, "merged (Q + s R^dagger) ybar"), ("hbm", 24.0 * DP, "y, H y rows read, ybar rows written")],
+                f"k_grad_gemm<{2 if rank1 == 1 else 3}>": [("mfma_bf16", 24 * gp * D * D, f"three rank-1 sums as GEMMs, {gp} piece products"),
+                                                          ("hbm", 16.0 * DP, "y and ybar rows read: 32 DP B per pair-step")]}
+    if fam == "pair":
+        return {"k_fwd_pair": [("mfma_bf16", 24 * D * D, "R u, Q u (16x16x32, 4 of 16 A rows useful: issued 4 x) + H y (32x32x16)"),
+                               ("hbm", 16.0 * DP, "y and H y rows written")],
+                "k_bwd_pair": [("mfma_bf16", 16 * D * D, "Q ybar, R^dagger ybar (16x16x32, 4 of 16 A rows useful: issued 4 x)"),
+                               ("hbm", 24.0 * DP, "y, H y rows read, ybar rows written")],
+                "k_grad_gemm<1>": [("mfma_bf16", 24 * D * D, "three rank-1 sums as bf16 GEMMs"), ("hbm", 16.0 * DP, "y and ybar rows read")]}
+    return {"k_fwd_block": [("valu_fp32", 24 * D * D, "three fp32 mat-vecs")], "k_bwd_block": [("valu_fp32", 56 * D * D, "all of it on the VALU")]}
+
+
+def kernel_records(fam, D, T, B, rank1, ktimes):
+    """ktimes: {name: (summed ms, launches)} of backend.kernel_times()."""
+    DP = (D + 31) // 32 * 32
+    units = float(B) * (T - 1)
+    model = kernel_work_model(fam, D, DP, rank1)
+    recs = []
+    for name, (ms_sum, calls) in ktimes.items():
+        ms = ms_sum / max(calls, 1)
+        if name not in model:
+            recs.append({"kernel": name, "duration_ms": ms, "launches_timed": calls})
+            continue
+        for pipe, per_unit, what in model[name]:
+            peak, unit = PIPE_PEAK[pipe]
+            work = per_unit * units
+            rate = work / (ms * 1e-3) / (1e9 if pipe == "hbm" else 1e12)
+            recs.append({"kernel": name, "pipe": pipe, ("executed_bytes" if pipe == "hbm" else "executed_flop"): work,
+                         "duration_ms": ms, "achieved": rate, "peak": peak, "unit": unit, "frac": rate / peak, "what": what,
+                         "launches_timed": calls})
+    return recs
+
+
+def roofline_record(D, T, B, variant, rank1, t_fwd, t_bwd, ms_per_step, ktimes=None):
     """The contract's roofline object for the dominant kernel + the per-pipe split of what is executed + the step's traffic."""
     N = T - 1
     units = float(B) * N
@@ -344,7 +408,6 @@ def roofline_record(D, T, B, variant, rank1, t_fwd, t_bwd, ms_per_step):
                "matrix_pipe_products_per_fp32_product": sp["mfma_products"],
                "matrix_pipe_frac_of_its_peak": mf_raw / (FP32_PEAK_TFLOPS if f32_matrix else BF16_PEAK_TFLOPS),
                "eliminated_frac_of_algorithmic": sp["eliminated"] / (24.0 if which == "fwd" else 56.0),
-               "frac_executed_fp32_equiv": (mf_eq if pair else valu + mf_eq) / peak,
                "what": sp["what"]}
         c = kernel_counters(doc, pmc_f if which == "fwd" else pmc_b)
         if c is not None and "derived" in c:
@@ -381,20 +444,53 @@ def roofline_record(D, T, B, variant, rank1, t_fwd, t_bwd, ms_per_step):
                         "what": "FETCH_SIZE x 2 + WRITE_SIZE of the scan launches of one step (rocprofv3 --pmc, separate passes; "
                                 "MI355X_MICROARCH.md corrections): implementation traffic = the per-step state stash, written by the "
                                 "forward and read by the reverse sweep", "source": doc["_source"]}
+    bytes_alg = 8.0 * B * T
+    krecs = kernel_records(fam, D, T, B, rank1, ktimes) if ktimes else None
+    if fam in ("wide", "pair"):
+        # Several kernels on different pipes per entry point: SURVEY's algorithmic flops over ONE pipe's peak is not a fraction of
+        # anything (round 3: 1.32).  The dominant kernel is the one with the longest launch; its record against ITS OWN pipe is the
+        # object's achieved / peak / frac; the algorithmic figure stays as a rate without a denominator.
+        comp = [r for r in (krecs or []) if r.get("pipe") in ("valu_fp32", "mfma_f32", "mfma_bf16")]
+        top = max(comp, key=lambda r: r["duration_ms"]) if comp else None
+        whole_alg = (alg["fwd"] + alg["bwd"]) / (1e-3 * ms_per_step) / 1e12
+        return {
+            "bound": "mfma",
+            "binding": ("one LDS round trip (store latency + barrier + operand burst) + 512 matrix-pipe cycles + the dependent tail per step of "
+                        "ONE wave per SIMD") if pair else
+                       "instruction issue of the float32 chain kernels (two waves per SIMD); the GEMM kernels sit at what hides behind an MFMA",
+            "kernel": top["kernel"] if top else (name_f if dom == "fwd" else name_b),
+            "pipe": top["pipe"] if top else None,
+            "achieved": top["achieved"] if top else None, "peak": top["peak"] if top else peak, "unit": "TFLOP/s",
+            "frac": top["frac"] if top else None,
+            "frac_is": "EXECUTED flops of the longest kernel on the pipe it runs on / its live launch time / that pipe's peak (`kernels` has "
+                       "every kernel and pipe of the family, HBM included)",
+            "launch_ms": top["duration_ms"] if top else tt[dom] * 1e3,
+            "traffic": traffic, "traffic_source": doc["_source"] if doc is not None else None,
+            "algorithmic_bytes": 4.0 * B * T,
+            "kernels": krecs,
+            "algorithmic": {"flops_per_step": alg["fwd"] + alg["bwd"], "whole_step_tflops": whole_alg,
+                            "fwd_entry_tflops": alg["fwd"] / t_fwd / 1e12, "bwd_entry_tflops": alg["bwd"] / t_bwd / 1e12,
+                            "note": "SURVEY 8(d): 80 D^2 flop per (clip, sample) over the entry points' times -- a rate, deliberately not divided "
+                                    "by a peak: the work is spread over the fp32 VALU and the bf16 matrix pipe"},
+            "entry_ms": {"cmps_psi_loss_fwd": t_fwd * 1e3, "cmps_psi_loss_bwd": t_bwd * 1e3},
+            "step_traffic": step_traffic,
+            "hbm": {"achieved_algorithmic": bytes_alg / (t_fwd + t_bwd) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac_algorithmic": bytes_alg / (t_fwd + t_bwd) / 1e9 / HBM_PEAK_GBS},
+        }
     ach = alg[dom] / tt[dom] / 1e12
     whole = (alg["fwd"] + alg["bwd"]) / (1e-3 * ms_per_step) / 1e12
-    bytes_alg = 8.0 * B * T
     return {
         "bound": "mfma",            # the contract's class for a compute-bound kernel (the other class is "hbm"): see `binding`
         "binding": ("instruction issue of ONE wave per SIMD: fp32 VALU mat-vecs on the serial chain, rank-1 / loss products beside them on "
                     "the matrix cores; 10 D^2 algorithmic flop per algorithmic byte, so never HBM") if not pair else
-                   "bf16 MFMA (4x4x4 batched) issue interval + one LDS round trip per step",
+                   "one LDS round trip (store latency + barrier + operand burst) + 512 matrix-pipe cycles + the dependent tail per step of ONE wave per SIMD",
         "kernel": name_f if dom == "fwd" else name_b, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
         "frac_is": "ALGORITHMIC flops (SURVEY 8(d)) / launch time / peak: includes work the kernel eliminates or runs on the other pipe; "
                    "`executed` has the per-pipe rates",
         "traffic": traffic, "traffic_source": doc["_source"] if doc is not None else None,
         "algorithmic_bytes": 4.0 * B * T, "launch_ms": tt[dom] * 1e3, "flops_per_launch": alg[dom],
         "executed": pipes(dom),
+        "kernels": krecs,
         "other_kernel": {"kernel": name_b if dom == "fwd" else name_f, "achieved": alg[oth] / tt[oth] / 1e12,
                          "frac": alg[oth] / tt[oth] / 1e12 / peak, "launch_ms": tt[oth] * 1e3, "executed": pipes(oth)},
         "whole_step": {"flops": alg["fwd"] + alg["bwd"], "achieved": whole, "frac": whole / peak,
@@ -472,6 +568,23 @@ class Run:
         return {"elapsed": elapsed, "local": local, "t_fwd": float(np.mean(tm["fwd"])) * 1e-3,
                 "t_bwd": float(np.mean(tm["bwd"])) * 1e-3, "last": self.last_loss()}
 
+    def kernel_pass(self, steps=3):
+        """Per-kernel live durations of the same step (HIP events around every launch, cmps_kernel_times): a separate short pass, so
+        the events never sit inside the timed region."""
+        import torch
+        be = self.backend
+        be.kernel_events(True)
+        try:
+            self.step()                                              # first launch with events: event creation
+            torch.cuda.synchronize()
+            be.kernel_times()
+            for _ in range(steps):
+                self.step()
+            torch.cuda.synchronize()
+            return be.kernel_times()
+        finally:
+            be.kernel_events(False)
+
     def parity(self, sample, ref, pair):
         """The GPU's per-clip loss and gradient sums on a host sample against the oracle's (chunks of at most B clips)."""
         import torch
@@ -492,9 +605,13 @@ class Run:
         per = np.concatenate(pers)
         g = unpack_grad(flat.astype(np.float32), D)
         loss_err = float(np.max(np.abs(per - ref["loss_per_clip"]) / np.maximum(np.abs(ref["loss_per_clip"]), 1.0)))
+        loss_err_plain = float(np.max(np.abs(per - ref["loss_per_clip"]) / np.maximum(np.abs(ref["loss_per_clip"]), 1e-30)))
         gerr = {k: rel_inf(g[k], gr[k]) for k in ("Rbar", "fbar", "psi0bar", "Abar")}
         tol_l, tol_g = (2e-3, 3e-2) if pair else (1e-5, 1e-4)
-        return {"clips": Bs, "max_rel_loss_err": loss_err, "max_rel_grad_err": max(gerr.values()), "grad_err_by_tensor": gerr,
+        return {"clips": Bs, "max_rel_loss_err": loss_err, "max_rel_loss_err_unfloored": loss_err_plain,
+                "loss_err_note": "max_rel_loss_err = |d| / max(|loss_b|, 1) (the tolerance's form); _unfloored = |d| / |loss_b|, with min |loss_b| = "
+                                 f"{float(np.min(np.abs(ref['loss_per_clip']))):.3g} on this sample",
+                "max_rel_grad_err": max(gerr.values()), "grad_err_by_tensor": gerr,
                 "tolerance": {"loss": tol_l, "grad": tol_g}, "ok": bool(loss_err <= tol_l and max(gerr.values()) <= tol_g),
                 "against": "oracle/cmps_oracle.c float32 (parity UNPINNED: no reference-held vectors exist)"}
 
@@ -530,7 +647,7 @@ def other_config_rows(ARGS, dp, dev):
             run = Run(D, T, B, variant, ARGS.rank1, ARGS.input, dp, dev, 1, 0, ARGS.host_optimizer, config_id=cid)
             r = run.timed(steps, 2)
             ms = 1e3 * r["elapsed"] / steps
-            roof = roofline_record(D, T, B, run.variant, run.backend.rank1, r["t_fwd"], r["t_bwd"], ms)
+            roof = roofline_record(D, T, B, run.variant, run.backend.rank1, r["t_fwd"], r["t_bwd"], ms, run.kernel_pass(2))
             clips = min(B, 16)
             sample = make_audio_host(ARGS.input, clips, T, run.hp.delta_t, run.seed)
             run.trainer.sync_to_host()
@@ -541,9 +658,10 @@ def other_config_rows(ARGS, dp, dev):
             rows.append({"config": name, "ms_per_step": ms, "value": B * T * steps / r["elapsed"], "unit": "samples/s", "steps": steps,
                          "kernel_variant": run.variant, "dtype": dtype_label(run.variant, D, run.backend.rank1),
                          "fwd_ms": r["t_fwd"] * 1e3, "bwd_ms": r["t_bwd"] * 1e3, "final_loss": r["last"],
-                         "dominant_kernel": roof["kernel"], "frac": roof["frac"], "peak": roof["peak"],
-                         "frac_executed_fp32_equiv": roof["executed"]["frac_executed_fp32_equiv"],
-                         "whole_step_frac": roof["whole_step"]["frac"],
+                         "dominant_kernel": roof["kernel"], "dominant_pipe": roof.get("pipe", "valu_fp32 (algorithmic flops, see roofline.frac_is)"),
+                         "frac": roof["frac"], "peak": roof["peak"], "kernels": roof.get("kernels"),
+                         "algorithmic_whole_step_tflops": (roof["algorithmic"]["whole_step_tflops"] if "algorithmic" in roof
+                                                           else roof["whole_step"]["achieved"]),
                          "cpu_port": {"value": clips * T / cpu_s, "unit": "samples/s", "cores": cores, "sample": f"{clips} clips, {cpu_s:.2f} s"},
                          "parity_in_bench": par})
         except Exception as exc:                                      # a failing side configuration must not take the headline down
@@ -558,7 +676,7 @@ def other_config_rows(ARGS, dp, dev):
 # ---------------------------------------------------------------------------------------------------
 def worker(ARGS):
     import torch
-    from audio_mps_amd.parallel import DataParallel
+    from audio_mps_amd.parallel import DataParallel, collective_settings
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -581,7 +699,13 @@ def worker(ARGS):
     if not np.isfinite(r["last"]):
         raise SystemExit(f"non-finite loss {r['last']}")
     allreduce_us = dp.collective_us()                            # mean HIP-event time of the collective (None at N = 1)
+    ktimes = run.kernel_pass(3) if (rank == 0 and world == 1) else None      # per-kernel durations, outside the timed region
     per_rank_ms = dp.gather_floats(1e3 * r["local"] / ARGS.steps)
+    # the data-parallel invariant: after the same all-reduced sums every rank holds bit-identical variables and Adam slots
+    replicas_ok = None
+    if world > 1 and not ARGS.host_optimizer:
+        st = run.trainer._dev
+        replicas_ok = all(dp.replicas_identical(st[k]) for k in ("vars", "m", "v"))
     rccl_world = dp.measured_world_size()                        # dist.get_world_size() after a GPU all-reduce of ones
 
     out = None
@@ -605,12 +729,14 @@ def worker(ARGS):
                        "optimizer_step": "host" if ARGS.host_optimizer else "device (cmps_psi_apply_step)",
                        "rank1_updates": (("exact fp32 MFMA (16-row layout)" if fam == "wave16" else RANK1_LABEL[rank1])
                                          if fam in ("wave", "wave16", "wide") else None)},
-            "roofline": roofline_record(D, T, B, variant, rank1, r["t_fwd"], r["t_bwd"], ms_per_step),
+            "roofline": roofline_record(D, T, B, variant, rank1, r["t_fwd"], r["t_bwd"], ms_per_step, ktimes),
             "final_loss": float(r["last"]),
             "per_rank_ms_per_step": {"min": float(np.min(per_rank_ms)), "max": float(np.max(per_rank_ms))},
             "rccl_world_size": rccl_world,
             "allreduce_us": allreduce_us,
             "collective_backend": dp.backend,                    # "nccl" (= RCCL), "gloo" (rehearsal) or None (N = 1 in process)
+            "collective": {"message_bytes": 4 * (2 * D * D + 3 * D + 2), "calls_per_step": 1, "op": "all_reduce(sum), in place on the device buffer",
+                           "settings": collective_settings(), "replicas_bit_identical_after_run": replicas_ok},
         }
         if ARGS.rehearse_on_one_gpu:
             out["rehearsal"] = "all ranks share cuda:0 and reduce over gloo on the host: NOT a scaling measurement"

@@ -65,7 +65,11 @@ enum {
 enum {
     CMPS_OPT_RANK1 = 1 /* arithmetic of the rank-1 gradient sums: the wave-per-clip reverse scan of 17 <= D <= 32 (the 16-row layout
                         * of D <= 16 always uses exact fp32 MFMAs) and the gradient GEMM of the wide kernels (32 < D <= 128:
-                        * BF16X2 = two pieces / three products, anything else = three pieces / six products) */
+                        * BF16X2 = two pieces / three products, anything else = three pieces / six products) */,
+    CMPS_OPT_KERNEL_EVENTS = 2 /* 1: every kernel cmps_psi_loss_fwd / _bwd launch is bracketed by two HIP events on the caller's stream
+                        * (read and reset with cmps_kernel_times); 0 (default): nothing is recorded.  A measurement aid -- the reference
+                        * has no counterpart (no tracing / profiling hooks); bench.py uses it OUTSIDE its timed region to price
+                        * each kernel of a multi-kernel family against the pipe it runs on */
 };
 /* values of CMPS_OPT_RANK1.  All three accumulate in fp32; they differ in how the two factors of every product
  * dR += a b^dagger enter the matrix cores:
@@ -88,13 +92,17 @@ int cmps_create(int D, cmps_handle_t* out);
 int cmps_destroy(cmps_handle_t h);
 const char* cmps_last_error(cmps_handle_t h);
 int cmps_set_variant(cmps_handle_t h, int variant);
-/* The variant the next launch will use (after AUTO resolution): CMPS_VARIANT_BLOCK, _WAVE, _PAIR or _WAVE32. */
+/* The variant the next launch will use (after AUTO resolution): CMPS_VARIANT_BLOCK, _WAVE, _PAIR, _WAVE32 or _WIDE. */
 int cmps_get_variant(cmps_handle_t h);
 /* Numerical options of the gradient path; the reference has one arithmetic (TensorFlow float32 kernels behind
  * train.py:89), so every value of every option must stay within the stated float32 tolerance of it.
  * cmps_get_option returns the value, or -1 for an unknown option / null handle. */
 int cmps_set_option(cmps_handle_t h, int option, int value);
 int cmps_get_option(cmps_handle_t h, int option);
+/* With CMPS_OPT_KERNEL_EVENTS on: waits for the recorded events, writes per kernel name (in first-launch order) the summed milliseconds
+ * and the launch count since the last call, the names '\n'-joined into `names`; returns the number of distinct kernels (<= cap), -1 on
+ * error (option off, bad argument, buffer too small).  Resets the record.  No reference counterpart (see CMPS_OPT_KERNEL_EVENTS). */
+int cmps_kernel_times(cmps_handle_t h, char* names, size_t names_bytes, float* ms_sum, int* calls, int cap);
 
 /* Bytes of device workspace the caller must provide for bond dimension D, B clips of T samples.
  * Returns 0 for invalid arguments. */

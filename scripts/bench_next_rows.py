@@ -67,7 +67,7 @@ t0 = time.perf_counter()
 O.legacy_loss_and_grads(lm.variables["H"], lm.variables["R"], lm.delta_t, audio[:8, :1000].cpu().numpy())
 cpu = 8 * 1000 / (time.perf_counter() - t0)
 res["legacy_audiomps"] = {"shape": f"D=32, T={T}, B={B}, fwd+bwd", "kernel": "k_fwd_wave2<LEGACY> + k_bwd_wave<LEGACY> (the pure-state wave kernels in legacy mode)", "ms": ms,
-                          "samples_per_s": B * T / ms * 1e3, "cpu_numpy_samples_per_s": cpu, "bound": "straight-line wave-per-clip kernels: two wave reductions per forward step, three exact fp32 MFMAs per reverse step (latency)"}
+                          "samples_per_s": B * T / ms * 1e3, "cpu_numpy_samples_per_s": cpu, "bound": "instruction issue of one wave per SIMD, as the headline kernels (the pure-state wave kernels in legacy mode: merged mat-vec chain, loss wave and rank-1 sums on the matrix cores)"}
 
 # ---- rank 3: RhoCMPS forward + backward (rank-r column kernels), D = 32, rank 4 and 32, T = 1000, 256 clips
 for rank in (4, 32):

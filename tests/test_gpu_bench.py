@@ -37,6 +37,10 @@ def test_two_rank_rehearsal_on_one_gpu():
     assert rec["value"] > 0 and rec["ms_per_step"] >= pr["max"] * 0.999          # max over ranks, barrier included
     assert rec["config"]["parallelism"] == "dp2" and "global 32" in rec["config"]["workload"]
     assert "rehearsal" in rec and rec["cpu_baseline"] is None
+    # one collective per step of 2 D^2 + 3 D + 2 floats, and every rank holds bit-identical variables and Adam slots after 3 steps
+    # (the invariant configs[3] rests on: same all-reduced sums -> same update everywhere; /root/reference has no counterpart)
+    assert rec["collective"]["message_bytes"] == 4 * (2 * 32 * 32 + 3 * 32 + 2) and rec["collective"]["calls_per_step"] == 1
+    assert rec["collective"]["replicas_bit_identical_after_run"] is True
     # whole-job aggregate: both ranks' samples over the max-over-ranks time
     assert rec["value"] == pytest.approx(2 * 16 * 600 * 2 / (rec["ms_per_step"] * 2e-3), rel=1e-6)
 
@@ -50,6 +54,7 @@ def test_one_rank_through_rccl_matches_in_process():
     spawned = _bench(["--gpus", "1", "--spawn"] + shape)
     inproc = _bench(["--gpus", "1"] + shape)
     assert spawned["n_gpus"] == 1 and spawned["collective_backend"] == "nccl" and spawned["rccl_world_size"] == 1
+    assert spawned["collective"]["settings"]["NCCL_PROTO"] == "LL"          # the low-latency default is in force under RCCL
     assert spawned["allreduce_us"] is not None and 0.0 < spawned["allreduce_us"] < 5e4
     assert inproc["collective_backend"] is None and inproc["allreduce_us"] is None
     assert spawned["final_loss"] == pytest.approx(inproc["final_loss"], rel=1e-5)      # same parameters after the same steps

@@ -300,3 +300,27 @@ def test_rho_gemm_sampler_matches_block_sampler(D, rank, length, n):
     assert np.max(np.abs(wa - wb)) <= 1e-4 * scale
     assert rel_inf(m.rho_evolve_with_sampling(n, length, noise=noise), blk.rho_evolve_with_sampling(n, length, noise=noise)) <= 1e-4
     np.testing.assert_allclose(m.purity(n, length, noise=noise), blk.purity(n, length, noise=noise), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("D,rank", [(8, 3), (24, 12), (40, 5)])      # column wave kernels, row-array GEMM kernels, block kernels
+def test_rho_entries_after_set_params_dev(D, rank):
+    """ADVICE r3: cmps_set_params_dev keeps A in device memory (Dev::Adev) and leaves Dev::A unset; the rho kernels used to read
+    Dev::A and divided by zero.  Every rho kernel family must give the same losses and gradient sums after cmps_set_params_dev
+    as after cmps_set_params with the same numbers."""
+    import torch
+    m, audio = _rho_model(D, 60, 3, rank=rank, rscale=0.3 if D > 32 else None)
+    be = m._get_backend()
+    p = m.effective_params()
+    dev_audio = m._to_device(audio)
+    be.set_params(p, 3, 60, train=True)
+    be.rho_set_state(m.columns(), 3, 60, train=True)
+    ref_loss, ref_grad = (t.cpu().numpy().copy() for t in be.rho_loss_and_grad_sums(dev_audio))
+    R = np.asarray(p.R)
+    flat = np.concatenate([R.real.ravel(), R.imag.ravel(), np.asarray(p.freqs), np.asarray(p.psi0).real, np.asarray(p.psi0).imag,
+                           [float(p.A)]]).astype(np.float32)
+    be.set_params_dev(torch.from_numpy(flat).to(be.device), p.sigma, p.delta_t, 3, 60, train=True)
+    be.rho_set_state(m.columns(), 3, 60, train=True)
+    loss, grad = (t.cpu().numpy() for t in be.rho_loss_and_grad_sums(dev_audio))
+    assert np.all(np.isfinite(loss)) and np.all(np.isfinite(grad))
+    np.testing.assert_allclose(loss, ref_loss, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(grad, ref_grad, rtol=1e-5, atol=1e-6 * np.max(np.abs(ref_grad)))
