@@ -198,10 +198,10 @@ __device__ __forceinline__ void load_frags(u4 (&frag)[PD / 8], int w, int kg, F&
         }
 }
 
-#if defined(CMPS_DIAG) && defined(PABL_NO_MFMA)       // diagnostic builds only (scripts/ablate.py)
-#define PAIR_ASM(TEXT) "s_nop 0"
+#if defined(CMPS_DIAG) && (defined(PABL_NO_MFMA) || defined(PABL_LOSS_NO_MFMA))      // diagnostic builds only (scripts/ablate.py)
+#define PAIR_LASM(TEXT) "s_nop 0"
 #else
-#define PAIR_ASM(TEXT) TEXT
+#define PAIR_LASM(TEXT) TEXT
 #endif
 // ---- LDS reads of the A operands, all in asm: issued back to back, awaited K-step by K-step with counted lgkmcnt waits (LDS
 // operations of a wave complete in order, so whatever else is in flight only makes a counted wait stricter) ----
@@ -576,6 +576,10 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
             }
             FHre[t] = u4{rr[0], rr[1], rr[2], rr[3]};
             FHim[t] = u4{ii[0], ii[1], ii[2], ii[3]};
+            // one fragment pair at a time ("memory": the loads of the next pair stay behind this point): with all 64 row loads in
+            // flight the prologue was the kernel's register peak, and the allocator then kept fragments in scratch memory for the
+            // whole loop (reloaded behind s_waitcnt vmcnt(0) in every step: 2 ms of the round-4 forward until this was found)
+            asm volatile("" : "+v"(FHre[t]), "+v"(FHim[t]) :: "memory");
         }
     }
     // byte offsets of this lane inside a ring slot: B operand rows (H_re part: own component; H_im part: -im for Re columns,
@@ -589,7 +593,7 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
     float loss0 = 0.f, loss1 = 0.f;
     f16t acc, accE;                                                    // the tile being accumulated / the finished tile of the batch before
     f4 yv[4];                                                          // y (float32) of this lane's column: rows 32 w + 8 g + 4 hk ..+3
-    float epE = 0.f;
+    float epE = 0.f, xp0 = 0.f, xp1 = 0.f;
     __syncthreads();
     // Batch bt of the loop: multiplies batch pb = bt - 1 (two MFMAs per step), reads its float32 y (steps 0-3) and stores it
     // (step 4); finishes batch pe = bt - 2 from the tile copied at the end of the iteration before: H y stores (step 0),
@@ -605,14 +609,23 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
         const unsigned char* bslot = &RG.b[(pb & 1) * FB + sb][0][0][0];
         const unsigned char* fslot = &RG.f[(pb & 1) * FB + sb][0][0][0];
         const int step_b = FB * pb + sb, step_e = FB * pe + sb;       // this lane's step in either batch
+#if defined(CMPS_DIAG) && defined(PABL_LOSS_NO_READS)     // diagnostic builds only (scripts/ablate.py)
+#define PAIR_LOSS_BV(p) u4{(unsigned)(uintptr_t)(p), 1u, 2u, 3u}
+#else
+#define PAIR_LOSS_BV(p) (*reinterpret_cast<const u4*>(p))
+#endif
 #define PAIR_LOSS_STEP(J)                                                                                                  \
         {                                                                                                                  \
-            if constexpr (LOSS_SLEEP > 0) __builtin_amdgcn_s_sleep(LOSS_SLEEP);                                            \
             if (fin) {                                                                                                     \
-                if ((J) == 0 && SAVE && step_e < N) {                /* H y of batch pe */                                 \
-                    float* hp = stash + pair_stash_index<PD>(blockIdx.x, N, step_e, 1, clip, comp, 32 * w + 4 * hk);       \
-                    _Pragma("unroll") for (int g = 0; g < 4; ++g)                                                          \
-                        *reinterpret_cast<f4*>(hp + 8 * g) = f4{accE[4 * g], accE[4 * g + 1], accE[4 * g + 2], accE[4 * g + 3]}; \
+                if (((J) & 1) == 0 && SAVE && step_e < N) {          /* H y of batch pe: ONE 16-byte store per lane and step (J = 0, 2, 4, 6) -- */ \
+                    constexpr int g = (J) / 2;                         /* four in one step made that step the slowest of the batch, and every    */ \
+                    float* hp = stash + pair_stash_index<PD>(blockIdx.x, N, step_e, 1, clip, comp, 32 * w + 4 * hk);   /* barrier waits for the slowest wave */ \
+                    *reinterpret_cast<f4*>(hp + 8 * g) = f4{accE[4 * g], accE[4 * g + 1], accE[4 * g + 2], accE[4 * g + 3]}; \
+                }                                                                                                          \
+                if ((J) == 1) {                                      /* the two audio samples of this lane's step, four steps before their use */ \
+                    const bool in = step_e < N;                                                                            \
+                    xp0 = in ? xr_c[step_e] : 0.f;                                                                         \
+                    xp1 = (in && step_e + 1 < T) ? xr_c[step_e + 1] : 0.f;                                                 \
                 }                                                                                                          \
                 if ((J) == 1) {                                                                                            \
                     float ep = half_add(epE, epE);                     /* + the other row half */                          \
@@ -623,8 +636,7 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
                 if ((J) == 5) {                                      /* e of (step, clip) = lane & 15, the loss, the e row */ \
                     const float e = sum_waves<PWV>(&RG.ee[pe & 1][n & 15][0]);                                            \
                     const bool in = step_e < N;                                                                            \
-                    const float x0 = in ? xr_c[step_e] : 0.f, x1 = (in && step_e + 1 < T) ? xr_c[step_e + 1] : 0.f;        \
-                    const float lv = in ? -logf(1.0f + (e * (x1 - x0)) / A) : 0.f;  /* model.py:294 operation order */      \
+                    const float lv = in ? -logf(1.0f + (e * (xp1 - xp0)) / A) : 0.f;  /* model.py:294 operation order */    \
                     if (SAVE && w == 0 && lane < 2 * FB && in && clip_live)                                                 \
                         sc_c[(size_t)(step_e / PCH) * 128 + 64 + (step_e & (PCH - 1))] = e;                               \
                     _Pragma("unroll") for (int jj = 0; jj < FB; ++jj) {  /* model.py:279: sequential in time */             \
@@ -635,26 +647,33 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
             }                                                                                                              \
             if (mul) {                                                                                                     \
                 if ((J) < 4) yv[(J) & 3] = *reinterpret_cast<const f4*>(fslot + of + 32 * ((J) & 3));                      \
-                if ((J) == 4 && SAVE && step_b < N) {                /* y of batch pb (the repeated clip of an odd batch too) */ \
+                if (((J) & 1) == 1 && SAVE && step_b < N) {          /* y of batch pb (the repeated clip of an odd batch too): one store per */ \
+                    constexpr int g = (J) / 2;                         /* lane at J = 1, 3, 5, 7 (yv[g] was read at J = g)                     */ \
                     float* yp = stash + pair_stash_index<PD>(blockIdx.x, N, step_b, 0, clip, comp, 32 * w + 4 * hk);       \
-                    _Pragma("unroll") for (int g = 0; g < 4; ++g) *reinterpret_cast<f4*>(yp + 8 * g) = yv[g];              \
-                    if (w == 0 && lane < 2 * FB && clip_live)                                                              \
-                        sc_c[(size_t)(step_b / PCH) * 128 + (step_b & (PCH - 1))] =                                        \
-                            sum_waves<PWV>(&RG.nrm[(pb & 1) * FB + sb][clip][0]);                                          \
+                    *reinterpret_cast<f4*>(yp + 8 * g) = yv[g];                                                            \
+                }                                                                                                          \
+                if ((J) == 4 && SAVE && step_b < N && w == 0 && lane < 2 * FB && clip_live)                                 \
+                    sc_c[(size_t)(step_b / PCH) * 128 + (step_b & (PCH - 1))] = sum_waves<PWV>(&RG.nrm[(pb & 1) * FB + sb][clip][0]); \
+                u4 bvs[KT / FB];                                                                                           \
+                _Pragma("unroll") for (int t = (J) * KT / FB; t < ((J) + 1) * KT / FB; ++t)                                \
+                    bvs[t - (J) * KT / FB] = PAIR_LOSS_BV(bslot + (t < KS ? ob1 : ob2) + 32 * (t < KS ? t : t - KS));      \
+                if constexpr (LOSS_SLEEP > 0) {                      /* the MFMAs go to the matrix pipe when the chain is in its tail */ \
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
+                    __builtin_amdgcn_s_sleep(LOSS_SLEEP);                                                                  \
                 }                                                                                                          \
                 _Pragma("unroll") for (int t = (J) * KT / FB; t < ((J) + 1) * KT / FB; ++t) {                              \
                     const int tt = t < KS ? t : t - KS;                                                                    \
-                    const u4 bv = *reinterpret_cast<const u4*>(bslot + (t < KS ? ob1 : ob2) + 32 * tt);                    \
+                    const u4 bv = bvs[t - (J) * KT / FB];                                                                  \
                     /* asm (fixed issue points); no AGPR operand anywhere in this kernel: see kstep */                           \
                     if (t == 0)                                                                                            \
-                        asm volatile(PAIR_ASM("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0") : "=&v"(acc) : "v"(FHre[0]), "v"(bv));     \
+                        asm volatile(PAIR_LASM("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0") : "=&v"(acc) : "v"(FHre[0]), "v"(bv));     \
                     else if (t == KT - 1)       /* + the wait states before the VALU reads the tile (8 passes) */          \
-                        asm volatile(PAIR_ASM("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 7")          \
+                        asm volatile(PAIR_LASM("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 7")          \
                                      : "+v"(acc) : "v"(FHim[KS - 1]), "v"(bv));                                            \
                     else if (t < KS)                                                                                       \
-                        asm volatile(PAIR_ASM("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0") : "+v"(acc) : "v"(FHre[tt]), "v"(bv));   \
+                        asm volatile(PAIR_LASM("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0") : "+v"(acc) : "v"(FHre[tt]), "v"(bv));   \
                     else                                                                                                   \
-                        asm volatile(PAIR_ASM("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0") : "+v"(acc) : "v"(FHim[tt]), "v"(bv));   \
+                        asm volatile(PAIR_LASM("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0") : "+v"(acc) : "v"(FHim[tt]), "v"(bv));   \
                 }                                                                                                          \
                 if ((J) == FB - 1) {                                 /* the tile is complete: e partial, hand the tile over */ \
                     float ep = 0.f;                                                                                        \
@@ -669,6 +688,7 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
         PAIR_LOSS_STEP(0) PAIR_LOSS_STEP(1) PAIR_LOSS_STEP(2) PAIR_LOSS_STEP(3)
         PAIR_LOSS_STEP(4) PAIR_LOSS_STEP(5) PAIR_LOSS_STEP(6) PAIR_LOSS_STEP(7)
 #undef PAIR_LOSS_STEP
+#undef PAIR_LOSS_BV
     }
     if (w == 0 && lane == 0) {
         loss_out[b0] = loss0;
