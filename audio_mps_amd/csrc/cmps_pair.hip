@@ -654,7 +654,7 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
                 }                                                                                                          \
                 if ((J) == 4 && SAVE && step_b < N && w == 0 && lane < 2 * FB && clip_live)                                 \
                     sc_c[(size_t)(step_b / PCH) * 128 + (step_b & (PCH - 1))] = sum_waves<PWV>(&RG.nrm[(pb & 1) * FB + sb][clip][0]); \
-                u4 bvs[KT / FB];                                                                                           \
+                u4 bvs[(KT + FB - 1) / FB];                                                                                \
                 _Pragma("unroll") for (int t = (J) * KT / FB; t < ((J) + 1) * KT / FB; ++t)                                \
                     bvs[t - (J) * KT / FB] = PAIR_LOSS_BV(bslot + (t < KS ? ob1 : ob2) + 32 * (t < KS ? t : t - KS));      \
                 if constexpr (LOSS_SLEEP > 0) {                      /* the MFMAs go to the matrix pipe when the chain is in its tail */ \
