@@ -213,7 +213,7 @@ __device__ __forceinline__ void rd_own(unsigned lo0, unsigned hi0, u4& vlo, u4& 
 }
 // two 16-byte table rows (x0, x1: per-step scalars, rho rows, norm partials) and then the K-steps tau = 1 .. KH - 1 of both halves:
 // 2 + 2 (KH - 1) reads; v[tau - 1] / v[KH - 1 + tau - 1]
-template <int KH, int POFF>
+template <int KH, int POFF, bool TABLES_LAST>
 __device__ __forceinline__ void rd_rest(unsigned ax0, unsigned ax1, const unsigned (&lo)[KH], const unsigned (&hi)[KH], f4& x0, f4& x1,
                                         u4 (&v)[2 * KH - 2]) {
 #if defined(CMPS_DIAG) && defined(PABL_NO_READS)      // diagnostic builds only (scripts/ablate.py): the table rows only
@@ -222,23 +222,43 @@ __device__ __forceinline__ void rd_rest(unsigned ax0, unsigned ax1, const unsign
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     return;
 #endif
-    if constexpr (KH == 4)
-        asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\t"
-                     "ds_read_b128 %2, %10 offset:%16\n\tds_read_b128 %3, %11 offset:%16\n\tds_read_b128 %4, %12 offset:%16\n\t"
-                     "ds_read_b128 %5, %13 offset:%16\n\tds_read_b128 %6, %14 offset:%16\n\tds_read_b128 %7, %15 offset:%16"
-                     : "=&v"(x0), "=&v"(x1), "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5])
-                     : "v"(ax0), "v"(ax1), "v"(lo[1]), "v"(lo[2]), "v"(lo[3]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]), "n"(POFF) : "memory");
-    else if constexpr (KH == 3)
-        asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %7\n\t"
-                     "ds_read_b128 %2, %8 offset:%12\n\tds_read_b128 %3, %9 offset:%12\n\t"
-                     "ds_read_b128 %4, %10 offset:%12\n\tds_read_b128 %5, %11 offset:%12"
-                     : "=&v"(x0), "=&v"(x1), "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
-                     : "v"(ax0), "v"(ax1), "v"(lo[1]), "v"(lo[2]), "v"(hi[1]), "v"(hi[2]), "n"(POFF) : "memory");
-    else
-        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\t"
-                     "ds_read_b128 %2, %6 offset:%8\n\tds_read_b128 %3, %7 offset:%8"
-                     : "=&v"(x0), "=&v"(x1), "=&v"(v[0]), "=&v"(v[1])
-                     : "v"(ax0), "v"(ax1), "v"(lo[1]), "v"(hi[1]), "n"(POFF) : "memory");
+    if constexpr (!TABLES_LAST) {
+        if constexpr (KH == 4)
+            asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\t"
+                         "ds_read_b128 %2, %10 offset:%16\n\tds_read_b128 %3, %11 offset:%16\n\tds_read_b128 %4, %12 offset:%16\n\t"
+                         "ds_read_b128 %5, %13 offset:%16\n\tds_read_b128 %6, %14 offset:%16\n\tds_read_b128 %7, %15 offset:%16"
+                         : "=&v"(x0), "=&v"(x1), "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5])
+                         : "v"(ax0), "v"(ax1), "v"(lo[1]), "v"(lo[2]), "v"(lo[3]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]), "n"(POFF) : "memory");
+        else if constexpr (KH == 3)
+            asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %7\n\t"
+                         "ds_read_b128 %2, %8 offset:%12\n\tds_read_b128 %3, %9 offset:%12\n\t"
+                         "ds_read_b128 %4, %10 offset:%12\n\tds_read_b128 %5, %11 offset:%12"
+                         : "=&v"(x0), "=&v"(x1), "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+                         : "v"(ax0), "v"(ax1), "v"(lo[1]), "v"(lo[2]), "v"(hi[1]), "v"(hi[2]), "n"(POFF) : "memory");
+        else
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\t"
+                         "ds_read_b128 %2, %6 offset:%8\n\tds_read_b128 %3, %7 offset:%8"
+                         : "=&v"(x0), "=&v"(x1), "=&v"(v[0]), "=&v"(v[1])
+                         : "v"(ax0), "v"(ax1), "v"(lo[1]), "v"(hi[1]), "n"(POFF) : "memory");
+    } else {                       // the operands first: the table rows are not needed before the step's tail
+        if constexpr (KH == 4)
+            asm volatile("ds_read_b128 %2, %10 offset:%16\n\tds_read_b128 %3, %11 offset:%16\n\tds_read_b128 %4, %12 offset:%16\n\t"
+                         "ds_read_b128 %5, %13 offset:%16\n\tds_read_b128 %6, %14 offset:%16\n\tds_read_b128 %7, %15 offset:%16\n\t"
+                         "ds_read_b128 %0, %8\n\tds_read_b128 %1, %9"
+                         : "=&v"(x0), "=&v"(x1), "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5])
+                         : "v"(ax0), "v"(ax1), "v"(lo[1]), "v"(lo[2]), "v"(lo[3]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]), "n"(POFF) : "memory");
+        else if constexpr (KH == 3)
+            asm volatile("ds_read_b128 %2, %8 offset:%12\n\tds_read_b128 %3, %9 offset:%12\n\t"
+                         "ds_read_b128 %4, %10 offset:%12\n\tds_read_b128 %5, %11 offset:%12\n\t"
+                         "ds_read_b128 %0, %6\n\tds_read_b128 %1, %7"
+                         : "=&v"(x0), "=&v"(x1), "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+                         : "v"(ax0), "v"(ax1), "v"(lo[1]), "v"(lo[2]), "v"(hi[1]), "v"(hi[2]), "n"(POFF) : "memory");
+        else
+            asm volatile("ds_read_b128 %2, %6 offset:%8\n\tds_read_b128 %3, %7 offset:%8\n\t"
+                         "ds_read_b128 %0, %4\n\tds_read_b128 %1, %5"
+                         : "=&v"(x0), "=&v"(x1), "=&v"(v[0]), "=&v"(v[1])
+                         : "v"(ax0), "v"(ax1), "v"(lo[1]), "v"(hi[1]), "n"(POFF) : "memory");
+    }
 }
 // wait until at most W LDS operations are outstanding; the named registers are the reads this makes available
 template <int W>
@@ -298,36 +318,37 @@ __device__ __forceinline__ void mfma_valu_pipeline() {
         __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);     // two VALU
     }
 }
-template <int PD, int I, typename Piece>
+template <int PD, int I, int XTRA, typename Piece>
 __device__ __forceinline__ void ksteps_rest(const u4 (&FA)[PD / 8], const u4 (&FB)[PD / 8], u4 (&v)[PD / 16 - 2], f4& a0, f4& a1, f4& b0, f4& b1,
                                             Piece&& piece) {
     constexpr int KS = PD / 16, KH = PD / 32, NR = KS - 2;     // NR reads of the rest: lo tau = 1 .. KH - 1, then hi tau = 1 .. KH - 1
     if constexpr (I < NR) {
         constexpr int T = I < KH - 1 ? 1 + I : KH + 1 + (I - (KH - 1));   // index into the wave's fragment order
-        kstep<NR - 1 - I, false>(FA[T], FA[KS + T], FB[T], FB[KS + T], v[I], a0, a1, b0, b1);
+        kstep<NR - 1 - I + XTRA, false>(FA[T], FA[KS + T], FB[T], FB[KS + T], v[I], a0, a1, b0, b1);
         piece(ic<I + 1>{});
         mfma_valu_pipeline<4>();
         __builtin_amdgcn_sched_barrier(0);
-        ksteps_rest<PD, I + 1>(FA, FB, v, a0, a1, b0, b1, piece);
+        ksteps_rest<PD, I + 1, XTRA>(FA, FB, v, a0, a1, b0, b1, piece);
     } else if constexpr (I < 7) {
         piece(ic<I + 1>{});
-        ksteps_rest<PD, I + 1>(FA, FB, v, a0, a1, b0, b1, piece);
+        ksteps_rest<PD, I + 1, XTRA>(FA, FB, v, a0, a1, b0, b1, piece);
     }
 }
-template <int PD, int POFF, typename Piece>
+template <int PD, int POFF, bool TABLES_LAST, typename Piece>
 __device__ __forceinline__ void matvec2(const u4 (&FA)[PD / 8], const u4 (&FB)[PD / 8], const ChainLane<PD / 32>& g, unsigned ax0, unsigned ax1,
                                         u4& vlo, u4& vhi, f4& x0, f4& x1, f4& a0, f4& a1, f4& b0, f4& b1, Piece&& piece) {
     constexpr int KS = PD / 16, KH = PD / 32;
     u4 v[KS - 2];
-    rd_rest<KH, POFF>(ax0, ax1, g.lo, g.hi, x0, x1, v);
+    rd_rest<KH, POFF, TABLES_LAST>(ax0, ax1, g.lo, g.hi, x0, x1, v);
     __builtin_amdgcn_sched_barrier(0);
     kstep<KS, true>(FA[0], FA[KS], FB[0], FB[KS], vlo, a0, a1, b0, b1);          // (the counts are no-ops: vlo, vhi arrived
     kstep<KS, false>(FA[KH], FA[KS + KH], FB[KH], FB[KS + KH], vhi, a0, a1, b0, b1);   // before the barrier)
-    lds_wait2<KS - 2>(x0, x1);
+    if constexpr (!TABLES_LAST) lds_wait2<KS - 2>(x0, x1);
     piece(ic<0>{});
     mfma_valu_pipeline<8>();
     __builtin_amdgcn_sched_barrier(0);
-    ksteps_rest<PD, 0>(FA, FB, v, a0, a1, b0, b1, piece);
+    ksteps_rest<PD, 0, TABLES_LAST ? 2 : 0>(FA, FB, v, a0, a1, b0, b1, piece);
+    if constexpr (TABLES_LAST) lds_wait2<0>(x0, x1);
 }
 
 // rho rows are staged through LDS one 32-step chunk at a time (a row per step straight from L2 / HBM costs its full
@@ -415,7 +436,6 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
     const float* xr0 = audio + (size_t)b0 * T;
     const float* xr1 = audio + (size_t)b1 * T;
     const float A = dev_A(P);
-    const int tid = threadIdx.x;
     // both kinds run the same number of iterations (one barrier each): batch bt of the loss waves multiplies batch bt - 1 and
     // finishes batch bt - 2
     const int NBT = (N - 1) / FB + 3;
@@ -488,7 +508,7 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
             f4 xn, rh, cR0, cR1, cQ0, cQ1;                                                                                 \
             float inv, s;                                                                                                  \
             PAIR_FSTAMP_A();                                                                                               \
-            matvec2<PD, p * VEC>(FR, FQ, g, ax0, ax1, vlo, vhi, xn, rh, cR0, cR1, cQ0, cQ1, [&](auto pc) {                 \
+            matvec2<PD, p * VEC, false>(FR, FQ, g, ax0, ax1, vlo, vhi, xn, rh, cR0, cR1, cQ0, cQ1, [&](auto pc) {                 \
                 if constexpr (decltype(pc)::value == 0) {                                                                  \
                     inv = __builtin_amdgcn_rsqf(fmaxf(sum4<PWV>(xn), 1e-12f));           /* model.py:332 */                \
                     if ((J) == 0 && bt == 0) inv = 1.f;                                                                    \
@@ -739,6 +759,10 @@ struct StepTab {
 };
 
 constexpr int GB = 8;          // steps per block of the unrolled sweep
+#ifndef PAIR_BWD_TL
+#define PAIR_BWD_TL 1
+#endif
+constexpr bool PAIR_BWD_TABLES_LAST = PAIR_BWD_TL != 0;     // the scalar rows of step k - 2 behind the operand reads (A/B: -DPAIR_BWD_TL=0)
 #if defined(CMPS_DIAG) && defined(PABL_NO_PIECES)     // diagnostic builds only (scripts/ablate.py): the reverse scan without its off-chain work
 constexpr bool PAIR_NO_PIECES = true;
 #else
@@ -925,16 +949,15 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
         rd_own<p * VEC>(g.lo[0], g.hi[0], vlo, vhi);                                                                               \
         PAIR_STAMP(2);                                                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                                                         \
-        /* ---- behind the stores ---- */                                                                                          \
+        /* ---- behind the stores (about 70 cycles of store latency are free here; more would delay the barrier) ---- */            \
         float pyba, pybb;                                                                                                          \
+        const float una_ = una, unb_ = unb;                          /* u_{k+1}: the pieces below overwrite una .. only at the step's end */ \
         if constexpr (!PAIR_NO_PIECES) {                                                                                           \
             *reinterpret_cast<float2*>(ybar_base + (size_t)k * (4 * PD)) = make_float2(yba, ybb);    /* for the gradient GEMM */   \
-            pyba = partner16(yba, odd); pybb = partner16(ybb, odd);                                                                \
             facca += S1.z * (pga * una - ga * puna);                  /* the frequency gradient (meaningful in the Re lanes) */    \
             faccb += S1.z * (pgb * unb - gb * punb);                                                                               \
-            accS += (sda * una + sdb * unb) * ssy;                    /* Re(d^dagger u) of the step before: its u_k is this step's u_{k+1} */ \
         } else { pyba = yba; pybb = ybb; }                                                                                         \
-        PAIR_PIN2(facca, accS);                                                                                                    \
+        PAIR_PIN2(facca, faccb);                                                                                                   \
         PAIR_STAMP(3);                                                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                                                         \
         lds_barrier();                                                                                                             \
@@ -942,7 +965,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
         f4 cQ0, cQ1, cD0, cD1;                                                                                                     \
         float uka, ukb, puka, pukb, ypa, ypb, pypa, pypb;                                                                          \
         const unsigned ax0 = a_tab + 64 * (((km2 / PCH) & 1) * PCH + (km2 & (PCH - 1)));                                           \
-        matvec2<PD, p * VEC>(FQ, FD, g, ax0, ax0 + 16, vlo, vhi, nS0, nS1, cQ0, cQ1, cD0, cD1, [&](auto pc) {                      \
+        matvec2<PD, p * VEC, PAIR_BWD_TABLES_LAST>(FQ, FD, g, ax0, ax0 + 16, vlo, vhi, nS0, nS1, cQ0, cQ1, cD0, cD1, [&](auto pc) {                      \
             constexpr int PI = decltype(pc)::value;                                                                                \
             const float invp = SP0.y;                                                                                              \
             if constexpr (PI < 7) { PAIR_STAMP(5 + PI); }                                                                          \
@@ -952,19 +975,28 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
                 ypa = PRV.x * invp; ypb = PRV.y * invp;                                                                            \
                 pypa = partner16(ypa, odd); pypb = partner16(ypb, odd);                                                            \
                 PAIR_PIN4(ypa, ypb, pypa, pypb);                                                                                   \
-            } else if constexpr (PI == 1) {          /* u_k = rho_{k-1} yhat_{k-1}, both components */                             \
-                const float ria = sgn * rhp.y, rib = sgn * rhp.w;                                                                  \
+            } else if constexpr (PI == 1) {          /* u_k = rho_{k-1} yhat_{k-1}, both components: row ia .. */                  \
+                const float ria = sgn * rhp.y;                                                                                     \
                 uka = rhp.x * ypa + ria * pypa;   puka = rhp.x * pypa - ria * ypa;                                                 \
+                PAIR_PIN2(uka, puka);                                                                                              \
+            } else if constexpr (PI == 2) {          /* .. and row ib */                                                           \
+                const float rib = sgn * rhp.w;                                                                                     \
                 ukb = rhp.z * ypb + rib * pypb;   pukb = rhp.z * pypb - rib * ypb;                                                 \
-                PAIR_PIN4(uka, ukb, puka, pukb);                                                                                   \
-            } else if constexpr (PI == 2) {          /* the g-independent part of ybar_{k-1} */                                    \
+                PAIR_PIN2(ukb, pukb);                                                                                              \
+            } else if constexpr (PI == 3) {          /* the g-independent part of ybar_{k-1} */                                    \
                 const float radk = S1.x * SP0.z * invp;                /* rad_k ok_{k-1} inv_{k-1} */                              \
                 c3a = fmaf(SP0.w, PRV.z, -(ypa * radk));                                                                           \
                 c3b = fmaf(SP0.w, PRV.w, -(ypb * radk));                                                                           \
                 PAIR_PIN2(c3a, c3b);                                                                                               \
-            } else if constexpr (PI == 3) {                                                                                        \
+            } else if constexpr (PI == 4) {          /* the partner's ybar_k (row ia) and Re(d^dagger u) of the step before (its u_k is this step's u_{k+1}) */ \
+                pyba = partner16(yba, odd);                                                                                        \
+                accS += (sda * una_ + sdb * unb_) * ssy;                                                                           \
+                PAIR_PIN2(pyba, accS);                                                                                             \
+            } else if constexpr (PI == 5) {                                                                                        \
+                pybb = partner16(ybb, odd);                                                                                        \
+                PAIR_PIN1(pybb);                                                                                                   \
                 CUR = row_at(k - 8);                                  /* this slot's next row (row k is dead from here on) */      \
-            } else if constexpr (PI == 4) {                                                                                        \
+            } else if constexpr (PI == 6) {                                                                                        \
                 nrh = rho_rows(km2);                                  /* rho row of step k - 2 */                                  \
             }                                                                                                                      \
         });                                                                                                                        \
