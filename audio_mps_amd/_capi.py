@@ -32,7 +32,9 @@ CMPS_OPT_KERNEL_EVENTS = 2
 CMPS_RANK1_EXACT_F32 = 0
 CMPS_RANK1_BF16X2 = 1
 CMPS_RANK1_BF16X3 = 2
-RANK1_NAMES = {0: "exact_f32", 1: "bf16x2", 2: "bf16x3"}
+CMPS_RANK1_F16X2 = 3
+CMPS_RANK1_DEFAULT = 4
+RANK1_NAMES = {0: "exact_f32", 1: "bf16x2", 2: "bf16x3", 3: "f16x2", 4: "default"}
 
 # every symbol include/cmps.h declares
 SYMBOLS = (

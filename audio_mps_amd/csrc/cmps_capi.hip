@@ -16,7 +16,7 @@ namespace cmps { thread_local KTimer* g_ktimer = nullptr; }
 struct cmps_handle_s {
     int D = 0;
     int variant_req = CMPS_VARIANT_AUTO;
-    int rank1_mode = CMPS_RANK1_BF16X3;
+    int rank1_mode = CMPS_RANK1_DEFAULT;
     bool params_set = false;
     bool legacy = false;       // the tables currently hold the legacy AudioMPS arithmetic (cmps_legacy_set_params)
     bool fwd_saved = false;
@@ -77,6 +77,9 @@ int resolve_variant(const cmps_handle_s* h) {
     return h->D <= 32 ? CMPS_VARIANT_WAVE : CMPS_VARIANT_WIDE;
 }
 
+// CMPS_OPT_RANK1 as the wave-per-clip reverse scans understand it: exact fp32, two bf16 pieces, or (every other value) three
+int wave_rank1(int mode) { return mode == CMPS_RANK1_EXACT_F32 || mode == CMPS_RANK1_BF16X2 ? mode : CMPS_RANK1_BF16X3; }
+
 }  // namespace
 
 extern "C" {
@@ -119,7 +122,7 @@ int cmps_get_variant(cmps_handle_t h) { return h ? resolve_variant(h) : 0; }
 int cmps_set_option(cmps_handle_t h, int option, int value) {
     if (!h) return CMPS_ERR_BAD_ARG;
     if (option == CMPS_OPT_RANK1) {
-        if (value < CMPS_RANK1_EXACT_F32 || value > CMPS_RANK1_BF16X3)
+        if (value < CMPS_RANK1_EXACT_F32 || value > CMPS_RANK1_DEFAULT)
             return fail(h, CMPS_ERR_BAD_ARG, "cmps_set_option: unknown value for CMPS_OPT_RANK1");
         h->rank1_mode = value;
         return CMPS_OK;
@@ -181,6 +184,7 @@ static int set_params_impl(cmps_handle_t h, const float* R_re_dev, const float* 
     P.hst = (flags & CMPS_WS_TRAIN) ? reinterpret_cast<float*>(ws + L.off_hst) : nullptr;
     P.scal = (flags & CMPS_WS_TRAIN) ? reinterpret_cast<float*>(ws + L.off_scal) : nullptr;
     P.gops = ((flags & CMPS_WS_TRAIN) && L.D > 32) ? static_cast<void*>(ws + L.off_gops) : nullptr;
+    P.opmax = ((flags & CMPS_WS_TRAIN) && L.D > 32) ? reinterpret_cast<float*>(ws + L.off_opmax) : nullptr;
     P.slabs = (flags & CMPS_WS_TRAIN) ? reinterpret_cast<float*>(ws + L.off_slabs) : nullptr;
     P.sums = (flags & CMPS_WS_TRAIN) ? reinterpret_cast<float*>(ws + L.off_sums) : nullptr;
     P.slab_floats = L.slab_floats;
@@ -316,8 +320,9 @@ int cmps_psi_loss_bwd(cmps_handle_t h, const float* audio_dev, int B, int T, flo
         hipError_t e;
         { KScope ks("k_bwd_wide", s); e = launch_bwd_wide(P, audio_dev, s); }
         if (e == hipSuccess) {
-            KScope ks(h->rank1_mode == CMPS_RANK1_BF16X2 ? "k_grad_gemm<2>" : "k_grad_gemm<3>", s);
-            e = launch_grad_wide(P, audio_dev, h->rank1_mode == CMPS_RANK1_BF16X2 ? 2 : 3, s);
+            const int rm = h->rank1_mode == CMPS_RANK1_DEFAULT ? CMPS_RANK1_F16X2 : h->rank1_mode;
+            KScope ks(rm == CMPS_RANK1_F16X2 ? "k_grad_gemm<f16x2>" : rm == CMPS_RANK1_BF16X2 ? "k_grad_gemm<2>" : "k_grad_gemm<3>", s);
+            e = launch_grad_wide(P, audio_dev, rm == CMPS_RANK1_F16X2 ? -2 : rm == CMPS_RANK1_BF16X2 ? 2 : 3, s);
         }
         if (e != hipSuccess) return fail_hip(h, e, "cmps_psi_loss_bwd (wide scan)");
         Dev Pp = P;
@@ -334,7 +339,7 @@ int cmps_psi_loss_bwd(cmps_handle_t h, const float* audio_dev, int B, int T, flo
     hipError_t e;
     {
         KScope ks(!wave ? "k_bwd_block" : w16 ? "k_bwd_wave16" : "k_bwd_wave", s);
-        e = !wave ? launch_bwd_block(P, audio_dev, s) : w16 ? launch_bwd_wave16(P, audio_dev, s) : launch_bwd_wave(P, audio_dev, h->rank1_mode, s);
+        e = !wave ? launch_bwd_block(P, audio_dev, s) : w16 ? launch_bwd_wave16(P, audio_dev, s) : launch_bwd_wave(P, audio_dev, wave_rank1(h->rank1_mode), s);
     }
     if (e != hipSuccess) return fail_hip(h, e, "cmps_psi_loss_bwd (scan)");
     P.abar_fix = wave ? 1 : 0;
@@ -460,7 +465,7 @@ int cmps_legacy_loss_bwd(cmps_handle_t h, const float* audio_dev, int B, int T, 
     Dev P = h->P;
     P.B = B;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipError_t e = h->saved_variant == CMPS_VARIANT_WAVE ? launch_bwd_legacy_wave(P, audio_dev, h->rank1_mode, s) : launch_bwd_legacy(P, audio_dev, s);
+    hipError_t e = h->saved_variant == CMPS_VARIANT_WAVE ? launch_bwd_legacy_wave(P, audio_dev, wave_rank1(h->rank1_mode), s) : launch_bwd_legacy(P, audio_dev, s);
     if (e != hipSuccess) return fail_hip(h, e, "cmps_legacy_loss_bwd (scan)");
     e = launch_reduce_only(P, s);
     if (e == hipSuccess) e = launch_finalize_legacy(P, h->saved_loss, grad_dev, s);

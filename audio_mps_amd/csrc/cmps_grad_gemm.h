@@ -10,6 +10,13 @@
 // unit; the raw rows are fetched a unit before that.
 //   NPC = 3 / 2: every operand split exactly into NPC bf16 pieces (truncation) and the piece products a + b <= NPC - 1 kept (24 / 16
 //                operand bits: float32-faithful products); a unit = 4 steps, NPC (NPC + 1) / 2 groups of 6 PD / 32 MFMAs.
+//   F16 (NPC = 2): the two pieces are fp16 (round to nearest: hi = f16(x), lo = f16(x - hi), |x - hi - lo| <= 2^-24 |x| inside fp16's
+//                normal range) and the MFMA is v_mfma_f32_32x32x16_f16: the three products of BF16X2 with the 22 + 2 operand bits of
+//                BF16X3.  fp16 has 5 exponent bits, so every operand class is scaled by a power of two per pair of clips (exact; folded
+//                into the per-step scalars, so the build is no longer than BF16X2's): A operands to [.., 2^15), from max |ybar| (left
+//                behind by the reverse scan, Dev::opmax) and bounds of the per-step scalars formed in a pre-pass; B operands (y, u) to
+//                [.., 2^13).  Below 2^-3 of a class's scaled bound lo is subnormal (spacing 2^-24: an ABSOLUTE error <= 2^-39 of the
+//                bound); the accumulators are unscaled when they are written out.
 //   NPC = 1:     every operand rounded to bf16 once (the rounding points of oracle/cmps_oracle.py::psi_bf16_scan); a unit = 8 steps
 //                (two sub-units = two groups), so that a barrier interval holds 12 PD / 32 MFMAs and the second sub-unit's operand
 //                reads are issued behind the first one's MFMAs.
@@ -35,6 +42,7 @@ typedef float v4 __attribute__((ext_vector_type(4)));
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
 typedef short bf8 __attribute__((ext_vector_type(8)));
 typedef float f16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
 constexpr int CH = 64;       // steps per chunk of per-step scalars (the forward's scal rows)
 
@@ -52,6 +60,23 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {           
     unsigned r;
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
     return r;
+}
+__device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi) {                   // round to nearest even, (lo, hi) packed
+    unsigned r;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+template <bool F16>
+__device__ __forceinline__ f16 mma(bf8 a, bf8 b, f16 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// the largest power of two S with bound S < 2^target (bound = m 2^e, 1/2 <= m < 1); exponent clamped so that S and 1 / S are normal
+__device__ __forceinline__ float pow2_scale(float bound, int target) {
+    const int e = (int)((__float_as_uint(bound) >> 23) & 0xFFu) - 126;
+    int se = target - e;
+    se = se > 100 ? 100 : se < -100 ? -100 : se;
+    return __uint_as_float((unsigned)(127 + se) << 23);
 }
 __device__ __forceinline__ bf8 xor_bits(bf8 v, unsigned mask) {
     u4 t = __builtin_bit_cast(u4, v);
@@ -87,9 +112,10 @@ constexpr int free_slots(int t) {               // slots below t that take slice
 //   y_off(tid, c) / yb_off(tid, c): float offset of component c of this thread's (row, clip) inside a step's y / ybar row;
 //   rsq(m): 1 / sqrt(m) exactly as the family's reverse kernel computes it.
 // Rows of step k: y at stash + ((pair N + k) 2) 4 PD (the y half of the (y, H y) row pair), ybar at gops + (pair N + k) 4 PD.
-template <int PD, int NPC, typename ROWS>
+template <int PD, int NPC, typename ROWS, bool F16 = false>
 __global__ __launch_bounds__(2 * PD, 1) void k_grad_gemm(Dev P, const float* __restrict__ audio) {
     using namespace gg;
+    static_assert(!F16 || NPC == 2, "the fp16 split has two pieces");
     constexpr int PWV = PD / 32;                                  // waves = 32-row blocks
     constexpr int NSUB = NPC == 1 ? 2 : 1;                        // 4-step sub-units per unit
     constexpr int GU = 4 * NSUB;                                  // steps per unit
@@ -113,11 +139,49 @@ __global__ __launch_bounds__(2 * PD, 1) void k_grad_gemm(Dev P, const float* __r
     const int prow = 8 * (tid >> 4) + (tid & 7), pclip = (tid >> 3) & 1;
     const float* stf = reinterpret_cast<const float*>(P.stash) + (size_t)blockIdx.x * N * (8 * PD);   // uniform bases
     const float* ybs = reinterpret_cast<const float*>(P.gops) + (size_t)blockIdx.x * N * (4 * PD);
-    const float2 ps0 = P.psi0[prow];
+    float2 ps0 = P.psi0[prow];
     // ---- MFMA role: wave w owns the 32-row block w of Re Rbar, Im Rbar, Re Qbar, Im Qbar ----
     const int mr = lane & 31, mh = lane >> 5;
     const unsigned imask = mh ? 0x80008000u : 0u;                 // Im form: K half 1 is -a_re
     const int a_re_off = mh * PD + 32 * w + mr, a_im_off = (mh ^ 1) * PD + 32 * w + mr, b_off = (6 + mh) * PD + mr;
+
+    // fp16 pieces: power-of-two scales of the operand classes (te y | s ybar: sR, ybar: sQ, y | u: sB), see the header
+    float sR = 1.f, sQ = 1.f, sB = 1.f;
+    if constexpr (F16) {
+        float m_s = 0.f, m_t = 0.f, m_n = 1.f;                    // max |s|, max |te| |y|, max |y|^2 over the pair's steps
+        for (int e = tid; e < 2 * N; e += 2 * PD) {
+            const int idx = e >> 1, cl = e & 1;
+            if (cl && !two) continue;
+            const float* xr = audio + (size_t)(cl ? b1 : b0) * T;
+            const float* sc = P.scal + ((size_t)(cl ? b1 : b0) * NC + idx / CH) * 128;
+            const float inc = (idx + 1 < T ? xr[idx + 1] : 0.f) - xr[idx];
+            const float nv = sc[idx & (CH - 1)], ev = sc[64 + (idx & (CH - 1))];
+            const float zbar = -1.0f / (1.0f + (ev * inc) / A);
+            m_s = fmaxf(m_s, fabsf(inc / A));
+            m_t = fmaxf(m_t, fabsf(2.0f * (zbar * inc / A)) * sqrtf(nv));
+            m_n = fmaxf(m_n, nv);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            m_s = fmaxf(m_s, __shfl_xor(m_s, off, 64));
+            m_t = fmaxf(m_t, __shfl_xor(m_t, off, 64));
+            m_n = fmaxf(m_n, __shfl_xor(m_n, off, 64));
+        }
+        if (lane == 0) tab[w] = v4{m_s, m_t, m_n, 0.f};
+        __syncthreads();
+#pragma unroll
+        for (int ww = 0; ww < PWV; ++ww) {
+            const v4 t = tab[ww];
+            m_s = fmaxf(m_s, t.x); m_t = fmaxf(m_t, t.y); m_n = fmaxf(m_n, t.z);
+        }
+        __syncthreads();
+        const float ymax = P.opmax[blockIdx.x];
+        auto uni = [](float x) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(x))); };
+        sR = uni(pow2_scale(fmaxf(m_t, m_s * ymax), 15));
+        sQ = uni(pow2_scale(ymax, 15));
+        sB = uni(pow2_scale(sqrtf(m_n), 13));                     // |u| <= 1 <= max |y|
+        ps0.x *= sB; ps0.y *= sB;
+    }
 
     f16 Rre[PWV], Rim[PWV], Qre[PWV], Qim[PWV];
 #pragma unroll
@@ -141,7 +205,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_grad_gemm(Dev P, const float* __r
             const float zbar = -1.0f / (1.0f + z);
             const bool on = in && (cl == 0 || two);
             tab[((cj & 1) * CH + st) * 2 + cl] =
-                v4{on ? inc / A : 0.f, ROWS::rsq(fmaxf(nv, 1e-12f)), on ? 1.f : 0.f, on ? 2.0f * (zbar * inc / A) : 0.f};
+                v4{on ? (inc / A) * sR : 0.f, ROWS::rsq(fmaxf(nv, 1e-12f)) * sB, on ? sQ : 0.f, on ? (2.0f * (zbar * inc / A)) * sR : 0.f};
         }
     };
     // raw rows of one unit: y_{kb-1 .. kb+GU-1}, ybar_{kb .. kb+GU-1} (both components), rho_{kb-1 .. kb+GU-2}; fetched one unit
@@ -190,6 +254,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_grad_gemm(Dev P, const float* __r
         float t1 = 0.f, t2 = 0.f;
         float sv[2][3];                                           // (x, x - hi, x - hi - mid) of the two steps being packed
         unsigned w0[3] = {0u, 0u, 0u};
+        unsigned hpk = 0u, lpk = 0u;
         bf8 Areg[6], By[PWV], Bu[PWV];
         auto a_off = [&](int ap) { return (ap < 2 ? 0 : ap < 4 ? 4 * PD : 2 * PD) + ((ap & 1) ? a_im_off : a_re_off); };
         auto read_a = [&](int ap, int arr) { Areg[ap] = __builtin_bit_cast(bf8, RD[(size_t)arr * OPS + a_off(ap)]); };
@@ -220,7 +285,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_grad_gemm(Dev P, const float* __r
                         val[c][j][0] = sk[j].w * rY[c][j + 1];
                         val[c][j][1] = sk[j].x * rYB[c][j];
                         val[c][j][2] = sk[j].z * rYB[c][j];
-                        val[c][j][3] = rY[c][j + 1];
+                        val[c][j][3] = F16 ? rY[c][j + 1] * sB : rY[c][j + 1];
                     }
                 } else if constexpr (r < 16 + NLD) {              // one load of the unit after
 #if !(defined(CMPS_DIAG) && defined(WABL_GRAD_NO_LOADS))          // diagnostic builds only (results are wrong)
@@ -233,7 +298,26 @@ __global__ __launch_bounds__(2 * PD, 1) void k_grad_gemm(Dev P, const float* __r
                                                               cvt_pk_bf16(val[c][4 * s + 2][o], val[c][4 * s + 3][o]));
                 } else {                                          // split two steps of one operand, pack, store
                     constexpr int x = r - 16 - NLD, c = x / 30, o = (x / 6) % 5, jp = (x / 3) % 2, part = x % 3;
-                    if constexpr (part == 0) {                    // the two steps' chains interleaved: back-to-back dependent VALU
+                    if constexpr (F16) {
+                        if constexpr (part == 0) {
+                            const float v0 = val[c][4 * s + 2 * jp][o], v1 = val[c][4 * s + 2 * jp + 1][o];
+                            const unsigned hp = cvt_pk_f16(v0, v1);
+                            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                            const h2 hh = __builtin_bit_cast(h2, hp);
+                            hpk = hp;
+                            sv[0][1] = v0 - (float)hh.x;
+                            sv[1][1] = v1 - (float)hh.y;
+                        } else if constexpr (part == 1) {
+                            lpk = cvt_pk_f16(sv[0][1], sv[1][1]);
+                        } else if constexpr (jp == 0) {
+                            w0[0] = hpk; w0[1] = lpk;
+                        } else {
+                            unsigned* d0 = reinterpret_cast<unsigned*>(WR + (o * 2 + c) * PD + prow) + 2 * pclip;
+                            unsigned* d1 = reinterpret_cast<unsigned*>(WR + (size_t)OPS + (o * 2 + c) * PD + prow) + 2 * pclip;
+                            *reinterpret_cast<uint2*>(d0) = make_uint2(w0[0], hpk);
+                            *reinterpret_cast<uint2*>(d1) = make_uint2(w0[1], lpk);
+                        }
+                    } else if constexpr (part == 0) {             // the two steps' chains interleaved: back-to-back dependent VALU
                         const float v0 = val[c][4 * s + 2 * jp][o], v1 = val[c][4 * s + 2 * jp + 1][o];   // do not hide behind an MFMA
                         const unsigned h0 = __float_as_uint(v0) & 0xFFFF0000u, h1 = __float_as_uint(v1) & 0xFFFF0000u;
                         sv[0][0] = v0; sv[1][0] = v1;
@@ -285,12 +369,12 @@ __global__ __launch_bounds__(2 * PD, 1) void k_grad_gemm(Dev P, const float* __r
             if constexpr (MAC) {
                 constexpr int g = t / (6 * PWV), ap = (t / PWV) % 6, cb = t % PWV;
                 constexpr int ng = g + 1;
-                if constexpr (ap == 0) Rre[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Areg[0], By[cb], Rre[cb], 0, 0, 0);
-                if constexpr (ap == 1) Rim[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Areg[1], By[cb], Rim[cb], 0, 0, 0);
-                if constexpr (ap == 2) Qre[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Areg[2], Bu[cb], Qre[cb], 0, 0, 0);
-                if constexpr (ap == 3) Qim[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Areg[3], Bu[cb], Qim[cb], 0, 0, 0);
-                if constexpr (ap == 4) Rre[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Areg[4], Bu[cb], Rre[cb], 0, 0, 0);
-                if constexpr (ap == 5) Rim[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Areg[5], Bu[cb], Rim[cb], 0, 0, 0);
+                if constexpr (ap == 0) Rre[cb] = mma<F16>(Areg[0], By[cb], Rre[cb]);
+                if constexpr (ap == 1) Rim[cb] = mma<F16>(Areg[1], By[cb], Rim[cb]);
+                if constexpr (ap == 2) Qre[cb] = mma<F16>(Areg[2], Bu[cb], Qre[cb]);
+                if constexpr (ap == 3) Qim[cb] = mma<F16>(Areg[3], Bu[cb], Qim[cb]);
+                if constexpr (ap == 4) Rre[cb] = mma<F16>(Areg[4], Bu[cb], Rre[cb]);
+                if constexpr (ap == 5) Rim[cb] = mma<F16>(Areg[5], Bu[cb], Rim[cb]);
                 if constexpr (cb == PWV - 1) {
                     // the Im pieces carry the sign of their K half: applied a row of MFMAs after the read was issued
                     if constexpr (g == 0 && ap == 0) fix_a(3);                                 // (first group: read before slot 0)
@@ -339,16 +423,17 @@ __global__ __launch_bounds__(2 * PD, 1) void k_grad_gemm(Dev P, const float* __r
 
     float* slab = P.slabs + (size_t)blockIdx.x * P.slab_floats;
     constexpr int DD = PD * PD;
+    const float iR = 1.0f / sR, iQ = 1.0f / sQ, iB = 1.0f / sB;     // exact (powers of two); 1 without the fp16 scales
 #pragma unroll
     for (int cb = 0; cb < PWV; ++cb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = 32 * w + (r & 3) + 8 * (r >> 2) + 4 * mh;    // C/D layout of the 32x32 MFMA: column = lane & 31
             const int o = row * PD + 32 * cb + mr;
-            slab[o] = Rre[cb][r];
-            slab[DD + o] = Rim[cb][r];
-            slab[2 * DD + o] = Qre[cb][r];
-            slab[3 * DD + o] = Qim[cb][r];
+            slab[o] = F16 ? Rre[cb][r] * iR * iB : Rre[cb][r];
+            slab[DD + o] = F16 ? Rim[cb][r] * iR * iB : Rim[cb][r];
+            slab[2 * DD + o] = F16 ? Qre[cb][r] * iQ * iB : Qre[cb][r];
+            slab[3 * DD + o] = F16 ? Qim[cb][r] * iQ * iB : Qim[cb][r];
         }
 }
 

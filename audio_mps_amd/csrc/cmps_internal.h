@@ -59,7 +59,7 @@ struct KScope {
 struct Layout {
     int D, DP, B, T, N, flags;
     size_t off_R, off_RT, off_Q, off_QT, off_psi0, off_freqs, off_ttab, off_dtk, off_rho, off_rfix,
-        off_stash, off_hst, off_scal, off_slabs, off_sums, off_gops, total;
+        off_stash, off_hst, off_scal, off_slabs, off_sums, off_gops, off_opmax, total;
     size_t slab_floats;  // 4*DP*DP + 3*DP + 2
 };
 
@@ -91,6 +91,7 @@ inline Layout make_layout(int D, int B, int T, int flags) {
     L.off_slabs = o;
     L.off_sums = o;
     L.off_gops = o;
+    L.off_opmax = o;
     if (flags & 1) {
         // the two variants never run on the same stash: their layouts share one region
         // D > 32: the pair kernels (D = 128) keep (y, H y) per step, 16 B per component; the block kernels use half of it
@@ -106,6 +107,9 @@ inline Layout make_layout(int D, int B, int T, int flags) {
         // ybar rows: exactly [pairs][N][4 DP] floats (k_grad_gemm clamps every row it requests to the pair's range and its buffer
         // descriptors end at the last row; round 3's 32 rows of slack behind the section had no reader left -- ADVICE r3)
         if (D > 32) o = align256(o + (size_t)((B + 1) / 2) * N * 4 * DP * sizeof(float));
+        // max |ybar| per pair (wide reverse scan -> the gradient GEMM's fp16 operand scale, CMPS_RANK1_F16X2)
+        L.off_opmax = o;
+        if (D > 32) o = align256(o + (size_t)((B + 1) / 2) * sizeof(float));
     }
     L.total = o;
     return L;
@@ -130,6 +134,7 @@ struct Dev {
                          // 4: wide rows (cmps_wide.hip): [pair][step][y | H y][wave][lane] float
     float* scal;         // [B][NC][2][64]
     void* gops;          // ybar rows for the gradient GEMM (see the layout comment), D > 32 only
+    float* opmax;        // [pairs] max |ybar| over the pair's steps and rows (written by k_bwd_wide), D > 32 only
     float* slabs;        // [B][slab]
     float* sums;         // [slab]
     size_t slab_floats;

@@ -732,6 +732,7 @@ __global__ __launch_bounds__(4 * PD) void k_bwd_wide(Dev P, const float* __restr
     v4f S0 = tab_row(k0, 0), S1 = tab_row(k0, 1);
     v4f SP0 = tab_row(k0 > 0 ? k0 - 1 : 0, 0), SP1 = tab_row(k0 > 0 ? k0 - 1 : 0, 1);
     float g = 0.f, unext = 0.f, facc = 0.f, accS = 0.f;
+    float ymx = 0.f;                                              // max |ybar| (the gradient GEMM's fp16 operand scale)
     float c3;
     {
         const Row cur = row_at(k0);
@@ -752,6 +753,7 @@ __global__ __launch_bounds__(4 * PD) void k_bwd_wide(Dev P, const float* __restr
         const float yb = fmaf(hb, S0.y, c3);
         reinterpret_cast<float*>(vec[p])[own_f] = yb;
         ybs[wide_ybar_vec<PD>(blockIdx.x, N, k) + pos] = yb;
+        ymx = fmaxf(ymx, fabsf(yb));
         wide_barrier();
         const int kl = k & (WCH - 1);
         const bool par = ((k / WCH) & 1) != 0;
@@ -816,6 +818,17 @@ __global__ __launch_bounds__(4 * PD) void k_bwd_wide(Dev P, const float* __restr
             slab[4 * DD + 3 * PD] = tot;
             slab[4 * DD + 3 * PD + 1] = 0.f;
         }
+        __syncthreads();
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ymx = fmaxf(ymx, __shfl_xor(ymx, off, 64));
+        if (lane == 0) redA[w] = ymx;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float m = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) m = fmaxf(m, redA[ww]);
+            P.opmax[blockIdx.x] = m;
+        }
     }
 }
 
@@ -878,15 +891,19 @@ hipError_t launch_bwd_wide(const Dev& P, const float* audio, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int PD, int NPC>
+template <int PD, int NPC, bool F16 = false>
 static hipError_t grad_wide_t(const Dev& P, const float* audio, hipStream_t s) {
     const unsigned nb = (unsigned)((P.B + 1) / 2);
-    hipLaunchKernelGGL((k_grad_gemm<PD, NPC, WideRows<PD>>), dim3(nb), dim3(2 * PD), 0, s, P, audio);   // static LDS: 2 x NPC x 160 PD + 4 KB
+    hipLaunchKernelGGL((k_grad_gemm<PD, NPC, WideRows<PD>, F16>), dim3(nb), dim3(2 * PD), 0, s, P, audio);   // static LDS: 2 x NPC x 160 PD + 4 KB
     return hipGetLastError();
 }
 
 hipError_t launch_grad_wide(const Dev& P, const float* audio, int pieces, hipStream_t s) {
-    if (pieces == 3) {
+    if (pieces == -2) {                                           // two fp16 pieces (CMPS_RANK1_F16X2)
+        if (P.DP == 128) return grad_wide_t<128, 2, true>(P, audio, s);
+        if (P.DP == 96) return grad_wide_t<96, 2, true>(P, audio, s);
+        if (P.DP == 64) return grad_wide_t<64, 2, true>(P, audio, s);
+    } else if (pieces == 3) {
         if (P.DP == 128) return grad_wide_t<128, 3>(P, audio, s);
         if (P.DP == 96) return grad_wide_t<96, 3>(P, audio, s);
         if (P.DP == 64) return grad_wide_t<64, 3>(P, audio, s);

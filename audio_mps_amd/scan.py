@@ -96,6 +96,16 @@ class HipScan:
     def rank1(self) -> int:
         return int(self._lib.cmps_get_option(self._h, _capi.CMPS_OPT_RANK1))
 
+    @property
+    def effective_rank1(self) -> int:
+        """The arithmetic the selected kernels run for the current option value (include/cmps.h): the wide kernels' gradient GEMM
+        knows two bf16 pieces, three bf16 pieces (also for EXACT_F32) and two fp16 pieces (also for DEFAULT); the wave reverse scan
+        exact fp32, two bf16 pieces and three bf16 pieces (every other value)."""
+        mode, wide = self.rank1, self.variant == _capi.CMPS_VARIANT_WIDE
+        if wide:
+            return {0: _capi.CMPS_RANK1_BF16X3, 4: _capi.CMPS_RANK1_F16X2}.get(mode, mode)
+        return mode if mode in (_capi.CMPS_RANK1_EXACT_F32, _capi.CMPS_RANK1_BF16X2) else _capi.CMPS_RANK1_BF16X3
+
     def kernel_events(self, on: bool):
         """cmps_set_option(CMPS_OPT_KERNEL_EVENTS): bracket every kernel of forward() / backward() with HIP events (a measurement aid,
         used by bench.py outside its timed region)."""

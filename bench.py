@@ -48,9 +48,10 @@ sys.path.insert(0, ROOT)
 FP32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 vector peak == fp32-input MFMA peak (dense)
 BF16_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA peak (never the 2:1-sparsity figure)
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec peak
-RANK1_MODES = {"exact_f32": 0, "bf16x2": 1, "bf16x3": 2}
+RANK1_MODES = {"exact_f32": 0, "bf16x2": 1, "bf16x3": 2, "f16x2": 3, "default": 4}
 RANK1_LABEL = {0: "exact fp32 MFMA", 1: "bf16x2 split (16 operand bits), fp32 accumulate",
-               2: "bf16x3 split (24 operand bits, fp32-faithful products), fp32 accumulate"}
+               2: "bf16x3 split (24 operand bits, fp32-faithful products), fp32 accumulate",
+               3: "f16x2 split (power-of-two scaled operands, 11+1+11+1 operand bits: bf16x3's accuracy class), fp32 accumulate"}
 V_BLOCK, V_WAVE, V_PAIR, V_WAVE32, V_WIDE = 1, 2, 3, 4, 5
 
 
@@ -65,7 +66,7 @@ def parse_args(argv=None):
     p.add_argument("--variant", type=int, default=0,
                    help="0 auto (float32: wave-per-clip kernels for D <= 32, wide kernels above), 1 block-per-clip, 2 wave-per-clip, "
                         "3 MFMA pair kernels (32 < D <= 128; bf16 operands), 5 float32 wide kernels (32 < D <= 128)")
-    p.add_argument("--rank1", choices=sorted(RANK1_MODES), default="bf16x3",
+    p.add_argument("--rank1", choices=sorted(RANK1_MODES), default="default",
                    help="arithmetic of the rank-1 gradient sums (cmps_set_option): wave reverse scan of 17 <= D <= 32, gradient GEMM of "
                         "the wide kernels")
     p.add_argument("--input", choices=["damped_sine", "damped_sine_noise", "bandlimited"], default="damped_sine",
@@ -285,12 +286,12 @@ def executed_split(variant, D, rank1):
                 "bwd": {"valu_fp32": 12, "mfma_fp32_equiv": 24, "mfma_products": 1, "eliminated": 20,
                         "what": "merged mat-vec on the VALU; rank-1 sums as exact fp32 MFMAs (16x16x4) on the gradient wave"}}
     if variant == V_WIDE:
-        prod = 3 if rank1 == 1 else 6
+        prod = 6 if rank1 == 2 else 3
         return {"fwd": {"valu_fp32": 12, "mfma_fp32_equiv": 8, "mfma_products": 6, "eliminated": 4,
                         "what": "k_fwd_wide: merged (Q + s R) u, fp32 v_pk_fma (8 + 4 forming it); k_hy_wide: H y for all (clip, step) pairs "
                                 "as a bf16x3-split GEMM; k_loss_wide: the sequential float32 loss sums"},
                 "bwd": {"valu_fp32": 12, "mfma_fp32_equiv": 24, "mfma_products": prod, "eliminated": 20,
-                        "what": "k_bwd_wide: merged (Q + s R^dagger) ybar on the VALU; k_grad_gemm (NPC = 3 or 2): rank-1 sums as split-bf16 GEMMs"}}
+                        "what": "k_bwd_wide: merged (Q + s R^dagger) ybar on the VALU; k_grad_gemm: rank-1 sums as split-operand GEMMs (three bf16, two bf16 or two fp16 pieces)"}}
     if variant == V_PAIR:
         return {"fwd": {"valu_fp32": 0, "mfma_fp32_equiv": 24, "mfma_products": 1, "eliminated": 0, "what": "R u, Q u (16x16x32 bf16), H y (32x32x16 bf16)"},
                 "bwd": {"valu_fp32": 0, "mfma_fp32_equiv": 40, "mfma_products": 1, "eliminated": 16,
@@ -329,7 +330,7 @@ PIPE_PEAK = {"valu_fp32": (FP32_PEAK_TFLOPS, "TFLOP/s"), "mfma_f32": (FP32_PEAK_
 
 def kernel_work_model(fam, D, DP, rank1):
     """{kernel name as cmps_kernel_times reports it: [(pipe, D^2-flop per (clip, sample) | bytes per (clip, sample), what)]}"""
-    prod = {0: 1, 1: 3, 2: 6}[rank1]
+    prod = {0: 1, 1: 3, 2: 6, 3: 3}[rank1]
     rp = "mfma_f32" if rank1 == 0 else "mfma_bf16"
     if fam == "wave":
         return {"k_fwd_wave2": [("valu_fp32", 12 * D * D, "merged (Q + s R) u mat-vec 8 + forming it 4"),
@@ -343,14 +344,15 @@ def kernel_work_model(fam, D, DP, rank1):
                 "k_bwd_wave16": [("valu_fp32", 12 * D * D, "merged mat-vec"), ("mfma_f32", 24 * D * D, "rank-1 sums, exact fp32 16x16x4 MFMAs"),
                                  ("hbm", 512.0, "stash rows read")]}
     if fam == "wide":
-        gp = 3 if rank1 == 1 else 6
+        gp = 6 if rank1 == 2 else 3
+        gname = {1: "k_grad_gemm<2>", 2: "k_grad_gemm<3>", 3: "k_grad_gemm<f16x2>"}[rank1]
         return {"k_fwd_wide": [("valu_fp32", 12 * D * D, "merged (Q + s R) u, v_pk_fma_f32"), ("hbm", 8.0 * DP, "y rows written: 16 DP B per pair-step")],
                 "k_hy_wide": [("mfma_bf16", 8 * 6 * D * D, "H y for all (clip, step) pairs, bf16x3 split: 6 piece products"),
                               ("hbm", 16.0 * DP, "y rows read + H y rows written")],
                 "k_loss_wide": [("hbm", 8.0, "e_k, |y_k|^2 scalars")],
                 "k_bwd_wide": [("valu_fp32", 12 * D * D, "merged (Q + s R^dagger) ybar"), ("hbm", 24.0 * DP, "y, H y rows read, ybar rows written")],
-                f"k_grad_gemm<{2 if rank1 == 1 else 3}>": [("mfma_bf16", 24 * gp * D * D, f"three rank-1 sums as GEMMs, {gp} piece products"),
-                                                          ("hbm", 16.0 * DP, "y and ybar rows read: 32 DP B per pair-step")]}
+                gname: [("mfma_bf16", 24 * gp * D * D, f"three rank-1 sums as GEMMs, {gp} piece products (fp16 and bf16 MFMAs have the same dense peak)"),
+                        ("hbm", 16.0 * DP, "y and ybar rows read: 32 DP B per pair-step")]}
     if fam == "pair":
         return {"k_fwd_pair": [("mfma_bf16", 24 * D * D, "R u, Q u (16x16x32, 4 of 16 A rows useful: issued 4 x) + H y (32x32x16)"),
                                ("hbm", 16.0 * DP, "y and H y rows written")],
@@ -626,7 +628,8 @@ def dtype_label(variant, D, rank1):
                 + tail + ")")
     if variant == V_WIDE:
         return ("f32 (fp32 FMA chains for every mat-vec; rank-1 gradient sums: " +
-                ("bf16x2-split operands (16 bits)" if rank1 == 1 else "bf16x3-split operands (24 bits, fp32-faithful)") +
+                {1: "bf16x2-split operands (16 bits)", 2: "bf16x3-split operands (24 bits, fp32-faithful)",
+                 3: "f16x2-split operands (scaled, 24 bits: bf16x3's accuracy class at half the products)"}[rank1] +
                 " on the matrix cores, fp32 accumulate)")
     return "f32"
 
@@ -647,7 +650,7 @@ def other_config_rows(ARGS, dp, dev):
             run = Run(D, T, B, variant, ARGS.rank1, ARGS.input, dp, dev, 1, 0, ARGS.host_optimizer, config_id=cid)
             r = run.timed(steps, 2)
             ms = 1e3 * r["elapsed"] / steps
-            roof = roofline_record(D, T, B, run.variant, run.backend.rank1, r["t_fwd"], r["t_bwd"], ms, run.kernel_pass(2))
+            roof = roofline_record(D, T, B, run.variant, run.backend.effective_rank1, r["t_fwd"], r["t_bwd"], ms, run.kernel_pass(2))
             clips = min(B, 16)
             sample = make_audio_host(ARGS.input, clips, T, run.hp.delta_t, run.seed)
             run.trainer.sync_to_host()
@@ -656,7 +659,7 @@ def other_config_rows(ARGS, dp, dev):
             cpu_s = time.perf_counter() - t0
             par = run.parity(sample, ref, run.variant == V_PAIR)
             rows.append({"config": name, "ms_per_step": ms, "value": B * T * steps / r["elapsed"], "unit": "samples/s", "steps": steps,
-                         "kernel_variant": run.variant, "dtype": dtype_label(run.variant, D, run.backend.rank1),
+                         "kernel_variant": run.variant, "dtype": dtype_label(run.variant, D, run.backend.effective_rank1),
                          "fwd_ms": r["t_fwd"] * 1e3, "bwd_ms": r["t_bwd"] * 1e3, "final_loss": r["last"],
                          "dominant_kernel": roof["kernel"], "dominant_pipe": roof.get("pipe", "valu_fp32 (algorithmic flops, see roofline.frac_is)"),
                          "frac": roof["frac"], "peak": roof["peak"], "kernels": roof.get("kernels"),
@@ -694,7 +697,7 @@ def worker(ARGS):
 
     D, T, B = ARGS.bond_dim, ARGS.T, ARGS.batch_per_gpu
     run = Run(D, T, B, ARGS.variant, ARGS.rank1, ARGS.input, dp, dev, world, rank, ARGS.host_optimizer)
-    variant, rank1 = run.variant, run.backend.rank1
+    variant, rank1 = run.variant, run.backend.effective_rank1
     r = run.timed(ARGS.steps, ARGS.warmup)
     if not np.isfinite(r["last"]):
         raise SystemExit(f"non-finite loss {r['last']}")
@@ -749,7 +752,7 @@ def worker(ARGS):
         out["parity_in_bench"] = run.parity(sample, ref, pair)
         if fam in ("wave", "wide") and not ARGS.no_precision_ab:
             ab = {}
-            modes = RANK1_MODES if fam == "wave" else {"bf16x2": 1, "bf16x3": 2}
+            modes = {"exact_f32": 0, "bf16x2": 1, "bf16x3": 2} if fam == "wave" else {"bf16x2": 1, "bf16x3": 2, "f16x2": 3}
             for name, mode in modes.items():                     # accuracy first: the timed steps below move the parameters
                 run.backend.set_rank1(mode)
                 pr = run.parity(sample, ref, False)
@@ -763,7 +766,7 @@ def worker(ARGS):
             out["precision_ab"] = {"what": "rank-1 gradient sums (k_bwd_wave / k_grad_gemm); everything else is identical fp32 code.  All "
                                            "modes sit in float32 reorder noise of the oracle: the label 'fp32-faithful' of bf16x3 rests on its "
                                            "operand-bit argument (24 bits kept), not on a difference this comparison can resolve",
-                                   "headline_mode": ARGS.rank1, "modes": ab}
+                                   "headline_mode": {v: k for k, v in RANK1_MODES.items()}[rank1], "modes": ab}
         if (D, T, B) == (32, 16000, 1024):
             out["cpu_baseline"]["reference_style"] = cpu_reference_style()
             if not ARGS.no_other_configs:

@@ -65,22 +65,30 @@ enum {
 enum {
     CMPS_OPT_RANK1 = 1 /* arithmetic of the rank-1 gradient sums: the wave-per-clip reverse scan of 17 <= D <= 32 (the 16-row layout
                         * of D <= 16 always uses exact fp32 MFMAs) and the gradient GEMM of the wide kernels (32 < D <= 128:
-                        * BF16X2 = two pieces / three products, anything else = three pieces / six products) */,
+                        * BF16X2 = two bf16 pieces / three products, F16X2 = two fp16 pieces / three products, anything else = three
+                        * bf16 pieces / six products) */,
     CMPS_OPT_KERNEL_EVENTS = 2 /* 1: every kernel cmps_psi_loss_fwd / _bwd launch is bracketed by two HIP events on the caller's stream
                         * (read and reset with cmps_kernel_times); 0 (default): nothing is recorded.  A measurement aid -- the reference
                         * has no counterpart (no tracing / profiling hooks); bench.py uses it OUTSIDE its timed region to price
                         * each kernel of a multi-kernel family against the pipe it runs on */
 };
-/* values of CMPS_OPT_RANK1.  All three accumulate in fp32; they differ in how the two factors of every product
+/* values of CMPS_OPT_RANK1.  All accumulate in fp32; they differ in how the two factors of every product
  * dR += a b^dagger enter the matrix cores:
  *   EXACT_F32  v_mfma_f32_32x32x2_f32, bit-for-bit an fp32 fma chain (slowest: it holds the fp32 ALUs)
  *   BF16X2     each factor split into two bf16 pieces, 3 products: 16 operand bits, error <= ~2^-16 |a||b|
  *   BF16X3     each factor split EXACTLY into three bf16 pieces (8+8+8 bits), 6 products: 24 operand bits,
- *              error <= 2^-23 |a||b| (what is dropped is below the fp32 rounding of the product); the default */
+ *              error <= 2^-23 |a||b| (what is dropped is below the fp32 rounding of the product)
+ *   F16X2      (wide kernels' gradient GEMM only; elsewhere it means BF16X3) each factor scaled by a power of two per pair of clips
+ *              and split into two fp16 pieces, round to nearest (11+1+11+1 bits), 3 products on v_mfma_f32_32x32x16_f16: BF16X2's
+ *              instruction count at BF16X3's accuracy class, error <= ~2^-22 |a||b| for factors within 2^-18 of their class's
+ *              largest value in the pair and <= 2^-39 of that largest value below */
 enum {
     CMPS_RANK1_EXACT_F32 = 0,
     CMPS_RANK1_BF16X2 = 1,
-    CMPS_RANK1_BF16X3 = 2
+    CMPS_RANK1_BF16X3 = 2,
+    CMPS_RANK1_F16X2 = 3,
+    CMPS_RANK1_DEFAULT = 4   /* a new handle's setting: BF16X3 in the wave reverse scan, F16X2 in the wide kernels' gradient GEMM --
+                              * the cheapest arithmetic of the 24-operand-bit class on each (scripts/rank1_accuracy_wide.py) */
 };
 
 /* Library version (major * 10000 + minor * 100 + patch). */

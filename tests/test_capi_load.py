@@ -93,15 +93,17 @@ def test_workspace_bytes_pair_variant(hip_lib):
 
 
 def test_options_default_and_errors(hip_lib):
-    """cmps_set_option / cmps_get_option (no device work): the rank-1 arithmetic defaults to BF16X3."""
+    """cmps_set_option / cmps_get_option (no device work): the rank-1 arithmetic defaults to DEFAULT (BF16X3 in the wave reverse
+    scan, F16X2 in the wide kernels' gradient GEMM)."""
     from audio_mps_amd import _capi
     h = ctypes.c_void_p()
     assert hip_lib.cmps_create(32, ctypes.byref(h)) == _capi.CMPS_OK
-    assert hip_lib.cmps_get_option(h, _capi.CMPS_OPT_RANK1) == _capi.CMPS_RANK1_BF16X3
-    for v in (_capi.CMPS_RANK1_EXACT_F32, _capi.CMPS_RANK1_BF16X2, _capi.CMPS_RANK1_BF16X3):
+    assert hip_lib.cmps_get_option(h, _capi.CMPS_OPT_RANK1) == _capi.CMPS_RANK1_DEFAULT == 4
+    for v in (_capi.CMPS_RANK1_EXACT_F32, _capi.CMPS_RANK1_BF16X2, _capi.CMPS_RANK1_BF16X3, _capi.CMPS_RANK1_F16X2, _capi.CMPS_RANK1_DEFAULT):
         assert hip_lib.cmps_set_option(h, _capi.CMPS_OPT_RANK1, v) == _capi.CMPS_OK
         assert hip_lib.cmps_get_option(h, _capi.CMPS_OPT_RANK1) == v
-    assert hip_lib.cmps_set_option(h, _capi.CMPS_OPT_RANK1, 3) == _capi.CMPS_ERR_BAD_ARG
+    assert hip_lib.cmps_set_option(h, _capi.CMPS_OPT_RANK1, 5) == _capi.CMPS_ERR_BAD_ARG
+    assert hip_lib.cmps_set_option(h, _capi.CMPS_OPT_RANK1, -1) == _capi.CMPS_ERR_BAD_ARG
     assert hip_lib.cmps_set_option(h, 99, 0) == _capi.CMPS_ERR_BAD_ARG
     assert hip_lib.cmps_get_option(h, 99) == -1 and hip_lib.cmps_get_option(None, _capi.CMPS_OPT_RANK1) == -1
     # CMPS_WS_FRESH / CMPS_WS_REUSE_TABLES are requests, not layouts: they do not change the size

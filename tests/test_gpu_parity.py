@@ -165,12 +165,13 @@ def test_config3_reduced_batch():
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_rank1_modes(mode):
     """cmps_set_option(CMPS_OPT_RANK1): exact fp32 MFMA, bf16x2 split and bf16x3 split of the rank-1 gradient updates
-    (k_bwd_wave<0|1|2>) all stay inside the gradient bar; the default is BF16X3 (24 operand bits, fp32-faithful products).
+    (k_bwd_wave<0|1|2>) all stay inside the gradient bar; a new handle's DEFAULT means BF16X3 here (24 operand bits, fp32-faithful
+    products).
     T = 3000 spans many aligned octets plus an unaligned top (2999 steps) and a chunk boundary."""
     from audio_mps_amd import _capi
     m, audio = _model(32, 3000, 10, WAVE, seed=17)
     be = m._get_backend()
-    assert be.rank1 == _capi.CMPS_RANK1_BF16X3
+    assert be.rank1 == _capi.CMPS_RANK1_DEFAULT and be.effective_rank1 == _capi.CMPS_RANK1_BF16X3
     be.set_rank1(mode)
     assert be.rank1 == mode
     _check_against_oracle(m, audio, nthreads=10)
