@@ -274,7 +274,9 @@ int cmps_psi_loss_fwd(cmps_handle_t h, const float* audio_dev, int B, int T, flo
         KScope ks("k_fwd_pair", s);
         e = launch_fwd_pair(P, audio_dev, loss_dev, save_for_bwd != 0, s);
     } else if (variant == CMPS_VARIANT_WIDE) {
-        e = launch_fwd_wide(P, audio_dev, loss_dev, save_for_bwd != 0, s);      // k_fwd_wide, k_hy_wide, k_loss_wide: scopes inside
+        // k_fwd_wide, k_hy_wide, k_loss_wide (scopes inside); the loss product's pieces follow CMPS_OPT_RANK1 like the gradient GEMM's
+        e = launch_fwd_wide(P, audio_dev, loss_dev, save_for_bwd != 0,
+                            h->rank1_mode == CMPS_RANK1_DEFAULT || h->rank1_mode == CMPS_RANK1_F16X2, s);
     } else {
         KScope ks("k_fwd_block", s);
         e = launch_fwd_block(P, audio_dev, loss_dev, save_for_bwd != 0, s);

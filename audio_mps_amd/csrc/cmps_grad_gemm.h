@@ -75,7 +75,7 @@ __device__ __forceinline__ f16 mma(bf8 a, bf8 b, f16 c) {
 __device__ __forceinline__ float pow2_scale(float bound, int target) {
     const int e = (int)((__float_as_uint(bound) >> 23) & 0xFFu) - 126;
     int se = target - e;
-    se = se > 100 ? 100 : se < -100 ? -100 : se;
+    se = se > 60 ? 60 : se < -60 ? -60 : se;
     return __uint_as_float((unsigned)(127 + se) << 23);
 }
 __device__ __forceinline__ bf8 xor_bits(bf8 v, unsigned mask) {

@@ -400,7 +400,7 @@ struct HyGeom {
     static constexpr int FROW = PD + 4;                           // floats of one float32 row + padding
     static constexpr int FBUF = HU * 4 * FROW;                    // floats of one float32 unit buffer
     static constexpr size_t LDS = (size_t)2 * 3 * PIECE + (size_t)5 * FBUF * 4 + 2 * (PD / 32) * 16 * 4;   // pieces x2, y x3, H y x2, e
-};
+};                                                                // (the fp16 form has two pieces per buffer and leaves the third unused)
 
 }  // namespace
 
@@ -409,12 +409,16 @@ struct HyGeom {
 // | H y rows and e of unit u - 2 out to memory.  The issue order is written out as in k_grad_gemm (cmps_grad_gemm.h): slot t = MFMA t
 // + at most one small slice of the other four stages, fenced.  The sign of the Im form's second K half (-y_re) is applied to the
 // accumulator of that half (out = acc0 +- acc1 per column form), not to the operand reads.
-template <int PD>
+// F16 (CMPS_RANK1_F16X2 / DEFAULT): two fp16 pieces per operand instead of three bf16 ones and three products instead of six, as in
+// k_grad_gemm (cmps_grad_gemm.h): H is scaled by a power of two from its largest entry, the y rows of the workgroup's 512 steps from
+// their largest |y|^2 (the chain kernel's scalar stash); the product is unscaled where it leaves the accumulators.
+template <int PD, bool F16>
 __global__ __launch_bounds__(2 * PD, 1) void k_hy_wide(Dev P) {
     using HG = HyGeom<PD>;
     using gg::static_for;
     constexpr int PWV = PD / 32, KT = 2 * PD / 16, PROW = HG::PROW, PIECE = HG::PIECE, FROW = HG::FROW, FBUF = HG::FBUF;
-    constexpr int NM = 6 * KT;                                    // MFMAs per unit
+    constexpr int NPR = F16 ? 3 : 6;                              // piece products
+    constexpr int NM = NPR * KT;                                  // MFMAs per unit
     extern __shared__ __attribute__((aligned(16))) unsigned char wide_lds[];
     unsigned char* pcs = wide_lds;                                          // [2 buffers][3 pieces][PIECE]
     float* yf = reinterpret_cast<float*>(wide_lds + 2 * 3 * PIECE);         // [3][FBUF]: y, float32
@@ -433,9 +437,55 @@ __global__ __launch_bounds__(2 * PD, 1) void k_hy_wide(Dev P) {
     const int cs = mr >> 2, cc = (mr >> 1) & 1, cf = mr & 1;
     const float sgn = cf ? -1.f : 1.f;
 
-    // ---- A operand: row 32 w + mr of [H_re | -H_im], K values 16 t + 8 mh .. + 7, three bf16 pieces ----
-    bf8w Ah[KT], Am[KT], Al[KT];
-    {
+    // ---- A operand: row 32 w + mr of [H_re | -H_im], K values 16 t + 8 mh .. + 7, three bf16 pieces (two fp16 pieces) ----
+    bf8w Ah[KT], Am[F16 ? 1 : KT], Al[KT];
+    float sH = 1.f, sB = 1.f;
+    if constexpr (F16) {
+        const int row = 32 * w + mr;
+        float mH = 0.f, mN = 1.f;
+        for (int e = 0; e < PD / 2; ++e) {                        // this lane's half of its row of H
+            const int j = mh * (PD / 2) + e;
+            const float2 r = P.R[(size_t)row * PD + j], rt = P.RT[(size_t)row * PD + j];
+            mH = fmaxf(mH, fmaxf(fabsf(r.x + rt.x), fabsf(r.y - rt.y)));
+        }
+        for (int e = tid; e < 2 * (k_hi - k_lo); e += 2 * PD) {   // |y_k|^2 of the workgroup's steps (written by k_fwd_wide)
+            const int k = k_lo + (e >> 1);
+            mN = fmaxf(mN, P.scal[((size_t)((e & 1) ? b1 : b0) * NC + k / WCH) * 128 + (k & (WCH - 1))]);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mH = fmaxf(mH, __shfl_xor(mH, off, 64));
+            mN = fmaxf(mN, __shfl_xor(mN, off, 64));
+        }
+        if (lane == 0) { eacc[2 * w] = mH; eacc[2 * w + 1] = mN; }
+        __syncthreads();
+#pragma unroll
+        for (int ww = 0; ww < PWV; ++ww) { mH = fmaxf(mH, eacc[2 * ww]); mN = fmaxf(mN, eacc[2 * ww + 1]); }
+        __syncthreads();
+        auto uni = [](float x) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(x))); };
+        sH = uni(gg::pow2_scale(mH, 15));
+        sB = uni(gg::pow2_scale(sqrtf(mN), 13));
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+            unsigned ph[4], pl[4];
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                float v[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int k = 16 * t + 8 * mh + e + i, part = k / PD, j = k % PD;
+                    const float2 r = P.R[(size_t)row * PD + j], rt = P.RT[(size_t)row * PD + j];
+                    v[i] = (part == 0 ? r.x + rt.x : -(r.y - rt.y)) * sH;
+                }
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                ph[e >> 1] = gg::cvt_pk_f16(v[0], v[1]);
+                const h2 hh = __builtin_bit_cast(h2, ph[e >> 1]);
+                pl[e >> 1] = gg::cvt_pk_f16(v[0] - (float)hh.x, v[1] - (float)hh.y);
+            }
+            Ah[t] = __builtin_bit_cast(bf8w, u4w{ph[0], ph[1], ph[2], ph[3]});
+            Al[t] = __builtin_bit_cast(bf8w, u4w{pl[0], pl[1], pl[2], pl[3]});
+        }
+    } else {
         const int row = 32 * w + mr;
 #pragma unroll
         for (int t = 0; t < KT; ++t) {
@@ -485,8 +535,19 @@ __global__ __launch_bounds__(2 * PD, 1) void k_hy_wide(Dev P) {
         if (part == 0) {
             const bool in = k_lo + HU * u + j < k_hi;
             sv0 = in ? Y[j].x : 0.f; sv1 = in ? Y[j].y : 0.f;
-            sr0 = sv0 - __uint_as_float(__float_as_uint(sv0) & 0xFFFF0000u);
-            sr1 = sv1 - __uint_as_float(__float_as_uint(sv1) & 0xFFFF0000u);
+            if constexpr (F16) {
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                const float t0 = sv0 * sB, t1 = sv1 * sB;
+                sh[0] = gg::cvt_pk_f16(t0, t1);
+                const h2 hh = __builtin_bit_cast(h2, sh[0]);
+                sr0 = t0 - (float)hh.x;
+                sr1 = t1 - (float)hh.y;
+            } else {
+                sr0 = sv0 - __uint_as_float(__float_as_uint(sv0) & 0xFFFF0000u);
+                sr1 = sv1 - __uint_as_float(__float_as_uint(sv1) & 0xFFFF0000u);
+            }
+        } else if (part == 1 && F16) {
+            sh[1] = gg::cvt_pk_f16(sr0, sr1);
         } else if (part == 1) {
             const float q0 = sr0 - __uint_as_float(__float_as_uint(sr0) & 0xFFFF0000u);
             const float q1 = sr1 - __uint_as_float(__float_as_uint(sr1) & 0xFFFF0000u);
@@ -498,7 +559,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_hy_wide(Dev P) {
             unsigned char* d = pcs + (size_t)(u & 1) * 3 * PIECE + rowi * PROW + prow * 2;     // rows prow, prow + 1: one dword per piece
             *reinterpret_cast<unsigned*>(d) = sh[0];
             *reinterpret_cast<unsigned*>(d + PIECE) = sh[1];
-            *reinterpret_cast<unsigned*>(d + 2 * PIECE) = sh[2];
+            if constexpr (!F16) *reinterpret_cast<unsigned*>(d + 2 * PIECE) = sh[2];
             *reinterpret_cast<float2*>(&yf[(size_t)u3 * FBUF + rowi * FROW + prow]) = make_float2(sv0, sv1);
         }
     };
@@ -507,6 +568,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_hy_wide(Dev P) {
     f16w acc0[2], acc1[2];                                         // [unit parity]: K half 0 (H_re), K half 1 (-H_im)
     float ep_run = 0.f;
     float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float usc = (1.0f / sH) * (1.0f / sB), usgn = sgn * usc;   // exact powers of two (1 without the fp16 scales)
     auto run_unit = [&](auto par_c, auto mac_c, int u, int u3) {
         constexpr int PAR = decltype(par_c)::value;
         constexpr bool MAC = decltype(mac_c)::value;
@@ -525,7 +587,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_hy_wide(Dev P) {
             const unsigned char* src = pb + ((cs * 2 + cc) * 2 + comp) * PROW + j0 * 2;
             Bq[buf][0] = __builtin_bit_cast(bf8w, *reinterpret_cast<const u4w*>(src));
             Bq[buf][1] = __builtin_bit_cast(bf8w, *reinterpret_cast<const u4w*>(src + PIECE));
-            Bq[buf][2] = __builtin_bit_cast(bf8w, *reinterpret_cast<const u4w*>(src + 2 * PIECE));
+            if constexpr (!F16) Bq[buf][2] = __builtin_bit_cast(bf8w, *reinterpret_cast<const u4w*>(src + 2 * PIECE));
         };
         auto slice = [&](auto ic) {
             constexpr int I = decltype(ic)::value;
@@ -550,8 +612,12 @@ __global__ __launch_bounds__(2 * PD, 1) void k_hy_wide(Dev P) {
                 if constexpr (x < 8) {
                     constexpr int g = x / 2;
                     if constexpr ((x & 1) == 0) {
-                        hv = make_float4(acc0[1 - PAR][4 * g] + sgn * acc1[1 - PAR][4 * g], acc0[1 - PAR][4 * g + 1] + sgn * acc1[1 - PAR][4 * g + 1],
-                                         acc0[1 - PAR][4 * g + 2] + sgn * acc1[1 - PAR][4 * g + 2], acc0[1 - PAR][4 * g + 3] + sgn * acc1[1 - PAR][4 * g + 3]);
+                        if constexpr (F16)
+                            hv = make_float4(fmaf(acc0[1 - PAR][4 * g], usc, usgn * acc1[1 - PAR][4 * g]), fmaf(acc0[1 - PAR][4 * g + 1], usc, usgn * acc1[1 - PAR][4 * g + 1]),
+                                             fmaf(acc0[1 - PAR][4 * g + 2], usc, usgn * acc1[1 - PAR][4 * g + 2]), fmaf(acc0[1 - PAR][4 * g + 3], usc, usgn * acc1[1 - PAR][4 * g + 3]));
+                        else
+                            hv = make_float4(acc0[1 - PAR][4 * g] + sgn * acc1[1 - PAR][4 * g], acc0[1 - PAR][4 * g + 1] + sgn * acc1[1 - PAR][4 * g + 1],
+                                             acc0[1 - PAR][4 * g + 2] + sgn * acc1[1 - PAR][4 * g + 2], acc0[1 - PAR][4 * g + 3] + sgn * acc1[1 - PAR][4 * g + 3]);
                         if constexpr (g == 0) ep_run = 0.f;
                     } else {
                         const v4f yv = *reinterpret_cast<const v4f*>(yr + 8 * g);
@@ -577,14 +643,15 @@ __global__ __launch_bounds__(2 * PD, 1) void k_hy_wide(Dev P) {
         static_for<0, (MAC ? NM : NS)>([&](auto tc) {
             constexpr int t = decltype(tc)::value;
             if constexpr (MAC) {
-                constexpr int kt = t / 6, pr = t % 6, buf = kt & 1;
+                constexpr int kt = t / NPR, pr = t % NPR, buf = kt & 1;
                 if constexpr (pr == 0 && kt + 1 < KT) read_b(kt + 1, 1 - buf);
-                // piece products a + b <= 2: lo hi', hi lo', mid mid', mid hi', hi mid', hi hi'
-                const bf8w av = pr == 0 ? Al[kt] : (pr == 2 || pr == 3) ? Am[kt] : Ah[kt];
-                const bf8w bv = pr == 1 ? Bq[buf][2] : (pr == 2 || pr == 4) ? Bq[buf][1] : Bq[buf][0];
+                // piece products a + b <= 2: lo hi', hi lo', mid mid', mid hi', hi mid', hi hi'  (fp16: lo hi', hi lo', hi hi')
+                const bf8w av = pr == 0 ? Al[kt] : (!F16 && (pr == 2 || pr == 3)) ? Am[F16 ? 0 : kt] : Ah[kt];
+                const bf8w bv = F16 ? (pr == 1 ? Bq[buf][1] : Bq[buf][0])
+                                    : (pr == 1 ? Bq[buf][2] : (pr == 2 || pr == 4) ? Bq[buf][1] : Bq[buf][0]);
                 constexpr f16w zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                if constexpr (kt < KT / 2) acc0[PAR] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, t == 0 ? zero : acc0[PAR], 0, 0, 0);
-                else acc1[PAR] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, t == 6 * (KT / 2) ? zero : acc1[PAR], 0, 0, 0);
+                if constexpr (kt < KT / 2) acc0[PAR] = gg::mma<F16>(av, bv, t == 0 ? zero : acc0[PAR]);
+                else acc1[PAR] = gg::mma<F16>(av, bv, t == NPR * (KT / 2) ? zero : acc1[PAR]);
                 __builtin_amdgcn_sched_barrier(0);
                 static_for<(t * NS) / NM, ((t + 1) * NS) / NM>(slice);
             } else {
@@ -853,17 +920,22 @@ static hipError_t wide_lds_attr(K kernel, size_t shm) {
 }
 
 template <int PD>
-static hipError_t fwd_wide_t(const Dev& P, const float* audio, float* loss, bool save, hipStream_t s) {
+static hipError_t fwd_wide_t(const Dev& P, const float* audio, float* loss, bool save, bool hy_f16, hipStream_t s) {
     const unsigned nb = (unsigned)((P.B + 1) / 2);
     hipError_t e;
     if (save) {
         // the serial chain, then H y / e_k for all (clip, step) pairs as one GEMM launch, then the sequential loss sums
         const size_t shm = WideGeom<PD>::FWD_LDS_CHAIN, shm_hy = HyGeom<PD>::LDS;
         e = wide_lds_attr(k_fwd_wide<PD, true>, shm);
-        if (e == hipSuccess) e = wide_lds_attr(k_hy_wide<PD>, shm_hy);
+        if (e == hipSuccess) e = hy_f16 ? wide_lds_attr(k_hy_wide<PD, true>, shm_hy) : wide_lds_attr(k_hy_wide<PD, false>, shm_hy);
         if (e != hipSuccess) return e;
         { KScope ks("k_fwd_wide", s); hipLaunchKernelGGL((k_fwd_wide<PD, true>), dim3(nb), dim3(4 * PD), shm, s, P, audio, loss); }
-        { KScope ks("k_hy_wide", s); hipLaunchKernelGGL((k_hy_wide<PD>), dim3(nb, (unsigned)((P.N + HCHUNK - 1) / HCHUNK)), dim3(2 * PD), shm_hy, s, P); }
+        {
+            KScope ks(hy_f16 ? "k_hy_wide<f16x2>" : "k_hy_wide<3>", s);
+            const dim3 grid(nb, (unsigned)((P.N + HCHUNK - 1) / HCHUNK));
+            if (hy_f16) hipLaunchKernelGGL((k_hy_wide<PD, true>), grid, dim3(2 * PD), shm_hy, s, P);
+            else hipLaunchKernelGGL((k_hy_wide<PD, false>), grid, dim3(2 * PD), shm_hy, s, P);
+        }
         { KScope ks("k_loss_wide", s); hipLaunchKernelGGL(k_loss_wide, dim3((unsigned)P.B), dim3(64), 0, s, P, audio, loss); }
     } else {
         const size_t shm = WideGeom<PD>::FWD_LDS;
@@ -875,10 +947,10 @@ static hipError_t fwd_wide_t(const Dev& P, const float* audio, float* loss, bool
     return hipGetLastError();
 }
 
-hipError_t launch_fwd_wide(const Dev& P, const float* audio, float* loss, bool save, hipStream_t s) {
-    if (P.DP == 128) return fwd_wide_t<128>(P, audio, loss, save, s);
-    if (P.DP == 96) return fwd_wide_t<96>(P, audio, loss, save, s);
-    if (P.DP == 64) return fwd_wide_t<64>(P, audio, loss, save, s);
+hipError_t launch_fwd_wide(const Dev& P, const float* audio, float* loss, bool save, bool hy_f16, hipStream_t s) {
+    if (P.DP == 128) return fwd_wide_t<128>(P, audio, loss, save, hy_f16, s);
+    if (P.DP == 96) return fwd_wide_t<96>(P, audio, loss, save, hy_f16, s);
+    if (P.DP == 64) return fwd_wide_t<64>(P, audio, loss, save, hy_f16, s);
     return hipErrorInvalidValue;
 }
 
