@@ -9,19 +9,22 @@
 // that had to be summed with permlane swaps, and a lone wave issues it every 12 cycles instead of its 8):
 //
 //   D (16 x 16) = A (16 x 32) B (32 x 16):   A rows = vector forms, B columns = sixteen ROWS of the matrix, K = 32 entries of
-//   the real form.  Only A rows {0, 4, 8, 12} carry the four forms: row 4 f lands in accumulator register 0 of the lanes
-//   16 f .. 16 f + 15, so after the K loop register 0 of lane l IS  (M u)[row (l & 15)], form (l >> 4)  -- one useful value
-//   in every lane, K summed by the matrix pipe, no cross-lane reduction, no compaction (scripts/ubench/mfma16_matvec.hip
-//   checks the layout with integer data and times the instruction: 16 cycles back to back from a lone wave).
+//   the real form.  A rows {0, 4, 8, 12} carry the four forms: row 4 f lands in accumulator register 0 of the lanes
+//   16 f .. 16 f + 15, so after the K loop register 0 of lane l IS  (M u)[row (l & 15)], form (l >> 4)  -- K summed by the
+//   matrix pipe, no cross-lane reduction, no compaction (scripts/ubench/mfma16_matvec.hip checks the layout with integer
+//   data and times the instruction: 16 cycles back to back from a lone wave).  A rows {1, 5, 9, 13} carry the Re <-> Im
+//   PARTNER of each form and land in register 1 of the same lanes: the complex rotations of the chain (rho y, conj(rho) g)
+//   find both components of their row in-lane; the other eight A rows are unused.
 //
 //   workgroup = D / 32 chain waves (+ as many loss waves in the forward); wave w owns rows 32 w .. 32 w + 31 as TWO tiles
 //   (tile 0 = the even rows, tile 1 = the odd rows: a lane's two values are adjacent rows, one packed 4-byte LDS store).
 //   lane l = (j = l & 15, f = l >> 4): rows ia = 32 w + 2 j and ia + 1, component (f & 1 ? Im : Re) of clip f >> 1 -- every
 //     (row, component, clip) lives in exactly one lane; its Re <-> Im partner sits 16 lanes away (v_permlane16_swap).
-//   B operand (resident, AGPRs): 8 bf16 = columns 32 t + 8 (l >> 4) .. + 7 of  [M_re | M_im]  in row 32 w + 2 (l & 15) + tile,
+//   B operand (resident: AGPRs in the reverse scan; the forward has no AGPR operand at all, so hipcc selects the VGPR form of
+//     the MFMA and its lone chain wave uses all 256 registers as one file): 8 bf16 = columns 32 t + 8 (l >> 4) .. + 7 of  [M_re | M_im]  in row 32 w + 2 (l & 15) + tile,
 //     D / 16 K-steps t, two tiles: D / 2 registers per matrix and lane.
-//   A operand: lane l reads 16 bytes of form (l >> 2) & 3 (all four lanes of a quad read the same address: only A rows 0, 4,
-//     8, 12 matter) at K = 32 t + 8 (l >> 4): D / 16 ds_read_b128 per broadcast vector and lane, shared by both matrices.
+//   A operand: lane l reads 16 bytes of form (l >> 2) & 3, or of its partner in lanes with (l & 3) == 1 (the other two lanes
+//     of a quad feed unused A rows and read the form's address) at K = 32 t + 8 (l >> 4): D / 16 ds_read_b128 per broadcast vector and lane, shared by both matrices.
 //   Per step: 4 D / 16 MFMAs on the chain (R ut, Q ut; 512 matrix-pipe cycles at D = 128), ONE workgroup barrier.
 //   The identity part of y = ut + Q ut + s R ut stays float32; only the small correction goes through bf16.
 // Arithmetic restated (with the same rounding points) by oracle/cmps_oracle.py::psi_bf16_scan.

@@ -347,8 +347,10 @@ def kernel_work_model(fam, D, DP, rank1):
         gp = 6 if rank1 == 2 else 3
         gname = {1: "k_grad_gemm<2>", 2: "k_grad_gemm<3>", 3: "k_grad_gemm<f16x2>"}[rank1]
         return {"k_fwd_wide": [("valu_fp32", 12 * D * D, "merged (Q + s R) u, v_pk_fma_f32"), ("hbm", 8.0 * DP, "y rows written: 16 DP B per pair-step")],
-                "k_hy_wide": [("mfma_bf16", 8 * 6 * D * D, "H y for all (clip, step) pairs, bf16x3 split: 6 piece products"),
-                              ("hbm", 16.0 * DP, "y rows read + H y rows written")],
+                ("k_hy_wide<3>" if rank1 in (1, 2) else "k_hy_wide<f16x2>"):
+                    [("mfma_bf16", 8 * (6 if rank1 in (1, 2) else 3) * D * D,
+                      "H y for all (clip, step) pairs: bf16x3 split, 6 piece products (BF16X2 / BF16X3) or f16x2 split, 3 products"),
+                     ("hbm", 16.0 * DP, "y rows read + H y rows written")],
                 "k_loss_wide": [("hbm", 8.0, "e_k, |y_k|^2 scalars")],
                 "k_bwd_wide": [("valu_fp32", 12 * D * D, "merged (Q + s R^dagger) ybar"), ("hbm", 24.0 * DP, "y, H y rows read, ybar rows written")],
                 gname: [("mfma_bf16", 24 * gp * D * D, f"three rank-1 sums as GEMMs, {gp} piece products (fp16 and bf16 MFMAs have the same dense peak)"),
