@@ -383,8 +383,11 @@ int cmps_psi_sample(cmps_handle_t h, const float* noise_dev, int n, int length, 
         return fail(h, CMPS_ERR_BAD_ARG, "cmps_psi_sample: length exceeds T - 1 of cmps_set_params (the per-step tables)");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int sv = resolve_variant(h);
+    // wave-per-path kernel for D <= 32, the wide chain's sampling mode for 32 < D <= 128 (float32; also what the bf16 pair variant
+    // samples with: sampling has no reduced-precision form), the block kernel otherwise
     hipError_t e = (sv == CMPS_VARIANT_WAVE || sv == CMPS_VARIANT_WAVE32) ? launch_sample_wave(h->P, noise_dev, n, length, out_dev, s)
-                                                             : launch_sample_block(h->P, noise_dev, n, length, out_dev, s);
+                   : (sv == CMPS_VARIANT_WIDE || sv == CMPS_VARIANT_PAIR)  ? launch_sample_wide(h->P, noise_dev, n, length, out_dev, s)
+                                                                           : launch_sample_block(h->P, noise_dev, n, length, out_dev, s);
     if (e != hipSuccess) return fail_hip(h, e, "cmps_psi_sample");
     return CMPS_OK;
 }

@@ -256,6 +256,7 @@ hipError_t launch_fwd_legacy(const Dev& P, const float* audio, float* loss, bool
 hipError_t launch_bwd_legacy(const Dev& P, const float* audio, hipStream_t s);
 hipError_t launch_finalize_legacy(const Dev& P, const float* loss, float* grad_out, hipStream_t s);
 hipError_t launch_sample_wave(const Dev& P, const float* noise, int n, int length, float* out, hipStream_t s);
+hipError_t launch_sample_wide(const Dev& P, const float* noise, int n, int length, float* out, hipStream_t s);
 hipError_t launch_sample_block(const Dev& P, const float* noise, int n, int length, float* out, hipStream_t s);
 
 size_t apply_step_scratch_bytes(int D);

@@ -114,6 +114,20 @@ __device__ __forceinline__ void col_merged(v2f& aRe0, v2f& aIm0, v2f& aRe1, v2f&
         : "+v"(aRe0), "+v"(aIm0), "+v"(aRe1), "+v"(aIm1), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
         : "v"(r0), "v"(q0), "v"(r1), "v"(q1), "s"(s2), "v"(xre), "v"(xim));
 }
+// accR(two rows) += R[row][col] x[col], accQ(two rows) += Q[row][col] x[col] for both clips, unmerged (the sampler needs R ut by
+// itself: the increment it scales R ut with depends on <R>)
+__device__ __forceinline__ void col_two(v2f& rRe0, v2f& rIm0, v2f& rRe1, v2f& rIm1, v2f& qRe0, v2f& qIm0, v2f& qRe1, v2f& qIm1,
+                                        v2f r0, v2f q0, v2f r1, v2f q1, v2f xre, v2f xim) {
+#define WIDE_CMAC(RE, IM, M)                                                                            \
+    "v_pk_fma_f32 %" #RE ", %" #M ", %12, %" #RE " op_sel_hi:[0,1,1]\n\t"                                  \
+    "v_pk_fma_f32 %" #IM ", %" #M ", %13, %" #IM " op_sel_hi:[0,1,1]\n\t"                                  \
+    "v_pk_fma_f32 %" #RE ", %" #M ", %13, %" #RE " op_sel:[1,0,0] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"       \
+    "v_pk_fma_f32 %" #IM ", %" #M ", %12, %" #IM " op_sel:[1,0,0]\n\t"
+    asm(WIDE_CMAC(0, 1, 8) WIDE_CMAC(4, 5, 9) WIDE_CMAC(2, 3, 10) WIDE_CMAC(6, 7, 11)
+        : "+v"(rRe0), "+v"(rIm0), "+v"(rRe1), "+v"(rIm1), "+v"(qRe0), "+v"(qIm0), "+v"(qRe1), "+v"(qIm1)
+        : "v"(r0), "v"(q0), "v"(r1), "v"(q1), "v"(xre), "v"(xim));
+#undef WIDE_CMAC
+}
 // acc(two rows) += H[row][col .. col + 1] * y[col .. col + 1] for both clips; h = (re, im, re, im) of two adjacent columns
 __device__ __forceinline__ void col_pair_plain(v2f& aRe0, v2f& aIm0, v2f& aRe1, v2f& aIm1, v4f h0, v4f h1, v4f ya, v4f yb) {
     asm("v_pk_fma_f32 %0, %4, %8, %0 op_sel_hi:[0,1,1]\n\t"                                    // Re += h_re y_re
@@ -376,6 +390,109 @@ __global__ __launch_bounds__(4 * PD) void k_fwd_wide(Dev P, const float* __restr
     if (LOSS && w == 0 && lane == 0) {
         loss_out[b0] = loss0;
         if (two) loss_out[b1] = loss1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// PsiCMPS.sample (model.py:242-251, 284-291) for 32 < D <= 128 (round 4: a mode of the wide chain; before, the block sampler re-read
+// both matrices from L2 every step).  One workgroup per PAIR of paths, the forward chain's lane layout and broadcast; the step is
+//   e = 2 inv^2 Re(ut^dagger R ut)  ->  inc = e dt + noise_k,  samp += inc,  s = inc / A  ->  y_k = inv (ut + Q ut + s R ut),
+// with ut = rho_{k-1} y_{k-1} carried un-normalised as in the forward (inv = 1 / |y_{k-1}|, its partial sums ride with the broadcast).
+// R ut and Q ut stay separate (the increment that scales R ut depends on <R>), and the expectation needs one more exchange across
+// the waves: two LDS-only barriers per step instead of one.
+// ------------------------------------------------------------------------------------------------------------------------
+template <int PD>
+__global__ __launch_bounds__(4 * PD) void k_sample_wide(Dev P, const float* __restrict__ noise, int n_paths, int length,
+                                                        float* __restrict__ out) {
+    using G = WideGeom<PD>;
+    constexpr int NW = G::NW, KC = G::KC, VSL = G::VSL, VEC4 = G::VEC4;
+    __shared__ __attribute__((aligned(16))) v4f uvec[2 * VEC4];
+    __shared__ __attribute__((aligned(8))) float nrm[2 * NW * 2];
+    __shared__ __attribute__((aligned(8))) float ee[NW * 2];
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int q = lane >> 3, i = lane & 7;
+    const int rowsel = q >> 2, comp = (q >> 1) & 1, clip = q & 1;
+    const bool clip1 = clip != 0, im_lane = comp != 0;
+    const int row = 16 * w + 8 * rowsel + i;
+    const int b0 = 2 * blockIdx.x, b1 = (b0 + 1 < n_paths) ? b0 + 1 : b0;   // an odd count repeats its last path (not stored)
+    const bool two = b1 != b0;
+    const float* nr0 = noise + (size_t)b0 * length;
+    const float* nr1 = noise + (size_t)b1 * length;
+    float* orow = out + (size_t)(clip1 ? b1 : b0) * length;
+    const bool writer = w == 0 && i == 0 && q < 2 && (!clip1 || two);
+    const float A = dev_A(P), dt = P.dt;
+
+    v2f MR[2][KC], MQ[2][KC];
+    {
+        const int ra = 16 * w + i, rb = ra + 8, c0 = q * KC;
+#pragma unroll
+        for (int j = 0; j < KC; ++j) {
+            const float2 a = P.R[(size_t)ra * PD + c0 + j], b = P.R[(size_t)rb * PD + c0 + j];
+            const float2 c = P.Q[(size_t)ra * PD + c0 + j], d = P.Q[(size_t)rb * PD + c0 + j];
+            MR[0][j] = mkv2(a.x, a.y); MR[1][j] = mkv2(b.x, b.y);
+            MQ[0][j] = mkv2(c.x, c.y); MQ[1][j] = mkv2(d.x, d.y);
+        }
+    }
+    const int own_f = vec_float_index<PD>(row, comp, clip);
+    const int rd4 = q * VSL;
+    const float2 p0 = P.psi0[row];
+    float ut = im_lane ? p0.y : p0.x;
+    reinterpret_cast<float*>(uvec)[own_f] = ut;
+    float nz0 = 0.f, nz1 = 0.f;                                   // noise of the current 64 steps, lane <-> step
+    float samp = 0.f;                                             // model.py:244 batch_zeros (this lane's path)
+    float2 rho_next = P.rho[row];
+    __syncthreads();
+
+    for (int k = 0; k < length; ++k) {
+        const int p = k & 1, kl = k & (WCH - 1);
+        if (kl == 0) {
+            const int idx = k + lane;
+            nz0 = idx < length ? nr0[idx] : 0.f;
+            nz1 = idx < length ? nr1[idx] : 0.f;
+        }
+        const float2 rho_k = rho_next;
+        if (k + 1 < P.N) rho_next = P.rho[(size_t)(k + 1) * PD + row];
+        float n0 = 1.f, n1 = 1.f;
+        if (k >= 1) {
+            n0 = n1 = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) {
+                const float2 t = *reinterpret_cast<const float2*>(&nrm[(p * NW + ww) * 2]);
+                n0 += t.x; n1 += t.y;
+            }
+        }
+        const float inv = k >= 1 ? rsq_newton(fmaxf(clip1 ? n1 : n0, 1e-12f)) : 1.f;      // model.py:289 of the step before
+        v2f rRe0 = mkv2(0.f, 0.f), rIm0 = rRe0, rRe1 = rRe0, rIm1 = rRe0;
+        v2f qRe0 = rRe0, qIm0 = rRe0, qRe1 = rRe0, qIm1 = rRe0;
+        const v4f* uv = uvec + p * VEC4 + rd4;
+#pragma unroll
+        for (int j = 0; j < KC; ++j) {
+            const v4f x = uv[j];
+            col_two(rRe0, rIm0, rRe1, rIm1, qRe0, qIm0, qRe1, qIm1, MR[0][j], MQ[0][j], MR[1][j], MQ[1][j], lo_of(x), hi_of(x));
+        }
+        const float vs = reduce_slices(rRe0, rIm0, rRe1, rIm1, clip1);      // (R ut), (Q ut): this lane's (row, component, path)
+        const float qs = reduce_slices(qRe0, qIm0, qRe1, qIm1, clip1);
+        const float ep = clip_wave_sum(ut * vs);
+        if (i == 0 && q < 2) ee[w * 2 + clip] = ep;
+        wide_barrier();
+        float e0 = 0.f, e1 = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) {
+            const float2 t = *reinterpret_cast<const float2*>(&ee[ww * 2]);
+            e0 += t.x; e1 += t.y;
+        }
+        const float e = 2.0f * ((clip1 ? e1 : e0) * inv) * inv;   // _expectation on the normalised state (model.py:319-325)
+        const float inc = e * dt + (clip1 ? wrdl(nz1, kl) : wrdl(nz0, kl));   // model.py:286
+        samp += inc;                                              // :287
+        const float s = inc / A;                                  // :288 -> :303
+        const float y = inv * (ut + (qs + s * vs));
+        const float nn = clip_wave_sum(y * y);
+        if (i == 0 && q < 2) nrm[((p ^ 1) * NW + w) * 2 + clip] = nn;
+        const float py = partner16(y, im_lane);
+        ut = rho_k.x * y + (im_lane ? rho_k.y : -rho_k.y) * py;   // rho_k y_k, normalised in the next step
+        reinterpret_cast<float*>(uvec + (p ^ 1) * VEC4)[own_f] = ut;
+        if (writer) orow[k] = A * samp;                           // model.py:251
+        wide_barrier();
     }
 }
 
@@ -952,6 +1069,15 @@ hipError_t launch_fwd_wide(const Dev& P, const float* audio, float* loss, bool s
     if (P.DP == 96) return fwd_wide_t<96>(P, audio, loss, save, hy_f16, s);
     if (P.DP == 64) return fwd_wide_t<64>(P, audio, loss, save, hy_f16, s);
     return hipErrorInvalidValue;
+}
+
+hipError_t launch_sample_wide(const Dev& P, const float* noise, int n, int length, float* out, hipStream_t s) {
+    const unsigned nb = (unsigned)((n + 1) / 2);
+    if (P.DP == 128) hipLaunchKernelGGL(k_sample_wide<128>, dim3(nb), dim3(512), 0, s, P, noise, n, length, out);
+    else if (P.DP == 96) hipLaunchKernelGGL(k_sample_wide<96>, dim3(nb), dim3(384), 0, s, P, noise, n, length, out);
+    else if (P.DP == 64) hipLaunchKernelGGL(k_sample_wide<64>, dim3(nb), dim3(256), 0, s, P, noise, n, length, out);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
 }
 
 hipError_t launch_bwd_wide(const Dev& P, const float* audio, hipStream_t s) {

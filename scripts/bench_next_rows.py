@@ -3,7 +3,7 @@
 
 For every row: device time of one call at a stated shape (HIP events around the launches, median of a few rounds, inputs
 resident in HBM), the throughput in audio samples/s, and the same arithmetic on the host CPU (the numpy oracle, one
-process, a bounded sample) for scale.  Prints one JSON object; scripts/.. -> profiles/r3_next_rows.json.
+process, a bounded sample) for scale.  Prints one JSON object; scripts/.. -> profiles/r4_next_rows.json.
 """
 import json
 import os
@@ -55,6 +55,29 @@ O.psi_sample(O.HParams(**hp.values()), O.Variables(np.asarray(m.variables["A"]),
 cpu = 16 * 2000 / (time.perf_counter() - t0)
 res["sample_psi"] = {"shape": "D=32, 1024 paths x 16000 steps", "kernel": "k_sample_wave", "ms": ms, "samples_per_s": n * length / ms * 1e3,
                      "cpu_numpy_samples_per_s": cpu, "bound": "serial chain: two wave reductions per step (latency)"}
+
+# ---- rank 1 above D = 32 (round 4): the wide chain's sampling mode against the block sampler, D = 128, 512 paths x 4000 steps
+from audio_mps_amd.scan import HipScan
+n, length = 512, 4000
+hp = HParams(minibatch_size=n, bond_dim=128, sigma=0.05)
+noise = (0.05 * np.sqrt(hp.delta_t) * np.random.default_rng(1).standard_normal((length, n))).astype(np.float32)
+d_noise = torch.from_numpy(np.ascontiguousarray(noise.T)).cuda()
+d_out = torch.empty((n, length), dtype=torch.float32, device="cuda")
+row = {}
+for name, variant in (("k_sample_wide", 5), ("k_sample_block", 1)):
+    mw = PsiCMPS(hp, seed=0, backend=HipScan(128, variant=variant))
+    mw.variables["Rx"] *= np.float32(0.35)
+    mw.variables["Ry"] *= np.float32(0.35)
+    bw = mw._get_backend()
+    bw.set_params(mw.effective_params(), n, length + 1, train=False)
+    row[name] = dev_ms(lambda: _capi.check(bw._h, bw._lib.cmps_psi_sample(bw._h, d_noise.data_ptr(), n, length, d_out.data_ptr(), bw._stream())))
+    row[name + "_out"] = d_out.cpu().numpy().copy()
+dev = float(np.max(np.abs(row["k_sample_wide_out"] - row["k_sample_block_out"])) / max(1.0, float(np.max(np.abs(row["k_sample_block_out"])))))
+res["sample_psi_d128"] = {"shape": "D=128, 512 paths x 4000 steps", "kernel": "k_sample_wide (one workgroup per pair of paths; the forward chain's layout, R ut and Q ut unmerged, two LDS barriers per step)",
+                          "ms": row["k_sample_wide"], "us_per_step": row["k_sample_wide"] * 1e3 / length,
+                          "samples_per_s": n * length / row["k_sample_wide"] * 1e3,
+                          "block_sampler_ms": row["k_sample_block"], "max_dev_from_block_sampler": dev,
+                          "bound": "serial chain: 256 v_pk_fma_f32 per wave and step + two cross-wave exchanges (LDS latency)"}
 
 # ---- rank 2: legacy AudioMPS forward + backward (block kernels), D = 32, T = 4000, 1024 clips
 T, B = 4000, 1024

@@ -148,6 +148,30 @@ def test_rank1_f16x2_accuracy_class():
         assert 8 * d3 <= d2, (D, T, amp, d2, d3)
 
 
+@pytest.mark.parametrize("D,length,n,variant", [(33, 150, 2, WIDE), (64, 300, 5, WIDE), (96, 200, 3, AUTO), (128, 260, 4, WIDE), (128, 65, 1, WIDE),
+                                                (128, 130, 3, 3)])
+def test_sampling_matches_oracle(D, length, n, variant):
+    """PsiCMPS.sample (model.py:242-251) above D = 32: the wide chain's sampling mode (k_sample_wide; also what the bf16 pair variant
+    samples with) against the numpy oracle and the block sampler, even and odd path counts, lengths around the 64-step noise chunks."""
+    from oracle import cmps_oracle as O
+    from _util import oracle_hparams, oracle_variables
+    from audio_mps_amd import HParams, PsiCMPS
+    from audio_mps_amd.scan import HipScan
+    hp = HParams(minibatch_size=n, bond_dim=D, sigma=1.0, A=10.0)
+    m = PsiCMPS(hp, seed=D, backend=HipScan(D, variant=variant))
+    mb = PsiCMPS(hp, seed=D, backend=HipScan(D, variant=BLOCK))
+    for mm in (m, mb):
+        mm.variables["Rx"] *= np.float32(0.03)
+        mm.variables["Ry"] *= np.float32(0.03)
+    noise = O.sample_noise(oracle_hparams(hp), n, length, temp=0.5, seed=D)
+    ref = O.psi_sample(oracle_hparams(hp), oracle_variables(m), noise)
+    out = m.sample(n, length, noise=noise)
+    assert out.shape == (n, length) and np.all(np.isfinite(out))
+    scale = max(1.0, np.max(np.abs(ref)))
+    assert np.max(np.abs(out - ref)) <= 2e-5 * scale
+    assert np.max(np.abs(out - mb.sample(n, length, noise=noise))) <= 2e-5 * scale
+
+
 def test_bit_reproducible():
     m, audio = _wide_model(96, 300, 5, seed=4)
     a = m.grad_sums()[0].cpu().numpy().copy()
