@@ -17,6 +17,7 @@ struct cmps_handle_s {
     int D = 0;
     int variant_req = CMPS_VARIANT_AUTO;
     int rank1_mode = CMPS_RANK1_DEFAULT;
+    int wide_chain = CMPS_WIDE_CHAIN_VALU;
     bool params_set = false;
     bool legacy = false;       // the tables currently hold the legacy AudioMPS arithmetic (cmps_legacy_set_params)
     bool fwd_saved = false;
@@ -127,6 +128,12 @@ int cmps_set_option(cmps_handle_t h, int option, int value) {
         h->rank1_mode = value;
         return CMPS_OK;
     }
+    if (option == CMPS_OPT_WIDE_CHAIN) {
+        if (value != CMPS_WIDE_CHAIN_VALU && value != CMPS_WIDE_CHAIN_MFMA)
+            return fail(h, CMPS_ERR_BAD_ARG, "cmps_set_option: unknown value for CMPS_OPT_WIDE_CHAIN");
+        h->wide_chain = value;
+        return CMPS_OK;
+    }
     if (option == CMPS_OPT_KERNEL_EVENTS) {
         if (value != 0 && value != 1) return fail(h, CMPS_ERR_BAD_ARG, "cmps_set_option: CMPS_OPT_KERNEL_EVENTS takes 0 or 1");
         if (value && !h->ktimer) h->ktimer = new cmps::KTimer();
@@ -140,6 +147,7 @@ int cmps_get_option(cmps_handle_t h, int option) {
     if (!h) return -1;
     if (option == CMPS_OPT_RANK1) return h->rank1_mode;
     if (option == CMPS_OPT_KERNEL_EVENTS) return h->ktimer ? 1 : 0;
+    if (option == CMPS_OPT_WIDE_CHAIN) return h->wide_chain;
     return -1;
 }
 
@@ -276,7 +284,7 @@ int cmps_psi_loss_fwd(cmps_handle_t h, const float* audio_dev, int B, int T, flo
     } else if (variant == CMPS_VARIANT_WIDE) {
         // k_fwd_wide, k_hy_wide, k_loss_wide (scopes inside); the loss product's pieces follow CMPS_OPT_RANK1 like the gradient GEMM's
         e = launch_fwd_wide(P, audio_dev, loss_dev, save_for_bwd != 0,
-                            h->rank1_mode == CMPS_RANK1_DEFAULT || h->rank1_mode == CMPS_RANK1_F16X2, s);
+                            h->rank1_mode == CMPS_RANK1_DEFAULT || h->rank1_mode == CMPS_RANK1_F16X2, h->wide_chain == CMPS_WIDE_CHAIN_MFMA, s);
     } else {
         KScope ks("k_fwd_block", s);
         e = launch_fwd_block(P, audio_dev, loss_dev, save_for_bwd != 0, s);

@@ -1037,7 +1037,7 @@ static hipError_t wide_lds_attr(K kernel, size_t shm) {
 }
 
 template <int PD>
-static hipError_t fwd_wide_t(const Dev& P, const float* audio, float* loss, bool save, bool hy_f16, hipStream_t s) {
+static hipError_t fwd_wide_t(const Dev& P, const float* audio, float* loss, bool save, bool hy_f16, bool chain_mfma, hipStream_t s) {
     const unsigned nb = (unsigned)((P.B + 1) / 2);
     hipError_t e;
     if (save) {
@@ -1046,7 +1046,13 @@ static hipError_t fwd_wide_t(const Dev& P, const float* audio, float* loss, bool
         e = wide_lds_attr(k_fwd_wide<PD, true>, shm);
         if (e == hipSuccess) e = hy_f16 ? wide_lds_attr(k_hy_wide<PD, true>, shm_hy) : wide_lds_attr(k_hy_wide<PD, false>, shm_hy);
         if (e != hipSuccess) return e;
-        { KScope ks("k_fwd_wide", s); hipLaunchKernelGGL((k_fwd_wide<PD, true>), dim3(nb), dim3(4 * PD), shm, s, P, audio, loss); }
+        if (chain_mfma) {
+            KScope ks("k_fwd_chain16", s);
+            if ((e = launch_fwd_chain16(P, audio, s)) != hipSuccess) return e;
+        } else {
+            KScope ks("k_fwd_wide", s);
+            hipLaunchKernelGGL((k_fwd_wide<PD, true>), dim3(nb), dim3(4 * PD), shm, s, P, audio, loss);
+        }
         {
             KScope ks(hy_f16 ? "k_hy_wide<f16x2>" : "k_hy_wide<3>", s);
             const dim3 grid(nb, (unsigned)((P.N + HCHUNK - 1) / HCHUNK));
@@ -1064,10 +1070,10 @@ static hipError_t fwd_wide_t(const Dev& P, const float* audio, float* loss, bool
     return hipGetLastError();
 }
 
-hipError_t launch_fwd_wide(const Dev& P, const float* audio, float* loss, bool save, bool hy_f16, hipStream_t s) {
-    if (P.DP == 128) return fwd_wide_t<128>(P, audio, loss, save, hy_f16, s);
-    if (P.DP == 96) return fwd_wide_t<96>(P, audio, loss, save, hy_f16, s);
-    if (P.DP == 64) return fwd_wide_t<64>(P, audio, loss, save, hy_f16, s);
+hipError_t launch_fwd_wide(const Dev& P, const float* audio, float* loss, bool save, bool hy_f16, bool chain_mfma, hipStream_t s) {
+    if (P.DP == 128) return fwd_wide_t<128>(P, audio, loss, save, hy_f16, chain_mfma, s);
+    if (P.DP == 96) return fwd_wide_t<96>(P, audio, loss, save, hy_f16, chain_mfma, s);
+    if (P.DP == 64) return fwd_wide_t<64>(P, audio, loss, save, hy_f16, chain_mfma, s);
     return hipErrorInvalidValue;
 }
 

@@ -96,6 +96,14 @@ class HipScan:
     def rank1(self) -> int:
         return int(self._lib.cmps_get_option(self._h, _capi.CMPS_OPT_RANK1))
 
+    def set_wide_chain(self, mode: int):
+        """cmps_set_option(CMPS_OPT_WIDE_CHAIN): 0 = fp32 VALU chain, 1 = fp16 x 2 split operands on the matrix cores (wide kernels' training forward)."""
+        _capi.check(self._h, self._lib.cmps_set_option(self._h, _capi.CMPS_OPT_WIDE_CHAIN, int(mode)))
+
+    @property
+    def wide_chain(self) -> int:
+        return int(self._lib.cmps_get_option(self._h, _capi.CMPS_OPT_WIDE_CHAIN))
+
     @property
     def effective_rank1(self) -> int:
         """The arithmetic the selected kernels run for the current option value (include/cmps.h): the wide kernels' gradient GEMM

@@ -67,6 +67,7 @@ enum {
                         * of D <= 16 always uses exact fp32 MFMAs) and the gradient GEMM of the wide kernels (32 < D <= 128:
                         * BF16X2 = two bf16 pieces / three products, F16X2 = two fp16 pieces / three products, anything else = three
                         * bf16 pieces / six products) */,
+    CMPS_OPT_WIDE_CHAIN = 3 /* how the wide kernels (32 < D <= 128, float32) run the training forward's serial chain: see the values below */,
     CMPS_OPT_KERNEL_EVENTS = 2 /* 1: every kernel cmps_psi_loss_fwd / _bwd launch is bracketed by two HIP events on the caller's stream
                         * (read and reset with cmps_kernel_times); 0 (default): nothing is recorded.  A measurement aid -- the reference
                         * has no counterpart (no tracing / profiling hooks); bench.py uses it OUTSIDE its timed region to price
@@ -90,6 +91,14 @@ enum {
     CMPS_RANK1_F16X2 = 3,
     CMPS_RANK1_DEFAULT = 4   /* a new handle's setting: BF16X3 in the wave reverse scan, F16X2 in the wide kernels' gradient GEMM --
                               * the cheapest arithmetic of the 24-operand-bit class on each (scripts/rank1_accuracy_wide.py) */
+};
+
+/* values of CMPS_OPT_WIDE_CHAIN */
+enum {
+    CMPS_WIDE_CHAIN_VALU = 0,   /* k_fwd_wide: the mat-vec as fp32 v_pk_fma_f32 chains (R, Q register resident) */
+    CMPS_WIDE_CHAIN_MFMA = 1    /* k_fwd_chain16: the correction (Q + s R) u as power-of-two scaled fp16 x 2 split operands on
+                                 * v_mfma_f32_16x16x32_f16 (three products, fp32 accumulate: the accuracy class of CMPS_RANK1_F16X2);
+                                 * identity part and everything behind the mat-vec in float32 */
 };
 
 /* Library version (major * 10000 + minor * 100 + patch). */

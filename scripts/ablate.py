@@ -24,7 +24,7 @@ if "--only" in args:
 shape = ["32", "16000", "1024", "4"]
 if "--shape" in args:
     i = args.index("--shape")
-    shape = args[i + 1:i + 6]
+    shape = args[i + 1:]                  # D T B ROUNDS VARIANT [RANK1 [WIDE_CHAIN]]: everything scripts/time_kernels.py takes
     args = args[:i]
 variants = {}
 for a in args or ["base="]:

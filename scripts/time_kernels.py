@@ -19,6 +19,8 @@ audio = torch.from_numpy((x + 0.02 * rng.standard_normal(x.shape)).astype(np.flo
 variant = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 rank1 = int(sys.argv[6]) if len(sys.argv) > 6 else None      # cmps_set_option(CMPS_OPT_RANK1): 0 exact, 1 bf16x2, 2 bf16x3
 be = HipScan(D, variant=variant, rank1=rank1)
+if len(sys.argv) > 7:                                         # cmps_set_option(CMPS_OPT_WIDE_CHAIN): 0 VALU chain, 1 fp16 x 2 on the matrix cores
+    be.set_wide_chain(int(sys.argv[7]))
 m = PsiCMPS(hp, seed=0, backend=be)
 be.set_params(m.effective_params(), B, T, train=True)
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]

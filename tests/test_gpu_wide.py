@@ -6,7 +6,7 @@ so the bars are the ones of the D <= 32 kernels (tests/test_gpu_parity.py):
 import numpy as np
 import pytest
 
-from _util import make_audio, rel_inf
+from _util import c_oracle_run, make_audio, rel_inf
 from test_gpu_parity import BLOCK, GRAD_RTOL, LOSS_RTOL, _check_against_oracle, _model
 
 pytestmark = pytest.mark.gpu
@@ -170,6 +170,58 @@ def test_sampling_matches_oracle(D, length, n, variant):
     scale = max(1.0, np.max(np.abs(ref)))
     assert np.max(np.abs(out - ref)) <= 2e-5 * scale
     assert np.max(np.abs(out - mb.sample(n, length, noise=noise))) <= 2e-5 * scale
+
+
+def _mfma_chain_model(D, T, B, sigma=1e-4, seed=0, rscale=None):
+    m, audio = _wide_model(D, T, B, sigma=sigma, seed=seed, rscale=rscale)
+    m._get_backend().set_wide_chain(1)
+    assert m._get_backend().wide_chain == 1
+    return m, audio
+
+
+@pytest.mark.parametrize("D,T,B,sigma", [
+    (64, 300, 4, 1e-4), (96, 260, 3, 1e-4), (128, 200, 4, 1e-4),
+    (33, 150, 2, 1e-4), (40, 131, 5, 1e-4), (72, 140, 3, 1e-4), (100, 100, 1, 1e-4), (127, 90, 2, 1e-4),
+    (64, 257, 3, 1.0), (128, 130, 2, 1.0), (96, 150, 2, 1.0),
+    (64, 2, 3, 1e-4), (64, 3, 2, 1e-4), (64, 4, 1, 1e-4), (64, 33, 2, 1e-4), (64, 34, 2, 1e-4), (64, 65, 3, 1e-4), (64, 66, 3, 1e-4), (64, 130, 2, 1e-4),
+])
+def test_mfma_chain_oracle_parity(D, T, B, sigma):
+    """CMPS_OPT_WIDE_CHAIN = MFMA (k_fwd_chain16: the training forward's chain with fp16 x 2 split operands on the matrix cores) inside
+    the unchanged float32 bars: the three padded sizes, zero-padded rows, odd batches, sigma = 1, clip lengths around the two-step
+    loop, the 32-step rho chunks and the 64-step scalar chunks."""
+    m, audio = _mfma_chain_model(D, T, B, sigma=sigma, seed=D + T)
+    _check_against_oracle(m, audio)
+
+
+def test_mfma_chain_long_clip_and_states():
+    """D = 128 at T = 16000 against the C oracle, and the stashed states (psi_evolve_with_data reads the y rows the chain kernel left)
+    against the VALU chain's."""
+    m, audio = _mfma_chain_model(128, 16000, 4, seed=5)
+    _check_against_oracle(m, audio, nthreads=16)
+    m2, audio2 = _mfma_chain_model(96, 400, 3, seed=8)
+    mv, _ = _wide_model(96, 400, 3, seed=8)
+    m2.grad_sums(); mv.grad_sums()
+    s2, sv = m2.psi_evolve_with_data(), mv.psi_evolve_with_data()
+    assert s2.shape == sv.shape and np.max(np.abs(s2 - sv)) < 1e-5
+    pm, pv = m2.loss_per_clip(), mv.loss_per_clip()           # (the forward-only path is the VALU kernel in both)
+    np.testing.assert_array_equal(pm, pv)
+
+
+def test_mfma_chain_operand_scales():
+    """The power-of-two operand scales: tiny and large R (entries 1e-6 .. 30 x the usual), loud audio (large |s| |R|), against the oracle."""
+    for rscale, amp, seed in ((1e-6, 1.0, 1), (3.0, 0.05, 2), (0.35, 8.0, 3), (1e-3, 300.0, 4)):
+        m, audio = _mfma_chain_model(128, 150, 2, seed=seed, rscale=rscale)
+        audio = (audio * np.float32(amp)).astype(np.float32)
+        ref = c_oracle_run(m, audio, "f32")
+        if not np.all(np.isfinite(ref["loss_per_clip"])):
+            continue
+        from audio_mps_amd.scan import unpack_grad
+        from oracle import c_oracle as C
+        flat = m.grad_sums(audio)[0].cpu().numpy()
+        g, gr = unpack_grad(flat, 128), C.unpack_grad(ref["grad"], 128)
+        assert abs(g["loss_sum"] - gr["loss_sum"]) <= LOSS_RTOL * max(abs(gr["loss_sum"]), 2.0), (rscale, amp)
+        for k in ("Rbar", "fbar", "psi0bar", "Abar"):
+            assert rel_inf(g[k], gr[k]) <= GRAD_RTOL, (rscale, amp, k)
 
 
 def test_bit_reproducible():
