@@ -288,8 +288,10 @@ def executed_split(variant, D, rank1):
     if variant == V_WIDE:
         prod = 6 if rank1 == 2 else 3
         return {"fwd": {"valu_fp32": 12, "mfma_fp32_equiv": 8, "mfma_products": 6, "eliminated": 4,
-                        "what": "k_fwd_wide: merged (Q + s R) u, fp32 v_pk_fma (8 + 4 forming it); k_hy_wide: H y for all (clip, step) pairs "
-                                "as a bf16x3-split GEMM; k_loss_wide: the sequential float32 loss sums"},
+                        "what": "the chain: k_fwd_chain16 (default: (Q + s R) u as f16x2-split operands on the matrix cores, three products; then "
+                                "valu_fp32 = 0 and the matrix cores carry all 16 D^2) or k_fwd_wide (CMPS_OPT_WIDE_CHAIN = VALU: merged (Q + s R) u, fp32 "
+                                "v_pk_fma, 8 + 4 forming it); k_hy_wide: H y for all (clip, step) pairs as a split-operand GEMM; k_loss_wide: the "
+                                "sequential float32 loss sums"},
                 "bwd": {"valu_fp32": 12, "mfma_fp32_equiv": 24, "mfma_products": prod, "eliminated": 20,
                         "what": "k_bwd_wide: merged (Q + s R^dagger) ybar on the VALU; k_grad_gemm: rank-1 sums as split-operand GEMMs (three bf16, two bf16 or two fp16 pieces)"}}
     if variant == V_PAIR:
@@ -347,6 +349,10 @@ def kernel_work_model(fam, D, DP, rank1):
         gp = 6 if rank1 == 2 else 3
         gname = {1: "k_grad_gemm<2>", 2: "k_grad_gemm<3>", 3: "k_grad_gemm<f16x2>"}[rank1]
         return {"k_fwd_wide": [("valu_fp32", 12 * D * D, "merged (Q + s R) u, v_pk_fma_f32"), ("hbm", 8.0 * DP, "y rows written: 16 DP B per pair-step")],
+                "k_fwd_chain16": [("mfma_bf16", 128 * DP * DP, "(Q + s R) u as f16x2-split operands on v_mfma_f32_16x16x32_f16: DP / 32 waves x DP / 16 K-steps x 8 "
+                                                                 "MFMAs per pair and step (R three products, Q one: the |Q|_F <= 2^-19 instance; 12 otherwise), as "
+                                                                 "issued (8 of the 16 A rows carry forms)"),
+                                  ("hbm", 8.0 * DP, "y rows written: 16 DP B per pair-step")],
                 ("k_hy_wide<3>" if rank1 in (1, 2) else "k_hy_wide<f16x2>"):
                     [("mfma_bf16", 8 * (6 if rank1 in (1, 2) else 3) * D * D,
                       "H y for all (clip, step) pairs: bf16x3 split, 6 piece products (BF16X2 / BF16X3) or f16x2 split, 3 products"),

@@ -174,9 +174,22 @@ def test_sampling_matches_oracle(D, length, n, variant):
 
 def _mfma_chain_model(D, T, B, sigma=1e-4, seed=0, rscale=None):
     m, audio = _wide_model(D, T, B, sigma=sigma, seed=seed, rscale=rscale)
+    assert m._get_backend().wide_chain == 1                      # a new handle's setting
     m._get_backend().set_wide_chain(1)
-    assert m._get_backend().wide_chain == 1
     return m, audio
+
+
+@pytest.mark.parametrize("D,T,B,sigma", [(64, 300, 4, 1e-4), (96, 260, 3, 1e-4), (128, 200, 4, 1e-4), (40, 131, 5, 1e-4), (64, 257, 3, 1.0),
+                                         (128, 130, 2, 1.0), (64, 2, 3, 1e-4), (64, 66, 3, 1e-4), (100, 100, 1, 1e-4)])
+def test_valu_chain_oracle_parity(D, T, B, sigma):
+    """CMPS_OPT_WIDE_CHAIN = VALU: the training forward's chain as fp32 v_pk_fma_f32 code (k_fwd_wide<SAVE>; rounds 3's form, still
+    selectable) against the oracle."""
+    m, audio = _wide_model(D, T, B, sigma=sigma, seed=D + T)
+    m._get_backend().set_wide_chain(0)
+    assert m._get_backend().wide_chain == 0
+    _check_against_oracle(m, audio)
+    with pytest.raises(Exception):
+        m._get_backend().set_wide_chain(2)
 
 
 @pytest.mark.parametrize("D,T,B,sigma", [
@@ -200,6 +213,7 @@ def test_mfma_chain_long_clip_and_states():
     _check_against_oracle(m, audio, nthreads=16)
     m2, audio2 = _mfma_chain_model(96, 400, 3, seed=8)
     mv, _ = _wide_model(96, 400, 3, seed=8)
+    mv._get_backend().set_wide_chain(0)
     m2.grad_sums(); mv.grad_sums()
     s2, sv = m2.psi_evolve_with_data(), mv.psi_evolve_with_data()
     assert s2.shape == sv.shape and np.max(np.abs(s2 - sv)) < 1e-5
