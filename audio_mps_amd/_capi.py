@@ -37,6 +37,7 @@ CMPS_RANK1_DEFAULT = 4
 CMPS_OPT_WIDE_CHAIN = 3
 CMPS_WIDE_CHAIN_VALU = 0
 CMPS_WIDE_CHAIN_MFMA = 1
+CMPS_WIDE_CHAIN_MFMA_FWD = 2
 RANK1_NAMES = {0: "exact_f32", 1: "bf16x2", 2: "bf16x3", 3: "f16x2", 4: "default"}
 
 # every symbol include/cmps.h declares

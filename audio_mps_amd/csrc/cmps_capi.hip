@@ -17,7 +17,7 @@ struct cmps_handle_s {
     int D = 0;
     int variant_req = CMPS_VARIANT_AUTO;
     int rank1_mode = CMPS_RANK1_DEFAULT;
-    int wide_chain = CMPS_WIDE_CHAIN_MFMA;
+    int wide_chain = CMPS_WIDE_CHAIN_MFMA_FWD;
     bool params_set = false;
     bool legacy = false;       // the tables currently hold the legacy AudioMPS arithmetic (cmps_legacy_set_params)
     bool fwd_saved = false;
@@ -129,7 +129,7 @@ int cmps_set_option(cmps_handle_t h, int option, int value) {
         return CMPS_OK;
     }
     if (option == CMPS_OPT_WIDE_CHAIN) {
-        if (value != CMPS_WIDE_CHAIN_VALU && value != CMPS_WIDE_CHAIN_MFMA)
+        if (value < CMPS_WIDE_CHAIN_VALU || value > CMPS_WIDE_CHAIN_MFMA_FWD)
             return fail(h, CMPS_ERR_BAD_ARG, "cmps_set_option: unknown value for CMPS_OPT_WIDE_CHAIN");
         h->wide_chain = value;
         return CMPS_OK;
@@ -284,7 +284,7 @@ int cmps_psi_loss_fwd(cmps_handle_t h, const float* audio_dev, int B, int T, flo
     } else if (variant == CMPS_VARIANT_WIDE) {
         // k_fwd_wide, k_hy_wide, k_loss_wide (scopes inside); the loss product's pieces follow CMPS_OPT_RANK1 like the gradient GEMM's
         e = launch_fwd_wide(P, audio_dev, loss_dev, save_for_bwd != 0,
-                            h->rank1_mode == CMPS_RANK1_DEFAULT || h->rank1_mode == CMPS_RANK1_F16X2, h->wide_chain == CMPS_WIDE_CHAIN_MFMA, s);
+                            h->rank1_mode == CMPS_RANK1_DEFAULT || h->rank1_mode == CMPS_RANK1_F16X2, h->wide_chain != CMPS_WIDE_CHAIN_VALU, s);
     } else {
         KScope ks("k_fwd_block", s);
         e = launch_fwd_block(P, audio_dev, loss_dev, save_for_bwd != 0, s);
@@ -328,7 +328,8 @@ int cmps_psi_loss_bwd(cmps_handle_t h, const float* audio_dev, int B, int T, flo
     if (h->saved_variant == CMPS_VARIANT_WIDE) {
         // float32 reverse scan, then the gradient GEMM (operands split into bf16 pieces on the fly); one slab per PAIR of clips
         hipError_t e;
-        { KScope ks("k_bwd_wide", s); e = launch_bwd_wide(P, audio_dev, s); }
+        if (h->wide_chain == CMPS_WIDE_CHAIN_MFMA) { KScope ks("k_bwd_chain16", s); e = launch_bwd_chain16(P, audio_dev, s); }
+        else { KScope ks("k_bwd_wide", s); e = launch_bwd_wide(P, audio_dev, s); }
         if (e == hipSuccess) {
             const int rm = h->rank1_mode == CMPS_RANK1_DEFAULT ? CMPS_RANK1_F16X2 : h->rank1_mode;
             KScope ks(rm == CMPS_RANK1_F16X2 ? "k_grad_gemm<f16x2>" : rm == CMPS_RANK1_BF16X2 ? "k_grad_gemm<2>" : "k_grad_gemm<3>", s);

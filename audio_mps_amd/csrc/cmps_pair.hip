@@ -1440,6 +1440,393 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// float32-faithful reverse chain on the matrix cores (round 4): the wide family's reverse scan when CMPS_OPT_WIDE_CHAIN = MFMA.
+// k_bwd_pair's lane layout and step structure with k_bwd_wide's arithmetic (its per-step scalars, rows, slab and Abar conventions)
+// and k_fwd_chain16's operands: two fp16 pieces per value, three products (Q: one in the QLITE instance), 12 (8) MFMAs per K-step.
+// What is new here is the scale of the broadcast vector: ybar_k has no a-priori size (in the forward |ut| <= 1 + |M|), and an fp16
+// overflow would be silent.  Every step derives a power of two per clip from a GUARANTEED bound, identical in all lanes and known
+// before the image is written:
+//   |ybar_{k-1}|_max <= inv_{k-1} sqrt2 (1 + |Q|_inf + |s_k| |R^dagger|_inf) |ybar_k|_max  +  |te_{k-1}| |H|_inf |y_{k-1}| + |rad_k| ok_{k-1} inv_{k-1}
+// (row-sum norms from the prologue; |ybar_k|_max is the MEASURED maximum of the step before, which every wave leaves in LDS in front
+// of that step's barrier; the rest are the step's table scalars).  The bound is loose by the usual norm factors (2^4 .. 2^6), which
+// costs nothing: pieces are exact down to 2^-18 of the scaled bound.
+// ------------------------------------------------------------------------------------------------
+template <int PD, bool QLITE>
+__global__ __launch_bounds__(2 * PD, 1) void k_bwd_chain16(Dev P, const float* __restrict__ audio) {
+    constexpr int PWV = PD / 32, KH = PD / 32, KS = PD / 16, VEC = Chain16Lds<PD>::VEC, NR = 2 * KH - 2;
+    __shared__ Chain16Lds<PD> L;
+    __shared__ StepTab<PWV> TB;
+    __shared__ RhoStage<PD> RS;
+    __shared__ __attribute__((aligned(16))) float ymx_tab[2][4][4];     // [step parity][wave][form row]: max |ybar| of the wave's lanes
+    __shared__ float redA[PWV];
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane0 = threadIdx.x & 63;
+    const int N = P.N, T = P.T, NC = (N + PCH - 1) / PCH;
+    const int b0 = 2 * blockIdx.x, b1 = (b0 + 1 < P.B) ? b0 + 1 : b0;
+    const bool two = b1 != b0;
+    const float A = dev_A(P);
+
+    // ---- matrix scales and norms: max entries (-> fp16 scales), Frobenius norm of Q (QLITE), row sums of |Q|, |R^dagger|, |H| ----
+    float sQ, sD, Qinf, Dinf, Hinf;
+    {
+        const int row0 = 32 * w + (lane0 & 31), c0 = (lane0 >> 5) * (PD / 2);
+        float mQ = 0.f, mD = 0.f, fQ = 0.f, rQ = 0.f, rD = 0.f, rH = 0.f;
+        for (int c = 0; c < PD / 2; ++c) {
+            const float2 qq = P.Q[(size_t)row0 * PD + c0 + c], rt = P.RT[(size_t)row0 * PD + c0 + c], r = P.R[(size_t)row0 * PD + c0 + c];
+            mQ = fmaxf(mQ, fmaxf(fabsf(qq.x), fabsf(qq.y)));
+            mD = fmaxf(mD, fmaxf(fabsf(rt.x), fabsf(rt.y)));
+            fQ += qq.x * qq.x + qq.y * qq.y;
+            rQ += sqrtf(qq.x * qq.x + qq.y * qq.y);
+            rD += sqrtf(rt.x * rt.x + rt.y * rt.y);
+            rH += sqrtf((r.x + rt.x) * (r.x + rt.x) + (r.y - rt.y) * (r.y - rt.y));      // H = R + R^dagger
+        }
+        rQ += __shfl_xor(rQ, 32, 64); rD += __shfl_xor(rD, 32, 64); rH += __shfl_xor(rH, 32, 64);     // the two halves of a row
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mQ = fmaxf(mQ, __shfl_xor(mQ, off, 64)); mD = fmaxf(mD, __shfl_xor(mD, off, 64));
+            rQ = fmaxf(rQ, __shfl_xor(rQ, off, 64)); rD = fmaxf(rD, __shfl_xor(rD, off, 64)); rH = fmaxf(rH, __shfl_xor(rH, off, 64));
+            fQ += __shfl_xor(fQ, off, 64);
+        }
+        if (lane0 == 0) { L.red[w][0] = mQ; L.red[w][1] = mD; L.red[w][2] = fQ; L.nrm[0][0][w] = rQ; L.nrm[0][1][w] = rD; L.nrm[1][0][w] = rH; }
+        __syncthreads();
+        mQ = mD = fQ = rQ = rD = rH = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < PWV; ++ww) {
+            mQ = fmaxf(mQ, L.red[ww][0]); mD = fmaxf(mD, L.red[ww][1]); fQ += L.red[ww][2];
+            rQ = fmaxf(rQ, L.nrm[0][0][ww]); rD = fmaxf(rD, L.nrm[0][1][ww]); rH = fmaxf(rH, L.nrm[1][0][ww]);
+        }
+        __syncthreads();
+        if ((sqrtf(fQ) <= 1.9073486e-6f) != QLITE) return;            // as k_fwd_chain16
+        auto uni = [](float x) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(x))); };
+        sQ = uni(gg::pow2_scale(mQ, 15));
+        sD = uni(gg::pow2_scale(mD, 15));
+        Qinf = uni(1.001f * rQ); Dinf = uni(1.001f * rD); Hinf = uni(1.001f * rH);
+    }
+    const float iQ = 1.0f / sQ, iD = 1.0f / sD;
+
+    u4 FQh[PD / 8], FQl[QLITE ? 1 : PD / 8], FDh[PD / 8], FDl[PD / 8];  // Q (Hermitian) and R^dagger
+    {
+        const int row0 = 32 * w + 2 * (lane0 & 15);
+        const float2* Qrow = P.Q + (size_t)row0 * PD;
+        const float2* RTrow = P.RT + (size_t)row0 * PD;                // R^dagger[i][j] = conj(RT[i][j])
+        load_frags_f16<PD>(FDh, FDl, w, lane0 >> 4, sD, [&](int tile, int half, int c) { return half ? -RTrow[tile * PD + c].y : RTrow[tile * PD + c].x; });
+        if constexpr (QLITE) {
+            u4 dump[PD / 8];
+            load_frags_f16<PD, false>(FQh, dump, w, lane0 >> 4, sQ, [&](int tile, int half, int c) { return half ? Qrow[tile * PD + c].y : Qrow[tile * PD + c].x; });
+            FQl[0] = u4{0u, 0u, 0u, 0u};
+        } else {
+            load_frags_f16<PD>(FQh, FQl, w, lane0 >> 4, sQ, [&](int tile, int half, int c) { return half ? Qrow[tile * PD + c].y : Qrow[tile * PD + c].x; });
+        }
+    }
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const ChainLane<KH> g = chain_lane<PD>(w, lane, lds_addr_of(&L.vec[0][0][0]));
+    const int q = g.q, ia = g.ia, ib = g.ib;
+    const bool odd = g.odd;
+    const float wq = (q == 0 || two) ? 1.f : 0.f;
+    const float* xr0 = audio + (size_t)b0 * T;
+    const float* xr1 = audio + (size_t)b1 * T;
+    const float* sc0 = P.scal + ((size_t)b0 * NC) * 128;
+    const float* sc1 = P.scal + ((size_t)b1 * NC) * 128;
+    const int wpos = wide_pos(ia, odd ? 1 : 0, q);
+    const float* stf = reinterpret_cast<const float*>(P.stash) + (size_t)blockIdx.x * N * (8 * PD) + wpos;     // + k 8 PD (+ 4 PD: H y)
+    float* ybar_base = reinterpret_cast<float*>(P.gops) + (size_t)blockIdx.x * N * (4 * PD) + wpos;            // + k 4 PD
+    const float sgn = odd ? 1.f : -1.f;
+
+    // per-step scalars exactly as cmps_wide.hip::step_scalars forms them (the gradient GEMM recomputes them the same way)
+    float accA = 0.f;
+    auto chunk_rows = [&](int cj) {
+        const int idx = cj * PCH + lane;
+        const bool in = idx < N;
+        const float dtv = in ? P.dtk[idx] : 0.f;
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+            const float* xr = qq ? xr1 : xr0;
+            const float* sc = qq ? sc1 : sc0;
+            const float x0 = idx < T ? xr[idx] : 0.f, x1 = idx + 1 < T ? xr[idx + 1] : 0.f;
+            const float inc = x1 - x0;
+            const float nv = in ? sc[(size_t)cj * 128 + lane] : 1.f;
+            const float ev = in ? sc[(size_t)cj * 128 + 64 + lane] : 0.f;
+            const float ex = ev * inc;
+            const float z = ex / A;
+            const float zbar = -1.0f / (1.0f + z);
+            f4 r0, r1;
+            r0.x = inc / A;
+            r0.y = gg_rsq_newton(fmaxf(nv, 1e-12f));
+            r0.z = nv > 1e-12f ? 1.f : 0.f;
+            r0.w = 2.0f * (zbar * inc / A);
+            r1.x = r0.w * ev;
+            r1.y = dtv;
+            r1.z = 0.f;
+            r1.w = 0.f;
+            TB.row[w][cj & 1][lane][qq][0] = r0;
+            TB.row[w][cj & 1][lane][qq][1] = r1;
+            if (in && w == 0 && (qq == 0 || two)) accA += zbar * ex;
+        }
+    };
+    chunk_rows((N - 1) / PCH);
+    if ((N - 1) / PCH > 0 && ((N - 1) & (PCH - 1)) == 0) chunk_rows((N - 1) / PCH - 1);
+    {
+        const int cl = (N - 1) / RCH;
+        rho_stage<PD>(P, RS, cl, cl & 1, 64 * w + lane);
+        if (cl > 0) rho_stage<PD>(P, RS, cl - 1, (cl - 1) & 1, 64 * w + lane);
+    }
+    if (threadIdx.x < 32) reinterpret_cast<float*>(ymx_tab)[threadIdx.x] = 0.f;
+    __syncthreads();
+
+    f2 ga = f2{0.f, 0.f}, gb = ga;                      // g: cotangent of u_{k+1}, (own component, the partner's: MFMA register 1)
+    f2 una = ga, unb = ga;                              // u_{k+1} = rho_k yhat_k, (own, partner)
+    float facca = 0.f, faccb = 0.f, accS = 0.f, ymx = 0.f;
+    float sda = 0.f, sdb = 0.f;                         // ((Q + s R^dagger) ybar) rows of the step before: its Abar term is added a step late
+    u4 o00, o01, o10, o11;
+    float4 rh, rhp;
+    f4 S0, S1, SP0, SP1;
+    float c3a, c3b, c3bound;                            // te_k (H y_k) - ok_k yhat_k rad_{k+1} inv_k, and a bound of its size
+    float sS = 1.f, iS = 1.f;                           // the vector's scale of the step about to run, and its inverse
+    auto rho_rows = [&](int k) { return *reinterpret_cast<const float4*>(&RS.row[(k / RCH) & 1][k & (RCH - 1)][ia]); };
+    auto tab_row = [&](int k, int half) { return TB.row[w][(k / PCH) & 1][k & (PCH - 1)][q][half]; };
+    auto row_at = [&](int k) {
+        const int kc = k > 0 ? k : 0;
+        const float2 y = *reinterpret_cast<const float2*>(stf + (size_t)kc * (8 * PD));
+        const float2 h = *reinterpret_cast<const float2*>(stf + (size_t)kc * (8 * PD) + 4 * PD);
+        return make_float4(y.x, y.y, h.x, h.y);
+    };
+    auto c3_bound = [&](const f4& T0, float rad_next) {           // |c3| of the step whose row is T0: |te| |H|_inf |y| + |rad'| ok inv, |y| <= 1 / inv
+        return fabsf(T0.w) * Hinf * (1.001f / T0.y) + fabsf(rad_next) * T0.z * T0.y;
+    };
+    float4 ring0, ring1, ring2, ring3, ring4, ring5, ring6, ring7;
+    {
+        const int k0 = N - 1;
+        ring0 = row_at(k0 - ((k0 - 0) & 7));
+        ring1 = row_at(k0 - ((k0 - 1) & 7));
+        ring2 = row_at(k0 - ((k0 - 2) & 7));
+        ring3 = row_at(k0 - ((k0 - 3) & 7));
+        ring4 = row_at(k0 - ((k0 - 4) & 7));
+        ring5 = row_at(k0 - ((k0 - 5) & 7));
+        ring6 = row_at(k0 - ((k0 - 6) & 7));
+        ring7 = row_at(k0 - ((k0 - 7) & 7));
+        const int k1 = k0 > 0 ? k0 - 1 : 0;
+        rh = rho_rows(k0);
+        S0 = tab_row(k0, 0);
+        S1 = tab_row(k0, 1);
+        rhp = rho_rows(k1);
+        SP0 = tab_row(k1, 0);
+        SP1 = tab_row(k1, 1);
+        const float4 cur = row_at(k0);
+        c3a = S0.w * cur.z;                             // rad_N = 0
+        c3b = S0.w * cur.w;
+        c3bound = c3_bound(S0, 0.f);
+        sS = gg::pow2_scale(c3bound, 15);               // ybar_{N-1} = c3_{N-1} (g = 0)
+        iS = __uint_as_float(0x7F000000u - __float_as_uint(sS));
+    }
+    const float2 psa = P.psi0[ia], psb = P.psi0[ib];
+    const f2 ps0a = odd ? f2{psa.y, psa.x} : f2{psa.x, psa.y}, ps0b = odd ? f2{psb.y, psb.x} : f2{psb.x, psb.y};   // u_0 = psi_0 (own, partner)
+    const unsigned a_tab = lds_addr_of(&TB.row[w][0][0][q][0]);
+    const unsigned a_ym = lds_addr_of(&ymx_tab[0][0][0]);
+    auto write_image = [&](int par, float xa, float xb) {
+        unsigned hi, lo;
+        split_f16x2(xa, xb, hi, lo);
+        unsigned char* b0p = L.vec[par][0];
+        unsigned char* b1p = L.vec[par][1];
+        *reinterpret_cast<unsigned*>(b0p + g.wr1) = hi;
+        *reinterpret_cast<unsigned*>(b0p + g.wr2) = hi ^ 0x80008000u;
+        *reinterpret_cast<unsigned*>(b1p + g.wr1) = lo;
+        *reinterpret_cast<unsigned*>(b1p + g.wr2) = lo ^ 0x80008000u;
+    };
+#define QL_(i) FQl[QLITE ? 0 : (i)]
+    // one step; J = k & 7 (static: ring slots and the image parity).  The chain is  g -> conj(rho) g -> ybar -> scaled fp16 pieces (own K
+    // ranges read back) -> [barrier] -> K-steps -> g; the slots behind the MFMA pairs carry the step's LDS reads (two K-steps ahead of
+    // their use, k_fwd_chain16) and the off-chain work of k_bwd_pair's pieces.
+#define C16B_STEP(J, CUR, PRV, COND)                                                                                               \
+    if (COND) {                                                                                                                    \
+        constexpr int p = (J) & 1;                                                                                                 \
+        const int k = 8 * blk + (J);                                                                                               \
+        const int km2 = k > 1 ? k - 2 : 0;                                                                                         \
+        if ((k & (PCH - 1)) == 1 && k > 1) chunk_rows(k / PCH - 1);                                                                \
+        if ((k & (RCH - 1)) == RCH - 1 && k != N - 1 && k >= RCH)                                                                  \
+            rho_stage<PD>(P, RS, k / RCH - 1, (k / RCH - 1) & 1, 64 * w + lane);                                                   \
+        /* ---- the chain ---- */                                                                                                  \
+        const float hba = rh.x * ga.x - sgn * rh.y * ga.y;           /* conj(rho_k) g */                                           \
+        const float hbb = rh.z * gb.x - sgn * rh.w * gb.y;                                                                         \
+        const float yba = fmaf(hba, S0.y, c3a), ybb = fmaf(hbb, S0.y, c3b);                                                        \
+        write_image(p, yba * sS, ybb * sS);                                                                                        \
+        rd_own<p * 2 * VEC>(g.lo[0], g.hi[0], o00, o10);                                                                           \
+        rd_own<p * 2 * VEC + VEC>(g.lo[0], g.hi[0], o01, o11);                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                                         \
+        /* ---- behind the stores: ybar out, its maximum over this wave's rows for the next step's scale, the frequency gradient ---- */ \
+        *reinterpret_cast<float2*>(ybar_base + (size_t)k * (4 * PD)) = make_float2(yba, ybb);                                      \
+        {                                                                                                                          \
+            float m = fmaxf(fabsf(yba), fabsf(ybb));                                                                               \
+            ymx = fmaxf(ymx, m);                                                                                                   \
+            m = fmaxf(m, dpp_mov<0x128>(m)); m = fmaxf(m, dpp_mov<0x124>(m)); m = fmaxf(m, dpp_mov<0x122>(m)); m = fmaxf(m, dpp_mov<0x121>(m)); \
+            if ((lane & 15) == 0) ymx_tab[p][w][lane >> 4] = m;                                                                    \
+        }                                                                                                                          \
+        facca += S1.y * (ga.y * una.x - ga.x * una.y);               /* dt_k Im(g conj(u_{k+1})) (meaningful in the Re lanes) */   \
+        faccb += S1.y * (gb.y * unb.x - gb.x * unb.y);                                                                             \
+        const f2 una_ = una, unb_ = unb;                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                                         \
+        lds_barrier();                                                                                                             \
+        f4 cQ0, cQ1, cD0, cD1, nS0, nS1;                                                                                           \
+        u4 v[4 * KH - 4];                                                                                                          \
+        float4 nrh;                                                                                                                \
+        f2 uka, ukb;                                                                                                               \
+        float ypa, ypb, pypa, pypb, pyba, pybb, c3bn, sSn;                                                                         \
+        f4 ym[4];                                                                                                                  \
+        const unsigned ax0 = a_tab + 64 * (((km2 / PCH) & 1) * PCH + (km2 & (PCH - 1)));                                           \
+        const float invp = SP0.y;                                                                                                  \
+        auto slot = [&](auto kidx_c, auto sl_c) {                                                                                  \
+            constexpr int kidx = decltype(kidx_c)::value, sl = decltype(sl_c)::value;                                              \
+            if constexpr (kidx < NR && (sl == 0 || sl == 2)) {       /* operands of rest K-step kidx */                            \
+                constexpr int n = 2 * kidx + sl / 2, half = n / NR, t = 1 + (n % NR) / 2, pc = n & 1;                              \
+                rd128<p * 2 * VEC + pc * VEC>(half ? g.hi[t] : g.lo[t], v[n]);                                                     \
+            }                                                                                                                      \
+            if constexpr (kidx == NR && sl == 0) rd128<0>(ax0, nS0);  /* scalar rows of step k - 2 */                              \
+            if constexpr (kidx == NR && sl == 2) rd128<16>(ax0, nS1);                                                              \
+            /* the pieces (k_bwd_pair): one small group of VALU per slot, pinned so that it stays in its slot */                    \
+            if constexpr (kidx == 0 && sl == 1) { ypa = PRV.x * invp; ypb = PRV.y * invp; PAIR_PIN2(ypa, ypb); }                   \
+            if constexpr (kidx == 0 && sl == 3) { pypa = partner16(ypa, odd); PAIR_PIN1(pypa); }                                   \
+            if constexpr (kidx == 0 && sl == 5) { pypb = partner16(ypb, odd); PAIR_PIN1(pypb); }                                   \
+            if constexpr (kidx == 1 && sl == 1) {                                                                                  \
+                const float ria = sgn * rhp.y;                                                                                     \
+                uka = f2{rhp.x * ypa + ria * pypa, rhp.x * pypa - ria * ypa};                                                      \
+                PAIR_PIN1(uka);                                                                                                    \
+            }                                                                                                                      \
+            if constexpr (kidx == 1 && sl == 3) {                                                                                  \
+                const float rib = sgn * rhp.w;                                                                                     \
+                ukb = f2{rhp.z * ypb + rib * pypb, rhp.z * pypb - rib * ypb};                                                      \
+                PAIR_PIN1(ukb);                                                                                                    \
+            }                                                                                                                      \
+            if constexpr (kidx == 1 && sl == 5) {                    /* the g-independent part of ybar_{k-1} and its bound */      \
+                const float radk = S1.x * SP0.z * invp;                                                                            \
+                c3a = fmaf(SP0.w, PRV.z, -(ypa * radk));                                                                           \
+                c3b = fmaf(SP0.w, PRV.w, -(ypb * radk));                                                                           \
+                c3bn = c3_bound(SP0, S1.x);                                                                                        \
+                PAIR_PIN2(c3a, c3b);                                                                                               \
+            }                                                                                                                      \
+            if constexpr (kidx == 2 && sl == 1) { pyba = partner16(yba, odd); PAIR_PIN1(pyba); }             \
+            if constexpr (kidx == 2 && sl == 3) { pybb = partner16(ybb, odd); PAIR_PIN1(pybb); }                        \
+            if constexpr (kidx == 2 && sl == 5) { accS += sda * una_.x + sdb * unb_.x; PAIR_PIN1(accS); }               \
+            if constexpr (kidx == 3 && sl == 1) CUR = row_at(k - 8);                                                    \
+            if constexpr (kidx == 3 && sl == 3) nrh = rho_rows(km2);                                                    \
+            /* max |ybar_k| rows of the waves (written in front of this step's barrier): read early, used by the last K-step's piece */ \
+            if constexpr (kidx == 0 && sl == 4) rd128<0>(a_ym + 64 * p, ym[0]);                                                    \
+            if constexpr (kidx == 0 && sl == 5) rd128<16>(a_ym + 64 * p, ym[1]);                                                   \
+            if constexpr (kidx == 1 && sl == 4 && PWV > 2) rd128<32>(a_ym + 64 * p, ym[2]);                                        \
+            if constexpr (kidx == 1 && sl == 5 && PWV > 3) rd128<48>(a_ym + 64 * p, ym[3]);                                        \
+            if constexpr (kidx == NR + 1 && sl == 1) {               /* the scale of ybar_{k-1}'s image: the bound of the header (everything  \
+                                                                        older than the two table rows has landed: this K-step's counted wait) */ \
+                asm volatile("" : "+v"(ym[0]), "+v"(ym[1]), "+v"(ym[PWV > 2 ? 2 : 0]), "+v"(ym[PWV > 3 ? 3 : 0]));                   \
+                float m = q ? fmaxf(fmaxf(ym[0].z, ym[0].w), fmaxf(ym[1].z, ym[1].w)) : fmaxf(fmaxf(ym[0].x, ym[0].y), fmaxf(ym[1].x, ym[1].y)); \
+                if constexpr (PWV > 2) m = fmaxf(m, q ? fmaxf(ym[2].z, ym[2].w) : fmaxf(ym[2].x, ym[2].y));                         \
+                if constexpr (PWV > 3) m = fmaxf(m, q ? fmaxf(ym[3].z, ym[3].w) : fmaxf(ym[3].x, ym[3].y));                         \
+                const float bnd = invp * (1.4143f * (1.0f + Qinf + fabsf(S0.x) * Dinf)) * m + c3bn;                                \
+                sSn = gg::pow2_scale(bnd, 15);                                                                                     \
+                PAIR_PIN1(sSn);                                                                                                    \
+            }                                                                                                                      \
+        };                                                                                                                         \
+        kstep12<15, true, true, QLITE>(FDh[0], FDl[0], FDh[KS], FDl[KS], FQh[0], QL_(0), FQh[KS], QL_(KS), o00, o01, cD0, cD1, cQ0, cQ1, \
+                                       [&](auto sl) { slot(ic<0>{}, sl); });                                                       \
+        kstep12<15, false, true, QLITE>(FDh[KH], FDl[KH], FDh[KS + KH], FDl[KS + KH], FQh[KH], QL_(KH), FQh[KS + KH], QL_(KS + KH), o10, o11, \
+                                        cD0, cD1, cQ0, cQ1, [&](auto sl) { slot(ic<1>{}, sl); });                                  \
+        gg::static_for<0, NR>([&](auto ic_) {                                                                                      \
+            constexpr int I = decltype(ic_)::value;                                                                                \
+            constexpr int T_ = I < KH - 1 ? 1 + I : KH + 1 + (I - (KH - 1));                                                       \
+            kstep12<(I == 0 ? 2 + PWV : I == 1 ? 2 + (PWV > 2 ? PWV - 2 : 0) : 2), false, true, QLITE>(FDh[T_], FDl[T_], FDh[KS + T_], FDl[KS + T_], FQh[T_], QL_(T_), FQh[KS + T_], \
+                                                              QL_(KS + T_), v[2 * I], v[2 * I + 1], cD0, cD1, cQ0, cQ1,            \
+                                                              [&](auto sl) { slot(ic<I + 2>{}, sl); });                            \
+        });                                                                                                                        \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nS0), "+v"(nS1) :: "memory");                                                   \
+        if (k == 0) { uka = ps0a; ukb = ps0b; }                      /* u_0 = psi_0 */                                             \
+        {   /* g = ybar + (Q + s R^dagger) ybar, (own, partner) pairs; the accumulators carry the scales sQ sS and sD sS */           \
+            const float cq = iQ * iS, cd = S0.x * (iD * iS);                                                                       \
+            const f2 da = f2{cQ0[0], cQ0[1]} * cq + cd * f2{cD0[0], cD0[1]};                                                       \
+            const f2 db = f2{cQ1[0], cQ1[1]} * cq + cd * f2{cD1[0], cD1[1]};                                                       \
+            ga = f2{yba, pyba} + da;                                                                                               \
+            gb = f2{ybb, pybb} + db;                                                                                               \
+            sda = da.x; sdb = db.x;                                                                                                \
+        }                                                                                                                          \
+        sS = sSn;                                                                                                                  \
+        iS = __uint_as_float(0x7F000000u - __float_as_uint(sSn));    /* 1 / sS: exact for a power of two */                        \
+        una = uka; unb = ukb;                                                                                                      \
+        rh = rhp; S0 = SP0; S1 = SP1;                                                                                              \
+        rhp = nrh; SP0 = nS0; SP1 = nS1;                                                                                           \
+    }
+
+    int blk = (N + 7) / 8 - 1;
+    if (N & 7) {
+        C16B_STEP(7, ring7, ring6, 8 * blk + 7 < N)
+        C16B_STEP(6, ring6, ring5, 8 * blk + 6 < N)
+        C16B_STEP(5, ring5, ring4, 8 * blk + 5 < N)
+        C16B_STEP(4, ring4, ring3, 8 * blk + 4 < N)
+        C16B_STEP(3, ring3, ring2, 8 * blk + 3 < N)
+        C16B_STEP(2, ring2, ring1, 8 * blk + 2 < N)
+        C16B_STEP(1, ring1, ring0, 8 * blk + 1 < N)
+        C16B_STEP(0, ring0, ring7, true)
+        --blk;
+    }
+    for (; blk >= 0; --blk) {
+        C16B_STEP(7, ring7, ring6, true)
+        C16B_STEP(6, ring6, ring5, true)
+        C16B_STEP(5, ring5, ring4, true)
+        C16B_STEP(4, ring4, ring3, true)
+        C16B_STEP(3, ring3, ring2, true)
+        C16B_STEP(2, ring2, ring1, true)
+        C16B_STEP(1, ring1, ring0, true)
+        C16B_STEP(0, ring0, ring7, true)
+    }
+#undef C16B_STEP
+#undef QL_
+    accS += sda * una.x + sdb * unb.x;                                 // the Abar term of step 0
+    // ---- the pair's slab: f | psi0bar_re | psi0bar_im | A (as k_bwd_wide; the R / Q sections are written by k_grad_gemm) ----
+    float* slab = P.slabs + (size_t)blockIdx.x * P.slab_floats;
+    const int DD = PD * PD;
+    {
+        const float fta = both_clips(facca * wq), ftb = both_clips(faccb * wq);
+        const float gta = both_clips(ga.x * wq), gtb = both_clips(gb.x * wq);
+        if (g.f == 0) {
+            slab[4 * DD + ia] = fta;
+            slab[4 * DD + ib] = ftb;
+            slab[4 * DD + PD + ia] = gta;
+            slab[4 * DD + PD + ib] = gtb;
+        } else if (g.f == 1) {
+            slab[4 * DD + 2 * PD + ia] = gta;
+            slab[4 * DD + 2 * PD + ib] = gtb;
+        }
+    }
+    {
+        float t = accS * wq, a = (w == 0 ? accA : 0.f);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { t += __shfl_xor(t, off, 64); a += __shfl_xor(a, off, 64); ymx = fmaxf(ymx, __shfl_xor(ymx, off, 64)); }
+        if (lane == 0) { redA[w] = -(a / (A * A)) - t / A; L.red[w][0] = ymx; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float tot = 0.f, m = 0.f;
+#pragma unroll
+            for (int i = 0; i < PWV; ++i) { tot += redA[i]; m = fmaxf(m, L.red[i][0]); }
+            slab[4 * DD + 3 * PD] = tot;
+            slab[4 * DD + 3 * PD + 1] = 0.f;
+            P.opmax[blockIdx.x] = m;
+        }
+    }
+}
+
+hipError_t launch_bwd_chain16(const Dev& P, const float* audio, hipStream_t s) {
+    const unsigned nb = (unsigned)((P.B + 1) / 2);
+    if (P.DP == 128) {
+        hipLaunchKernelGGL((k_bwd_chain16<128, true>), dim3(nb), dim3(256), 0, s, P, audio);
+        hipLaunchKernelGGL((k_bwd_chain16<128, false>), dim3(nb), dim3(256), 0, s, P, audio);
+    } else if (P.DP == 96) {
+        hipLaunchKernelGGL((k_bwd_chain16<96, true>), dim3(nb), dim3(192), 0, s, P, audio);
+        hipLaunchKernelGGL((k_bwd_chain16<96, false>), dim3(nb), dim3(192), 0, s, P, audio);
+    } else if (P.DP == 64) {
+        hipLaunchKernelGGL((k_bwd_chain16<64, true>), dim3(nb), dim3(128), 0, s, P, audio);
+        hipLaunchKernelGGL((k_bwd_chain16<64, false>), dim3(nb), dim3(128), 0, s, P, audio);
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_bwd_pair(const Dev& P, const float* audio, hipStream_t s) {
     const unsigned nb = (unsigned)((P.B + 1) / 2);
     if (P.DP == 128) hipLaunchKernelGGL(k_bwd_pair<128>, dim3(nb), dim3(256), 0, s, P, audio);

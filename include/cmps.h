@@ -96,7 +96,8 @@ enum {
 /* values of CMPS_OPT_WIDE_CHAIN */
 enum {
     CMPS_WIDE_CHAIN_VALU = 0,   /* k_fwd_wide: the mat-vec as fp32 v_pk_fma_f32 chains (R, Q register resident) */
-    CMPS_WIDE_CHAIN_MFMA = 1    /* (a new handle's setting) k_fwd_chain16: the correction (Q + s R) u as power-of-two scaled fp16 x 2 split operands on
+    CMPS_WIDE_CHAIN_MFMA_FWD = 2,  /* the forward as MFMA below, the reverse scan as VALU (k_bwd_wide): for A/B measurements */
+    CMPS_WIDE_CHAIN_MFMA = 1    /* (a new handle's setting) k_fwd_chain16 / k_bwd_chain16: the correction (Q + s R) u as power-of-two scaled fp16 x 2 split operands on
                                  * v_mfma_f32_16x16x32_f16 (three products, fp32 accumulate: the accuracy class of CMPS_RANK1_F16X2);
                                  * identity part and everything behind the mat-vec in float32 */
 };

@@ -174,7 +174,7 @@ def test_sampling_matches_oracle(D, length, n, variant):
 
 def _mfma_chain_model(D, T, B, sigma=1e-4, seed=0, rscale=None):
     m, audio = _wide_model(D, T, B, sigma=sigma, seed=seed, rscale=rscale)
-    assert m._get_backend().wide_chain == 1                      # a new handle's setting
+    assert m._get_backend().wide_chain in (1, 2)                 # a new handle's setting
     m._get_backend().set_wide_chain(1)
     return m, audio
 
@@ -189,7 +189,7 @@ def test_valu_chain_oracle_parity(D, T, B, sigma):
     assert m._get_backend().wide_chain == 0
     _check_against_oracle(m, audio)
     with pytest.raises(Exception):
-        m._get_backend().set_wide_chain(2)
+        m._get_backend().set_wide_chain(3)
 
 
 @pytest.mark.parametrize("D,T,B,sigma", [
