@@ -17,7 +17,7 @@ struct cmps_handle_s {
     int D = 0;
     int variant_req = CMPS_VARIANT_AUTO;
     int rank1_mode = CMPS_RANK1_DEFAULT;
-    int wide_chain = CMPS_WIDE_CHAIN_MFMA_FWD;
+    int wide_chain = CMPS_WIDE_CHAIN_MFMA;
     bool params_set = false;
     bool legacy = false;       // the tables currently hold the legacy AudioMPS arithmetic (cmps_legacy_set_params)
     bool fwd_saved = false;

@@ -359,6 +359,8 @@ def kernel_work_model(fam, D, DP, rank1):
                      ("hbm", 16.0 * DP, "y rows read + H y rows written")],
                 "k_loss_wide": [("hbm", 8.0, "e_k, |y_k|^2 scalars")],
                 "k_bwd_wide": [("valu_fp32", 12 * D * D, "merged (Q + s R^dagger) ybar"), ("hbm", 24.0 * DP, "y, H y rows read, ybar rows written")],
+                "k_bwd_chain16": [("mfma_bf16", 128 * DP * DP, "(Q + s R^dagger) ybar as f16x2-split operands on v_mfma_f32_16x16x32_f16, as issued (see k_fwd_chain16)"),
+                                  ("hbm", 24.0 * DP, "y, H y rows read, ybar rows written")],
                 gname: [("mfma_bf16", 24 * gp * D * D, f"three rank-1 sums as GEMMs, {gp} piece products (fp16 and bf16 MFMAs have the same dense peak)"),
                         ("hbm", 16.0 * DP, "y and ybar rows read: 32 DP B per pair-step")]}
     if fam == "pair":

@@ -174,9 +174,18 @@ def test_sampling_matches_oracle(D, length, n, variant):
 
 def _mfma_chain_model(D, T, B, sigma=1e-4, seed=0, rscale=None):
     m, audio = _wide_model(D, T, B, sigma=sigma, seed=seed, rscale=rscale)
-    assert m._get_backend().wide_chain in (1, 2)                 # a new handle's setting
+    assert m._get_backend().wide_chain == 1                      # a new handle's setting: forward and reverse chains on the matrix cores
     m._get_backend().set_wide_chain(1)
     return m, audio
+
+
+@pytest.mark.parametrize("D,T,B,sigma", [(64, 300, 4, 1e-4), (96, 260, 3, 1e-4), (128, 200, 4, 1e-4), (40, 131, 5, 1e-4), (64, 257, 3, 1.0),
+                                         (128, 130, 2, 1.0), (64, 2, 3, 1e-4), (64, 66, 3, 1e-4), (100, 100, 1, 1e-4)])
+def test_mfma_forward_valu_reverse(D, T, B, sigma):
+    """CMPS_OPT_WIDE_CHAIN = MFMA_FWD: k_fwd_chain16 with the VALU reverse scan k_bwd_wide (the A/B setting)."""
+    m, audio = _wide_model(D, T, B, sigma=sigma, seed=D + T)
+    m._get_backend().set_wide_chain(2)
+    _check_against_oracle(m, audio)
 
 
 @pytest.mark.parametrize("D,T,B,sigma", [(64, 300, 4, 1e-4), (96, 260, 3, 1e-4), (128, 200, 4, 1e-4), (40, 131, 5, 1e-4), (64, 257, 3, 1.0),
@@ -219,6 +228,37 @@ def test_mfma_chain_long_clip_and_states():
     assert s2.shape == sv.shape and np.max(np.abs(s2 - sv)) < 1e-5
     pm, pv = m2.loss_per_clip(), mv.loss_per_clip()           # (the forward-only path is the VALU kernel in both)
     np.testing.assert_array_equal(pm, pv)
+
+
+@pytest.mark.parametrize("T", [5, 8, 9, 10, 16, 17, 31, 32, 33, 34, 63, 64, 65, 66, 67, 129, 257])
+def test_mfma_chain_block_boundaries(T):
+    """T - 1 steps around the reverse scan's eight-step blocks, the 32-step rho chunks and the 64-step scalar chunks, D = 96 (three waves)."""
+    m, audio = _mfma_chain_model(96, T, 3, seed=T)
+    _check_against_oracle(m, audio)
+
+
+def test_mfma_chain_vector_scale_jumps():
+    """The reverse scan's per-step vector scale: audio with silent stretches, clicks and a 1e4 x amplitude step (ybar changes by orders
+    of magnitude from one step to the next; a wrong bound would overflow the fp16 pieces: inf / NaN), both clips different."""
+    from audio_mps_amd.scan import unpack_grad
+    from oracle import c_oracle as C
+    rng = np.random.default_rng(7)
+    m, audio = _mfma_chain_model(128, 400, 4, seed=11)
+    audio = audio.copy()
+    audio[0, :150] = 0.0                                          # silence, then the signal
+    audio[1, 200:] *= np.float32(1e-4)                            # a loud start, then nearly nothing
+    audio[2] = 0.0
+    audio[2, 100] = 0.3; audio[2, 101] = -0.2; audio[2, 300] = 0.25      # clicks
+    audio[3] = (1e-3 * rng.standard_normal(400)).astype(np.float32)
+    audio[3, 250:] *= np.float32(100.0)
+    ref = c_oracle_run(m, audio, "f32")
+    assert np.all(np.isfinite(ref["loss_per_clip"]))
+    flat = m.grad_sums(audio)[0].cpu().numpy()
+    assert np.all(np.isfinite(flat))
+    g, gr = unpack_grad(flat, 128), C.unpack_grad(ref["grad"], 128)
+    assert abs(g["loss_sum"] - gr["loss_sum"]) <= LOSS_RTOL * max(abs(gr["loss_sum"]), 4.0)
+    for k in ("Rbar", "fbar", "psi0bar", "Abar"):
+        assert rel_inf(g[k], gr[k]) <= GRAD_RTOL, k
 
 
 def test_mfma_chain_operand_scales():
