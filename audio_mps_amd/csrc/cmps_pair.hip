@@ -72,6 +72,8 @@ __device__ __forceinline__ float half_add(float a0, float a1) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 template <int CTRL>
+__device__ __forceinline__ unsigned dpp_movu(unsigned x) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, true); }
+template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
 }
@@ -1447,9 +1449,11 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
 // What is new here is the scale of the broadcast vector: ybar_k has no a-priori size (in the forward |ut| <= 1 + |M|), and an fp16
 // overflow would be silent.  Every step derives a power of two per clip from a GUARANTEED bound, identical in all lanes and known
 // before the image is written:
-//   |ybar_{k-1}|_max <= inv_{k-1} sqrt2 (1 + |Q|_inf + |s_k| |R^dagger|_inf) |ybar_k|_max  +  |te_{k-1}| |H|_inf |y_{k-1}| + |rad_k| ok_{k-1} inv_{k-1}
-// (row-sum norms from the prologue; |ybar_k|_max is the MEASURED maximum of the step before, which every wave leaves in LDS in front
-// of that step's barrier; the rest are the step's table scalars).  The bound is loose by the usual norm factors (2^4 .. 2^6), which
+//   Y_{j} <= a_j Y_{j+1} + c_j,   a_j = inv_j sqrt2 (1 + |Q|_inf + |s_{j+1}| |R^dagger|_inf),   c_j = |te_j| |H|_inf |y_j| + |rad_{j+1}| ok_j inv_j
+// applied twice: Y_{k-2} <= a_{k-2} (a_{k-1} Y_k + c_{k-1}) + c_{k-2}  (Y_j = max |ybar_j|; row-sum norms from the prologue; Y_k is the
+// MEASURED maximum of two steps before: every wave leaves its own in LDS behind the MFMAs of step k, the barrier of step k - 1
+// publishes it, and it is used for the image written at the top of step k - 2 -- nothing of this sits on the chain; the a's and c's
+// are the steps' table scalars).  The bound is loose by the usual norm factors (2^4 .. 2^6), which
 // costs nothing: pieces are exact down to 2^-18 of the scaled bound.
 // ------------------------------------------------------------------------------------------------
 template <int PD, bool QLITE>
@@ -1458,7 +1462,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_chain16(Dev P, const float* _
     __shared__ Chain16Lds<PD> L;
     __shared__ StepTab<PWV> TB;
     __shared__ RhoStage<PD> RS;
-    __shared__ __attribute__((aligned(16))) float ymx_tab[2][4][4];     // [step parity][wave][form row]: max |ybar| of the wave's lanes
+    __shared__ __attribute__((aligned(16))) unsigned ymx_tab[2][2][4][2];  // [step parity][clip][wave][component]: max |ybar| of the wave's lanes (float bits)
     __shared__ float redA[PWV];
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane0 = threadIdx.x & 63;
     const int N = P.N, T = P.T, NC = (N + PCH - 1) / PCH;
@@ -1529,8 +1533,10 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_chain16(Dev P, const float* _
     const float* sc0 = P.scal + ((size_t)b0 * NC) * 128;
     const float* sc1 = P.scal + ((size_t)b1 * NC) * 128;
     const int wpos = wide_pos(ia, odd ? 1 : 0, q);
-    const float* stf = reinterpret_cast<const float*>(P.stash) + (size_t)blockIdx.x * N * (8 * PD) + wpos;     // + k 8 PD (+ 4 PD: H y)
-    float* ybar_base = reinterpret_cast<float*>(P.gops) + (size_t)blockIdx.x * N * (4 * PD) + wpos;            // + k 4 PD
+    // rows through buffer instructions: descriptor + SGPR row offset + this lane's loop-invariant offset (no address arithmetic on the VALU)
+    const auto rs_st = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(P.stash) + (size_t)blockIdx.x * N * (8 * PD), 0, N * (8 * PD * 4), 0x00020000);
+    const auto rs_yb = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(P.gops) + (size_t)blockIdx.x * N * (4 * PD), 0, N * (4 * PD * 4), 0x00020000);
+    const int voff = wpos * 4;
     const float sgn = odd ? 1.f : -1.f;
 
     // per-step scalars exactly as cmps_wide.hip::step_scalars forms them (the gradient GEMM recomputes them the same way)
@@ -1557,7 +1563,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_chain16(Dev P, const float* _
             r0.w = 2.0f * (zbar * inc / A);
             r1.x = r0.w * ev;
             r1.y = dtv;
-            r1.z = 0.f;
+            r1.z = 1.001f * sqrtf(fmaxf(nv, 1e-12f));                  // >= |y_k| (the c3 bound)
             r1.w = 0.f;
             TB.row[w][cj & 1][lane][qq][0] = r0;
             TB.row[w][cj & 1][lane][qq][1] = r1;
@@ -1571,29 +1577,33 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_chain16(Dev P, const float* _
         rho_stage<PD>(P, RS, cl, cl & 1, 64 * w + lane);
         if (cl > 0) rho_stage<PD>(P, RS, cl - 1, (cl - 1) & 1, 64 * w + lane);
     }
-    if (threadIdx.x < 32) reinterpret_cast<float*>(ymx_tab)[threadIdx.x] = 0.f;
+    if (threadIdx.x < 32) reinterpret_cast<unsigned*>(ymx_tab)[threadIdx.x] = 0u;
     __syncthreads();
 
     f2 ga = f2{0.f, 0.f}, gb = ga;                      // g: cotangent of u_{k+1}, (own component, the partner's: MFMA register 1)
     f2 una = ga, unb = ga;                              // u_{k+1} = rho_k yhat_k, (own, partner)
-    float facca = 0.f, faccb = 0.f, accS = 0.f, ymx = 0.f;
+    float facca = 0.f, faccb = 0.f, accS = 0.f;
+    unsigned ymxb = 0u;                                 // max |ybar| of this lane over the clip (float bits), for the gradient GEMM's scale
     float sda = 0.f, sdb = 0.f;                         // ((Q + s R^dagger) ybar) rows of the step before: its Abar term is added a step late
     u4 o00, o01, o10, o11;
     float4 rh, rhp;
     f4 S0, S1, SP0, SP1;
-    float c3a, c3b, c3bound;                            // te_k (H y_k) - ok_k yhat_k rad_{k+1} inv_k, and a bound of its size
+    float c3a, c3b, c3bound, c3bprev;                   // te_k (H y_k) - ok_k yhat_k rad_{k+1} inv_k; bounds of its size: this step's, the step before's
+    float sprev = 0.f;                                  // s_{k+1}
     float sS = 1.f, iS = 1.f;                           // the vector's scale of the step about to run, and its inverse
     auto rho_rows = [&](int k) { return *reinterpret_cast<const float4*>(&RS.row[(k / RCH) & 1][k & (RCH - 1)][ia]); };
     auto tab_row = [&](int k, int half) { return TB.row[w][(k / PCH) & 1][k & (PCH - 1)][q][half]; };
+    typedef unsigned u2b __attribute__((ext_vector_type(2)));
     auto row_at = [&](int k) {
         const int kc = k > 0 ? k : 0;
-        const float2 y = *reinterpret_cast<const float2*>(stf + (size_t)kc * (8 * PD));
-        const float2 h = *reinterpret_cast<const float2*>(stf + (size_t)kc * (8 * PD) + 4 * PD);
-        return make_float4(y.x, y.y, h.x, h.y);
+        const u2b y = __builtin_amdgcn_raw_buffer_load_b64(rs_st, voff, kc * (8 * PD * 4), 0);
+        const u2b h = __builtin_amdgcn_raw_buffer_load_b64(rs_st, voff + 4 * PD * 4, kc * (8 * PD * 4), 0);
+        return make_float4(__uint_as_float(y.x), __uint_as_float(y.y), __uint_as_float(h.x), __uint_as_float(h.y));
     };
-    auto c3_bound = [&](const f4& T0, float rad_next) {           // |c3| of the step whose row is T0: |te| |H|_inf |y| + |rad'| ok inv, |y| <= 1 / inv
-        return fabsf(T0.w) * Hinf * (1.001f / T0.y) + fabsf(rad_next) * T0.z * T0.y;
+    auto c3_bound = [&](const f4& T0, const f4& T1, float rad_next) {   // |c3| of the step whose rows are T0, T1: |te| |H|_inf |y| + |rad'| ok inv
+        return fabsf(T0.w) * Hinf * T1.z + fabsf(rad_next) * T0.z * T0.y;
     };
+    auto growth = [&](float inv_j, float s_next) { return inv_j * (1.4143f * (1.0f + Qinf + fabsf(s_next) * Dinf)); };   // a_j
     float4 ring0, ring1, ring2, ring3, ring4, ring5, ring6, ring7;
     {
         const int k0 = N - 1;
@@ -1615,14 +1625,15 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_chain16(Dev P, const float* _
         const float4 cur = row_at(k0);
         c3a = S0.w * cur.z;                             // rad_N = 0
         c3b = S0.w * cur.w;
-        c3bound = c3_bound(S0, 0.f);
+        c3bound = c3_bound(S0, S1, 0.f);
         sS = gg::pow2_scale(c3bound, 15);               // ybar_{N-1} = c3_{N-1} (g = 0)
+        c3bprev = c3bound;                              // c_{N-1}
         iS = __uint_as_float(0x7F000000u - __float_as_uint(sS));
     }
     const float2 psa = P.psi0[ia], psb = P.psi0[ib];
     const f2 ps0a = odd ? f2{psa.y, psa.x} : f2{psa.x, psa.y}, ps0b = odd ? f2{psb.y, psb.x} : f2{psb.x, psb.y};   // u_0 = psi_0 (own, partner)
     const unsigned a_tab = lds_addr_of(&TB.row[w][0][0][q][0]);
-    const unsigned a_ym = lds_addr_of(&ymx_tab[0][0][0]);
+    const unsigned a_ym = lds_addr_of(&ymx_tab[0][q][0][0]);        // + 64 parity: this clip's eight entries
     auto write_image = [&](int par, float xa, float xb) {
         unsigned hi, lo;
         split_f16x2(xa, xb, hi, lo);
@@ -1633,6 +1644,16 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_chain16(Dev P, const float* _
         *reinterpret_cast<unsigned*>(b1p + g.wr1) = lo;
         *reinterpret_cast<unsigned*>(b1p + g.wr2) = lo ^ 0x80008000u;
     };
+#if defined(CMPS_DIAG) && defined(C16_TIMING)              // diagnostic builds only: s_memtime stamps of a step's phases
+    unsigned long long tS[7] = {0, 0, 0, 0, 0, 0, 0}, tAcc[6] = {0, 0, 0, 0, 0, 0}, tN = 0;
+#define C16_STAMP(i) tS[i] = __builtin_readcyclecounter();
+#define C16_STAMP_DEP(i, x) { asm volatile("" : "+v"(x)); tS[i] = __builtin_readcyclecounter(); }
+#define C16_STAMPS_END() { for (int z = 0; z < 6; ++z) tAcc[z] += tS[z + 1] - tS[z]; ++tN; }
+#else
+#define C16_STAMP(i)
+#define C16_STAMP_DEP(i, x)
+#define C16_STAMPS_END()
+#endif
 #define QL_(i) FQl[QLITE ? 0 : (i)]
     // one step; J = k & 7 (static: ring slots and the image parity).  The chain is  g -> conj(rho) g -> ybar -> scaled fp16 pieces (own K
     // ranges read back) -> [barrier] -> K-steps -> g; the slots behind the MFMA pairs carry the step's LDS reads (two K-steps ahead of
@@ -1645,6 +1666,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_chain16(Dev P, const float* _
         if ((k & (PCH - 1)) == 1 && k > 1) chunk_rows(k / PCH - 1);                                                                \
         if ((k & (RCH - 1)) == RCH - 1 && k != N - 1 && k >= RCH)                                                                  \
             rho_stage<PD>(P, RS, k / RCH - 1, (k / RCH - 1) & 1, 64 * w + lane);                                                   \
+        C16_STAMP(0)                                                                                                               \
         /* ---- the chain ---- */                                                                                                  \
         const float hba = rh.x * ga.x - sgn * rh.y * ga.y;           /* conj(rho_k) g */                                           \
         const float hbb = rh.z * gb.x - sgn * rh.w * gb.y;                                                                         \
@@ -1653,25 +1675,21 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_chain16(Dev P, const float* _
         rd_own<p * 2 * VEC>(g.lo[0], g.hi[0], o00, o10);                                                                           \
         rd_own<p * 2 * VEC + VEC>(g.lo[0], g.hi[0], o01, o11);                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                                         \
-        /* ---- behind the stores: ybar out, its maximum over this wave's rows for the next step's scale, the frequency gradient ---- */ \
-        *reinterpret_cast<float2*>(ybar_base + (size_t)k * (4 * PD)) = make_float2(yba, ybb);                                      \
-        {                                                                                                                          \
-            float m = fmaxf(fabsf(yba), fabsf(ybb));                                                                               \
-            ymx = fmaxf(ymx, m);                                                                                                   \
-            m = fmaxf(m, dpp_mov<0x128>(m)); m = fmaxf(m, dpp_mov<0x124>(m)); m = fmaxf(m, dpp_mov<0x122>(m)); m = fmaxf(m, dpp_mov<0x121>(m)); \
-            if ((lane & 15) == 0) ymx_tab[p][w][lane >> 4] = m;                                                                    \
-        }                                                                                                                          \
-        facca += S1.y * (ga.y * una.x - ga.x * una.y);               /* dt_k Im(g conj(u_{k+1})) (meaningful in the Re lanes) */   \
-        faccb += S1.y * (gb.y * unb.x - gb.x * unb.y);                                                                             \
-        const f2 una_ = una, unb_ = unb;                                                                                           \
+        C16_STAMP(1)                                                                                                               \
+        /* ---- behind the stores: ybar out (for the gradient GEMM) ---- */                                                        \
+        __builtin_amdgcn_raw_buffer_store_b64(u2b{__float_as_uint(yba), __float_as_uint(ybb)}, rs_yb, voff, k * (4 * PD * 4), 0);   \
+        const f2 una_ = una, unb_ = unb, ga_ = ga, gb_ = gb;                                                                       \
+        unsigned mbits = max(__float_as_uint(yba) & 0x7FFFFFFFu, __float_as_uint(ybb) & 0x7FFFFFFFu);     /* max |ybar| as float bits */ \
         __builtin_amdgcn_sched_barrier(0);                                                                                         \
+        C16_STAMP_DEP(2, mbits)                                                                                                    \
         lds_barrier();                                                                                                             \
+        C16_STAMP(3)                                                                                                               \
         f4 cQ0, cQ1, cD0, cD1, nS0, nS1;                                                                                           \
         u4 v[4 * KH - 4];                                                                                                          \
         float4 nrh;                                                                                                                \
         f2 uka, ukb;                                                                                                               \
         float ypa, ypb, pypa, pypb, pyba, pybb, c3bn, sSn;                                                                         \
-        f4 ym[4];                                                                                                                  \
+        u4 ym[2];                                                                                                                  \
         const unsigned ax0 = a_tab + 64 * (((km2 / PCH) & 1) * PCH + (km2 & (PCH - 1)));                                           \
         const float invp = SP0.y;                                                                                                  \
         auto slot = [&](auto kidx_c, auto sl_c) {                                                                                  \
@@ -1700,7 +1718,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_chain16(Dev P, const float* _
                 const float radk = S1.x * SP0.z * invp;                                                                            \
                 c3a = fmaf(SP0.w, PRV.z, -(ypa * radk));                                                                           \
                 c3b = fmaf(SP0.w, PRV.w, -(ypb * radk));                                                                           \
-                c3bn = c3_bound(SP0, S1.x);                                                                                        \
+                c3bn = c3_bound(SP0, SP1, S1.x);                                                                                   \
                 PAIR_PIN2(c3a, c3b);                                                                                               \
             }                                                                                                                      \
             if constexpr (kidx == 2 && sl == 1) { pyba = partner16(yba, odd); PAIR_PIN1(pyba); }             \
@@ -1708,18 +1726,31 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_chain16(Dev P, const float* _
             if constexpr (kidx == 2 && sl == 5) { accS += sda * una_.x + sdb * unb_.x; PAIR_PIN1(accS); }               \
             if constexpr (kidx == 3 && sl == 1) CUR = row_at(k - 8);                                                    \
             if constexpr (kidx == 3 && sl == 3) nrh = rho_rows(km2);                                                    \
-            /* max |ybar_k| rows of the waves (written in front of this step's barrier): read early, used by the last K-step's piece */ \
-            if constexpr (kidx == 0 && sl == 4) rd128<0>(a_ym + 64 * p, ym[0]);                                                    \
-            if constexpr (kidx == 0 && sl == 5) rd128<16>(a_ym + 64 * p, ym[1]);                                                   \
-            if constexpr (kidx == 1 && sl == 4 && PWV > 2) rd128<32>(a_ym + 64 * p, ym[2]);                                        \
-            if constexpr (kidx == 1 && sl == 5 && PWV > 3) rd128<48>(a_ym + 64 * p, ym[3]);                                        \
-            if constexpr (kidx == NR + 1 && sl == 1) {               /* the scale of ybar_{k-1}'s image: the bound of the header (everything  \
-                                                                        older than the two table rows has landed: this K-step's counted wait) */ \
-                asm volatile("" : "+v"(ym[0]), "+v"(ym[1]), "+v"(ym[PWV > 2 ? 2 : 0]), "+v"(ym[PWV > 3 ? 3 : 0]));                   \
-                float m = q ? fmaxf(fmaxf(ym[0].z, ym[0].w), fmaxf(ym[1].z, ym[1].w)) : fmaxf(fmaxf(ym[0].x, ym[0].y), fmaxf(ym[1].x, ym[1].y)); \
-                if constexpr (PWV > 2) m = fmaxf(m, q ? fmaxf(ym[2].z, ym[2].w) : fmaxf(ym[2].x, ym[2].y));                         \
-                if constexpr (PWV > 3) m = fmaxf(m, q ? fmaxf(ym[3].z, ym[3].w) : fmaxf(ym[3].x, ym[3].y));                         \
-                const float bnd = invp * (1.4143f * (1.0f + Qinf + fabsf(S0.x) * Dinf)) * m + c3bn;                                \
+            /* the frequency gradient and the wave's max |ybar_k| (-> LDS, for the scale two steps on) */                            \
+            if constexpr (kidx == 2 && sl == 4) {                                                                                  \
+                facca += S1.y * (ga_.y * una_.x - ga_.x * una_.y);   /* dt_k Im(g conj(u_{k+1})) (meaningful in the Re lanes) */   \
+                faccb += S1.y * (gb_.y * unb_.x - gb_.x * unb_.y);                                                                 \
+                PAIR_PIN2(facca, faccb);                                                                                           \
+            }                                                                                                                      \
+            if constexpr (kidx == 3 && sl == 4) {                                                                                  \
+                ymxb = max(ymxb, mbits);                                                                                           \
+                mbits = max(mbits, dpp_movu<0x128>(mbits)); mbits = max(mbits, dpp_movu<0x124>(mbits));                            \
+                PAIR_PIN1(mbits);                                                                                                  \
+            }                                                                                                                      \
+            if constexpr (kidx == 3 && sl == 5) {                                                                                  \
+                mbits = max(mbits, dpp_movu<0x122>(mbits)); mbits = max(mbits, dpp_movu<0x121>(mbits));                            \
+                if ((lane & 15) == 0) ymx_tab[p][q][w][odd ? 1 : 0] = mbits;                                                       \
+            }                                                                                                                      \
+            /* max |ybar_{k+1}| of this lane's clip over the waves (left by the step before, published by this step's barrier) */      \
+            if constexpr (kidx == 0 && sl == 4) rd128<0>(a_ym + 64 * (p ^ 1), ym[0]);                                              \
+            if constexpr (kidx == 0 && sl == 5) rd128<16>(a_ym + 64 * (p ^ 1), ym[1]);                                             \
+            if constexpr (kidx == NR + 1 && sl == 1) {               /* the scale of ybar_{k-1}'s image: the header's bound from Y_{k+1}       \
+                                                                        (everything older than the two table rows has landed: this K-step's counted wait) */ \
+                asm volatile("" : "+v"(ym[0]), "+v"(ym[1]));                                                                       \
+                unsigned mb = max(max(ym[0].x, ym[0].y), max(ym[0].z, ym[0].w));                                                   \
+                if constexpr (PWV > 2) mb = max(mb, max(ym[1].x, ym[1].y));                                                        \
+                if constexpr (PWV > 3) mb = max(mb, max(ym[1].z, ym[1].w));                                                        \
+                const float bnd = growth(invp, S0.x) * (growth(S0.y, sprev) * __uint_as_float(mb) + c3bprev) + c3bn;               \
                 sSn = gg::pow2_scale(bnd, 15);                                                                                     \
                 PAIR_PIN1(sSn);                                                                                                    \
             }                                                                                                                      \
@@ -1731,11 +1762,13 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_chain16(Dev P, const float* _
         gg::static_for<0, NR>([&](auto ic_) {                                                                                      \
             constexpr int I = decltype(ic_)::value;                                                                                \
             constexpr int T_ = I < KH - 1 ? 1 + I : KH + 1 + (I - (KH - 1));                                                       \
-            kstep12<(I == 0 ? 2 + PWV : I == 1 ? 2 + (PWV > 2 ? PWV - 2 : 0) : 2), false, true, QLITE>(FDh[T_], FDl[T_], FDh[KS + T_], FDl[KS + T_], FQh[T_], QL_(T_), FQh[KS + T_], \
+            kstep12<(I == 0 ? 4 : 2), false, true, QLITE>(FDh[T_], FDl[T_], FDh[KS + T_], FDl[KS + T_], FQh[T_], QL_(T_), FQh[KS + T_], \
                                                               QL_(KS + T_), v[2 * I], v[2 * I + 1], cD0, cD1, cQ0, cQ1,            \
                                                               [&](auto sl) { slot(ic<I + 2>{}, sl); });                            \
         });                                                                                                                        \
+        C16_STAMP(4)                                                                                                               \
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nS0), "+v"(nS1) :: "memory");                                                   \
+        C16_STAMP_DEP(5, cQ1[1])                                                                                                   \
         if (k == 0) { uka = ps0a; ukb = ps0b; }                      /* u_0 = psi_0 */                                             \
         {   /* g = ybar + (Q + s R^dagger) ybar, (own, partner) pairs; the accumulators carry the scales sQ sS and sD sS */           \
             const float cq = iQ * iS, cd = S0.x * (iD * iS);                                                                       \
@@ -1746,10 +1779,13 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_chain16(Dev P, const float* _
             sda = da.x; sdb = db.x;                                                                                                \
         }                                                                                                                          \
         sS = sSn;                                                                                                                  \
+        c3bprev = c3bn; sprev = S0.x;                                                                                              \
         iS = __uint_as_float(0x7F000000u - __float_as_uint(sSn));    /* 1 / sS: exact for a power of two */                        \
         una = uka; unb = ukb;                                                                                                      \
         rh = rhp; S0 = SP0; S1 = SP1;                                                                                              \
         rhp = nrh; SP0 = nS0; SP1 = nS1;                                                                                           \
+        C16_STAMP_DEP(6, ga)                                                                                                       \
+        C16_STAMPS_END()                                                                                                           \
     }
 
     int blk = (N + 7) / 8 - 1;
@@ -1776,6 +1812,12 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_chain16(Dev P, const float* _
     }
 #undef C16B_STEP
 #undef QL_
+#if defined(CMPS_DIAG) && defined(C16_TIMING)
+    if (blockIdx.x == 0 && lane == 0)
+        printf("k_bwd_chain16 wave %d, cycles per step: chain VALU + image stores + own reads issued %.1f | behind the stores %.1f | wait + barrier %.1f | "
+               "K-steps issued %.1f | tables + accumulators ready %.1f | tail %.1f\n", w, (double)tAcc[0] / tN, (double)tAcc[1] / tN, (double)tAcc[2] / tN,
+               (double)tAcc[3] / tN, (double)tAcc[4] / tN, (double)tAcc[5] / tN);
+#endif
     accS += sda * una.x + sdb * unb.x;                                 // the Abar term of step 0
     // ---- the pair's slab: f | psi0bar_re | psi0bar_im | A (as k_bwd_wide; the R / Q sections are written by k_grad_gemm) ----
     float* slab = P.slabs + (size_t)blockIdx.x * P.slab_floats;
@@ -1795,6 +1837,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_chain16(Dev P, const float* _
     }
     {
         float t = accS * wq, a = (w == 0 ? accA : 0.f);
+        float ymx = __uint_as_float(ymxb);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { t += __shfl_xor(t, off, 64); a += __shfl_xor(a, off, 64); ymx = fmaxf(ymx, __shfl_xor(ymx, off, 64)); }
         if (lane == 0) { redA[w] = -(a / (A * A)) - t / A; L.red[w][0] = ymx; }
