@@ -801,6 +801,17 @@ __device__ __forceinline__ void kstep12(const u4& rh0, const u4& rl0, const u4& 
     if constexpr (FIRST) { aR0 = f4{0.f, 0.f, 0.f, 0.f}; aR1 = aR0; aQ0 = aR0; aQ1 = aR0; }
     const h8 a0 = __builtin_bit_cast(h8, v0), a1 = __builtin_bit_cast(h8, v1);
 #define C16_MMA(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, __builtin_bit_cast(h8, B), ACC, 0, 0, 0)
+#if defined(C16_PIPE)                   // A/B: the slots' code first, then the MFMAs, interleaved by a (1 MFMA, 2 VALU) pipeline
+    if constexpr (SLOTS) {
+        slot(ic<0>{}); slot(ic<1>{}); slot(ic<2>{}); slot(ic<3>{}); slot(ic<4>{}); slot(ic<5>{});
+        C16_MMA(aR0, a0, rh0); C16_MMA(aQ0, a0, qh0); C16_MMA(aR1, a0, rh1); C16_MMA(aQ1, a0, qh1);
+        C16_MMA(aR0, a0, rl0); if constexpr (!QLITE) C16_MMA(aQ0, a0, ql0); C16_MMA(aR1, a0, rl1); if constexpr (!QLITE) C16_MMA(aQ1, a0, ql1);
+        C16_MMA(aR0, a1, rh0); if constexpr (!QLITE) C16_MMA(aQ0, a1, qh0); C16_MMA(aR1, a1, rh1); if constexpr (!QLITE) C16_MMA(aQ1, a1, qh1);
+        mfma_valu_pipeline<QLITE ? 8 : 12>();
+        __builtin_amdgcn_sched_barrier(0);
+        return;
+    }
+#endif
     if constexpr (SLOTS) {              // the own K-steps: the step's LDS reads are issued one by one behind pairs of MFMAs
         if constexpr (QLITE) {          // |Q|_F below 2^-19: its cross products are below the float32 rounding of u + Q u (the caller's test)
             C16_MMA(aR0, a0, rh0); C16_MMA(aQ0, a0, qh0); __builtin_amdgcn_sched_barrier(0); slot(ic<0>{}); __builtin_amdgcn_sched_barrier(0);
