@@ -801,7 +801,7 @@ __device__ __forceinline__ void kstep12(const u4& rh0, const u4& rl0, const u4& 
     if constexpr (FIRST) { aR0 = f4{0.f, 0.f, 0.f, 0.f}; aR1 = aR0; aQ0 = aR0; aQ1 = aR0; }
     const h8 a0 = __builtin_bit_cast(h8, v0), a1 = __builtin_bit_cast(h8, v1);
 #define C16_MMA(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, __builtin_bit_cast(h8, B), ACC, 0, 0, 0)
-#if defined(C16_PIPE)                   // A/B: the slots' code first, then the MFMAs, interleaved by a (1 MFMA, 2 VALU) pipeline
+#if defined(CMPS_DIAG) && defined(C16_PIPE)     // A/B builds (scripts/ablate.py): the slots' code first, then the MFMAs, interleaved by a (1 MFMA, 2 VALU) pipeline
     if constexpr (SLOTS) {
         slot(ic<0>{}); slot(ic<1>{}); slot(ic<2>{}); slot(ic<3>{}); slot(ic<4>{}); slot(ic<5>{});
         C16_MMA(aR0, a0, rh0); C16_MMA(aQ0, a0, qh0); C16_MMA(aR1, a0, rh1); C16_MMA(aQ1, a0, qh1);
@@ -828,18 +828,9 @@ __device__ __forceinline__ void kstep12(const u4& rh0, const u4& rl0, const u4& 
         C16_MMA(aR1, a1, rh1); C16_MMA(aQ1, a1, qh1); __builtin_amdgcn_sched_barrier(0); slot(ic<5>{}); __builtin_amdgcn_sched_barrier(0);
         return;
     }
-#if defined(CMPS_DIAG) && defined(C16_NO_MFMA)          // diagnostic builds only (scripts/ablate.py): results are wrong
-    aR0[0] += __uint_as_float(v0.x + rh0.x + rl0.x); aR1[0] += __uint_as_float(v1.x + rh1.x + rl1.x);
-    aQ0[0] += __uint_as_float(qh0.x + ql0.x); aQ1[0] += __uint_as_float(qh1.x + ql1.x);
-#else
     C16_MMA(aR0, a0, rh0); C16_MMA(aQ0, a0, qh0); C16_MMA(aR1, a0, rh1); C16_MMA(aQ1, a0, qh1);
-#if !(defined(CMPS_DIAG) && defined(C16_ONE_PRODUCT))  // diagnostic builds only: the hi hi' product alone (what 64 MFMAs cost in place)
     C16_MMA(aR0, a0, rl0); C16_MMA(aQ0, a0, ql0); C16_MMA(aR1, a0, rl1); C16_MMA(aQ1, a0, ql1);
     C16_MMA(aR0, a1, rh0); C16_MMA(aQ0, a1, qh0); C16_MMA(aR1, a1, rh1); C16_MMA(aQ1, a1, qh1);
-#else
-    aR0[1] += __uint_as_float(v1.x + rl0.x + ql0.x); aR1[1] += __uint_as_float(rl1.x + ql1.x);
-#endif
-#endif
 #undef C16_MMA
 }
 
@@ -1082,6 +1073,10 @@ __global__ __launch_bounds__(2 * PD, 1) void k_fwd_chain16(Dev P, const float* _
                (double)tAcc[4] / tN);
 #endif
 }
+
+#undef C16_STAMP
+#undef C16_STAMP_DEP
+#undef C16_STAMPS_END
 
 hipError_t launch_fwd_chain16(const Dev& P, const float* audio, hipStream_t s) {
     const unsigned nb = (unsigned)((P.B + 1) / 2);
@@ -1614,7 +1609,8 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_chain16(Dev P, const float* _
     auto c3_bound = [&](const f4& T0, const f4& T1, float rad_next) {   // |c3| of the step whose rows are T0, T1: |te| |H|_inf |y| + |rad'| ok inv
         return fabsf(T0.w) * Hinf * T1.z + fabsf(rad_next) * T0.z * T0.y;
     };
-    auto growth = [&](float inv_j, float s_next) { return inv_j * (1.4143f * (1.0f + Qinf + fabsf(s_next) * Dinf)); };   // a_j
+    const float gr0 = 1.4143f * (1.0f + Qinf), gr1 = 1.4143f * Dinf;
+    auto growth = [&](float inv_j, float s_next) { return inv_j * fmaf(fabsf(s_next), gr1, gr0); };   // a_j
     float4 ring0, ring1, ring2, ring3, ring4, ring5, ring6, ring7;
     {
         const int k0 = N - 1;
@@ -1863,6 +1859,10 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_chain16(Dev P, const float* _
         }
     }
 }
+
+#undef C16_STAMP
+#undef C16_STAMP_DEP
+#undef C16_STAMPS_END
 
 hipError_t launch_bwd_chain16(const Dev& P, const float* audio, hipStream_t s) {
     const unsigned nb = (unsigned)((P.B + 1) / 2);
