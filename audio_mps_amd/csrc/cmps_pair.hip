@@ -339,15 +339,59 @@ __device__ __forceinline__ void ksteps_rest(const u4 (&FA)[PD / 8], const u4 (&F
         ksteps_rest<PD, I + 1, XTRA>(FA, FB, v, a0, a1, b0, b1, piece);
     }
 }
+// read number IDX of a step's LDS read sequence (the order the counted waits of matvec2 assume): the two table rows first or last,
+// the other waves' K ranges (M_re half tau = 1 .. KH - 1, then the M_im half) in between
+template <int KH, int POFF, bool TABLES_LAST, int IDX>
+__device__ __forceinline__ void rd_seq(unsigned ax0, unsigned ax1, const unsigned (&lo)[KH], const unsigned (&hi)[KH], f4& x0, f4& x1, u4 (&v)[2 * KH - 2]) {
+    constexpr int NV = 2 * KH - 2;
+    constexpr int vi = TABLES_LAST ? IDX : IDX - 2;             // index into v, or a table row outside [0, NV)
+    if constexpr (IDX >= NV + 2) {
+    } else if constexpr (vi >= 0 && vi < NV) {
+        if constexpr (vi < KH - 1) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(v[vi]) : "v"(lo[1 + vi]), "n"(POFF) : "memory");
+        else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(v[vi]) : "v"(hi[1 + vi - (KH - 1)]), "n"(POFF) : "memory");
+    } else if constexpr ((TABLES_LAST ? IDX - NV : IDX) == 0) {
+        asm volatile("ds_read_b128 %0, %1" : "=&v"(x0) : "v"(ax0) : "memory");
+    } else {
+        asm volatile("ds_read_b128 %0, %1" : "=&v"(x1) : "v"(ax1) : "memory");
+    }
+}
+// an own K-step (its operand arrived before the barrier) with four of the step's LDS reads issued behind its MFMAs, one each: in one
+// burst in front of the own K-steps the 2 KH reads took ~25 cycles apiece with the matrix pipe idle (measured on k_fwd_chain16,
+// profiles/r4_c5wide_chain16_ablations.log)
+template <bool FIRST, typename Rd>
+__device__ __forceinline__ void kstep_own(const u4& fa0, const u4& fa1, const u4& fb0, const u4& fb1, u4& v, f4& a0, f4& a1, f4& b0, f4& b1, Rd&& rd) {
+    if constexpr (FIRST) { a0 = f4{0.f, 0.f, 0.f, 0.f}; a1 = a0; b0 = a0; b1 = a0; }
+    const bf8 av = __builtin_bit_cast(bf8, v);
+#if defined(CMPS_DIAG) && defined(PABL_NO_MFMA)       // diagnostic builds only (scripts/ablate.py)
+    a0[0] += __uint_as_float(v.x); a1[0] += __uint_as_float(fa1.x); b0[0] += __uint_as_float(fb0.x); b1[0] += __uint_as_float(fb1.x + fa0.x);
+    rd(ic<0>{}); rd(ic<1>{}); rd(ic<2>{}); rd(ic<3>{});
+#else
+    a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf8, fa0), a0, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0); rd(ic<0>{}); __builtin_amdgcn_sched_barrier(0);
+    b0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf8, fb0), b0, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0); rd(ic<1>{}); __builtin_amdgcn_sched_barrier(0);
+    a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf8, fa1), a1, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0); rd(ic<2>{}); __builtin_amdgcn_sched_barrier(0);
+    b1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf8, fb1), b1, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0); rd(ic<3>{}); __builtin_amdgcn_sched_barrier(0);
+#endif
+}
 template <int PD, int POFF, bool TABLES_LAST, typename Piece>
 __device__ __forceinline__ void matvec2(const u4 (&FA)[PD / 8], const u4 (&FB)[PD / 8], const ChainLane<PD / 32>& g, unsigned ax0, unsigned ax1,
                                         u4& vlo, u4& vhi, f4& x0, f4& x1, f4& a0, f4& a1, f4& b0, f4& b1, Piece&& piece) {
     constexpr int KS = PD / 16, KH = PD / 32;
     u4 v[KS - 2];
+#if defined(CMPS_DIAG) && (defined(PABL_NO_READS) || defined(PABL_READ_BURST))     // diagnostic / A/B builds: all reads in front of the own K-steps (rounds 1-3 and the first round-4 form)
     rd_rest<KH, POFF, TABLES_LAST>(ax0, ax1, g.lo, g.hi, x0, x1, v);
     __builtin_amdgcn_sched_barrier(0);
     kstep<KS, true>(FA[0], FA[KS], FB[0], FB[KS], vlo, a0, a1, b0, b1);          // (the counts are no-ops: vlo, vhi arrived
     kstep<KS, false>(FA[KH], FA[KS + KH], FB[KH], FB[KS + KH], vhi, a0, a1, b0, b1);   // before the barrier)
+#else
+    kstep_own<true>(FA[0], FA[KS], FB[0], FB[KS], vlo, a0, a1, b0, b1,
+                    [&](auto i_) { rd_seq<KH, POFF, TABLES_LAST, decltype(i_)::value>(ax0, ax1, g.lo, g.hi, x0, x1, v); });
+    kstep_own<false>(FA[KH], FA[KS + KH], FB[KH], FB[KS + KH], vhi, a0, a1, b0, b1,
+                     [&](auto i_) { rd_seq<KH, POFF, TABLES_LAST, 4 + decltype(i_)::value>(ax0, ax1, g.lo, g.hi, x0, x1, v); });
+#endif
     if constexpr (!TABLES_LAST) lds_wait2<KS - 2>(x0, x1);
     piece(ic<0>{});
     mfma_valu_pipeline<8>();
@@ -794,15 +838,17 @@ __device__ __forceinline__ void load_frags_f16(u4 (&fh)[PD / 8], u4 (&fl)[PD / 8
 // one K-step: both pieces of the A operand (vector forms) against both pieces of R and Q, two tiles: 12 MFMAs, the four accumulators in
 // rotation (a dependent MFMA is four instructions = 64 cycles behind its predecessor)
 struct NoSlot { template <typename I> __device__ __forceinline__ void operator()(I) const {} };
-template <int W, bool FIRST, bool SLOTS = false, bool QLITE = false, typename Slot = NoSlot>
+template <int W, bool FIRST, bool SLOTS = false, bool QLITE = false, bool PIPE = false, typename Slot = NoSlot>
 __device__ __forceinline__ void kstep12(const u4& rh0, const u4& rl0, const u4& rh1, const u4& rl1, const u4& qh0, const u4& ql0, const u4& qh1,
                                         const u4& ql1, u4& v0, u4& v1, f4& aR0, f4& aR1, f4& aQ0, f4& aQ1, Slot&& slot = NoSlot{}) {
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(v0), "+v"(v1) : "n"(W) : "memory");
     if constexpr (FIRST) { aR0 = f4{0.f, 0.f, 0.f, 0.f}; aR1 = aR0; aQ0 = aR0; aQ1 = aR0; }
     const h8 a0 = __builtin_bit_cast(h8, v0), a1 = __builtin_bit_cast(h8, v1);
 #define C16_MMA(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, __builtin_bit_cast(h8, B), ACC, 0, 0, 0)
-#if defined(CMPS_DIAG) && defined(C16_PIPE)     // A/B builds (scripts/ablate.py): the slots' code first, then the MFMAs, interleaved by a (1 MFMA, 2 VALU) pipeline
-    if constexpr (SLOTS) {
+    // PIPE (the reverse scan, whose slots carry ~150 instructions of off-chain work per step): the slots' code first, then the MFMAs,
+    // interleaved by a (1 MFMA, 2 VALU) sched_group_barrier pipeline instead of walls around every slot: -0.6 ms of 16.7 at C5, three
+    // interleaved A/B rounds (profiles/r4_c5wide_chain16_ablations.log); no gain for the forward, whose slots hold LDS reads only
+    if constexpr (SLOTS && PIPE) {
         slot(ic<0>{}); slot(ic<1>{}); slot(ic<2>{}); slot(ic<3>{}); slot(ic<4>{}); slot(ic<5>{});
         C16_MMA(aR0, a0, rh0); C16_MMA(aQ0, a0, qh0); C16_MMA(aR1, a0, rh1); C16_MMA(aQ1, a0, qh1);
         C16_MMA(aR0, a0, rl0); if constexpr (!QLITE) C16_MMA(aQ0, a0, ql0); C16_MMA(aR1, a0, rl1); if constexpr (!QLITE) C16_MMA(aQ1, a0, ql1);
@@ -811,7 +857,6 @@ __device__ __forceinline__ void kstep12(const u4& rh0, const u4& rl0, const u4& 
         __builtin_amdgcn_sched_barrier(0);
         return;
     }
-#endif
     if constexpr (SLOTS) {              // the own K-steps: the step's LDS reads are issued one by one behind pairs of MFMAs
         if constexpr (QLITE) {          // |Q|_F below 2^-19: its cross products are below the float32 rounding of u + Q u (the caller's test)
             C16_MMA(aR0, a0, rh0); C16_MMA(aQ0, a0, qh0); __builtin_amdgcn_sched_barrier(0); slot(ic<0>{}); __builtin_amdgcn_sched_barrier(0);
@@ -1762,14 +1807,14 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_chain16(Dev P, const float* _
                 PAIR_PIN1(sSn);                                                                                                    \
             }                                                                                                                      \
         };                                                                                                                         \
-        kstep12<15, true, true, QLITE>(FDh[0], FDl[0], FDh[KS], FDl[KS], FQh[0], QL_(0), FQh[KS], QL_(KS), o00, o01, cD0, cD1, cQ0, cQ1, \
+        kstep12<15, true, true, QLITE, true>(FDh[0], FDl[0], FDh[KS], FDl[KS], FQh[0], QL_(0), FQh[KS], QL_(KS), o00, o01, cD0, cD1, cQ0, cQ1, \
                                        [&](auto sl) { slot(ic<0>{}, sl); });                                                       \
-        kstep12<15, false, true, QLITE>(FDh[KH], FDl[KH], FDh[KS + KH], FDl[KS + KH], FQh[KH], QL_(KH), FQh[KS + KH], QL_(KS + KH), o10, o11, \
+        kstep12<15, false, true, QLITE, true>(FDh[KH], FDl[KH], FDh[KS + KH], FDl[KS + KH], FQh[KH], QL_(KH), FQh[KS + KH], QL_(KS + KH), o10, o11, \
                                         cD0, cD1, cQ0, cQ1, [&](auto sl) { slot(ic<1>{}, sl); });                                  \
         gg::static_for<0, NR>([&](auto ic_) {                                                                                      \
             constexpr int I = decltype(ic_)::value;                                                                                \
             constexpr int T_ = I < KH - 1 ? 1 + I : KH + 1 + (I - (KH - 1));                                                       \
-            kstep12<(I == 0 ? 4 : 2), false, true, QLITE>(FDh[T_], FDl[T_], FDh[KS + T_], FDl[KS + T_], FQh[T_], QL_(T_), FQh[KS + T_], \
+            kstep12<(I == 0 ? 4 : 2), false, true, QLITE, true>(FDh[T_], FDl[T_], FDh[KS + T_], FDl[KS + T_], FQh[T_], QL_(T_), FQh[KS + T_], \
                                                               QL_(KS + T_), v[2 * I], v[2 * I + 1], cD0, cD1, cQ0, cQ1,            \
                                                               [&](auto sl) { slot(ic<I + 2>{}, sl); });                            \
         });                                                                                                                        \

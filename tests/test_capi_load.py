@@ -118,7 +118,7 @@ def test_options_default_and_errors(hip_lib):
     ("cmps_wave2.hip", ["-DCMPS_DIAG_NO_LOSS"]), ("cmps_wave2.hip", ["-DCMPS_DIAG_NO_CHAIN"]),
     ("cmps_pair.hip", ["-DPABL_NO_MFMA", "-DPABL_NO_BARRIER"]), ("cmps_pair.hip", ["-DPABL_TIMING"]),
     ("cmps_wave16.hip", ["-DW16_TIMING"]), ("cmps_wide.hip", ["-DWABL_NO_LOSSMV", "-DWABL_GRAD_NO_LOADS", "-DWABL_GRAD_NO_STORE"]),
-    ("cmps_pair.hip", ["-DWABL_GRAD_NO_SLICES"]), ("cmps_pair.hip", ["-DC16_TIMING", "-DC16_PIPE"]),
+    ("cmps_pair.hip", ["-DWABL_GRAD_NO_SLICES"]), ("cmps_pair.hip", ["-DC16_TIMING", "-DPABL_READ_BURST"]),
 ])
 def test_diagnostic_switches_compile(source, flags, tmp_path):
     """The timing-only switches of scripts/ablate.py live behind -DCMPS_DIAG; each must keep compiling for gfx950."""
