@@ -243,7 +243,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_grad_gemm(Dev P, const float* __r
     // one unit: the MFMAs of unit u from RD (MAC), the operands of unit u + 1 into WR, the raw rows of unit u + 2
     auto run_unit = [&](auto mac_c, const u4* RD, u4* WR, int u) {
         constexpr bool MAC = decltype(mac_c)::value;
-        constexpr int NX = NPC == 1 ? 10 : 60;                    // split / pack / store slices per sub-unit
+        constexpr int NX = NPC == 1 ? 10 : F16 ? 40 : 60;         // split / pack / store slices per sub-unit
         constexpr int BLK = 16 + NLD + NX;                        // slices per sub-unit: math | loads | split, pack, store
         constexpr int NS = 1 + NSUB * BLK;                        // + the table slice
         const int kb = GU * (u + 1);                              // first step of the unit being built
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_grad_gemm(Dev P, const float* __r
         float t1 = 0.f, t2 = 0.f;
         float sv[2][3];                                           // (x, x - hi, x - hi - mid) of the two steps being packed
         unsigned w0[3] = {0u, 0u, 0u};
-        unsigned hpk = 0u, lpk = 0u;
+        unsigned hp0 = 0u, lp0 = 0u, hp1 = 0u;                   // fp16 pieces of the operand being packed: steps (0, 1) and the hi piece of (2, 3)
         bf8 Areg[6], By[PWV], Bu[PWV];
         auto a_off = [&](int ap) { return (ap < 2 ? 0 : ap < 4 ? 4 * PD : 2 * PD) + ((ap & 1) ? a_im_off : a_re_off); };
         auto read_a = [&](int ap, int arr) { Areg[ap] = __builtin_bit_cast(bf8, RD[(size_t)arr * OPS + a_off(ap)]); };
@@ -299,23 +299,24 @@ __global__ __launch_bounds__(2 * PD, 1) void k_grad_gemm(Dev P, const float* __r
                 } else {                                          // split two steps of one operand, pack, store
                     constexpr int x = r - 16 - NLD, c = x / 30, o = (x / 6) % 5, jp = (x / 3) % 2, part = x % 3;
                     if constexpr (F16) {
-                        if constexpr (part == 0) {
-                            const float v0 = val[c][4 * s + 2 * jp][o], v1 = val[c][4 * s + 2 * jp + 1][o];
+                        // two slices per pair of steps: hi piece + residuals | lo piece (and, behind the second pair, the two 8-byte stores)
+                        constexpr int xf = r - 16 - NLD, cf = xf / 20, of = (xf / 4) % 5, jpf = (xf / 2) % 2, partf = xf % 2;
+                        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                        if constexpr (partf == 0) {
+                            const float v0 = val[cf][4 * s + 2 * jpf][of], v1 = val[cf][4 * s + 2 * jpf + 1][of];
                             const unsigned hp = cvt_pk_f16(v0, v1);
-                            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
                             const h2 hh = __builtin_bit_cast(h2, hp);
-                            hpk = hp;
+                            if constexpr (jpf == 0) hp0 = hp; else hp1 = hp;
                             sv[0][1] = v0 - (float)hh.x;
                             sv[1][1] = v1 - (float)hh.y;
-                        } else if constexpr (part == 1) {
-                            lpk = cvt_pk_f16(sv[0][1], sv[1][1]);
-                        } else if constexpr (jp == 0) {
-                            w0[0] = hpk; w0[1] = lpk;
+                        } else if constexpr (jpf == 0) {
+                            lp0 = cvt_pk_f16(sv[0][1], sv[1][1]);
                         } else {
-                            unsigned* d0 = reinterpret_cast<unsigned*>(WR + (o * 2 + c) * PD + prow) + 2 * pclip;
-                            unsigned* d1 = reinterpret_cast<unsigned*>(WR + (size_t)OPS + (o * 2 + c) * PD + prow) + 2 * pclip;
-                            *reinterpret_cast<uint2*>(d0) = make_uint2(w0[0], hpk);
-                            *reinterpret_cast<uint2*>(d1) = make_uint2(w0[1], lpk);
+                            const unsigned lp1 = cvt_pk_f16(sv[0][1], sv[1][1]);
+                            unsigned* d0 = reinterpret_cast<unsigned*>(WR + (of * 2 + cf) * PD + prow) + 2 * pclip;
+                            unsigned* d1 = reinterpret_cast<unsigned*>(WR + (size_t)OPS + (of * 2 + cf) * PD + prow) + 2 * pclip;
+                            *reinterpret_cast<uint2*>(d0) = make_uint2(hp0, hp1);
+                            *reinterpret_cast<uint2*>(d1) = make_uint2(lp0, lp1);
                         }
                     } else if constexpr (part == 0) {             // the two steps' chains interleaved: back-to-back dependent VALU
                         const float v0 = val[c][4 * s + 2 * jp][o], v1 = val[c][4 * s + 2 * jp + 1][o];   // do not hide behind an MFMA
