@@ -104,6 +104,12 @@ def test_options_default_and_errors(hip_lib):
         assert hip_lib.cmps_get_option(h, _capi.CMPS_OPT_RANK1) == v
     assert hip_lib.cmps_set_option(h, _capi.CMPS_OPT_RANK1, 5) == _capi.CMPS_ERR_BAD_ARG
     assert hip_lib.cmps_set_option(h, _capi.CMPS_OPT_RANK1, -1) == _capi.CMPS_ERR_BAD_ARG
+    # CMPS_OPT_WIDE_CHAIN: a new handle runs the wide kernels' chains on the matrix cores; VALU and MFMA_FWD stay selectable
+    assert hip_lib.cmps_get_option(h, _capi.CMPS_OPT_WIDE_CHAIN) == _capi.CMPS_WIDE_CHAIN_MFMA == 1
+    for v in (_capi.CMPS_WIDE_CHAIN_VALU, _capi.CMPS_WIDE_CHAIN_MFMA_FWD, _capi.CMPS_WIDE_CHAIN_MFMA):
+        assert hip_lib.cmps_set_option(h, _capi.CMPS_OPT_WIDE_CHAIN, v) == _capi.CMPS_OK
+        assert hip_lib.cmps_get_option(h, _capi.CMPS_OPT_WIDE_CHAIN) == v
+    assert hip_lib.cmps_set_option(h, _capi.CMPS_OPT_WIDE_CHAIN, 3) == _capi.CMPS_ERR_BAD_ARG
     assert hip_lib.cmps_set_option(h, 99, 0) == _capi.CMPS_ERR_BAD_ARG
     assert hip_lib.cmps_get_option(h, 99) == -1 and hip_lib.cmps_get_option(None, _capi.CMPS_OPT_RANK1) == -1
     # CMPS_WS_FRESH / CMPS_WS_REUSE_TABLES are requests, not layouts: they do not change the size
