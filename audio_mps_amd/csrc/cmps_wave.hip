@@ -58,7 +58,9 @@ struct Pre {
 }  // namespace
 
 // RANK1: how the three rank-1 gradient updates of a step are applied (cmps_set_option(CMPS_OPT_RANK1)):
-//   0 exact fp32 MFMA every step; 1 bf16 hi/lo split, 3 products; 2 bf16 hi/mid/lo split, 6 products (see below)
+//   0 exact fp32 MFMA every step; 1 bf16 hi/lo split, 3 products; 2 bf16 hi/mid/lo split, 6 products; 3 (round 4) two fp16 pieces,
+//   round to nearest (11 + 1 + 11 + 1 bits: BF16X3's accuracy class), 3 products on v_mfma_f32_32x32x16_f16, with power-of-two
+//   scales per 64-step chunk from a guaranteed bound of |ybar| (see below)
 // LEGACY: the reverse sweep of the previous-generation AudioMPS arithmetic (cmps_legacy.hip) on the same chain.  With rho = 1 in the
 // tables, g = cotangent of psi_{k+1} without its own loss term, and e_k = psi_k^dagger H psi_k (degree 0 in y_{k-1}):
 //   ybar_k = (g_{k+1} - yhat_k dot) inv_k + te_{k+1} inv_k^2 (H y_k),   dot = Re(yhat_k^dagger g_{k+1}) + te_{k+1} e_{k+1}
@@ -95,6 +97,25 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
         }
     }
     v16f Rre = {}, Rim = {}, Qre = {}, Qim = {};
+    // RANK1 == 3: power-of-two scales of the split operands.  a1 | a2 = s ybar share sR (both land in Rre / Rim), ybar has sQ, the
+    // unit vectors yhat, u are scaled by 2^13.  sR, sQ are chosen per 64-step chunk of per-step scalars from a guaranteed bound:
+    // with f_j(x) = a_j x + c_j,  a_j = inv_j (1 + |Q|_F + |s_{j+1}| |R|_F),  c_j = |te_j| 2 |R|_F |y_j| + |rad_{j+1}| invok_j |y_j| inv_j
+    // (2-norms: |ybar_j| <= a_j |ybar_{j+1}| + c_j),  the chunk's steps satisfy  |ybar_j| <= A_j Y + C_j  with (A_j, C_j) the composition
+    // f_j o ... o f_top (a suffix scan over the lanes of scal_commit) and Y = |ybar| of the step above the chunk, MEASURED when the chain
+    // gets there; the accumulators are multiplied by the exact ratio of new to old scale at every chunk boundary.
+    constexpr float SB16 = 8192.f;
+    float sR = 1.f, sQ = 1.f;                     // current scales (wave-uniform)
+    float cbA = 0.f, cbC = 0.f, cbsA = 0.f, cbsC = 0.f, cbT = 0.f;   // max_j A_j, C_j, |s_j| A_j, |s_j| C_j, |ten_j| of the chunk last committed
+    float s_above = 0.f, rad_above = 0.f;         // s, rad of the first step of the chunk above (no step N: 0)
+    float ybar_last = 0.f;                        // ybar of the step the chain did last (this lane's component)
+    float Qn = 0.f, Rn = 0.f;
+    if constexpr (RANK1 == 3) {
+        float q2 = 0.f, r2 = 0.f;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) { q2 += MQ[m].x * MQ[m].x + MQ[m].y * MQ[m].y; r2 += MRd[m].x * MRd[m].x + MRd[m].y * MRd[m].y; }
+        Qn = 1.001f * sqrtf(sum64(q2));
+        Rn = 1.001f * sqrtf(sum64(r2));
+    }
 
     const unsigned aBw = lds_addr(&bcB[w][0]) + i * 8 + h * 4, aBr = lds_addr(&bcB[w][0]) + h * 128;
     const unsigned aYown = lds_addr(&stY[w][0]) + (2 * i + h) * 8;   // stash rows: 64 (y[n], (H y)[n]) pairs, n = 2 i + {re, im}
@@ -150,6 +171,43 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
         scl[w][2 * lane] = make_float4(sv, rdt, invv, tev * nv);
         scl[w][2 * lane + 1] = make_float4(tev, invokv, tev * ev, 0.f);
         if (idx < N) accA += zbar * ex;
+        if constexpr (RANK1 == 3) {
+            const bool in = idx < N;
+            const float radv = tev * ev;
+            float s_up = __shfl_down(sv, 1, 64), rad_up = __shfl_down(radv, 1, 64);     // step j + 1
+            if (lane == 63) { s_up = s_above; rad_up = rad_above; }
+            s_above = rdlane(sv, 0); rad_above = rdlane(radv, 0);
+            const float ynorm = 1.001f * sqrtf(fmaxf(nv, 1e-12f));
+            float Aj = in ? invv * (1.0f + Qn + fabsf(s_up) * Rn) : 1.f;
+            float Cj = in ? fabsf(tev) * (2.0f * Rn) * ynorm + fabsf(rad_up) * invokv * (ynorm * invv) : 0.f;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {            // suffix scan from the chunk's top step (lane 63) down: f_j o (f_{j+1} o ...)
+                const float Ag = __shfl_down(Aj, d, 64), Cg = __shfl_down(Cj, d, 64);
+                if (lane + d < 64) { Cj = fmaf(Aj, Cg, Cj); Aj *= Ag; }
+            }
+            const float as = in ? fabsf(sv) : 0.f;
+            float m0 = Aj, m1 = Cj, m2 = as * Aj, m3 = as * Cj, m4 = in ? fabsf(tev * nv) : 0.f;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                m0 = fmaxf(m0, __shfl_xor(m0, off, 64)); m1 = fmaxf(m1, __shfl_xor(m1, off, 64)); m2 = fmaxf(m2, __shfl_xor(m2, off, 64));
+                m3 = fmaxf(m3, __shfl_xor(m3, off, 64)); m4 = fmaxf(m4, __shfl_xor(m4, off, 64));
+            }
+            cbA = rdlane(m0, 0); cbC = rdlane(m1, 0); cbsA = rdlane(m2, 0); cbsC = rdlane(m3, 0); cbT = rdlane(m4, 0);
+        }
+    };
+    // RANK1 == 3: scales of the chunk just committed from |ybar| of the step above it; the accumulators follow (exact ratios)
+    auto pow2_of = [](float bound) {                   // the largest power of two S with bound S < 2^15 (exponent clamped)
+        int se = 15 - ((int)((__float_as_uint(bound) >> 23) & 0xFFu) - 126);
+        se = se > 60 ? 60 : se < -60 ? -60 : se;
+        return __uint_as_float((unsigned)(127 + se) << 23);
+    };
+    auto pow2_inv = [](float sc2) { return __uint_as_float(0x7F000000u - __float_as_uint(sc2)); };
+    auto rescale = [&](float Y) {
+        const float nR = pow2_of(fmaxf(cbT, fmaf(cbsA, Y, cbsC))), nQ = pow2_of(fmaf(cbA, Y, cbC));
+        const float fR = nR * pow2_inv(sR), fQ = nQ * pow2_inv(sQ);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { Rre[r] *= fR; Rim[r] *= fR; Qre[r] *= fQ; Qim[r] *= fQ; }
+        sR = nR; sQ = nQ;
     };
     auto stage_load_all = [&](int hh) {
         stage_load512<16>(sty4, hh * CHB, N - 1, lane, sry);
@@ -187,6 +245,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
     scal_load(hl >> 1);
     stage_commit_all();
     scal_commit(hl >> 1);
+    if constexpr (RANK1 == 3) { sR = pow2_of(fmaxf(cbT, cbsC)); sQ = pow2_of(cbC); }      // nothing above the top chunk: |ybar| = 0 there
     v4f qc[8];
     v2f yh_j, rho_j;
     v4f c0_j, c1_j;
@@ -225,6 +284,19 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
     unsigned fM[RANK1 == 2 ? 7 : 1][4];
     float fsave[7], hold_e[7], hold_o[7];
     auto split_pair = [&](int v, int reg, float ve, float vo) {
+        if constexpr (RANK1 == 3) {
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            const float sc2 = (v == 0 || v == 2) ? sR : v == 1 ? sQ : SB16;
+            const float te_ = ve * sc2, to_ = vo * sc2;
+            unsigned hi, lo;
+            asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(te_), "v"(to_));
+            const h2 hh = __builtin_bit_cast(h2, hi);
+            const float re_ = te_ - (float)hh.x, ro_ = to_ - (float)hh.y;
+            asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(re_), "v"(ro_));
+            fH[v][reg] = hi;
+            fL[v][reg] = lo;
+            return;
+        }
         const unsigned xe = __float_as_uint(ve), xo = __float_as_uint(vo);
         fH[v][reg] = __builtin_amdgcn_perm(xo, xe, 0x07060302u);
         v2f lo;
@@ -273,6 +345,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
         for (int r = 0; r < 4; ++r) { fH[v][r] = 0u; fL[v][r] = 0u; if constexpr (RANK1 == 2) fM[v][r] = 0u; }
     }
     constexpr int PER_PAIR = RANK1 == 2 ? 6 : 3, UNITS = 6 * PER_PAIR, PER_HOOK = RANK1 == 2 ? 2 : 1;
+    typedef _Float16 hf8 __attribute__((ext_vector_type(8)));
     // hook points of a step: A-points 0..5 (both modes) and B-points 0..5 (BF16X3 only): point q = 0..17 over the three steps
     // issues unit q (BF16X2) or unit 2 q at the A-point and unit 2 q + 1 at the B-point (BF16X3): never two MFMAs in a row
     auto mf_unit = [&](auto usel) {
@@ -288,8 +361,12 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
         constexpr int WA = K == 0 ? 0 : K == 1 ? 0 : K == 2 ? 1 : K == 3 ? 0 : K == 4 ? 2 : 1;
         constexpr int WB = K == 0 ? 0 : K == 1 ? 1 : K == 2 ? 0 : K == 3 ? 2 : K == 4 ? 0 : 1;
         auto mf = [&](v16f& acc, int ia, int ib) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(piece(std::integral_constant<int, WA>{}, ia)),
-                                                          frag(piece(std::integral_constant<int, WB>{}, ib)), acc, 0, 0, 0);
+            if constexpr (RANK1 == 3)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf8, frag(piece(std::integral_constant<int, WA>{}, ia))),
+                                                             __builtin_bit_cast(hf8, frag(piece(std::integral_constant<int, WB>{}, ib))), acc, 0, 0, 0);
+            else
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(piece(std::integral_constant<int, WA>{}, ia)),
+                                                              frag(piece(std::integral_constant<int, WB>{}, ib)), acc, 0, 0, 0);
         };
         if constexpr (PR == 0) mf(Rre, 0, LEGACY ? 5 : 3);
         if constexpr (PR == 1) mf(Rim, 0, LEGACY ? 6 : 4);
@@ -384,13 +461,16 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
         //   (the sign of the Im tiles is applied once at the end)
         const float a1 = LEGACY ? S.ten * uk : S.ten * S.yh;   // 2 ebar n yhat  (y y^dagger = n yhat yhat^dagger); legacy: te_k psi_k
         const float a2 = S.s * ybar;
+        ybar_last = ybar;
         if constexpr (decltype(slot)::value < 0) {
-            Rre = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, LEGACY ? uk : S.yh, Rre, 0, 0, 0);
-            Rim = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, LEGACY ? uko : S.yho, Rim, 0, 0, 0);
-            Qre = __builtin_amdgcn_mfma_f32_32x32x2f32(ybar, uk, Qre, 0, 0, 0);
-            Qim = __builtin_amdgcn_mfma_f32_32x32x2f32(ybar, uko, Qim, 0, 0, 0);
-            Rre = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, uk, Rre, 0, 0, 0);
-            Rim = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, uko, Rim, 0, 0, 0);
+            // (RANK1 == 3: the accumulators carry the scales sR 2^13 and sQ 2^13 -- exact powers of two on the operands of the exact MFMA)
+            const float kA = RANK1 == 3 ? sR : 1.f, kQ = RANK1 == 3 ? sQ : 1.f, kB = RANK1 == 3 ? SB16 : 1.f;
+            Rre = __builtin_amdgcn_mfma_f32_32x32x2f32(a1 * kA, (LEGACY ? uk : S.yh) * kB, Rre, 0, 0, 0);
+            Rim = __builtin_amdgcn_mfma_f32_32x32x2f32(a1 * kA, (LEGACY ? uko : S.yho) * kB, Rim, 0, 0, 0);
+            Qre = __builtin_amdgcn_mfma_f32_32x32x2f32(ybar * kQ, uk * kB, Qre, 0, 0, 0);
+            Qim = __builtin_amdgcn_mfma_f32_32x32x2f32(ybar * kQ, uko * kB, Qim, 0, 0, 0);
+            Rre = __builtin_amdgcn_mfma_f32_32x32x2f32(a2 * kA, uk * kB, Rre, 0, 0, 0);
+            Rim = __builtin_amdgcn_mfma_f32_32x32x2f32(a2 * kA, uko * kB, Rim, 0, 0, 0);
         } else {
             const float val[7] = {a1, ybar, a2, S.yh, S.yho, uk, uko};
             record(slot, val);
@@ -431,7 +511,22 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
         }
 #undef BWD_STEP8
         if (hh > 0) stage_commit_all();
-        if (new_scal) scal_commit((hh >> 1) - 1);
+        if (new_scal) {
+            if constexpr (RANK1 == 3) {
+                // the chain stands at the chunk boundary: issue what is pending under the old scales, clear the fragments (the hooks
+                // of the next three steps are unconditional), commit the chunk's scalars and bound coefficients, take the new scales
+                if (pend) flush_octet();
+#pragma unroll
+                for (int v = 0; v < 7; ++v)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { fH[v][r] = 0u; fL[v][r] = 0u; }
+                const float Y = 1.001f * sqrtf(sum64(ybar_last * ybar_last));
+                scal_commit((hh >> 1) - 1);
+                rescale(Y);
+            } else {
+                scal_commit((hh >> 1) - 1);
+            }
+        }
     }
     if (pend) flush_octet();
     S = chain_step(S, u0, u0o, std::false_type{}, 0, true, std::integral_constant<int, -1>{});   // step 0: u_0 = psi_0
@@ -446,10 +541,11 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * h;   // C/D layout of the 32x32 MFMA: column = lane & 31
         const int o = row * DPW + i;
-        slab[o] = Rre[r];
-        slab[DD + o] = -Rim[r];
-        slab[2 * DD + o] = Qre[r];
-        slab[3 * DD + o] = -Qim[r];
+        const float uR = RANK1 == 3 ? pow2_inv(sR) * (1.0f / SB16) : 1.f, uQ = RANK1 == 3 ? pow2_inv(sQ) * (1.0f / SB16) : 1.f;
+        slab[o] = Rre[r] * uR;
+        slab[DD + o] = -Rim[r] * uR;
+        slab[2 * DD + o] = Qre[r] * uQ;
+        slab[3 * DD + o] = -Qim[r] * uQ;
     }
     const float sumS = sum64(accS);
     const float sumA = sum64(accA);
@@ -598,6 +694,8 @@ hipError_t launch_bwd_wave(const Dev& P, const float* audio, int rank1_mode, hip
         hipLaunchKernelGGL(k_bwd_wave<0>, dim3(nb), dim3(64 * WAVES), 0, s, P, audio);
     else if (rank1_mode == 1)
         hipLaunchKernelGGL(k_bwd_wave<1>, dim3(nb), dim3(64 * WAVES), 0, s, P, audio);
+    else if (rank1_mode == 3)
+        hipLaunchKernelGGL(k_bwd_wave<3>, dim3(nb), dim3(64 * WAVES), 0, s, P, audio);
     else
         hipLaunchKernelGGL(k_bwd_wave<2>, dim3(nb), dim3(64 * WAVES), 0, s, P, audio);
     return hipGetLastError();

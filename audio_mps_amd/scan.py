@@ -112,7 +112,7 @@ class HipScan:
         mode, wide = self.rank1, self.variant == _capi.CMPS_VARIANT_WIDE
         if wide:
             return {0: _capi.CMPS_RANK1_BF16X3, 4: _capi.CMPS_RANK1_F16X2}.get(mode, mode)
-        return mode if mode in (_capi.CMPS_RANK1_EXACT_F32, _capi.CMPS_RANK1_BF16X2) else _capi.CMPS_RANK1_BF16X3
+        return mode if mode in (_capi.CMPS_RANK1_EXACT_F32, _capi.CMPS_RANK1_BF16X2, _capi.CMPS_RANK1_F16X2) else _capi.CMPS_RANK1_BF16X3
 
     def kernel_events(self, on: bool):
         """cmps_set_option(CMPS_OPT_KERNEL_EVENTS): bracket every kernel of forward() / backward() with HIP events (a measurement aid,

@@ -275,7 +275,7 @@ def kernel_counters(doc, kernel):
 # ---------------------------------------------------------------------------------------------------
 def executed_split(variant, D, rank1):
     if variant in (V_WAVE, V_WAVE32) and not (variant == V_WAVE and D <= 16):
-        prod = {0: 1, 1: 3, 2: 6}[rank1]
+        prod = {0: 1, 1: 3, 2: 6, 3: 3}[rank1]
         return {"fwd": {"valu_fp32": 12, "mfma_fp32_equiv": 8, "mfma_products": 6, "eliminated": 4,
                         "what": "merged (Q + s R) u mat-vec 8 + forming it 4 on the VALU; H y as a bf16x3 GEMM over 32-step chunks"},
                 "bwd": {"valu_fp32": 12, "mfma_fp32_equiv": 24, "mfma_products": prod, "eliminated": 20,
@@ -633,7 +633,8 @@ def dtype_label(variant, D, rank1):
         return "bf16 (mat-vec operands; fp32 state and accumulate)"
     if variant in (V_WAVE, V_WAVE32) and not (variant == V_WAVE and D <= 16):
         tail = {1: "rank-1 gradient sums: bf16x2 split, 16 operand bits", 0: "rank-1 gradient sums: exact fp32 MFMA",
-                2: "rank-1 gradient sums: the same bf16x3 split"}[rank1]
+                2: "rank-1 gradient sums: the same bf16x3 split",
+                3: "rank-1 gradient sums: f16x2 split (power-of-two scales per 64-step chunk, 24 operand bits: bf16x3's accuracy class at half the products)"}[rank1]
         return ("f32 (fp32 FMA chains on the serial path; loss product H y: bf16x3-split operands on the matrix cores, fp32 accumulate; "
                 + tail + ")")
     if variant == V_WIDE:
@@ -762,7 +763,7 @@ def worker(ARGS):
         out["parity_in_bench"] = run.parity(sample, ref, pair)
         if fam in ("wave", "wide") and not ARGS.no_precision_ab:
             ab = {}
-            modes = {"exact_f32": 0, "bf16x2": 1, "bf16x3": 2} if fam == "wave" else {"bf16x2": 1, "bf16x3": 2, "f16x2": 3}
+            modes = {"exact_f32": 0, "bf16x2": 1, "bf16x3": 2, "f16x2": 3} if fam == "wave" else {"bf16x2": 1, "bf16x3": 2, "f16x2": 3}
             for name, mode in modes.items():                     # accuracy first: the timed steps below move the parameters
                 run.backend.set_rank1(mode)
                 pr = run.parity(sample, ref, False)

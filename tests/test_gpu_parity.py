@@ -162,7 +162,7 @@ def test_config3_reduced_batch():
     _check_against_oracle(m, audio, nthreads=16)
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 def test_rank1_modes(mode):
     """cmps_set_option(CMPS_OPT_RANK1): exact fp32 MFMA, bf16x2 split and bf16x3 split of the rank-1 gradient updates
     (k_bwd_wave<0|1|2>) all stay inside the gradient bar; a new handle's DEFAULT means BF16X3 here (24 operand bits, fp32-faithful
@@ -185,15 +185,17 @@ def test_rank1_modes_order_of_accuracy():
     m, audio = _model(32, 2000, 8, WAVE, seed=23)
     be = m._get_backend()
     flats = {}
-    for mode in (0, 1, 2):
+    for mode in (0, 1, 2, 3):
         be.set_rank1(mode)
         flats[mode] = m.grad_sums()[0].cpu().numpy().astype(np.float64)[:2 * 32 * 32]
     e2 = rel_inf(flats[1], flats[0])
     e3 = rel_inf(flats[2], flats[0])
-    print(f"rank-1 sums vs exact fp32 MFMA: bf16x2 {e2:.2e}, bf16x3 {e3:.2e}")
+    e16 = rel_inf(flats[3], flats[0])
+    print(f"rank-1 sums vs exact fp32 MFMA: bf16x2 {e2:.2e}, bf16x3 {e3:.2e}, f16x2 {e16:.2e}")
     assert e3 <= 1e-5, e3          # fp32 summation-order noise only (the MFMA adds 16 products per instruction)
     assert e2 <= 5e-5, e2
     assert e3 <= e2
+    assert e16 <= 1e-5 and e16 <= 4 * e3 + 2e-6, (e16, e3)       # the fp16 split (round 4): bf16x3's class
 
 
 def test_variants_agree():
