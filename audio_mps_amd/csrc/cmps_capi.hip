@@ -81,6 +81,7 @@ int resolve_variant(const cmps_handle_s* h) {
 // CMPS_OPT_RANK1 as the wave-per-clip reverse scans understand it: exact fp32, two bf16 pieces, two fp16 pieces (the 32-row kernel of
 // the PsiCMPS arithmetic; the legacy mode maps it to three bf16 pieces), or (every other value) three bf16 pieces
 int wave_rank1(int mode) {
+    if (mode == CMPS_RANK1_DEFAULT) return CMPS_RANK1_F16X2;
     return mode == CMPS_RANK1_EXACT_F32 || mode == CMPS_RANK1_BF16X2 || mode == CMPS_RANK1_F16X2 ? mode : CMPS_RANK1_BF16X3;
 }
 

@@ -360,6 +360,11 @@ __device__ __forceinline__ void rd_seq(unsigned ax0, unsigned ax1, const unsigne
 // profiles/r4_c5wide_chain16_ablations.log)
 template <bool FIRST, typename Rd>
 __device__ __forceinline__ void kstep_own(const u4& fa0, const u4& fa1, const u4& fb0, const u4& fb1, u4& v, f4& a0, f4& a1, f4& b0, f4& b1, Rd&& rd) {
+    // The operand was read in the previous step's tail (rd_own, asm) and has landed by the barrier's lgkmcnt(0) -- but the compiler only
+    // sees a register defined by that asm: without this statement (asm volatile statements keep their order, the barrier is one) it is
+    // free to issue the MFMAs that read it ABOVE the barrier.  (The first interleaved version had dropped the no-op wait that did this
+    // job in kstep<>: intermittent garbage in tests/test_gpu_pair.py, about every second run.)
+    asm volatile("" : "+v"(v) :: "memory");
     if constexpr (FIRST) { a0 = f4{0.f, 0.f, 0.f, 0.f}; a1 = a0; b0 = a0; b1 = a0; }
     const bf8 av = __builtin_bit_cast(bf8, v);
 #if defined(CMPS_DIAG) && defined(PABL_NO_MFMA)       // diagnostic builds only (scripts/ablate.py)

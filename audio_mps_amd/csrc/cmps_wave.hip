@@ -98,15 +98,18 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
     }
     v16f Rre = {}, Rim = {}, Qre = {}, Qim = {};
     // RANK1 == 3: power-of-two scales of the split operands.  a1 | a2 = s ybar share sR (both land in Rre / Rim), ybar has sQ, the
-    // unit vectors yhat, u are scaled by 2^13.  sR, sQ are chosen per 64-step chunk of per-step scalars from a guaranteed bound:
-    // with f_j(x) = a_j x + c_j,  a_j = inv_j (1 + |Q|_F + |s_{j+1}| |R|_F),  c_j = |te_j| 2 |R|_F |y_j| + |rad_{j+1}| invok_j |y_j| inv_j
-    // (2-norms: |ybar_j| <= a_j |ybar_{j+1}| + c_j),  the chunk's steps satisfy  |ybar_j| <= A_j Y + C_j  with (A_j, C_j) the composition
-    // f_j o ... o f_top (a suffix scan over the lanes of scal_commit) and Y = |ybar| of the step above the chunk, MEASURED when the chain
-    // gets there; the accumulators are multiplied by the exact ratio of new to old scale at every chunk boundary.
+    // unit vectors yhat, u are scaled by 2^13.  sR, sQ follow a GUARANTEED bound of the octet about to run: with the affine maps
+    //   f_k(x) = a_k x + c_k,   a_k = inv_k (1 + |Q|_F + |s_{k+1}| |R|_F),   c_k = |te_k| 2 |R|_F |y_k| + |rad_{k+1}| invok_k |y_k| inv_k
+    // (2-norms: |ybar_k| <= a_k |ybar_{k+1}| + c_k) the eight steps of an octet satisfy |ybar_k| <= A_k Y + C_k, (A_k, C_k) = f_k o ... o
+    // f_top of the octet (a segmented suffix scan over the lanes of scal_commit) and Y = |ybar| of the step above the octet, MEASURED.
+    // (The horizon has to be this short: with the reference's initialisation |s| |R|_F is of order one, and a bound compounded over a
+    // 64-step chunk is loose by tens of binades -- the first version flushed everything to zero on tests/golden/reftest_d7_t256_b8.)
+    // The scales change only when the bound leaves [2^8, 2^15) in scaled units; the accumulators are then multiplied by the exact ratio.
     constexpr float SB16 = 8192.f;
     float sR = 1.f, sQ = 1.f;                     // current scales (wave-uniform)
-    float cbA = 0.f, cbC = 0.f, cbsA = 0.f, cbsC = 0.f, cbT = 0.f;   // max_j A_j, C_j, |s_j| A_j, |s_j| C_j, |ten_j| of the chunk last committed
+    float cbA = 0.f, cbC = 0.f, cbsA = 0.f, cbsC = 0.f, cbT = 0.f;   // per octet of the chunk last committed (lane 8 o + .. holds octet o): max A, C, |s| A, |s| C, |ten|
     float s_above = 0.f, rad_above = 0.f;         // s, rad of the first step of the chunk above (no step N: 0)
+    float a_above = 1.f, c_above = 0.f, as_above = 0.f, t_above = 0.f;   // the bound's (a, c, |s|, |ten|) of that step (nothing above the top chunk: identity)
     float ybar_last = 0.f;                        // ybar of the step the chain did last (this lane's component)
     float Qn = 0.f, Rn = 0.f;
     if constexpr (RANK1 == 3) {
@@ -173,26 +176,32 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
         if (idx < N) accA += zbar * ex;
         if constexpr (RANK1 == 3) {
             const bool in = idx < N;
-            const float radv = tev * ev;
+            const float radv = in ? tev * ev : 0.f;              // (rows behind the clip's last step hold whatever the workspace held: no step N, rad_N = 0)
             float s_up = __shfl_down(sv, 1, 64), rad_up = __shfl_down(radv, 1, 64);     // step j + 1
             if (lane == 63) { s_up = s_above; rad_up = rad_above; }
             s_above = rdlane(sv, 0); rad_above = rdlane(radv, 0);
             const float ynorm = 1.001f * sqrtf(fmaxf(nv, 1e-12f));
-            float Aj = in ? invv * (1.0f + Qn + fabsf(s_up) * Rn) : 1.f;
-            float Cj = in ? fabsf(tev) * (2.0f * Rn) * ynorm + fabsf(rad_up) * invokv * (ynorm * invv) : 0.f;
+            const float aj = in ? invv * (1.0f + Qn + fabsf(s_up) * Rn) : 1.f;
+            const float cj = in ? fabsf(tev) * (2.0f * Rn) * ynorm + fabsf(rad_up) * invokv * (ynorm * invv) : 0.f;
+            const float sj = in ? fabsf(sv) : 0.f, tj = in ? fabsf(tev * nv) : 0.f;
+            // The loop below runs the CHAIN one step ahead of the index its chunks are counted in (chain step k = j + 1): between two
+            // boundaries the chain does steps 64 c + 64 down to 64 c + 1.  The set of a chunk is therefore its own steps but the lowest,
+            // plus the lowest step of the chunk above (carried from that chunk's commit); position p <-> step 64 c + 1 + p.
+            float Aj = __shfl_down(aj, 1, 64), Cj = __shfl_down(cj, 1, 64), as = __shfl_down(sj, 1, 64), m4 = __shfl_down(tj, 1, 64);
+            if (lane == 63) { Aj = a_above; Cj = c_above; as = as_above; m4 = t_above; }
+            a_above = rdlane(aj, 0); c_above = rdlane(cj, 0); as_above = rdlane(sj, 0); t_above = rdlane(tj, 0);
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {            // suffix scan from the chunk's top step (lane 63) down: f_j o (f_{j+1} o ...)
+            for (int d = 1; d < 8; d <<= 1) {             // suffix scan inside each octet, from its top position down: f_p o (f_{p+1} o ...)
                 const float Ag = __shfl_down(Aj, d, 64), Cg = __shfl_down(Cj, d, 64);
-                if (lane + d < 64) { Cj = fmaf(Aj, Cg, Cj); Aj *= Ag; }
+                if ((lane & 7) + d < 8) { Cj = fmaf(Aj, Cg, Cj); Aj *= Ag; }
             }
-            const float as = in ? fabsf(sv) : 0.f;
-            float m0 = Aj, m1 = Cj, m2 = as * Aj, m3 = as * Cj, m4 = in ? fabsf(tev * nv) : 0.f;
+            float m0 = Aj, m1 = Cj, m2 = as * Aj, m3 = as * Cj;
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
+            for (int off = 4; off > 0; off >>= 1) {       // maxima over the octet's eight positions, in every lane of the octet
                 m0 = fmaxf(m0, __shfl_xor(m0, off, 64)); m1 = fmaxf(m1, __shfl_xor(m1, off, 64)); m2 = fmaxf(m2, __shfl_xor(m2, off, 64));
                 m3 = fmaxf(m3, __shfl_xor(m3, off, 64)); m4 = fmaxf(m4, __shfl_xor(m4, off, 64));
             }
-            cbA = rdlane(m0, 0); cbC = rdlane(m1, 0); cbsA = rdlane(m2, 0); cbsC = rdlane(m3, 0); cbT = rdlane(m4, 0);
+            cbA = m0; cbC = m1; cbsA = m2; cbsC = m3; cbT = m4;
         }
     };
     // RANK1 == 3: scales of the chunk just committed from |ybar| of the step above it; the accumulators follow (exact ratios)
@@ -202,12 +211,27 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
         return __uint_as_float((unsigned)(127 + se) << 23);
     };
     auto pow2_inv = [](float sc2) { return __uint_as_float(0x7F000000u - __float_as_uint(sc2)); };
-    auto rescale = [&](float Y) {
-        const float nR = pow2_of(fmaxf(cbT, fmaf(cbsA, Y, cbsC))), nQ = pow2_of(fmaf(cbA, Y, cbC));
-        const float fR = nR * pow2_inv(sR), fQ = nQ * pow2_inv(sQ);
+    // before an octet (chain steps 8 m + 8 .. 8 m + 1; `lane8` = any lane of the octet's group in the committed chunk): bounds from |ybar|
+    // of the step above, and -- only if a bound has left the window -- new scales, the pending MFMAs issued under the old ones, the
+    // accumulators multiplied by the exact ratios.  Returns with the fragments cleared when it rescaled (the hooks are unconditional).
+    auto scale_window = [](float bound, float sc) {      // true if bound * sc is outside [2^8, 2^15) (or sc was never set)
+        const float x = bound * sc;
+        return !(x >= 256.f && x < 32768.f);
+    };
+    float nRs = 1.f, nQs = 1.f;
+    auto octet_bounds = [&](int lane8, float Y) -> bool {  // true: the scales have to change (new ones in nRs, nQs)
+        const float bQ = fmaf(rdlane(cbA, lane8), Y, rdlane(cbC, lane8));
+        const float bR = fmaxf(rdlane(cbT, lane8), fmaf(rdlane(cbsA, lane8), Y, rdlane(cbsC, lane8)));
+        const bool chQ = bQ > 0.f && scale_window(bQ, sQ), chR = bR > 0.f && scale_window(bR, sR);
+        nQs = chQ ? pow2_of(bQ * 8.f) : sQ;               // the bound lands in [2^11, 2^12): room both ways
+        nRs = chR ? pow2_of(bR * 8.f) : sR;
+        return chQ || chR;
+    };
+    auto apply_scales = [&]() {
+        const float fR = nRs * pow2_inv(sR), fQ = nQs * pow2_inv(sQ);
 #pragma unroll
         for (int r = 0; r < 16; ++r) { Rre[r] *= fR; Rim[r] *= fR; Qre[r] *= fQ; Qim[r] *= fQ; }
-        sR = nR; sQ = nQ;
+        sR = nRs; sQ = nQs;
     };
     auto stage_load_all = [&](int hh) {
         stage_load512<16>(sty4, hh * CHB, N - 1, lane, sry);
@@ -245,7 +269,6 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
     scal_load(hl >> 1);
     stage_commit_all();
     scal_commit(hl >> 1);
-    if constexpr (RANK1 == 3) { sR = pow2_of(fmaxf(cbT, cbsC)); sQ = pow2_of(cbC); }      // nothing above the top chunk: |ybar| = 0 there
     v4f qc[8];
     v2f yh_j, rho_j;
     v4f c0_j, c1_j;
@@ -503,6 +526,18 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
             S = chain_step(S, 0.f, 0.f, std::true_type{}, jq, jq == jhi, std::integral_constant<int, (P)>{}); \
         }
         for (; j >= jlo; j -= 8) {
+            if constexpr (RANK1 == 3) {
+                // chain steps j + 1 .. j - 6 <-> positions (j & 63) - 7 .. (j & 63) of the chunk committed for loop indices j (scal_commit)
+                const float Y = 1.001f * sqrtf(sum64(ybar_last * ybar_last));
+                if (octet_bounds((j & (CH - 1)) & ~7, Y)) {
+                    if (pend) flush_octet();                   // what is recorded goes in under the old scales ..
+#pragma unroll
+                    for (int v = 0; v < 7; ++v)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { fH[v][r] = 0u; fL[v][r] = 0u; }    // .. the unconditional hooks then add zeros
+                    apply_scales();
+                }
+            }
             // rows of this octet in the staged chunk: j & 7 == 7 here, so row (j - 7 + P) = octet base + P
             const unsigned aYo8 = aYown + ((j - 7) & (CHB - 1)) * 512, aRo8 = aRho + ((j - 7) & (CHB - 1)) * 256;
             const unsigned aSo8 = aScl + ((j - 7) & (CH - 1)) * 32;
@@ -512,20 +547,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
 #undef BWD_STEP8
         if (hh > 0) stage_commit_all();
         if (new_scal) {
-            if constexpr (RANK1 == 3) {
-                // the chain stands at the chunk boundary: issue what is pending under the old scales, clear the fragments (the hooks
-                // of the next three steps are unconditional), commit the chunk's scalars and bound coefficients, take the new scales
-                if (pend) flush_octet();
-#pragma unroll
-                for (int v = 0; v < 7; ++v)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { fH[v][r] = 0u; fL[v][r] = 0u; }
-                const float Y = 1.001f * sqrtf(sum64(ybar_last * ybar_last));
-                scal_commit((hh >> 1) - 1);
-                rescale(Y);
-            } else {
-                scal_commit((hh >> 1) - 1);
-            }
+            scal_commit((hh >> 1) - 1);
         }
     }
     if (pend) flush_octet();

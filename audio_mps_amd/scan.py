@@ -108,10 +108,13 @@ class HipScan:
     def effective_rank1(self) -> int:
         """The arithmetic the selected kernels run for the current option value (include/cmps.h): the wide kernels' gradient GEMM
         knows two bf16 pieces, three bf16 pieces (also for EXACT_F32) and two fp16 pieces (also for DEFAULT); the wave reverse scan
-        exact fp32, two bf16 pieces and three bf16 pieces (every other value)."""
+        exact fp32, two bf16 pieces, two fp16 pieces (also for DEFAULT) and three bf16 pieces.  (The 16-row kernels of D <= 16 always
+        use exact fp32 MFMAs and the legacy mode maps the fp16 form to three bf16 pieces: this property describes the 32-row kernel.)"""
         mode, wide = self.rank1, self.variant == _capi.CMPS_VARIANT_WIDE
         if wide:
             return {0: _capi.CMPS_RANK1_BF16X3, 4: _capi.CMPS_RANK1_F16X2}.get(mode, mode)
+        if mode == _capi.CMPS_RANK1_DEFAULT:
+            return _capi.CMPS_RANK1_F16X2
         return mode if mode in (_capi.CMPS_RANK1_EXACT_F32, _capi.CMPS_RANK1_BF16X2, _capi.CMPS_RANK1_F16X2) else _capi.CMPS_RANK1_BF16X3
 
     def kernel_events(self, on: bool):

@@ -171,7 +171,7 @@ def test_rank1_modes(mode):
     from audio_mps_amd import _capi
     m, audio = _model(32, 3000, 10, WAVE, seed=17)
     be = m._get_backend()
-    assert be.rank1 == _capi.CMPS_RANK1_DEFAULT and be.effective_rank1 == _capi.CMPS_RANK1_BF16X3
+    assert be.rank1 == _capi.CMPS_RANK1_DEFAULT and be.effective_rank1 == _capi.CMPS_RANK1_F16X2
     be.set_rank1(mode)
     assert be.rank1 == mode
     _check_against_oracle(m, audio, nthreads=10)
@@ -196,6 +196,37 @@ def test_rank1_modes_order_of_accuracy():
     assert e2 <= 5e-5, e2
     assert e3 <= e2
     assert e16 <= 1e-5 and e16 <= 4 * e3 + 2e-6, (e16, e3)       # the fp16 split (round 4): bf16x3's class
+
+
+@pytest.mark.parametrize("D", [17, 24, 32])
+def test_rank1_f16x2_scale_jumps(D):
+    """The fp16 split of the 32-row reverse scan takes its power-of-two scales per 64-step chunk from a bound of |ybar|: audio with
+    silence -> signal, a 1e4 x amplitude step, isolated clicks and tiny noise (ybar moves by orders of magnitude inside and between
+    chunks; a wrong bound would overflow the fp16 pieces: inf / NaN), every clip different, against the oracle; and against BF16X3."""
+    from audio_mps_amd.scan import unpack_grad
+    rng = np.random.default_rng(D)
+    T = 777
+    m, audio = _model(D, T, 5, WAVE, seed=D)
+    audio = audio.copy()
+    audio[0, :300] = 0.0
+    audio[1, 400:] *= np.float32(1e-4)
+    audio[2] = 0.0
+    audio[2, 100] = 0.3; audio[2, 101] = -0.2; audio[2, 640] = 0.25
+    audio[3] = (1e-3 * rng.standard_normal(T)).astype(np.float32)
+    audio[3, 500:] *= np.float32(100.0)
+    audio[4] *= np.float32(1e-3)
+    be = m._get_backend()
+    be.set_rank1(3)
+    ref = c_oracle_run(m, audio, "f32")
+    assert np.all(np.isfinite(ref["loss_per_clip"]))
+    flat = m.grad_sums(audio)[0].cpu().numpy()
+    assert np.all(np.isfinite(flat))
+    g, gr = unpack_grad(flat, D), C.unpack_grad(ref["grad"], D)
+    for k in ("Rbar", "fbar", "psi0bar", "Abar"):
+        assert rel_inf(g[k], gr[k]) <= GRAD_RTOL, k
+    be.set_rank1(2)
+    g3 = unpack_grad(m.grad_sums(audio)[0].cpu().numpy(), D)
+    assert rel_inf(g["Rbar"], g3["Rbar"]) <= 2e-5
 
 
 def test_variants_agree():
