@@ -60,7 +60,7 @@ struct Pre {
 // RANK1: how the three rank-1 gradient updates of a step are applied (cmps_set_option(CMPS_OPT_RANK1)):
 //   0 exact fp32 MFMA every step; 1 bf16 hi/lo split, 3 products; 2 bf16 hi/mid/lo split, 6 products; 3 (round 4) two fp16 pieces,
 //   round to nearest (11 + 1 + 11 + 1 bits: BF16X3's accuracy class), 3 products on v_mfma_f32_32x32x16_f16, with power-of-two
-//   scales per 64-step chunk from a guaranteed bound of |ybar| (see below)
+//   scales per eight-step octet from a guaranteed bound of |ybar| (see below)
 // LEGACY: the reverse sweep of the previous-generation AudioMPS arithmetic (cmps_legacy.hip) on the same chain.  With rho = 1 in the
 // tables, g = cotangent of psi_{k+1} without its own loss term, and e_k = psi_k^dagger H psi_k (degree 0 in y_{k-1}):
 //   ybar_k = (g_{k+1} - yhat_k dot) inv_k + te_{k+1} inv_k^2 (H y_k),   dot = Re(yhat_k^dagger g_{k+1}) + te_{k+1} e_{k+1}

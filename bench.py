@@ -634,7 +634,7 @@ def dtype_label(variant, D, rank1):
     if variant in (V_WAVE, V_WAVE32) and not (variant == V_WAVE and D <= 16):
         tail = {1: "rank-1 gradient sums: bf16x2 split, 16 operand bits", 0: "rank-1 gradient sums: exact fp32 MFMA",
                 2: "rank-1 gradient sums: the same bf16x3 split",
-                3: "rank-1 gradient sums: f16x2 split (power-of-two scales per 64-step chunk, 24 operand bits: bf16x3's accuracy class at half the products)"}[rank1]
+                3: "rank-1 gradient sums: f16x2 split (power-of-two scales per eight-step octet from a guaranteed bound, 24 operand bits: bf16x3's accuracy class at half the products)"}[rank1]
         return ("f32 (fp32 FMA chains on the serial path; loss product H y: bf16x3-split operands on the matrix cores, fp32 accumulate; "
                 + tail + ")")
     if variant == V_WIDE:

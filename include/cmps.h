@@ -79,7 +79,7 @@ enum {
  *   BF16X2     each factor split into two bf16 pieces, 3 products: 16 operand bits, error <= ~2^-16 |a||b|
  *   BF16X3     each factor split EXACTLY into three bf16 pieces (8+8+8 bits), 6 products: 24 operand bits,
  *              error <= 2^-23 |a||b| (what is dropped is below the fp32 rounding of the product)
- *   F16X2      (the 32-row wave reverse scan, with scales per 64-step chunk; the wide kernels' gradient GEMM and loss product H y, with
+ *   F16X2      (the 32-row wave reverse scan, with scales per eight-step octet; the wide kernels' gradient GEMM and loss product H y, with
  *              scales per pair of clips; elsewhere it means BF16X3) each factor scaled by a power of two per pair of clips
  *              and split into two fp16 pieces, round to nearest (11+1+11+1 bits), 3 products on v_mfma_f32_32x32x16_f16: BF16X2's
  *              instruction count at BF16X3's accuracy class, error <= ~2^-22 |a||b| for factors within 2^-18 of their class's
