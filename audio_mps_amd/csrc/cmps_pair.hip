@@ -1597,6 +1597,8 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_chain16(Dev P, const float* _
 
     // per-step scalars exactly as cmps_wide.hip::step_scalars forms them (the gradient GEMM recomputes them the same way)
     float accA = 0.f;
+    const float gr0 = 1.4143f * (1.0f + Qinf), gr1 = 1.4143f * Dinf;
+    float s_ab0 = 0.f, s_ab1 = 0.f, rad_ab0 = 0.f, rad_ab1 = 0.f;      // s, rad of the lowest step of the chunk built before (the one above; no step N: 0)
     auto chunk_rows = [&](int cj) {
         const int idx = cj * PCH + lane;
         const bool in = idx < N;
@@ -1619,8 +1621,13 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_chain16(Dev P, const float* _
             r0.w = 2.0f * (zbar * inc / A);
             r1.x = r0.w * ev;
             r1.y = dtv;
-            r1.z = 1.001f * sqrtf(fmaxf(nv, 1e-12f));                  // >= |y_k| (the c3 bound)
-            r1.w = 0.f;
+            // the coefficients of the vector-scale bound (header): c_j and a_j of this step; they involve s and rad of step j + 1 (the
+            // lane above, or the chunk built before this one)
+            float s_up = __shfl_down(r0.x, 1, 64), rad_up = __shfl_down(r1.x, 1, 64);
+            if (lane == PCH - 1) { s_up = qq ? s_ab1 : s_ab0; rad_up = qq ? rad_ab1 : rad_ab0; }
+            if (qq) { s_ab1 = rdl(r0.x, 0); rad_ab1 = rdl(r1.x, 0); } else { s_ab0 = rdl(r0.x, 0); rad_ab0 = rdl(r1.x, 0); }
+            r1.z = fabsf(r0.w) * Hinf * (1.001f * sqrtf(fmaxf(nv, 1e-12f))) + fabsf(rad_up) * r0.z * r0.y;      // c_j >= |c3_j|
+            r1.w = r0.y * fmaf(fabsf(s_up), gr1, gr0);                                                        // a_j
             TB.row[w][cj & 1][lane][qq][0] = r0;
             TB.row[w][cj & 1][lane][qq][1] = r1;
             if (in && w == 0 && (qq == 0 || two)) accA += zbar * ex;
@@ -1644,8 +1651,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_chain16(Dev P, const float* _
     u4 o00, o01, o10, o11;
     float4 rh, rhp;
     f4 S0, S1, SP0, SP1;
-    float c3a, c3b, c3bound, c3bprev;                   // te_k (H y_k) - ok_k yhat_k rad_{k+1} inv_k; bounds of its size: this step's, the step before's
-    float sprev = 0.f;                                  // s_{k+1}
+    float c3a, c3b;                                     // te_k (H y_k) - ok_k yhat_k rad_{k+1} inv_k
     float sS = 1.f, iS = 1.f;                           // the vector's scale of the step about to run, and its inverse
     auto rho_rows = [&](int k) { return *reinterpret_cast<const float4*>(&RS.row[(k / RCH) & 1][k & (RCH - 1)][ia]); };
     auto tab_row = [&](int k, int half) { return TB.row[w][(k / PCH) & 1][k & (PCH - 1)][q][half]; };
@@ -1656,11 +1662,6 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_chain16(Dev P, const float* _
         const u2b h = __builtin_amdgcn_raw_buffer_load_b64(rs_st, voff + 4 * PD * 4, kc * (8 * PD * 4), 0);
         return make_float4(__uint_as_float(y.x), __uint_as_float(y.y), __uint_as_float(h.x), __uint_as_float(h.y));
     };
-    auto c3_bound = [&](const f4& T0, const f4& T1, float rad_next) {   // |c3| of the step whose rows are T0, T1: |te| |H|_inf |y| + |rad'| ok inv
-        return fabsf(T0.w) * Hinf * T1.z + fabsf(rad_next) * T0.z * T0.y;
-    };
-    const float gr0 = 1.4143f * (1.0f + Qinf), gr1 = 1.4143f * Dinf;
-    auto growth = [&](float inv_j, float s_next) { return inv_j * fmaf(fabsf(s_next), gr1, gr0); };   // a_j
     float4 ring0, ring1, ring2, ring3, ring4, ring5, ring6, ring7;
     {
         const int k0 = N - 1;
@@ -1682,9 +1683,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_chain16(Dev P, const float* _
         const float4 cur = row_at(k0);
         c3a = S0.w * cur.z;                             // rad_N = 0
         c3b = S0.w * cur.w;
-        c3bound = c3_bound(S0, S1, 0.f);
-        sS = gg::pow2_scale(c3bound, 15);               // ybar_{N-1} = c3_{N-1} (g = 0)
-        c3bprev = c3bound;                              // c_{N-1}
+        sS = gg::pow2_scale(S1.z, 15);                  // ybar_{N-1} = c3_{N-1} (g = 0): its bound c_{N-1} (rad_N = 0)
         iS = __uint_as_float(0x7F000000u - __float_as_uint(sS));
     }
     const float2 psa = P.psi0[ia], psb = P.psi0[ib];
@@ -1745,7 +1744,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_chain16(Dev P, const float* _
         u4 v[4 * KH - 4];                                                                                                          \
         float4 nrh;                                                                                                                \
         f2 uka, ukb;                                                                                                               \
-        float ypa, ypb, pypa, pypb, pyba, pybb, c3bn, sSn;                                                                         \
+        float ypa, ypb, pypa, pypb, pyba, pybb, sSn;                                                                         \
         u4 ym[2];                                                                                                                  \
         const unsigned ax0 = a_tab + 64 * (((km2 / PCH) & 1) * PCH + (km2 & (PCH - 1)));                                           \
         const float invp = SP0.y;                                                                                                  \
@@ -1775,7 +1774,6 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_chain16(Dev P, const float* _
                 const float radk = S1.x * SP0.z * invp;                                                                            \
                 c3a = fmaf(SP0.w, PRV.z, -(ypa * radk));                                                                           \
                 c3b = fmaf(SP0.w, PRV.w, -(ypb * radk));                                                                           \
-                c3bn = c3_bound(SP0, SP1, S1.x);                                                                                   \
                 PAIR_PIN2(c3a, c3b);                                                                                               \
             }                                                                                                                      \
             if constexpr (kidx == 2 && sl == 1) { pyba = partner16(yba, odd); PAIR_PIN1(pyba); }             \
@@ -1807,7 +1805,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_chain16(Dev P, const float* _
                 unsigned mb = max(max(ym[0].x, ym[0].y), max(ym[0].z, ym[0].w));                                                   \
                 if constexpr (PWV > 2) mb = max(mb, max(ym[1].x, ym[1].y));                                                        \
                 if constexpr (PWV > 3) mb = max(mb, max(ym[1].z, ym[1].w));                                                        \
-                const float bnd = growth(invp, S0.x) * (growth(S0.y, sprev) * __uint_as_float(mb) + c3bprev) + c3bn;               \
+                const float bnd = fmaf(SP1.w, fmaf(S1.w, __uint_as_float(mb), S1.z), SP1.z);    /* a_{k-1} (a_k Y_{k+1} + c_k) + c_{k-1} */ \
                 sSn = gg::pow2_scale(bnd, 15);                                                                                     \
                 PAIR_PIN1(sSn);                                                                                                    \
             }                                                                                                                      \
@@ -1836,7 +1834,6 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_chain16(Dev P, const float* _
             sda = da.x; sdb = db.x;                                                                                                \
         }                                                                                                                          \
         sS = sSn;                                                                                                                  \
-        c3bprev = c3bn; sprev = S0.x;                                                                                              \
         iS = __uint_as_float(0x7F000000u - __float_as_uint(sSn));    /* 1 / sS: exact for a power of two */                        \
         una = uka; unb = ukb;                                                                                                      \
         rh = rhp; S0 = SP0; S1 = SP1;                                                                                              \
