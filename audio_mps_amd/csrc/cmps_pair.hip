@@ -83,18 +83,6 @@ __device__ __forceinline__ float partner16(float x, bool odd) {
     const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
     return __uint_as_float(odd ? r[0] : r[1]);
 }
-// sum over the 32 lanes that carry the same clip (l >> 5); every lane receives its clip's total
-__device__ __forceinline__ float clip_sum(float x) {
-    {
-        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-        x = __uint_as_float(r[0]) + __uint_as_float(r[1]);      // Re row + Im row
-    }
-    x += dpp_mov<0x128>(x);       // row_ror:8
-    x += dpp_mov<0x124>(x);       // row_ror:4
-    x += dpp_mov<0x122>(x);       // row_ror:2
-    x += dpp_mov<0x121>(x);       // row_ror:1   -> total of the clip's 16 lanes x 2 components
-    return x;
-}
 // sum over the 16 lanes of a row (one clip, one component); every lane receives the total
 __device__ __forceinline__ float row_sum16(float x) {
     x += dpp_mov<0x128>(x);       // row_ror:8
@@ -878,9 +866,7 @@ __device__ __forceinline__ void kstep12(const u4& rh0, const u4& rl0, const u4& 
         C16_MMA(aR1, a1, rh1); C16_MMA(aQ1, a1, qh1); __builtin_amdgcn_sched_barrier(0); slot(ic<5>{}); __builtin_amdgcn_sched_barrier(0);
         return;
     }
-    C16_MMA(aR0, a0, rh0); C16_MMA(aQ0, a0, qh0); C16_MMA(aR1, a0, rh1); C16_MMA(aQ1, a0, qh1);
-    C16_MMA(aR0, a0, rl0); C16_MMA(aQ0, a0, ql0); C16_MMA(aR1, a0, rl1); C16_MMA(aQ1, a0, ql1);
-    C16_MMA(aR0, a1, rh0); C16_MMA(aQ0, a1, qh0); C16_MMA(aR1, a1, rh1); C16_MMA(aQ1, a1, qh1);
+    static_assert(SLOTS, "every K-step of the chain16 kernels carries slots");
 #undef C16_MMA
 }
 
@@ -889,19 +875,6 @@ __device__ __forceinline__ void kstep12(const u4& rh0, const u4& rl0, const u4& 
 template <int OFF, typename V>
 __device__ __forceinline__ void rd128(unsigned addr, V& v) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(v) : "v"(addr), "n"(OFF) : "memory");
-}
-// the other waves' K ranges of both pieces (tau = 1 .. KH - 1 of the M_re half, then of the M_im half; v[2 i], v[2 i + 1] = pieces of
-// rest K-step i), then three table rows: 4 KH - 4 + 3 reads (15 at D = 128: the lgkmcnt counter's range)
-template <int KH, int POFF, int PSTRIDE>
-__device__ __forceinline__ void rd_rest16(unsigned ax0, unsigned ax2, const unsigned (&lo)[KH], const unsigned (&hi)[KH], f4& x0, f4& x1, f4& x2,
-                                          u4 (&v)[4 * KH - 4]) {
-#pragma unroll
-    for (int t = 1; t < KH; ++t) { rd128<POFF>(lo[t], v[2 * (t - 1)]); rd128<POFF + PSTRIDE>(lo[t], v[2 * (t - 1) + 1]); }
-#pragma unroll
-    for (int t = 1; t < KH; ++t) { rd128<POFF>(hi[t], v[2 * (KH - 1 + t - 1)]); rd128<POFF + PSTRIDE>(hi[t], v[2 * (KH - 1 + t - 1) + 1]); }
-    rd128<0>(ax0, x0);
-    rd128<16>(ax0, x1);
-    rd128<0>(ax2, x2);
 }
 __device__ __forceinline__ float gg_rsq_newton(float m) {      // as cmps_wide.hip::rsq_newton (the family's reverse scan and GEMM recompute it)
     const float r = __builtin_amdgcn_rsqf(m);
