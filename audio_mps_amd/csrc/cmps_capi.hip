@@ -558,7 +558,7 @@ int cmps_rho_loss_fwd(cmps_handle_t h, const float* audio_dev, int B, int T, flo
     const bool wave = h->D <= 32 && h->W.rank <= 32 && h->variant_req != CMPS_VARIANT_BLOCK;
     const bool mfma = wave && h->variant_req != CMPS_VARIANT_WAVE32 && h->W.rank > 8;   // below rank ~10 the column loop is faster
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipError_t e = mfma ? launch_fwd_rho_mfma(P, h->W, audio_dev, loss_dev, save_for_bwd != 0, s)
+    hipError_t e = mfma ? launch_fwd_rho_mfma(P, h->W, audio_dev, loss_dev, save_for_bwd != 0, h->rank1_mode == CMPS_RANK1_DEFAULT || h->rank1_mode == CMPS_RANK1_F16X2, s)
                  : wave ? launch_fwd_rho_wave(P, h->W, audio_dev, loss_dev, save_for_bwd != 0, s)
                         : launch_fwd_rho(P, h->W, audio_dev, loss_dev, save_for_bwd != 0, s);
     if (e != hipSuccess) return fail_hip(h, e, "cmps_rho_loss_fwd");

@@ -43,6 +43,42 @@ __device__ __forceinline__ void mfma6(v16f& acc, const unsigned (&AH)[4], const 
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag4(AM), frag4(BM), acc, 0, 0, 0);
 }
 
+// ---- round 4: two fp16 pieces per value (round to nearest: hi = f16(x), lo = f16(x - hi), 11 + 1 + 11 + 1 bits) and three products
+// on v_mfma_f32_32x32x16_f16 instead of three bf16 pieces and six: the accuracy class of the split above at half the MFMAs and
+// 6 instead of 11 VALU per pair of values (cmps_grad_gemm.h).  fp16 has 5 exponent bits: the caller scales every
+// operand class by a power of two from a guaranteed bound and unscales the accumulators.
+typedef _Float16 hf8r __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split2h(float fe, float fo, unsigned& H, unsigned& L) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 hh = h2{(_Float16)fe, (_Float16)fo};
+    H = __builtin_bit_cast(unsigned, hh);
+    const float re = fe - (float)hh.x, ro = fo - (float)hh.y;
+    L = __builtin_bit_cast(unsigned, h2{(_Float16)re, (_Float16)ro});
+}
+__device__ __forceinline__ hf8r frag4h(const unsigned (&f)[4]) { return __builtin_bit_cast(hf8r, v4u{f[0], f[1], f[2], f[3]}); }
+// acc += A B over the piece pairs (hi,hi) (hi,lo) (lo,hi)
+__device__ __forceinline__ void mfma3(v16f& acc, const unsigned (&AH)[4], const unsigned (&AL)[4], const unsigned (&BH)[4], const unsigned (&BL)[4]) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag4h(AH), frag4h(BH), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag4h(AH), frag4h(BL), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag4h(AL), frag4h(BH), acc, 0, 0, 0);
+}
+__device__ __forceinline__ void pieces8h(const float (&x)[16], int s2, float sc, unsigned (&H)[4], unsigned (&L)[4]) {
+#pragma unroll
+    for (int e2 = 0; e2 < 4; ++e2) split2h(x[8 * s2 + 2 * e2] * sc, x[8 * s2 + 2 * e2 + 1] * sc, H[e2], L[e2]);
+}
+// the largest power of two S with bound S < 2^target (exponent clamped: S and 1 / S stay normal); 1 / S for such an S
+__device__ __forceinline__ float pow2_below(float bound, int target) {
+    int se = target - ((int)((__float_as_uint(bound) >> 23) & 0xFFu) - 126);
+    se = se > 60 ? 60 : se < -60 ? -60 : se;
+    return __uint_as_float((unsigned)(127 + se) << 23);
+}
+__device__ __forceinline__ float pow2_recip(float s) { return __uint_as_float(0x7F000000u - __float_as_uint(s)); }
+__device__ __forceinline__ float max64(float x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x = fmaxf(x, __shfl_xor(x, off, 64));
+    return x;
+}
+
 // W[m][n] of a complex 32 x 32 matrix M acting on (re, im)-interleaved vectors: (M y)[n = 2 i + c] = sum_m y[m = 2 j + c'] W[m][n],
 // W = Mr_ij for c' = c, -Mi_ij for (c', c) = (1, 0), +Mi_ij for (0, 1)
 __device__ __forceinline__ float wform(float2 mij, int cp, int cc) { return cp == cc ? mij.x : (cc ? mij.y : -mij.y); }
@@ -58,7 +94,7 @@ __device__ __forceinline__ float dpp_nb(float x) {      // the value of lane n ^
 
 }  // namespace
 
-template <bool SAVE>
+template <bool SAVE, bool F16>
 __global__ __launch_bounds__(64 * WAVES, 1) void k_fwd_rho_mfma(Dev P, RhoDev W, const float* __restrict__ audio,
                                                                 float* __restrict__ loss_out) {
     __shared__ __attribute__((aligned(16))) float Urow[WAVES][32 * RRLD];
@@ -73,7 +109,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_fwd_rho_mfma(Dev P, RhoDev W,
     // ---- constant operands: W forms of Q and R (fp32, merged per step) and the bf16 pieces of the W form of R + R^dagger;
     // lane (col, hk) holds W[16 ks + 8 hk + e][32 t + col], e = 0..7, for tile t and k-step ks
     float WQ[2][4][8], WR[2][4][8];
-    unsigned HH[2][4][4], HM[2][4][4], HL[2][4][4];
+    float HWraw[F16 ? 2 : 1][F16 ? 4 : 1][F16 ? 8 : 1];            // (F16: H's real form until its scale is known)
+    unsigned HH[2][4][4], HM[F16 ? 1 : 2][4][4], HL[2][4][4];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int n = 32 * t + col, ii = n >> 1, cc = n & 1;
@@ -88,9 +125,48 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_fwd_rho_mfma(Dev P, RhoDev W,
                 WR[t][ks][e] = wform(rij, cp, cc);
                 wh[e] = wform(make_float2(rij.x + rji.x, rij.y - rji.y), cp, cc);      // (R + R^dagger)[ii][jj]
             }
+            if constexpr (!F16) {
 #pragma unroll
-            for (int e2 = 0; e2 < 4; ++e2) split3(wh[2 * e2], wh[2 * e2 + 1], HH[t][ks][e2], HM[t][ks][e2], HL[t][ks][e2]);
+                for (int e2 = 0; e2 < 4; ++e2) split3(wh[2 * e2], wh[2 * e2 + 1], HH[t][ks][e2], HM[t][ks][e2], HL[t][ks][e2]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) HWraw[t][ks][e] = wh[e];
+            }
         }
+    }
+    // F16: power-of-two scales from guaranteed bounds.  U: the columns of rho, tr rho = 1 => |entries| <= 1 (2^13).  W_k = W_Q + s_k W_R:
+    // max |W_Q| + max |s| max |W_R| over the clip (2^15; the scale is folded into W_Q, W_R once).  Y = U + U W_k: rows of norm
+    // <= 1 + |W_Q|_F + max |s| |W_R|_F (2^13).  H = R + R^dagger: its largest entry (2^15).
+    float sU = 1.f, sW = 1.f, sY = 1.f, sH = 1.f, iUW = 1.f, iYH = 1.f, iYY = 1.f;
+    if constexpr (F16) {
+        float mq = 0.f, mr = 0.f, mh = 0.f, fq = 0.f, fr = 0.f, ms = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    mq = fmaxf(mq, fabsf(WQ[t][ks][e])); mr = fmaxf(mr, fabsf(WR[t][ks][e])); mh = fmaxf(mh, fabsf(HWraw[t][ks][e]));
+                    fq = fmaf(WQ[t][ks][e], WQ[t][ks][e], fq); fr = fmaf(WR[t][ks][e], WR[t][ks][e], fr);
+                }
+        const float* xr = audio + (size_t)b * T;
+        for (int idx = lane; idx < N; idx += 64) ms = fmaxf(ms, fabsf((xr[idx + 1] - xr[idx]) / dev_A(P)));
+        mq = max64(mq); mr = max64(mr); mh = max64(mh); ms = 1.001f * max64(ms);
+        const float nq = 1.001f * sqrtf(sum64(fq)), nr = 1.001f * sqrtf(sum64(fr));
+        sU = 8192.f;
+        sW = pow2_below(mq + ms * mr, 15);
+        sY = pow2_below(1.01f * (1.0f + nq + ms * nr), 13);
+        sH = pow2_below(mh, 15);
+        iUW = pow2_recip(sU) * pow2_recip(sW); iYH = pow2_recip(sY) * pow2_recip(sH); iYY = pow2_recip(sY) * pow2_recip(sY);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { WQ[t][ks][e] *= sW; WR[t][ks][e] *= sW; }
+#pragma unroll
+                for (int e2 = 0; e2 < 4; ++e2) split2h(HWraw[t][ks][2 * e2] * sH, HWraw[t][ks][2 * e2 + 1] * sH, HH[t][ks][e2], HL[t][ks][e2]);
+            }
     }
     // ---- initial columns: rows a < rank of U = phi_a (model.py:127-136), the rest zero
     for (int a = 0; a < 32; ++a) {
@@ -134,18 +210,28 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_fwd_rho_mfma(Dev P, RhoDev W,
                 const float4 f0 = *reinterpret_cast<const float4*>(U + col * RRLD + 16 * ks + 8 * hk);
                 const float4 f1 = *reinterpret_cast<const float4*>(U + col * RRLD + 16 * ks + 8 * hk + 4);
                 unsigned AH[4], AM[4], AL[4];
-                split3(f0.x, f0.y, AH[0], AM[0], AL[0]);
-                split3(f0.z, f0.w, AH[1], AM[1], AL[1]);
-                split3(f1.x, f1.y, AH[2], AM[2], AL[2]);
-                split3(f1.z, f1.w, AH[3], AM[3], AL[3]);
+                if constexpr (F16) {
+                    split2h(f0.x * sU, f0.y * sU, AH[0], AL[0]);
+                    split2h(f0.z * sU, f0.w * sU, AH[1], AL[1]);
+                    split2h(f1.x * sU, f1.y * sU, AH[2], AL[2]);
+                    split2h(f1.z * sU, f1.w * sU, AH[3], AL[3]);
+                } else {
+                    split3(f0.x, f0.y, AH[0], AM[0], AL[0]);
+                    split3(f0.z, f0.w, AH[1], AM[1], AL[1]);
+                    split3(f1.x, f1.y, AH[2], AM[2], AL[2]);
+                    split3(f1.z, f1.w, AH[3], AM[3], AL[3]);
+                }
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     unsigned BH[4], BM[4], BL[4];
 #pragma unroll
-                    for (int e2 = 0; e2 < 4; ++e2)
-                        split3(fmaf(s, WR[t][ks][2 * e2], WQ[t][ks][2 * e2]), fmaf(s, WR[t][ks][2 * e2 + 1], WQ[t][ks][2 * e2 + 1]),
-                               BH[e2], BM[e2], BL[e2]);
-                    mfma6(t ? a1 : a0, AH, AM, AL, BH, BM, BL);
+                    for (int e2 = 0; e2 < 4; ++e2) {
+                        const float we = fmaf(s, WR[t][ks][2 * e2], WQ[t][ks][2 * e2]), wo = fmaf(s, WR[t][ks][2 * e2 + 1], WQ[t][ks][2 * e2 + 1]);
+                        if constexpr (F16) split2h(we, wo, BH[e2], BL[e2]);       // (W_Q, W_R carry the scale sW)
+                        else split3(we, wo, BH[e2], BM[e2], BL[e2]);
+                    }
+                    if constexpr (F16) mfma3(t ? a1 : a0, AH, AL, BH, BL);
+                    else mfma6(t ? a1 : a0, AH, AM, AL, BH, BM, BL);
                 }
             }
             // ---- Y = U + U W_k in the C/D layout: column n = 32 t + col, rows (r & 3) + 8 (r >> 2) + 4 hk ----
@@ -154,8 +240,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_fwd_rho_mfma(Dev P, RhoDev W,
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int row = (q & 3) + 8 * (q >> 2) + 4 * hk;
-                y0[q] = U[row * RRLD + col] + a0[q];
-                y1[q] = U[row * RRLD + 32 + col] + a1[q];
+                y0[q] = F16 ? fmaf(a0[q], iUW, U[row * RRLD + col]) : U[row * RRLD + col] + a0[q];
+                y1[q] = F16 ? fmaf(a1[q], iUW, U[row * RRLD + 32 + col]) : U[row * RRLD + 32 + col] + a1[q];
                 accn = fmaf(y0[q], y0[q], accn);
                 accn = fmaf(y1[q], y1[q], accn);
                 Y[row * RRLD + col] = y0[q];
@@ -168,12 +254,25 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_fwd_rho_mfma(Dev P, RhoDev W,
                 const float4 f0 = *reinterpret_cast<const float4*>(Y + col * RRLD + 16 * ks + 8 * hk);
                 const float4 f1 = *reinterpret_cast<const float4*>(Y + col * RRLD + 16 * ks + 8 * hk + 4);
                 unsigned AH[4], AM[4], AL[4];
-                split3(f0.x, f0.y, AH[0], AM[0], AL[0]);
-                split3(f0.z, f0.w, AH[1], AM[1], AL[1]);
-                split3(f1.x, f1.y, AH[2], AM[2], AL[2]);
-                split3(f1.z, f1.w, AH[3], AM[3], AL[3]);
-                mfma6(h0, AH, AM, AL, HH[0][ks], HM[0][ks], HL[0][ks]);
-                mfma6(h1, AH, AM, AL, HH[1][ks], HM[1][ks], HL[1][ks]);
+                if constexpr (F16) {
+                    split2h(f0.x * sY, f0.y * sY, AH[0], AL[0]);
+                    split2h(f0.z * sY, f0.w * sY, AH[1], AL[1]);
+                    split2h(f1.x * sY, f1.y * sY, AH[2], AL[2]);
+                    split2h(f1.z * sY, f1.w * sY, AH[3], AL[3]);
+                    mfma3(h0, AH, AL, HH[0][ks], HL[0][ks]);
+                    mfma3(h1, AH, AL, HH[1][ks], HL[1][ks]);
+                } else {
+                    split3(f0.x, f0.y, AH[0], AM[0], AL[0]);
+                    split3(f0.z, f0.w, AH[1], AM[1], AL[1]);
+                    split3(f1.x, f1.y, AH[2], AM[2], AL[2]);
+                    split3(f1.z, f1.w, AH[3], AM[3], AL[3]);
+                    mfma6(h0, AH, AM, AL, HH[0][ks], HM[0][ks], HL[0][ks]);
+                    mfma6(h1, AH, AM, AL, HH[1][ks], HM[1][ks], HL[1][ks]);
+                }
+            }
+            if constexpr (F16 && SAVE) {                         // the stash keeps H y itself
+#pragma unroll
+                for (int q = 0; q < 16; ++q) { h0[q] *= iYH; h1[q] *= iYH; }
             }
             float acce = 0.f;
 #pragma unroll
@@ -182,7 +281,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_fwd_rho_mfma(Dev P, RhoDev W,
                 acce = fmaf(y1[q], h1[q], acce);
             }
             const float n = sum64(accn);                         // tr rho', :200
-            const float e = sum64(acce);                         // Re tr(x rho'), :195-196
+            const float e = (F16 && !SAVE) ? sum64(acce) * iYH : sum64(acce);   // Re tr(x rho'), :195-196
             nvec = lane == kk ? n : nvec;
             evec = lane == kk ? e : evec;
             if (SAVE) {
@@ -203,6 +302,24 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_fwd_rho_mfma(Dev P, RhoDev W,
                 const float inck = rdlane(incv, kk);
                 const float zb = -1.0f / (1.0f + (e * inck) / A);
                 const float te = 2.0f * (zb * inck / A);
+                if constexpr (F16) {
+                    // P1 += te (Y^T Y): the product of the step alone into fresh tiles (both operands are pieces of Y: split once), then
+                    // one scaled add per accumulator register -- te never meets an fp16 piece
+                    unsigned YH[2][2][4], YL[2][2][4];             // [tile][k-step s2]
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) { pieces8h(y0, s2, sY, YH[0][s2], YL[0][s2]); pieces8h(y1, s2, sY, YH[1][s2], YL[1][s2]); }
+                    const float tes = te * iYY;
+#pragma unroll
+                    for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+                        for (int tb = 0; tb < 2; ++tb) {
+                            v16f tmp = {};
+                            mfma3(tmp, YH[ta][0], YL[ta][0], YH[tb][0], YL[tb][0]);
+                            mfma3(tmp, YH[ta][1], YL[ta][1], YH[tb][1], YL[tb][1]);
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) P1[ta][tb][q] = fmaf(tes, tmp[q], P1[ta][tb][q]);
+                        }
+                } else {
                 float ty0[16], ty1[16];
 #pragma unroll
                 for (int q = 0; q < 16; ++q) { ty0[q] = te * y0[q]; ty1[q] = te * y1[q]; }
@@ -218,6 +335,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_fwd_rho_mfma(Dev P, RhoDev W,
 #pragma unroll
                         for (int ta = 0; ta < 2; ++ta) mfma6(P1[ta][tb], TH[ta], TM[ta], TL[ta], VH, VM, VL);
                     }
+                }
                 }
             }
             // ---- u_a' = rho_k (.) y_a / sqrt(n): the partner component sits in the neighbouring lane ----
@@ -619,12 +737,12 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_sample_rho_mfma(Dev P, RhoDev
     }
 }
 
-hipError_t launch_fwd_rho_mfma(const Dev& P, const RhoDev& W, const float* audio, float* loss, bool save, hipStream_t s) {
+hipError_t launch_fwd_rho_mfma(const Dev& P, const RhoDev& W, const float* audio, float* loss, bool save, bool f16, hipStream_t s) {
     const unsigned nb = (unsigned)((P.B + WAVES - 1) / WAVES);
-    if (save)
-        hipLaunchKernelGGL(k_fwd_rho_mfma<true>, dim3(nb), dim3(64 * WAVES), 0, s, P, W, audio, loss);
-    else
-        hipLaunchKernelGGL(k_fwd_rho_mfma<false>, dim3(nb), dim3(64 * WAVES), 0, s, P, W, audio, loss);
+    if (save && f16) hipLaunchKernelGGL((k_fwd_rho_mfma<true, true>), dim3(nb), dim3(64 * WAVES), 0, s, P, W, audio, loss);
+    else if (save) hipLaunchKernelGGL((k_fwd_rho_mfma<true, false>), dim3(nb), dim3(64 * WAVES), 0, s, P, W, audio, loss);
+    else if (f16) hipLaunchKernelGGL((k_fwd_rho_mfma<false, true>), dim3(nb), dim3(64 * WAVES), 0, s, P, W, audio, loss);
+    else hipLaunchKernelGGL((k_fwd_rho_mfma<false, false>), dim3(nb), dim3(64 * WAVES), 0, s, P, W, audio, loss);
     return hipGetLastError();
 }
 

@@ -1,0 +1,143 @@
+#!/usr/bin/env python3
+"""Static check of the shipped gfx950 code for the VALU-write -> MFMA-read issue distance.
+
+gfx950 needs two wait states between a VALU instruction that writes a VGPR and a v_mfma that reads it as SrcA / SrcB (what hipcc
+keeps for its own instructions, s_nop included; a packed-fp32 instruction counts as two).  It does not look inside inline asm: a VALU instruction written as asm
+(or an asm v_mfma) can land closer, and the matrix core then reads the register's previous contents (round 4: an asm
+v_cvt_pk_f16_f32 next to its v_mfma gave NaN gradients in k_fwd_rho_mfma on first launch only).  This script disassembles every
+code object in libcmps.so and reports each v_mfma whose A / B operand was written by a VALU instruction fewer than two wait
+states earlier, following fall-through and branch edges.
+
+usage: check_mfma_hazards.py [libcmps.so]      exit code 1 when a violation is found
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LLVM = "/opt/rocm/lib/llvm/bin"
+MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+NEED = 2                                                  # wait states between the VALU write and the MFMA read
+
+
+def code_objects(lib, tmp):
+    fat = os.path.join(tmp, "fat.bin")
+    subprocess.run([f"{LLVM}/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib, fat], capture_output=True)
+    blob = open(fat, "rb").read() if os.path.exists(fat) else b""
+    if not blob:                                          # a device-only object (hipcc --cuda-device-only -c): a bare bundle or code object
+        blob = open(lib, "rb").read()
+        if MAGIC not in blob:
+            return [lib]
+    starts = [m.start() for m in re.finditer(re.escape(MAGIC), blob)]
+    out = []
+    for n, s in enumerate(starts):
+        e = starts[n + 1] if n + 1 < len(starts) else len(blob)
+        part = os.path.join(tmp, f"bundle{n}.bin")
+        open(part, "wb").write(blob[s:e])
+        co = os.path.join(tmp, f"code{n}.co")
+        subprocess.run([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                        f"--input={part}", f"--output={co}"], check=True, capture_output=True)
+        if os.path.getsize(co):
+            out.append(co)
+    return out
+
+
+def vregs(tok):
+    tok = tok.strip()
+    m = re.match(r"v\[(\d+):(\d+)\]$", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r"v(\d+)$", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def is_valu(op):
+    return op.startswith("v_") and not op.startswith(("v_mfma", "v_smfmac", "v_accvgpr_write"))
+
+
+def packed_f32(op):
+    return op.startswith("v_pk_") and op.endswith("_f32")        # issues over two cycles
+
+
+def parse(dis):
+    """functions: name -> list of (addr, opcode, operands)"""
+    funcs, cur = {}, None
+    for line in open(dis):
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            cur = funcs.setdefault(m.group(1), [])
+            continue
+        m = re.match(r"^\s+(\S+)\s*(.*?)\s*//\s*([0-9A-F]+):", line)
+        if m and cur is not None:
+            cur.append((int(m.group(3), 16), m.group(1), m.group(2)))
+    return funcs
+
+
+def check(funcs):
+    bad, n_mfma = [], 0
+    for name, ins in funcs.items():
+        index = {a: i for i, (a, _, _) in enumerate(ins)}
+        preds = {}                                        # instruction index -> indices of branches that jump to it
+        # branch targets: the disassembler prints the word offset; the target address = addr + 4 + 4 * simm16
+        for i, (a, op, args) in enumerate(ins):
+            if op.startswith(("s_cbranch", "s_branch")):
+                t = a + 4 + 4 * int(args.split()[0])
+                if t in index:
+                    preds.setdefault(index[t], []).append(i)
+
+        def walk(i, need, src, seen):
+            """look back from instruction i (exclusive) while fewer than `need` wait states have passed"""
+            j = i - 1
+            while need > 0 and j >= 0:
+                for p in preds.get(j + 1, []):            # a branch lands between j and j + 1
+                    if (p, need) not in seen:
+                        seen.add((p, need))
+                        yield from walk(p + 1, need, src, seen)
+                a, op, args = ins[j]
+                if op in ("s_branch", "s_endpgm", "s_setpc_b64"):
+                    return                                # no fall-through from here
+                if op == "s_nop":
+                    need -= int(args.split()[0]) + 1
+                    j -= 1
+                    continue
+                if is_valu(op) and args:
+                    if vregs(args.split(",")[0]) & src:
+                        if not (packed_f32(op) and need == 1):           # (the compiler's own code: a packed producer needs one fewer)
+                            yield j
+                        return
+                need -= 2 if packed_f32(op) else 1
+                j -= 1
+
+        for i, (a, op, args) in enumerate(ins):
+            if not op.startswith(("v_mfma", "v_smfmac")):
+                continue
+            n_mfma += 1
+            ops = args.split(",")
+            src = vregs(ops[1]) | vregs(ops[2])
+            for j in walk(i, NEED, src, set()):
+                bad.append((name, ins[j], ins[i]))
+    return bad, n_mfma
+
+
+def main():
+    lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "audio_mps_amd", "lib", "libcmps.so")
+    total, bad = 0, []
+    with tempfile.TemporaryDirectory() as tmp:
+        cos = code_objects(lib, tmp)
+        for co in cos:
+            dis = os.path.join(tmp, os.path.basename(co) + ".dis")
+            with open(dis, "w") as f:
+                subprocess.run([f"{LLVM}/llvm-objdump", "-d", co], check=True, stdout=f)
+            b, n = check(parse(dis))
+            bad += b
+            total += n
+    for name, prod, cons in bad:
+        print(f"HAZARD in {name}:\n    {prod[0]:08X}: {prod[1]} {prod[2]}\n    {cons[0]:08X}: {cons[1]} {cons[2]}")
+    print(f"{len(cos)} code objects, {total} MFMA instructions checked, {len(bad)} closer than {NEED} wait states to a VALU producer")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -135,3 +135,16 @@ def test_diagnostic_switches_compile(source, flags, tmp_path):
           [os.path.join(build.CSRC, source), "-o", out]
     proc = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert proc.returncode == 0, proc.stderr[-3000:]
+
+
+def test_no_valu_write_next_to_mfma_read(hip_lib):
+    """Static check of the built code objects (scripts/check_mfma_hazards.py): no v_mfma reads a VGPR that a VALU instruction wrote
+    fewer than two wait states earlier.  hipcc keeps that distance for its own instructions but not around inline asm, of which
+    the kernels have plenty; the matrix core then reads the register's previous contents (round 4, k_fwd_rho_mfma)."""
+    import subprocess
+    import sys
+    from audio_mps_amd import build
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_mfma_hazards.py"), build.LIB_PATH],
+                          capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-2000:]
+    assert " 0 closer than" in proc.stdout
