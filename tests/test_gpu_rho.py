@@ -282,6 +282,32 @@ def test_rho_gemm_and_column_kernels_agree(D, rank, T, B):
         np.testing.assert_array_equal(ga[k], ga2[k])
 
 
+@pytest.mark.parametrize("amp,rscale,sigma", [(1.0, 0.5, 0.2), (15.0, 1.0, 0.5), (4.0, 2.0, 0.5), (1e-3, 1e-3, 1e-4)])
+def test_rho_gemm_forward_fp16_and_bf16_operands_agree(amp, rscale, sigma):
+    """The GEMM forward runs with fp16 x 2 operands by default (scales per clip from |W_Q|, max |s| |W_R|, tr rho = 1) and with bf16 x 3
+    under CMPS_RANK1_BF16X3: same loss and gradients to float32 tolerance, also for loud clips with a large R (W_k far from the
+    identity, scales 2^-4 ... 2^20) and for a nearly silent model (tiny operands: the scales clamp, the low pieces go subnormal)."""
+    from audio_mps_amd import RhoCMPS, _capi
+    from audio_mps_amd.scan import HipScan
+    D, rank, T, B = 32, 19, 200, 5
+    m, audio = _rho_model(D, T, B, rank=rank, sigma=sigma, seed=23, rscale=rscale)
+    audio = (audio * np.float32(amp)).astype(np.float32)
+    m = RhoCMPS(m.hparams, data_iterator=audio, seed=23)
+    m.variables["Rx"] *= np.float32(rscale)
+    m.variables["Ry"] *= np.float32(rscale)
+    ref = RhoCMPS(m.hparams, data_iterator=audio, seed=23, backend=HipScan(D, rank1=_capi.CMPS_RANK1_BF16X3))
+    for k in m.variables:
+        ref.variables[k] = m.variables[k].copy()
+    a, b = m.loss_per_clip(), ref.loss_per_clip()
+    assert np.all(np.isfinite(b)), "the case itself diverges (1 + z < 0): pick a quieter one"
+    assert np.all(np.isfinite(a)) and np.max(np.abs(a - b) / np.maximum(np.abs(b), 1.0)) <= LOSS_RTOL
+    la, ga = m.loss_and_grads()
+    lb, gb = ref.loss_and_grads()
+    assert abs(float(la) - float(lb)) <= LOSS_RTOL * max(abs(float(lb)), 1.0)
+    for k in ga:
+        assert np.all(np.isfinite(ga[k])) and rel_inf(ga[k], gb[k]) <= GRAD_RTOL, k
+
+
 @pytest.mark.parametrize("D,rank,length,n", [(32, 32, 150, 5), (20, 9, 130, 3), (32, 1, 70, 2)])
 def test_rho_gemm_sampler_matches_block_sampler(D, rank, length, n):
     """D <= 32 samples with the row-array GEMM kernel (one wavefront per path, cmps_rho_mfma.hip); CMPS_VARIANT_BLOCK keeps the
