@@ -8,6 +8,11 @@ v_cvt_pk_f16_f32 next to its v_mfma gave NaN gradients in k_fwd_rho_mfma on firs
 code object in libcmps.so and reports each v_mfma whose A / B operand was written by a VALU instruction fewer than two wait
 states earlier, following fall-through and branch edges.
 
+The same walk is done forwards for the second distance inline asm can break: a v_mfma's result may not be read (or overwritten) by
+anything but a dependent v_mfma accumulating into it before the matrix core has written it -- passes + 3 wait states for the
+4- and 8-pass bf16 / fp16 instructions (7 and 11), passes + 2 for the fp32 ones (the values hipcc itself keeps: the closest
+compiler-placed readers in this library sit at 8, 12 and 18).
+
 usage: check_mfma_hazards.py [libcmps.so]      exit code 1 when a violation is found
 """
 import os
@@ -51,6 +56,28 @@ def vregs(tok):
         return set(range(int(m.group(1)), int(m.group(2)) + 1))
     m = re.match(r"v(\d+)$", tok)
     return {int(m.group(1))} if m else set()
+
+
+def regs(tok):
+    """(file, index) of every VGPR / AGPR a disassembled operand names"""
+    tok = tok.strip().split(" ")[0]
+    m = re.match(r"([va])\[(\d+):(\d+)\]$", tok)
+    if m:
+        return {(m.group(1), i) for i in range(int(m.group(2)), int(m.group(3)) + 1)}
+    m = re.match(r"([va])(\d+)$", tok)
+    return {(m.group(1), int(m.group(2)))} if m else set()
+
+
+def result_wait_states(op):
+    """wait states before a v_mfma's result may be read: passes + 3 (XDL), passes + 2 (fp32)"""
+    m = re.match(r"v_mfma_f32_(\d+)x(\d+)x(\d+)_(\w+)", op)
+    if not m:
+        return 19
+    mm, _, kk, ty = int(m.group(1)), int(m.group(2)), int(m.group(3)), m.group(4)
+    if ty == "f32":
+        return {(32, 2): 16, (16, 4): 8, (32, 1): 16, (16, 1): 8, (4, 1): 2}.get((mm, kk), 16) + 2
+    passes = {(16, 32): 4, (32, 16): 8, (16, 16): 4, (32, 8): 8}.get((mm, kk), 16)
+    return passes + 3
 
 
 def is_valu(op):
@@ -110,6 +137,42 @@ def check(funcs):
                 need -= 2 if packed_f32(op) else 1
                 j -= 1
 
+        def walk_fwd(i, need, dst, seen):
+            """instructions after i that touch dst before `need` wait states have passed (a v_mfma chaining on SrcC is allowed)"""
+            j = i + 1
+            while need > 0 and j < len(ins):
+                a, op, args = ins[j]
+                if op == "s_nop":
+                    need -= int(args.split()[0]) + 1
+                    j += 1
+                    continue
+                if op in ("s_endpgm", "s_setpc_b64"):
+                    return
+                if op.startswith(("s_cbranch", "s_branch")):
+                    t = a + 4 + 4 * int(args.split()[0])
+                    if t in index and (index[t], need) not in seen:
+                        seen.add((index[t], need))
+                        yield from walk_fwd(index[t] - 1, need - 1, dst, seen)
+                    if op == "s_branch":
+                        return
+                    need -= 1
+                    j += 1
+                    continue
+                toks = args.split(",") if args else []
+                touched = set()
+                if op.startswith(("v_mfma", "v_smfmac")):
+                    touched = regs(toks[1]) | regs(toks[2])              # A / B read of a pending result
+                    if not touched & dst and (regs(toks[0]) | regs(toks[3])) & dst:
+                        return                                           # the next link of an accumulation chain: interlocked
+                else:
+                    for t in toks:
+                        touched |= regs(t)
+                if touched & dst:
+                    yield j
+                    return
+                need -= 1
+                j += 1
+
         for i, (a, op, args) in enumerate(ins):
             if not op.startswith(("v_mfma", "v_smfmac")):
                 continue
@@ -118,6 +181,8 @@ def check(funcs):
             src = vregs(ops[1]) | vregs(ops[2])
             for j in walk(i, NEED, src, set()):
                 bad.append((name, ins[j], ins[i]))
+            for j in walk_fwd(i, result_wait_states(op), regs(ops[0]), set()):
+                bad.append((name, ins[i], ins[j]))
     return bad, n_mfma
 
 
@@ -135,7 +200,7 @@ def main():
             total += n
     for name, prod, cons in bad:
         print(f"HAZARD in {name}:\n    {prod[0]:08X}: {prod[1]} {prod[2]}\n    {cons[0]:08X}: {cons[1]} {cons[2]}")
-    print(f"{len(cos)} code objects, {total} MFMA instructions checked, {len(bad)} closer than {NEED} wait states to a VALU producer")
+    print(f"{len(cos)} code objects, {total} MFMA instructions checked, {len(bad)} closer than {NEED} wait states to a VALU producer or read before the result is written")
     return 1 if bad else 0
 
 

@@ -147,4 +147,4 @@ def test_no_valu_write_next_to_mfma_read(hip_lib):
     proc = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_mfma_hazards.py"), build.LIB_PATH],
                           capture_output=True, text=True, timeout=600)
     assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-2000:]
-    assert " 0 closer than" in proc.stdout
+    assert " 0 closer than" in proc.stdout and "MFMA instructions checked" in proc.stdout
