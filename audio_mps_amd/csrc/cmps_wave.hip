@@ -488,12 +488,17 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
         if constexpr (decltype(slot)::value < 0) {
             // (RANK1 == 3: the accumulators carry the scales sR 2^13 and sQ 2^13 -- exact powers of two on the operands of the exact MFMA)
             const float kA = RANK1 == 3 ? sR : 1.f, kQ = RANK1 == 3 ? sQ : 1.f, kB = RANK1 == 3 ? SB16 : 1.f;
-            Rre = __builtin_amdgcn_mfma_f32_32x32x2f32(a1 * kA, (LEGACY ? uk : S.yh) * kB, Rre, 0, 0, 0);
-            Rim = __builtin_amdgcn_mfma_f32_32x32x2f32(a1 * kA, (LEGACY ? uko : S.yho) * kB, Rim, 0, 0, 0);
-            Qre = __builtin_amdgcn_mfma_f32_32x32x2f32(ybar * kQ, uk * kB, Qre, 0, 0, 0);
-            Qim = __builtin_amdgcn_mfma_f32_32x32x2f32(ybar * kQ, uko * kB, Qim, 0, 0, 0);
-            Rre = __builtin_amdgcn_mfma_f32_32x32x2f32(a2 * kA, uk * kB, Rre, 0, 0, 0);
-            Rim = __builtin_amdgcn_mfma_f32_32x32x2f32(a2 * kA, uko * kB, Rim, 0, 0, 0);
+            float o_a1 = a1 * kA, o_a2 = a2 * kA, o_yb = ybar * kQ, o_b1 = (LEGACY ? uk : S.yh) * kB, o_b1o = (LEGACY ? uko : S.yho) * kB;
+            float o_uk = uk * kB, o_uko = uko * kB;
+            // every operand is complete two wait states before the first MFMA reads it: hipcc places a v_pk_fma_f32 one instruction in
+            // front of the v_mfma that reads its result (the matrix core then sees the previous step's u_k)
+            asm volatile("s_nop 1" : "+v"(o_a1), "+v"(o_a2), "+v"(o_yb), "+v"(o_b1), "+v"(o_b1o), "+v"(o_uk), "+v"(o_uko));
+            Rre = __builtin_amdgcn_mfma_f32_32x32x2f32(o_a1, o_b1, Rre, 0, 0, 0);
+            Rim = __builtin_amdgcn_mfma_f32_32x32x2f32(o_a1, o_b1o, Rim, 0, 0, 0);
+            Qre = __builtin_amdgcn_mfma_f32_32x32x2f32(o_yb, o_uk, Qre, 0, 0, 0);
+            Qim = __builtin_amdgcn_mfma_f32_32x32x2f32(o_yb, o_uko, Qim, 0, 0, 0);
+            Rre = __builtin_amdgcn_mfma_f32_32x32x2f32(o_a2, o_uk, Rre, 0, 0, 0);
+            Rim = __builtin_amdgcn_mfma_f32_32x32x2f32(o_a2, o_uko, Rim, 0, 0, 0);
         } else {
             const float val[7] = {a1, ybar, a2, S.yh, S.yho, uk, uko};
             record(slot, val);

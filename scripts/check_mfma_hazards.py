@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
 """Static check of the shipped gfx950 code for the VALU-write -> MFMA-read issue distance.
 
-gfx950 needs two wait states between a VALU instruction that writes a VGPR and a v_mfma that reads it as SrcA / SrcB (what hipcc
-keeps for its own instructions, s_nop included; a packed-fp32 instruction counts as two).  It does not look inside inline asm: a VALU instruction written as asm
+gfx950 needs two wait states between a VALU instruction that writes a VGPR and a v_mfma that reads it as SrcA / SrcB.  hipcc keeps
+that distance for its own instructions (s_nop included) with ONE exception found in round 4: a v_pk_fma_f32 one instruction in front
+of the v_mfma_f32_32x32x2_f32 that reads its result (four sites in k_bwd_wave<0..2>: the matrix core read the previous step's
+operand, the Qbar sums of those steps were wrong, visible in the R gradient once sigma^2 |R|^2 dt is not negligible -- DESIGN 4.3e).
+The check therefore makes no exception for the compiler's own code.  hipcc also does not look inside inline asm: a VALU instruction written as asm
 (or an asm v_mfma) can land closer, and the matrix core then reads the register's previous contents (round 4: an asm
 v_cvt_pk_f16_f32 next to its v_mfma gave NaN gradients in k_fwd_rho_mfma on first launch only).  This script disassembles every
 code object in libcmps.so and reports each v_mfma whose A / B operand was written by a VALU instruction fewer than two wait
@@ -84,10 +87,6 @@ def is_valu(op):
     return op.startswith("v_") and not op.startswith(("v_mfma", "v_smfmac", "v_accvgpr_write"))
 
 
-def packed_f32(op):
-    return op.startswith("v_pk_") and op.endswith("_f32")        # issues over two cycles
-
-
 def parse(dis):
     """functions: name -> list of (addr, opcode, operands)"""
     funcs, cur = {}, None
@@ -131,10 +130,9 @@ def check(funcs):
                     continue
                 if is_valu(op) and args:
                     if vregs(args.split(",")[0]) & src:
-                        if not (packed_f32(op) and need == 1):           # (the compiler's own code: a packed producer needs one fewer)
-                            yield j
+                        yield j
                         return
-                need -= 2 if packed_f32(op) else 1
+                need -= 1
                 j -= 1
 
         def walk_fwd(i, need, dst, seen):

@@ -198,6 +198,32 @@ def test_rank1_modes_order_of_accuracy():
     assert e16 <= 1e-5 and e16 <= 4 * e3 + 2e-6, (e16, e3)       # the fp16 split (round 4): bf16x3's class
 
 
+@pytest.mark.parametrize("D,T", [(18, 60), (32, 60), (32, 501), (9, 47)])
+def test_qbar_sums_visible_at_large_sigma(D, T):
+    """With train.py's sigma = 1e-4 the term Q = -(dt sigma^2 / 2) R^dagger R is below float32 resolution and errors in Qbar = sum ybar u^dagger
+    never reach the R gradient.  sigma = 0.36 with a large R makes them visible: every arithmetic of the rank-1 sums must then sit at
+    the float32 oracle's own distance from float64.  (Round 4: hipcc put a v_pk_fma_f32 one instruction in front of the v_mfma_f32_32x32x2_f32
+    that reads its result in the steps updated immediately -- every step of EXACT_F32, the steps above the first aligned octet otherwise --
+    and the matrix core used the previous step's u_k: Rbar off by 3e-4 ... 3e-3 here, unnoticed at small sigma.  DESIGN 4.3e.)"""
+    from audio_mps_amd import HParams, PsiCMPS
+    from audio_mps_amd.scan import HipScan, unpack_grad
+    hp = HParams(minibatch_size=5, bond_dim=D, sigma=0.36, A=66.0)
+    audio = (make_audio(5, T, hp.delta_t, 3) * np.float32(0.09)).astype(np.float32)
+    g64 = own = None
+    for variant in (WAVE, 4):                               # 16-row layout below D = 17 / 32-row layout; the 32-row layout for every D
+        for mode in (0, 1, 2, 3):
+            m = PsiCMPS(hp, data_iterator=audio, seed=7, backend=HipScan(D, variant=variant, rank1=mode))
+            m.variables["Rx"] *= np.float32(0.69)
+            m.variables["Ry"] *= np.float32(0.69)
+            g = unpack_grad(m.grad_sums()[0].cpu().numpy(), D)
+            if g64 is None:
+                g64 = C.unpack_grad(c_oracle_run(m, audio, "f64")["grad"], D)
+                own = {k: rel_inf(C.unpack_grad(c_oracle_run(m, audio, "f32")["grad"], D)[k], g64[k]) for k in ("Rbar", "fbar", "psi0bar")}
+            for k in ("Rbar", "fbar", "psi0bar"):
+                bar = 3 * own[k] + (3e-5 if mode == 1 else 3e-6)         # BF16X2 carries 16 operand bits
+                assert rel_inf(g[k], g64[k]) <= bar, (variant, mode, k, rel_inf(g[k], g64[k]), own[k])
+
+
 @pytest.mark.parametrize("D", [17, 24, 32])
 def test_rank1_f16x2_scale_jumps(D):
     """The fp16 split of the 32-row reverse scan takes its power-of-two scales per 64-step chunk from a bound of |ybar|: audio with
