@@ -31,7 +31,8 @@ for it in range(60):                                   # pure-state wave / block
         continue
     cfg = (D, T, B, round(sigma, 5), round(rs, 3), variant, round(amp, 4), m._get_backend().effective_rank1)
     note("psi loss", float(np.max(np.abs(per - ref["loss_per_clip"]) / np.maximum(np.abs(ref["loss_per_clip"]), 1))), cfg)
-    note("psi grad", max(rel_inf(g[k], gr[k]) for k in ("Rbar", "fbar", "psi0bar", "Abar")), cfg)
+    note("psi grad", max(rel_inf(g[k], gr[k]) for k in ("Rbar", "fbar", "psi0bar")), cfg)
+    note("psi dA", rel_inf(g["Abar"], gr["Abar"]), cfg)   # one scalar, a cancelling sum: the float32 restatement itself sits up to 1e-2 from float64
 for it in range(16):                                   # wide kernels (float32, 32 < D <= 128; AUTO) vs the C restatement
     D = int(rng.integers(33, 129)); T = int(rng.integers(2, 500)); B = int(rng.integers(1, 8))
     sigma = float(10 ** rng.uniform(-4, 0)); rs = float(10 ** rng.uniform(-1.5, -0.3)); inp = str(rng.choice(["damped_sine", "damped_sine_noise", "bandlimited"]))
@@ -61,13 +62,17 @@ for it in range(8):                                    # device-resident optimis
     note("device-step trajectory", float(np.max(np.abs(dev - host) / np.maximum(np.abs(host), 1))), (D, T, B, round(hp.learning_rate, 4)))
 for it in range(14):                                   # pair kernels vs the bf16 emulation
     D = int(rng.integers(33, 129)); T = int(rng.integers(2, 400)); B = int(rng.integers(1, 7))
-    hp = HParams(minibatch_size=B, bond_dim=D)
+    sigma = float(10 ** rng.uniform(-4, -0.3)) if it % 2 else 1e-4      # (odd draws: Q = -(dt sigma^2 / 2) R^dagger R visible in float32)
+    hp = HParams(minibatch_size=B, bond_dim=D, sigma=sigma)
     audio = make_audio(B, T, hp.delta_t, 100 + it)
     m = PsiCMPS(hp, data_iterator=audio, seed=it, backend=HipScan(D, variant=3))
+    if it % 2:
+        rs = float(10 ** rng.uniform(-1.0, -0.2))
+        m.variables["Rx"] *= np.float32(rs); m.variables["Ry"] *= np.float32(rs)
     per = m.loss_per_clip(); flat, _ = m.grad_sums(); g = unpack_grad(flat.cpu().numpy(), D)
     em = O.psi_bf16_scan(oracle_hparams(hp), oracle_variables(m), audio)
-    note("pair loss", float(np.max(np.abs(per - em["loss_per_clip"]) / np.maximum(np.abs(em["loss_per_clip"]), 1))), (D, T, B))
-    note("pair grad", max(rel_inf(g[k], em[k]) for k in ("Rbar", "fbar", "psi0bar", "Abar")), (D, T, B))
+    note("pair loss", float(np.max(np.abs(per - em["loss_per_clip"]) / np.maximum(np.abs(em["loss_per_clip"]), 1))), (D, T, B, round(sigma, 5)))
+    note("pair grad", max(rel_inf(g[k], em[k]) for k in ("Rbar", "fbar", "psi0bar", "Abar")), (D, T, B, round(sigma, 5)))
 for it in range(34):                                   # RhoCMPS (column kernels for rank <= 8, GEMM kernels above, block kernels for D > 32)
     D = int(rng.integers(2, 41)); r = int(rng.integers(1, min(D, 32) + 1)); T = int(rng.integers(2, 150)); B = int(rng.integers(1, 6))
     rs, amp = 0.4, 1.0
