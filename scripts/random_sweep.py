@@ -19,6 +19,8 @@ for it in range(60):                                   # pure-state wave / block
     D = int(rng.integers(1, 33)); T = int(rng.integers(2, 700)); B = int(rng.integers(1, 14))
     sigma = float(10 ** rng.uniform(-4, 0)); rs = float(10 ** rng.uniform(-1.5, 0)); variant = int(rng.choice([1, 2]))
     hp = HParams(minibatch_size=B, bond_dim=D, sigma=sigma, A=float(10 ** rng.uniform(0, 2)))
+    if it % 4 == 1:                                    # other sampling rates: 3 kHz ... 100 kHz (rotation table, dt_k, the scale of Q)
+        hp = HParams(minibatch_size=B, bond_dim=D, sigma=sigma, A=hp.A, delta_t=float(10 ** rng.uniform(-5, -3.5)))
     amp = float(10 ** rng.uniform(-3, 0.3))           # (round 4: amplitudes over three decades, silent stretches: the fp16 scales)
     audio = (make_audio(B, T, hp.delta_t, it) * np.float32(amp)).astype(np.float32)
     if T > 40 and it % 3 == 0:
@@ -29,7 +31,7 @@ for it in range(60):                                   # pure-state wave / block
     ref = c_oracle_run(m, audio, "f32"); gr = C.unpack_grad(ref["grad"], D)
     if not np.all(np.isfinite(ref["loss_per_clip"])):
         continue
-    cfg = (D, T, B, round(sigma, 5), round(rs, 3), variant, round(amp, 4), m._get_backend().effective_rank1)
+    cfg = (D, T, B, round(sigma, 5), round(rs, 3), variant, round(amp, 4), m._get_backend().effective_rank1, float(f"{hp.delta_t:.3g}"))
     note("psi loss", float(np.max(np.abs(per - ref["loss_per_clip"]) / np.maximum(np.abs(ref["loss_per_clip"]), 1))), cfg)
     note("psi grad", max(rel_inf(g[k], gr[k]) for k in ("Rbar", "fbar", "psi0bar")), cfg)
     note("psi dA", rel_inf(g["Abar"], gr["Abar"]), cfg)   # one scalar, a cancelling sum: the float32 restatement itself sits up to 1e-2 from float64
