@@ -618,7 +618,8 @@ int cmps_rho_sample(cmps_handle_t h, const float* noise_dev, int n, int length, 
     // D <= 32 (rank <= 32): the row-array GEMM sampler, one wavefront per path (cmps_rho_mfma.hip); CMPS_VARIANT_BLOCK keeps the
     // general workgroup-per-path kernel (cross-check; 93 us per step at rank 32 against 2 us)
     const bool mfma = mfma_sampler;
-    hipError_t e = mfma ? launch_sample_rho_mfma(h->P, h->W, noise_dev, n, length, out_dev, save_states != 0, static_cast<hipStream_t>(stream))
+    hipError_t e = mfma ? launch_sample_rho_mfma(h->P, h->W, noise_dev, n, length, out_dev, save_states != 0,
+                                                 h->rank1_mode == CMPS_RANK1_DEFAULT || h->rank1_mode == CMPS_RANK1_F16X2, static_cast<hipStream_t>(stream))
                         : launch_sample_rho(h->P, h->W, noise_dev, n, length, out_dev, save_states != 0, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail_hip(h, e, "cmps_rho_sample");
     h->rho_saved = save_states != 0;

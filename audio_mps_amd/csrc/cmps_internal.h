@@ -225,7 +225,7 @@ hipError_t launch_fwd_rho_wave(const Dev& P, const RhoDev& W, const float* audio
 hipError_t launch_fwd_rho_mfma(const Dev& P, const RhoDev& W, const float* audio, float* loss, bool save, bool f16, hipStream_t s);
 hipError_t launch_bwd_rho_mfma(const Dev& P, const RhoDev& W, const float* audio, hipStream_t s);
 hipError_t launch_sample_rho_mfma(const Dev& P, const RhoDev& W, const float* noise, int n, int length, float* out, bool save,
-                                  hipStream_t s);
+                                  bool f16, hipStream_t s);
 hipError_t launch_bwd_rho_wave(const Dev& P, const RhoDev& W, const float* audio, hipStream_t s);
 hipError_t launch_prep(const Dev& P, const float* R_re, const float* R_im, const float* freqs,
                        const float* psi0_re, const float* psi0_im, float dt, bool rebuild_ttab,

@@ -621,7 +621,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_rho_mfma(Dev P, RhoDev W,
 // s = inc / A,  Y = (U + QU) + s V,  n = sum Y^2,  U' = rho_k (.) Y / sqrt(n).  Noise is [n_paths][length] (one 64-step chunk
 // per lane load), the waveform is written back the same way.  Stash (save): layout 2 rows of (y[n], 0).
 // ------------------------------------------------------------------------------------------------
-template <bool SAVE>
+template <bool SAVE, bool F16>
 __global__ __launch_bounds__(64 * WAVES, 1) void k_sample_rho_mfma(Dev P, RhoDev W, const float* __restrict__ noise, int n_paths,
                                                                    int length, float* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) float Urow[WAVES][32 * RRLD];
@@ -631,8 +631,22 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_sample_rho_mfma(Dev P, RhoDev
     const int r = W.rank;
     const int col = lane & 31, hk = lane >> 5;
     float* U = &Urow[w][0];
-    // bf16 pieces of the W forms of R and Q: lane (col, hk) holds W[16 ks + 8 hk + e][32 t + col], e = 0..7
-    unsigned RH[2][4][4], RM[2][4][4], RL[2][4][4], QH[2][4][4], QM[2][4][4], QL[2][4][4];
+    // pieces of the W forms of R and Q (bf16 x 3, or fp16 x 2 of the forms scaled to 2^15: both operands are constant, and U has
+    // unit trace, so every scale is fixed before the first step): lane (col, hk) holds W[16 ks + 8 hk + e][32 t + col], e = 0..7
+    unsigned RH[2][4][4], RM[F16 ? 1 : 2][4][4], RL[2][4][4], QH[2][4][4], QM[F16 ? 1 : 2][4][4], QL[2][4][4];
+    float sR = 1.f, sQ = 1.f;
+    if constexpr (F16) {
+        float mr = 0.f, mq = 0.f;
+        for (int idx = lane; idx < DPW * DPW; idx += 64) {
+            const float2 rr = P.R[idx], qq = P.Q[idx];
+            mr = fmaxf(mr, fmaxf(fabsf(rr.x), fabsf(rr.y)));
+            mq = fmaxf(mq, fmaxf(fabsf(qq.x), fabsf(qq.y)));
+        }
+        sR = pow2_below(max64(mr), 15);
+        sQ = pow2_below(max64(mq), 15);
+    }
+    constexpr float sU = 8192.f;
+    const float iUR = F16 ? pow2_recip(sU) * pow2_recip(sR) : 1.f, iUQ = F16 ? pow2_recip(sU) * pow2_recip(sQ) : 1.f;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int n = 32 * t + col, ii = n >> 1, cc = n & 1;
@@ -647,8 +661,13 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_sample_rho_mfma(Dev P, RhoDev
             }
 #pragma unroll
             for (int e2 = 0; e2 < 4; ++e2) {
-                split3(wr[2 * e2], wr[2 * e2 + 1], RH[t][ks][e2], RM[t][ks][e2], RL[t][ks][e2]);
-                split3(wq[2 * e2], wq[2 * e2 + 1], QH[t][ks][e2], QM[t][ks][e2], QL[t][ks][e2]);
+                if constexpr (F16) {
+                    split2h(wr[2 * e2] * sR, wr[2 * e2 + 1] * sR, RH[t][ks][e2], RL[t][ks][e2]);
+                    split2h(wq[2 * e2] * sQ, wq[2 * e2 + 1] * sQ, QH[t][ks][e2], QL[t][ks][e2]);
+                } else {
+                    split3(wr[2 * e2], wr[2 * e2 + 1], RH[t][ks][e2], RM[t][ks][e2], RL[t][ks][e2]);
+                    split3(wq[2 * e2], wq[2 * e2 + 1], QH[t][ks][e2], QM[t][ks][e2], QL[t][ks][e2]);
+                }
             }
         }
     }
@@ -679,14 +698,29 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_sample_rho_mfma(Dev P, RhoDev
                 const float4 f0 = *reinterpret_cast<const float4*>(U + col * RRLD + 16 * ks + 8 * hk);
                 const float4 f1 = *reinterpret_cast<const float4*>(U + col * RRLD + 16 * ks + 8 * hk + 4);
                 unsigned AH[4], AM[4], AL[4];
-                split3(f0.x, f0.y, AH[0], AM[0], AL[0]);
-                split3(f0.z, f0.w, AH[1], AM[1], AL[1]);
-                split3(f1.x, f1.y, AH[2], AM[2], AL[2]);
-                split3(f1.z, f1.w, AH[3], AM[3], AL[3]);
-                mfma6(v0, AH, AM, AL, RH[0][ks], RM[0][ks], RL[0][ks]);
-                mfma6(v1, AH, AM, AL, RH[1][ks], RM[1][ks], RL[1][ks]);
-                mfma6(q0, AH, AM, AL, QH[0][ks], QM[0][ks], QL[0][ks]);
-                mfma6(q1, AH, AM, AL, QH[1][ks], QM[1][ks], QL[1][ks]);
+                if constexpr (F16) {
+                    split2h(f0.x * sU, f0.y * sU, AH[0], AL[0]);
+                    split2h(f0.z * sU, f0.w * sU, AH[1], AL[1]);
+                    split2h(f1.x * sU, f1.y * sU, AH[2], AL[2]);
+                    split2h(f1.z * sU, f1.w * sU, AH[3], AL[3]);
+                    mfma3(v0, AH, AL, RH[0][ks], RL[0][ks]);
+                    mfma3(v1, AH, AL, RH[1][ks], RL[1][ks]);
+                    mfma3(q0, AH, AL, QH[0][ks], QL[0][ks]);
+                    mfma3(q1, AH, AL, QH[1][ks], QL[1][ks]);
+                } else {
+                    split3(f0.x, f0.y, AH[0], AM[0], AL[0]);
+                    split3(f0.z, f0.w, AH[1], AM[1], AL[1]);
+                    split3(f1.x, f1.y, AH[2], AM[2], AL[2]);
+                    split3(f1.z, f1.w, AH[3], AM[3], AL[3]);
+                    mfma6(v0, AH, AM, AL, RH[0][ks], RM[0][ks], RL[0][ks]);
+                    mfma6(v1, AH, AM, AL, RH[1][ks], RM[1][ks], RL[1][ks]);
+                    mfma6(q0, AH, AM, AL, QH[0][ks], QM[0][ks], QL[0][ks]);
+                    mfma6(q1, AH, AM, AL, QH[1][ks], QM[1][ks], QL[1][ks]);
+                }
+            }
+            if constexpr (F16) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) { v0[q] *= iUR; v1[q] *= iUR; q0[q] *= iUQ; q1[q] *= iUQ; }
             }
             // C/D layout: column n = 32 t + col, rows (q & 3) + 8 (q >> 2) + 4 hk
             float u0[16], u1[16];
@@ -747,12 +781,12 @@ hipError_t launch_fwd_rho_mfma(const Dev& P, const RhoDev& W, const float* audio
 }
 
 hipError_t launch_sample_rho_mfma(const Dev& P, const RhoDev& W, const float* noise, int n, int length, float* out, bool save,
-                                  hipStream_t s) {
+                                  bool f16, hipStream_t s) {
     const unsigned nb = (unsigned)((n + WAVES - 1) / WAVES);
-    if (save)
-        hipLaunchKernelGGL(k_sample_rho_mfma<true>, dim3(nb), dim3(64 * WAVES), 0, s, P, W, noise, n, length, out);
-    else
-        hipLaunchKernelGGL(k_sample_rho_mfma<false>, dim3(nb), dim3(64 * WAVES), 0, s, P, W, noise, n, length, out);
+    if (save && f16) hipLaunchKernelGGL((k_sample_rho_mfma<true, true>), dim3(nb), dim3(64 * WAVES), 0, s, P, W, noise, n, length, out);
+    else if (save) hipLaunchKernelGGL((k_sample_rho_mfma<true, false>), dim3(nb), dim3(64 * WAVES), 0, s, P, W, noise, n, length, out);
+    else if (f16) hipLaunchKernelGGL((k_sample_rho_mfma<false, true>), dim3(nb), dim3(64 * WAVES), 0, s, P, W, noise, n, length, out);
+    else hipLaunchKernelGGL((k_sample_rho_mfma<false, false>), dim3(nb), dim3(64 * WAVES), 0, s, P, W, noise, n, length, out);
     return hipGetLastError();
 }
 

@@ -125,7 +125,7 @@ for rank in (32, 4):
     rm.sample(n, length, noise=noise)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) * 1e3                      # host-timed (includes the upload of the noise and the download of the waveform)
-    res[f"sample_rho_rank{rank}"] = {"shape": f"D=32, rank={rank}, {n} paths x {length} steps", "kernel": "k_sample_rho_mfma (wave per path, two row-array GEMMs per step)",
+    res[f"sample_rho_rank{rank}"] = {"shape": f"D=32, rank={rank}, {n} paths x {length} steps", "kernel": "k_sample_rho_mfma<f16x2> (wave per path, two row-array GEMMs per step, fp16 x 2 operands with fixed scales)",
                                      "ms": ms, "samples_per_s": n * length / ms * 1e3, "us_per_step": ms * 1e3 / length,
                                      "bound": "serial: 96 32x32x16 bf16 MFMAs per step on one SIMD's matrix pipe (~1.5 us) + the operand splits; "
                                               "the workgroup-per-path kernel (CMPS_VARIANT_BLOCK) takes 93 us per step at rank 32, 12.7 us at rank 4"}
