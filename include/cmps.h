@@ -80,7 +80,7 @@ enum {
  *   BF16X3     each factor split EXACTLY into three bf16 pieces (8+8+8 bits), 6 products: 24 operand bits,
  *              error <= 2^-23 |a||b| (what is dropped is below the fp32 rounding of the product)
  *   F16X2      (the 32-row wave reverse scan, with scales per eight-step octet; the wide kernels' gradient GEMM and loss product H y, with
- *              scales per pair of clips; the RhoCMPS row-array GEMM forward, with scales per clip; elsewhere it means BF16X3) each factor scaled by a power of two per pair of clips
+ *              scales per pair of clips; the RhoCMPS row-array GEMM forward, with scales per clip, and sampler, with fixed scales; elsewhere it means BF16X3) each factor scaled by a power of two per pair of clips
  *              and split into two fp16 pieces, round to nearest (11+1+11+1 bits), 3 products on v_mfma_f32_32x32x16_f16: BF16X2's
  *              instruction count at BF16X3's accuracy class, error <= ~2^-22 |a||b| for factors within 2^-18 of their class's
  *              largest value in the pair and <= 2^-39 of that largest value below */
@@ -90,7 +90,7 @@ enum {
     CMPS_RANK1_BF16X3 = 2,
     CMPS_RANK1_F16X2 = 3,
     CMPS_RANK1_DEFAULT = 4   /* a new handle's setting: F16X2 wherever it exists (the 32-row wave reverse scan of the PsiCMPS arithmetic,
-                              * the wide kernels' GEMMs, the RhoCMPS GEMM forward), BF16X3 elsewhere -- the cheapest arithmetic of the 24-operand-bit class on each
+                              * the wide kernels' GEMMs, the RhoCMPS GEMM forward and sampler), BF16X3 elsewhere -- the cheapest arithmetic of the 24-operand-bit class on each
                               * kernel (scripts/rank1_accuracy_wide.py, tests/test_gpu_parity.py::test_rank1_modes_order_of_accuracy) */
 };
 

@@ -324,6 +324,11 @@ def test_rho_gemm_sampler_matches_block_sampler(D, rank, length, n):
     wa, wb = m.sample(n, length, noise=noise), blk.sample(n, length, noise=noise)
     scale = max(float(np.max(np.abs(wb))), 1e-6)
     assert np.max(np.abs(wa - wb)) <= 1e-4 * scale
+    # the GEMM sampler's two arithmetics: fp16 x 2 pieces with fixed scales (a new handle) and bf16 x 3 (CMPS_RANK1_BF16X3)
+    m3 = RhoCMPS(m.hparams, seed=17, backend=HipScan(D, rank1=2))
+    for k in m.variables:
+        m3.variables[k] = m.variables[k].copy()
+    assert np.max(np.abs(m3.sample(n, length, noise=noise) - wb)) <= 1e-4 * scale
     assert rel_inf(m.rho_evolve_with_sampling(n, length, noise=noise), blk.rho_evolve_with_sampling(n, length, noise=noise)) <= 1e-4
     np.testing.assert_allclose(m.purity(n, length, noise=noise), blk.purity(n, length, noise=noise), rtol=1e-4, atol=1e-6)
 
