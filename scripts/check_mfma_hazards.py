@@ -16,6 +16,9 @@ anything but a dependent v_mfma accumulating into it before the matrix core has 
 4- and 8-pass bf16 / fp16 instructions (7 and 11), passes + 2 for the fp32 ones (the values hipcc itself keeps: the closest
 compiler-placed readers in this library sit at 8, 12 and 18).
 
+Third distance of the same kind (the wave reductions are asm DPP chains): a DPP instruction may not read, as its permuted operand,
+a VGPR that a VALU instruction wrote fewer than two wait states earlier.
+
 usage: check_mfma_hazards.py [libcmps.so]      exit code 1 when a violation is found
 """
 import os
@@ -172,6 +175,12 @@ def check(funcs):
                 j += 1
 
         for i, (a, op, args) in enumerate(ins):
+            if "_dpp" in op and args:                     # third distance: VALU write -> DPP read of the permuted operand (src0), 2 wait states
+                toks = args.split(",")
+                if len(toks) >= 2:
+                    for j in walk(i, NEED, vregs(toks[1].strip().split(" ")[0]), set()):
+                        bad.append((name, ins[j], ins[i]))
+                continue
             if not op.startswith(("v_mfma", "v_smfmac")):
                 continue
             n_mfma += 1
