@@ -113,6 +113,25 @@ for rank in (4, 32):
                                              if rank > 8 else
                                              "straight-line wave-per-clip kernels, 3 r D^2 complex MACs + 6 r exact fp32 MFMAs per step (issue / LDS latency)")}
 
+# ---- the same two rows above D = 32, where they still run on the general one-workgroup-per-clip kernels (not built)
+T, B = 1000, 256
+audio64 = torch.from_numpy(make_audio(B, T, 1e-3, 1)).cuda()
+lm64 = LegacyAudioMPS(64, 1e-3, B, seed=1)
+lb64 = lm64._get_backend()
+lb64.legacy_set_params(lm64.variables["R"], lm64.Q, lm64.delta_t, B, T, train=True)
+ms = dev_ms(lambda: (lb64.legacy_forward(audio64, save_for_bwd=True), lb64.legacy_backward()), rounds=2)
+res["legacy_audiomps_d64"] = {"shape": f"D=64, T={T}, B={B}, fwd+bwd", "kernel": "k_fwd_legacy + k_bwd_legacy (general block kernels: one workgroup per clip)", "ms": ms,
+                              "samples_per_s": B * T / ms * 1e3, "bound": "not optimised: LDS-resident matrices, one workgroup per clip (the wide family has no legacy mode yet)"}
+hp = HParams(minibatch_size=B, bond_dim=64, initial_rank=16)
+a = make_audio(B, T, hp.delta_t, 2)
+rm = RhoCMPS(hp, data_iterator=a, seed=2)
+rm.variables["Rx"] *= np.float32(0.5); rm.variables["Ry"] *= np.float32(0.5)
+d_a = rm._to_device(a)
+rb = rm._prepare(B, T, train=True)
+ms = dev_ms(lambda: rb.rho_loss_and_grad_sums(d_a), rounds=2)
+res["rho_cmps_d64_rank16"] = {"shape": f"D=64, rank=16, T={T}, B={B}, fwd+bwd", "kernel": "k_fwd_rho + k_bwd_rho (general block kernels: one workgroup per clip, columns in LDS)", "ms": ms,
+                              "samples_per_s": B * T / ms * 1e3, "bound": "not optimised: the row-array GEMM kernels stop at D = 32"}
+
 # ---- rank 3b: RhoCMPS.sample (row-array GEMM sampler, one wavefront per path), D = 32, rank 32 and 4: 64 paths x 4000 steps
 for rank in (32, 4):
     hp = HParams(minibatch_size=64, bond_dim=32, initial_rank=rank, sigma=0.05)
