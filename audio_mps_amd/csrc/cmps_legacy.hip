@@ -29,6 +29,42 @@ __device__ __forceinline__ float lblock_sum(float v, float* red) {
     return s;
 }
 
+// body(j, M1[j][t], M2[j][t]) for j = 0 .. D-1 in order, the matrix elements (L2 resident above D = 32) fetched a block of rows ahead
+// of their use (round 4, as rho_jloop in cmps_rho.hip): one L2 round trip per block of 8 rows instead of one per row
+template <class Body>
+__device__ __forceinline__ void leg_jloop(const float2* __restrict__ M1, const float2* __restrict__ M2, int D, int DP, int t, Body body) {
+    constexpr int JB = 8;
+    float2 n1[JB], n2[JB];
+#pragma unroll
+    for (int jj = 0; jj < JB; ++jj) {
+        const int j = jj < D ? jj : D - 1;
+        n1[jj] = M1[j * DP + t];
+        n2[jj] = M2[j * DP + t];
+    }
+    for (int j0 = 0; j0 < D; j0 += JB) {
+        float2 c1[JB], c2[JB];
+#pragma unroll
+        for (int jj = 0; jj < JB; ++jj) { c1[jj] = n1[jj]; c2[jj] = n2[jj]; }
+        if (j0 + JB < D) {
+#pragma unroll
+            for (int jj = 0; jj < JB; ++jj) {
+                int j = j0 + JB + jj;
+                j = j < D ? j : D - 1;
+                n1[jj] = M1[j * DP + t];
+                n2[jj] = M2[j * DP + t];
+            }
+        }
+        if (j0 + JB <= D) {
+#pragma unroll
+            for (int jj = 0; jj < JB; ++jj) body(j0 + jj, c1[jj], c2[jj]);
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < JB; ++jj)
+                if (j0 + jj < D) body(j0 + jj, c1[jj], c2[jj]);
+        }
+    }
+}
+
 template <int NT>
 __global__ __launch_bounds__(NT) void k_fwd_legacy(Dev P, const float* __restrict__ audio,
                                                    float* __restrict__ loss_out, int save) {
@@ -49,11 +85,11 @@ __global__ __launch_bounds__(NT) void k_fwd_legacy(Dev P, const float* __restric
         __syncthreads();
         float2 v = make_float2(0.f, 0.f), q = make_float2(0.f, 0.f);
         if (act) {
-            for (int j = 0; j < D; ++j) {
+            leg_jloop(P.RT, P.QT, D, DP, t, [&](int j, float2 m1, float2 m2) {
                 const float2 pj = su[j];
-                v = cfma(P.RT[j * DP + t], pj, v);
-                q = cfma(P.QT[j * DP + t], pj, q);
-            }
+                v = cfma(m1, pj, v);
+                q = cfma(m2, pj, q);
+            });
         }
         const float e = 2.0f * lblock_sum<NT>(act ? (psi.x * v.x + psi.y * v.y) : 0.f, red);
         const float d = x - e;
@@ -92,11 +128,11 @@ __global__ __launch_bounds__(NT) void k_bwd_legacy(Dev P, const float* __restric
         __syncthreads();
         float2 v = zero, q = zero;
         if (act) {
-            for (int j = 0; j < D; ++j) {
+            leg_jloop(P.RT, P.QT, D, DP, t, [&](int j, float2 m1, float2 m2) {
                 const float2 pj = sp[j];
-                v = cfma(P.RT[j * DP + t], pj, v);
-                q = cfma(P.QT[j * DP + t], pj, q);
-            }
+                v = cfma(m1, pj, v);
+                q = cfma(m2, pj, q);
+            });
         }
         const float e = 2.0f * lblock_sum<NT>(act ? (p.x * v.x + p.y * v.y) : 0.f, red);
         const float2 y = make_float2(p.x + q.x + c * v.x, p.y + q.y + c * v.y);
@@ -115,10 +151,10 @@ __global__ __launch_bounds__(NT) void k_bwd_legacy(Dev P, const float* __restric
         __syncthreads();
         float2 a = zero, r = zero;
         if (act) {
-            for (int j = 0; j < D; ++j) {
-                a = cfma_conj_a(P.Q[j * DP + t], syb[j], a);     // (Q^dagger ybar)_t
-                r = cfma_conj_a(P.R[j * DP + t], svb[j], r);     // (R^dagger vbar)_t
-            }
+            leg_jloop(P.Q, P.R, D, DP, t, [&](int j, float2 m1, float2 m2) {
+                a = cfma_conj_a(m1, syb[j], a);     // (Q^dagger ybar)_t
+                r = cfma_conj_a(m2, svb[j], r);     // (R^dagger vbar)_t
+            });
         }
 #pragma unroll
         for (int m = 0; m < EPT; ++m) {

@@ -37,7 +37,44 @@ __device__ __forceinline__ float rblock_sum(float v, float* red) {
 // ------------------------------------------------------------------------------------------------
 // forward: RhoCMPS._build_loss_rho (model.py:133-144)
 // ------------------------------------------------------------------------------------------------
-template <int NT>
+constexpr int RHO_JB = 8;      // matrix rows fetched ahead per block
+
+// body(j, M1[j][tt], M2[j][tt]) for j = 0 .. D-1 in order, the matrix elements (L2 resident: three D x D tables do not fit L1 above
+// D = 32) fetched a block of RHO_JB rows ahead of their use: one L2 round trip per block instead of one per row
+template <class Body>
+__device__ __forceinline__ void rho_jloop(const float2* __restrict__ M1, const float2* __restrict__ M2, int D, int DP, int tt, Body body) {
+    float2 n1[RHO_JB], n2[RHO_JB];
+#pragma unroll
+    for (int jj = 0; jj < RHO_JB; ++jj) {
+        const int j = jj < D ? jj : D - 1;
+        n1[jj] = M1[j * DP + tt];
+        n2[jj] = M2[j * DP + tt];
+    }
+    for (int j0 = 0; j0 < D; j0 += RHO_JB) {
+        float2 c1[RHO_JB], c2[RHO_JB];
+#pragma unroll
+        for (int jj = 0; jj < RHO_JB; ++jj) { c1[jj] = n1[jj]; c2[jj] = n2[jj]; }
+        if (j0 + RHO_JB < D) {
+#pragma unroll
+            for (int jj = 0; jj < RHO_JB; ++jj) {
+                int j = j0 + RHO_JB + jj;
+                j = j < D ? j : D - 1;
+                n1[jj] = M1[j * DP + tt];
+                n2[jj] = M2[j * DP + tt];
+            }
+        }
+        if (j0 + RHO_JB <= D) {
+#pragma unroll
+            for (int jj = 0; jj < RHO_JB; ++jj) body(j0 + jj, c1[jj], c2[jj]);
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < RHO_JB; ++jj)
+                if (j0 + jj < D) body(j0 + jj, c1[jj], c2[jj]);
+        }
+    }
+}
+
+template <int NT, int CW>
 __global__ __launch_bounds__(NT) void k_fwd_rho(Dev P, RhoDev W, const float* __restrict__ audio,
                                                 float* __restrict__ loss_out, int save, float2* gcols) {
     extern __shared__ float2 sh[];
@@ -50,6 +87,10 @@ __global__ __launch_bounds__(NT) void k_fwd_rho(Dev P, RhoDev W, const float* __
     float* red = reinterpret_cast<float*>(gcols ? sh : sh + 2 * rD);
     const int b = blockIdx.x, t = threadIdx.x;
     const bool act = t < D;
+    // the mat-vecs: thread (tt, grp) owns component tt of the columns a0 .. a0 + CW - 1, a0 = CW (grp + NG i) -- one matrix element is
+    // loaded once per chunk of CW columns (round 4; before: once per column, with only D of the NT threads at work)
+    const int DPT = (NT == 64 || D <= 64) ? 64 : 128, tt = t & (DPT - 1), grp = t / DPT, NG = NT / DPT;
+    const bool mact = tt < D;
     const float* xrow = audio + (size_t)b * P.T;
     float2* st = save ? W.stash + (size_t)b * N * r * DP : nullptr;
     if (act)
@@ -59,35 +100,60 @@ __global__ __launch_bounds__(NT) void k_fwd_rho(Dev P, RhoDev W, const float* __
         const float x = xrow[k + 1] - xrow[k];     // model.py:138
         const float s = x / dev_A(P);                   // :175
         __syncthreads();
-        if (act) {
-            for (int a = 0; a < r; ++a) {
-                const float2* ua = cur + a * D;
-                float2 v = make_float2(0.f, 0.f), q = make_float2(0.f, 0.f);
-                for (int j = 0; j < D; ++j) {
-                    const float2 uj = ua[j];
-                    v = cfma(P.RT[j * DP + t], uj, v);            // (R u_a)_t
-                    q = cfma_conj_a(P.Q[j * DP + t], uj, q);      // (Q u_a)_t, Q Hermitian
-                }
-                const float2 u = ua[t];
-                const float2 y = make_float2(u.x + q.x + s * v.x, u.y + q.y + s * v.y);   // column of U rho U^dagger, :186
-                nxt[a * D + t] = y;
-                if (save) st[((size_t)k * r + a) * DP + t] = y;
+        if (mact) {
+            for (int a0 = grp * CW; a0 < r; a0 += NG * CW) {
+                const int na = (r - a0) < CW ? (r - a0) : CW;
+                int co[CW];                              // a ragged last chunk repeats its last column: no branch inside the j loop
+#pragma unroll
+                for (int c = 0; c < CW; ++c) co[c] = (a0 + (c < na ? c : na - 1)) * D;
+                float2 v[CW], q[CW];
+#pragma unroll
+                for (int c = 0; c < CW; ++c) v[c] = q[c] = make_float2(0.f, 0.f);
+                rho_jloop(P.RT, P.Q, D, DP, tt, [&](int j, float2 m1, float2 m2) {
+#pragma unroll
+                    for (int c = 0; c < CW; ++c) {
+                        const float2 uj = cur[co[c] + j];
+                        v[c] = cfma(m1, uj, v[c]);                // (R u_a)_t
+                        q[c] = cfma_conj_a(m2, uj, q[c]);         // (Q u_a)_t, Q Hermitian
+                    }
+                });
+#pragma unroll
+                for (int c = 0; c < CW; ++c)
+                    if (c < na) {
+                        const int a = a0 + c;
+                        const float2 u = cur[a * D + tt];
+                        const float2 y = make_float2(u.x + q[c].x + s * v[c].x, u.y + q[c].y + s * v[c].y);   // column of U rho U^dagger, :186
+                        nxt[a * D + tt] = y;
+                        if (save) st[((size_t)k * r + a) * DP + tt] = y;
+                    }
             }
         }
         __syncthreads();
         float pe = 0.f, pn = 0.f;
-        if (act) {
-            for (int a = 0; a < r; ++a) {
-                const float2* ya = nxt + a * D;
-                float2 hy = make_float2(0.f, 0.f);
-                for (int j = 0; j < D; ++j) {
-                    const float2 yj = ya[j];
-                    hy = cfma(P.RT[j * DP + t], yj, hy);
-                    hy = cfma_conj_a(P.R[j * DP + t], yj, hy);   // ((R + R^dagger) y_a)_t, :193-194
-                }
-                const float2 y = ya[t];
-                pe += y.x * hy.x + y.y * hy.y;
-                pn += y.x * y.x + y.y * y.y;
+        if (mact) {
+            for (int a0 = grp * CW; a0 < r; a0 += NG * CW) {
+                const int na = (r - a0) < CW ? (r - a0) : CW;
+                int co[CW];                              // a ragged last chunk repeats its last column: no branch inside the j loop
+#pragma unroll
+                for (int c = 0; c < CW; ++c) co[c] = (a0 + (c < na ? c : na - 1)) * D;
+                float2 hy[CW];
+#pragma unroll
+                for (int c = 0; c < CW; ++c) hy[c] = make_float2(0.f, 0.f);
+                rho_jloop(P.RT, P.R, D, DP, tt, [&](int j, float2 m1, float2 m2) {
+#pragma unroll
+                    for (int c = 0; c < CW; ++c) {
+                        const float2 yj = nxt[co[c] + j];
+                        hy[c] = cfma(m1, yj, hy[c]);
+                        hy[c] = cfma_conj_a(m2, yj, hy[c]);       // ((R + R^dagger) y_a)_t, :193-194
+                    }
+                });
+#pragma unroll
+                for (int c = 0; c < CW; ++c)
+                    if (c < na) {
+                        const float2 y = nxt[(a0 + c) * D + tt];
+                        pe += y.x * hy[c].x + y.y * hy[c].y;
+                        pn += y.x * y.x + y.y * y.y;
+                    }
             }
         }
         const float e = rblock_sum<NT>(pe, red);                  // Re tr(x rho'), :195-196
@@ -106,7 +172,7 @@ __global__ __launch_bounds__(NT) void k_fwd_rho(Dev P, RhoDev W, const float* __
 // ------------------------------------------------------------------------------------------------
 // reverse sweep
 // ------------------------------------------------------------------------------------------------
-template <int NT, int EPT>
+template <int NT, int EPT, int CW>
 __global__ __launch_bounds__(NT) void k_bwd_rho(Dev P, RhoDev W, const float* __restrict__ audio, float2* gcols) {
     extern __shared__ float2 sh[];
     const int D = P.D, DP = P.DP, N = P.N, r = W.rank, rD = r * D;
@@ -118,6 +184,8 @@ __global__ __launch_bounds__(NT) void k_bwd_rho(Dev P, RhoDev W, const float* __
     float* red = reinterpret_cast<float*>(gcols ? sh : sh + 4 * rD);
     const int b = blockIdx.x, t = threadIdx.x;
     const bool act = t < D;
+    const int DPT = (NT == 64 || D <= 64) ? 64 : 128, tt = t & (DPT - 1), grp = t / DPT, NG = NT / DPT;   // the mat-vecs: as in k_fwd_rho
+    const bool mact = tt < D;
     const float* xrow = audio + (size_t)b * P.T;
     const float2* st = W.stash + (size_t)b * N * r * DP;
     const float2 zero = make_float2(0.f, 0.f);
@@ -158,18 +226,30 @@ __global__ __launch_bounds__(NT) void k_bwd_rho(Dev P, RhoDev W, const float* __
         const float dot = rblock_sum<NT>(pd, red);
         __syncthreads();
         float pe = 0.f;
-        if (act) {
-            for (int a = 0; a < r; ++a) {
-                const float2* ya = Y + a * D;
-                float2 hy = zero;
-                for (int j = 0; j < D; ++j) {
-                    const float2 yj = ya[j];
-                    hy = cfma(P.RT[j * DP + t], yj, hy);
-                    hy = cfma_conj_a(P.R[j * DP + t], yj, hy);
-                }
-                const float2 y = ya[t];
-                pe += y.x * hy.x + y.y * hy.y;
-                U[a * D + t] = hy;
+        if (mact) {
+            for (int a0 = grp * CW; a0 < r; a0 += NG * CW) {
+                const int na = (r - a0) < CW ? (r - a0) : CW;
+                int co[CW];                              // a ragged last chunk repeats its last column: no branch inside the j loop
+#pragma unroll
+                for (int c = 0; c < CW; ++c) co[c] = (a0 + (c < na ? c : na - 1)) * D;
+                float2 hy[CW];
+#pragma unroll
+                for (int c = 0; c < CW; ++c) hy[c] = zero;
+                rho_jloop(P.RT, P.R, D, DP, tt, [&](int j, float2 m1, float2 m2) {
+#pragma unroll
+                    for (int c = 0; c < CW; ++c) {
+                        const float2 yj = Y[co[c] + j];
+                        hy[c] = cfma(m1, yj, hy[c]);
+                        hy[c] = cfma_conj_a(m2, yj, hy[c]);
+                    }
+                });
+#pragma unroll
+                for (int c = 0; c < CW; ++c)
+                    if (c < na) {
+                        const float2 y = Y[(a0 + c) * D + tt];
+                        pe += y.x * hy[c].x + y.y * hy[c].y;
+                        U[(a0 + c) * D + tt] = hy[c];
+                    }
             }
         }
         const float e = rblock_sum<NT>(pe, red);
@@ -212,18 +292,31 @@ __global__ __launch_bounds__(NT) void k_bwd_rho(Dev P, RhoDev W, const float* __
         }
         __syncthreads();
         float ps = 0.f;
-        if (act) {
-            for (int a = 0; a < r; ++a) {
-                const float2* yb = YB + a * D;
-                float2 bq = zero, d = zero;
-                for (int j = 0; j < D; ++j) {
-                    const float2 yj = yb[j];
-                    bq = cfma_conj_a(P.Q[j * DP + t], yj, bq);   // (Q ybar_a)_t
-                    d = cfma_conj_a(P.R[j * DP + t], yj, d);     // (R^dagger ybar_a)_t
-                }
-                const float2 uk = U[a * D + t], ybt = yb[t];
-                ps += d.x * uk.x + d.y * uk.y;
-                G[a * D + t] = make_float2(ybt.x + bq.x + s * d.x, ybt.y + bq.y + s * d.y);
+        if (mact) {
+            for (int a0 = grp * CW; a0 < r; a0 += NG * CW) {
+                const int na = (r - a0) < CW ? (r - a0) : CW;
+                int co[CW];                              // a ragged last chunk repeats its last column: no branch inside the j loop
+#pragma unroll
+                for (int c = 0; c < CW; ++c) co[c] = (a0 + (c < na ? c : na - 1)) * D;
+                float2 bq[CW], d[CW];
+#pragma unroll
+                for (int c = 0; c < CW; ++c) bq[c] = d[c] = zero;
+                rho_jloop(P.Q, P.R, D, DP, tt, [&](int j, float2 m1, float2 m2) {
+#pragma unroll
+                    for (int c = 0; c < CW; ++c) {
+                        const float2 yj = YB[co[c] + j];
+                        bq[c] = cfma_conj_a(m1, yj, bq[c]);      // (Q ybar_a)_t
+                        d[c] = cfma_conj_a(m2, yj, d[c]);        // (R^dagger ybar_a)_t
+                    }
+                });
+#pragma unroll
+                for (int c = 0; c < CW; ++c)
+                    if (c < na) {
+                        const int a = a0 + c;
+                        const float2 uk = U[a * D + tt], ybt = YB[a * D + tt];
+                        ps += d[c].x * uk.x + d[c].y * uk.y;
+                        G[a * D + tt] = make_float2(ybt.x + bq[c].x + s * d[c].x, ybt.y + bq[c].y + s * d[c].y);
+                    }
             }
         }
         const float sbar = rblock_sum<NT>(ps, red);
@@ -491,37 +584,39 @@ static float2* cols_if_needed(const RhoDev& W, size_t want_lds_bytes, size_t& sh
     return (W.cols && blocks <= W.cols_blocks) ? W.cols : reinterpret_cast<float2*>(1);   // 1: "needed but not provided"
 }
 
+// columns per mat-vec chunk (accumulators in registers): 8 when every column group has at least 8 columns, else 4
+template <int NT, int CW>
+static hipError_t run_fwd_rho(const Dev& P, const RhoDev& W, const float* audio, float* loss, bool save, float2* g, size_t shm, hipStream_t s) {
+    hipError_t e = want_lds(k_fwd_rho<NT, CW>, shm);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_fwd_rho<NT, CW>), dim3(P.B), dim3(NT), shm, s, P, W, audio, loss, save ? 1 : 0, g);
+    return hipGetLastError();
+}
+template <int NT, int EPT, int CW>
+static hipError_t run_bwd_rho(const Dev& P, const RhoDev& W, const float* audio, float2* g, size_t shm, hipStream_t s) {
+    hipError_t e = want_lds(k_bwd_rho<NT, EPT, CW>, shm);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_bwd_rho<NT, EPT, CW>), dim3(P.B), dim3(NT), shm, s, P, W, audio, g);
+    return hipGetLastError();
+}
+
 hipError_t launch_fwd_rho(const Dev& P, const RhoDev& W, const float* audio, float* loss, bool save, hipStream_t s) {
     size_t shm;
     float2* g = cols_if_needed(W, (size_t)2 * W.rank * P.D * sizeof(float2) + 128, shm, P.B);
     if (g == reinterpret_cast<float2*>(1)) return hipErrorInvalidValue;
-    hipError_t e;
-    if (P.D <= 64) {
-        if ((e = want_lds(k_fwd_rho<64>, shm)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_fwd_rho<64>, dim3(P.B), dim3(64), shm, s, P, W, audio, loss, save ? 1 : 0, g);
-    } else {
-        if ((e = want_lds(k_fwd_rho<128>, shm)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_fwd_rho<128>, dim3(P.B), dim3(128), shm, s, P, W, audio, loss, save ? 1 : 0, g);
-    }
-    return hipGetLastError();
+    if (P.D <= 32) return W.rank >= 8 ? run_fwd_rho<64, 8>(P, W, audio, loss, save, g, shm, s) : run_fwd_rho<64, 4>(P, W, audio, loss, save, g, shm, s);
+    const bool wide = W.rank >= 32;               // four column groups (of 64 threads up to D = 64, of 128 above)
+    if (P.D <= 64) return wide ? run_fwd_rho<256, 8>(P, W, audio, loss, save, g, shm, s) : run_fwd_rho<256, 4>(P, W, audio, loss, save, g, shm, s);
+    return wide ? run_fwd_rho<512, 8>(P, W, audio, loss, save, g, shm, s) : run_fwd_rho<512, 4>(P, W, audio, loss, save, g, shm, s);
 }
 
 hipError_t launch_bwd_rho(const Dev& P, const RhoDev& W, const float* audio, hipStream_t s) {
     size_t shm;
     float2* g = cols_if_needed(W, (size_t)4 * W.rank * P.D * sizeof(float2) + 128, shm, P.B);
     if (g == reinterpret_cast<float2*>(1)) return hipErrorInvalidValue;
-    hipError_t e;
-    if (P.D <= 32) {
-        if ((e = want_lds(k_bwd_rho<64, 16>, shm)) != hipSuccess) return e;
-        hipLaunchKernelGGL((k_bwd_rho<64, 16>), dim3(P.B), dim3(64), shm, s, P, W, audio, g);
-    } else if (P.D <= 64) {
-        if ((e = want_lds(k_bwd_rho<256, 16>, shm)) != hipSuccess) return e;
-        hipLaunchKernelGGL((k_bwd_rho<256, 16>), dim3(P.B), dim3(256), shm, s, P, W, audio, g);
-    } else {
-        if ((e = want_lds(k_bwd_rho<1024, 16>, shm)) != hipSuccess) return e;
-        hipLaunchKernelGGL((k_bwd_rho<1024, 16>), dim3(P.B), dim3(1024), shm, s, P, W, audio, g);
-    }
-    return hipGetLastError();
+    if (P.D <= 32) return W.rank >= 8 ? run_bwd_rho<64, 16, 8>(P, W, audio, g, shm, s) : run_bwd_rho<64, 16, 4>(P, W, audio, g, shm, s);
+    if (P.D <= 64) return W.rank >= 32 ? run_bwd_rho<256, 16, 8>(P, W, audio, g, shm, s) : run_bwd_rho<256, 16, 4>(P, W, audio, g, shm, s);
+    return W.rank >= 64 ? run_bwd_rho<1024, 16, 8>(P, W, audio, g, shm, s) : run_bwd_rho<1024, 16, 4>(P, W, audio, g, shm, s);   // eight groups
 }
 
 hipError_t launch_finalize_rho(const Dev& P, const RhoDev& W, float* grad_out, hipStream_t s) {
