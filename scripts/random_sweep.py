@@ -49,7 +49,8 @@ for it in range(16):                                   # wide kernels (float32, 
     ref = c_oracle_run(m, audio, "f32"); gr = C.unpack_grad(ref["grad"], D)
     cfg = (D, T, B, round(sigma, 5), round(rs, 3), inp, m._get_backend().effective_rank1, m._get_backend().wide_chain)
     note("wide loss", float(np.max(np.abs(per - ref["loss_per_clip"]) / np.maximum(np.abs(ref["loss_per_clip"]), 1))), cfg)
-    note("wide grad", max(rel_inf(g[k], gr[k]) for k in ("Rbar", "fbar", "psi0bar", "Abar")), cfg)
+    note("wide grad", max(rel_inf(g[k], gr[k]) for k in ("Rbar", "fbar", "psi0bar")), cfg)
+    note("wide dA", rel_inf(g["Abar"], gr["Abar"]), cfg)
 for it in range(8):                                    # device-resident optimiser step vs the host one, 10 steps
     from audio_mps_amd.train import Trainer
     D = int(rng.choice([3, 8, 16, 24, 32, 48])); T = int(rng.integers(20, 300)); B = int(rng.integers(1, 9))
@@ -74,10 +75,13 @@ for it in range(14):                                   # pair kernels vs the bf1
     per = m.loss_per_clip(); flat, _ = m.grad_sums(); g = unpack_grad(flat.cpu().numpy(), D)
     em = O.psi_bf16_scan(oracle_hparams(hp), oracle_variables(m), audio)
     note("pair loss", float(np.max(np.abs(per - em["loss_per_clip"]) / np.maximum(np.abs(em["loss_per_clip"]), 1))), (D, T, B, round(sigma, 5)))
-    note("pair grad", max(rel_inf(g[k], em[k]) for k in ("Rbar", "fbar", "psi0bar", "Abar")), (D, T, B, round(sigma, 5)))
+    note("pair grad", max(rel_inf(g[k], em[k]) for k in ("Rbar", "fbar", "psi0bar")), (D, T, B, round(sigma, 5)))
+    note("pair dA", rel_inf(g["Abar"], em["Abar"]), (D, T, B, round(sigma, 5)))
 for it in range(34):                                   # RhoCMPS (column kernels for rank <= 8, GEMM kernels above, block kernels for D > 32)
     D = int(rng.integers(2, 41)); r = int(rng.integers(1, min(D, 32) + 1)); T = int(rng.integers(2, 150)); B = int(rng.integers(1, 6))
     rs, amp = 0.4, 1.0
+    if it in (3, 7, 11):                               # (round 4) the general kernels' column groups: 32 < D <= 128, ragged ranks
+        D = int(rng.integers(33, 129)); r = int(rng.integers(1, min(D, 40) + 1)); T = int(rng.integers(2, 40)); B = int(rng.integers(1, 4))
     if it >= 31:                                       # the reference's default rank = D above the old LDS limit (workspace columns)
         D = int(rng.integers(72, 129)); r = D; T = int(rng.integers(2, 12)); B = int(rng.integers(1, 3))
     elif it >= 14:                                     # (round 4) the GEMM kernels: rank > 8 at D <= 32, the fp16 x 2 forward's scales --
