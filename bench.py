@@ -19,14 +19,16 @@ Inputs (`--input`): the reference's damped sine (data.py:8-22; SURVEY 8(d)'s gen
 or SURVEY 8(d)'s band-limited random walk; parameters by the reference's initialisation rules (model.py:36-39, 49, 218-219) with
 train.py:41-43 hyper-parameters, seed 0 (D > 64: SURVEY 8(d)'s scaled R_in, which keeps 1 + e x / A positive).
 
-Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (the longer of the two scan launches): `achieved` /
-`frac` are the contract's ALGORITHMIC flops (24 D^2 forward, 56 D^2 backward per clip-sample) over the launch time
-measured with HIP events on the launch stream; `executed` splits what the kernel really runs by pipe (fp32 VALU, matrix cores,
-eliminated algebraically) and `step_traffic` puts the whole step's counter bytes next to the algorithmic ones.
-`cpu_baseline` is the plain-C restatement (oracle/cmps_oracle.c) timed on this host's cores on a bounded sample,
-`parity_in_bench` compares the GPU results on that same sample with the oracle's (outside the timed region), `precision_ab` times
-the arithmetic modes of the rank-1 gradient sums side by side, `other_configs` runs BASELINE configs[0] (shape), [1] and [4]
-(float32 and bf16) for a few steps each with their own parity check.
+Output (rank 0).  The LAST stdout line is the contract's record: ONE compact JSON object (< 4 KB; `HEADLINE_LIMIT`) with
+metric / value / config, `roofline` for the dominant kernel (the longer of the two scan launches: `achieved` / `frac` are the
+contract's ALGORITHMIC flops -- SURVEY 8(d): 24 D^2 forward, 56 D^2 backward per clip-sample -- over the launch time measured with
+HIP events on the launch stream), `cpu_baseline` (the plain-C restatement oracle/cmps_oracle.c timed on this host's cores on a
+bounded sample) and `parity_in_bench` (the GPU results on that same sample against the oracle's, outside the timed region).
+Everything else goes out EARLIER, one JSON object per line, each of the form {"detail": name, "data": ...} (never a top-level
+"metric" key), and as sidecar files under gpurun_out/bench_detail/ when that directory can be written: `roofline_detail` (per-kernel
+/ per-pipe records, executed split, step traffic), `precision_ab` (the arithmetic modes of the rank-1 gradient sums side by side),
+`reference_style` (numpy restatement timings), `other_config:<name>` (BASELINE configs[0] shape, [1], [4] in float32 and as named,
+a few steps each with their own parity check; the headline keeps a one-line summary of each).
 """
 from __future__ import annotations
 
@@ -238,11 +240,105 @@ def rel_inf(a, b):
 
 
 # ---------------------------------------------------------------------------------------------------
+# output: detail lines first, ONE compact headline object as the last stdout line
+#   (round 4's single 23.5 KB line did not fit the driver's record: BENCH_r04.json.parsed = null)
+# ---------------------------------------------------------------------------------------------------
+HEADLINE_LIMIT = 4000          # bytes of the last line, asserted by tests/test_host.py and tests/test_gpu_train.py
+DETAIL_DIR = os.environ.get("CMPS_BENCH_DETAIL_DIR", os.path.join(ROOT, "gpurun_out", "bench_detail"))
+ROOFLINE_HEADLINE_KEYS = ("bound", "kernel", "pipe", "achieved", "peak", "unit", "frac", "frac_is", "traffic", "traffic_source",
+                          "algorithmic_bytes", "launch_ms", "flops_per_launch", "whole_step_frac_algorithmic")
+HEADLINE_DROP_ORDER = ("detail_lines", "other_configs", "per_rank_ms_per_step", "collective")     # if the line were ever too long
+
+
+def _jsonable(o):
+    if isinstance(o, (np.floating, np.integer)):
+        return o.item()
+    if isinstance(o, np.ndarray):
+        return o.tolist()
+    raise TypeError(type(o).__name__)
+
+
+def emit_detail(name, data, stream=None):
+    """One earlier stdout line {"detail": name, "data": data} + a sidecar file (best effort).  Returns the name."""
+    line = json.dumps({"detail": name, "data": data}, default=_jsonable)
+    assert not line.startswith('{"metric"')
+    print(line, file=stream or sys.stdout, flush=True)
+    try:
+        os.makedirs(DETAIL_DIR, exist_ok=True)
+        with open(os.path.join(DETAIL_DIR, re.sub(r"[^A-Za-z0-9_.-]+", "_", name) + ".json"), "w") as fh:
+            fh.write(line + "\n")
+    except OSError:
+        pass
+    return name
+
+
+def short(text, n):
+    text = str(text)
+    return text if len(text) <= n else text[:n - 1] + "~"
+
+
+def compact_roofline(full):
+    """The contract's roofline object without the per-kernel tables (those are the `roofline_detail` line)."""
+    if full is None:
+        return None
+    rec = {k: full[k] for k in ROOFLINE_HEADLINE_KEYS if k in full}
+    for k, n in (("frac_is", 150), ("kernel", 60), ("pipe", 60)):
+        if rec.get(k) is not None:
+            rec[k] = short(rec[k], n)
+    return rec
+
+
+def compact_parity(par):
+    if par is None:
+        return None
+    return {"clips": par["clips"], "max_rel_loss_err": par["max_rel_loss_err"], "max_rel_grad_err": par["max_rel_grad_err"],
+            "tolerance": par["tolerance"], "ok": par["ok"], "against": short(par["against"], 90)}
+
+
+def compact_other_config(row):
+    if "error" in row:
+        return {"key": row.get("key"), "config": short(row["config"], 40), "error": short(row["error"], 120)}
+    par = row.get("parity_in_bench") or {}
+    return {"key": row.get("key"), "config": short(row["config"], 40), "ms_per_step": round(row["ms_per_step"], 4), "value": float(f"{row['value']:.5g}"),
+            "dtype": short(row["dtype"], 12), "dominant_kernel": short(row["dominant_kernel"], 20),
+            "frac": None if row.get("frac") is None else round(row["frac"], 4),
+            "parity_ok": par.get("ok"), "loss_err": par.get("max_rel_loss_err"), "grad_err": par.get("max_rel_grad_err")}
+
+
+def _round_floats(o, digits):
+    if isinstance(o, (float, np.floating)):
+        return float(f"{float(o):.{digits}g}") if np.isfinite(o) else float(o)
+    if isinstance(o, dict):
+        return {k: _round_floats(v, digits) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_round_floats(v, digits) for v in o]
+    return o
+
+
+def headline_line(out):
+    """Serialise the headline object (top-level numbers to 10, nested ones to 6 significant digits); should it ever exceed
+    HEADLINE_LIMIT, optional keys go (in HEADLINE_DROP_ORDER) -- the contract's keys never do."""
+    out = {k: _round_floats(v, 6 if isinstance(v, (dict, list, tuple)) else 10) for k, v in out.items()}
+    line = json.dumps(out, default=_jsonable)
+    for key in HEADLINE_DROP_ORDER:
+        if len(line) <= HEADLINE_LIMIT:
+            break
+        if key in out:
+            out.pop(key)
+            out["dropped_for_size"] = out.get("dropped_for_size", []) + [key]
+            line = json.dumps(out, default=_jsonable)
+    if len(line) > HEADLINE_LIMIT:
+        raise RuntimeError(f"bench.py: headline line is {len(line)} bytes (> {HEADLINE_LIMIT})")
+    return line
+
+
+# ---------------------------------------------------------------------------------------------------
 # committed rocprofv3 summaries (profiles/*pmc_summary.json: scripts/profile_scan.sh + scripts/summarize_prof.py)
 # ---------------------------------------------------------------------------------------------------
-def profile_summary(D, T, B, variant):
+def profile_summary(D, T, B, variant, wide_chain=1):
     """The newest committed PMC summary of THIS workload and kernel family (None if there is none)."""
-    want = {V_WAVE: "k_bwd_wave", V_WAVE32: "k_bwd_wave", V_PAIR: "k_bwd_pair", V_WIDE: "k_bwd_wide", V_BLOCK: "k_bwd_block"}[variant]
+    want = {V_WAVE: "k_bwd_wave", V_WAVE32: "k_bwd_wave", V_PAIR: "k_bwd_pair", V_WIDE: "k_bwd_wide" if wide_chain == 0 else "k_bwd_chain16",
+            V_BLOCK: "k_bwd_block"}[variant]
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.json")))
     for path in reversed(files):                                 # names carry the round: the last one is the newest
         try:
@@ -273,7 +369,7 @@ def kernel_counters(doc, kernel):
 #   algorithmic: forward 24 = Q u (8) + s R u (8) + R y (8); backward 56 = R^dagger y, R ybar, R^dagger R ybar,
 #   R^dagger ybar (4 x 8) + three rank-1 sums (3 x 8)
 # ---------------------------------------------------------------------------------------------------
-def executed_split(variant, D, rank1):
+def executed_split(variant, D, rank1, wide_chain=1):
     if variant in (V_WAVE, V_WAVE32) and not (variant == V_WAVE and D <= 16):
         prod = {0: 1, 1: 3, 2: 6, 3: 3}[rank1]
         return {"fwd": {"valu_fp32": 12, "mfma_fp32_equiv": 8, "mfma_products": 6, "eliminated": 4,
@@ -287,13 +383,19 @@ def executed_split(variant, D, rank1):
                         "what": "merged mat-vec on the VALU; rank-1 sums as exact fp32 MFMAs (16x16x4) on the gradient wave"}}
     if variant == V_WIDE:
         prod = 6 if rank1 == 2 else 3
-        return {"fwd": {"valu_fp32": 12, "mfma_fp32_equiv": 8, "mfma_products": 6, "eliminated": 4,
-                        "what": "the chain: k_fwd_chain16 (default: (Q + s R) u as f16x2-split operands on the matrix cores, three products; then "
-                                "valu_fp32 = 0 and the matrix cores carry all 16 D^2) or k_fwd_wide (CMPS_OPT_WIDE_CHAIN = VALU: merged (Q + s R) u, fp32 "
-                                "v_pk_fma, 8 + 4 forming it); k_hy_wide: H y for all (clip, step) pairs as a split-operand GEMM; k_loss_wide: the "
-                                "sequential float32 loss sums"},
-                "bwd": {"valu_fp32": 12, "mfma_fp32_equiv": 24, "mfma_products": prod, "eliminated": 20,
-                        "what": "k_bwd_wide: merged (Q + s R^dagger) ybar on the VALU; k_grad_gemm: rank-1 sums as split-operand GEMMs (three bf16, two bf16 or two fp16 pieces)"}}
+        hyp = 6 if rank1 in (1, 2) else 3
+        fwd_mfma, bwd_mfma = wide_chain in (1, 2), wide_chain == 1
+        return {"fwd": {"valu_fp32": 0 if fwd_mfma else 12, "mfma_fp32_equiv": 24 if fwd_mfma else 8, "mfma_products": 3 if fwd_mfma else hyp,
+                        "eliminated": 0 if fwd_mfma else 4,
+                        "what": ("k_fwd_chain16: Q u and s R u as f16x2-split operands on the matrix cores (three products; the identity part and "
+                                 "everything behind the mat-vec in float32)" if fwd_mfma else
+                                 "k_fwd_wide: merged (Q + s R) u as fp32 v_pk_fma chains, 8 + 4 forming it") +
+                                "; k_hy_wide: H y for all (clip, step) pairs as a split-operand GEMM; k_loss_wide: the sequential float32 loss sums"},
+                "bwd": {"valu_fp32": 0 if bwd_mfma else 12, "mfma_fp32_equiv": 40 if bwd_mfma else 24, "mfma_products": prod,
+                        "eliminated": 16 if bwd_mfma else 20,
+                        "what": ("k_bwd_chain16: Q ybar and s R^dagger ybar as f16x2-split operands on the matrix cores" if bwd_mfma else
+                                 "k_bwd_wide: merged (Q + s R^dagger) ybar on the VALU") +
+                                "; k_grad_gemm: rank-1 sums as split-operand GEMMs (three bf16, two bf16 or two fp16 pieces); H y from the stash"}}
     if variant == V_PAIR:
         return {"fwd": {"valu_fp32": 0, "mfma_fp32_equiv": 24, "mfma_products": 1, "eliminated": 0, "what": "R u, Q u (16x16x32 bf16), H y (32x32x16 bf16)"},
                 "bwd": {"valu_fp32": 0, "mfma_fp32_equiv": 40, "mfma_products": 1, "eliminated": 16,
@@ -308,8 +410,12 @@ KERNEL_NAMES = {
                "k_bwd_wave16 (reverse scan, 16-row layout: chain wave + gradient wave)"),
     "pair": ("k_fwd_pair", "k_fwd_pair (forward scan: 16x16x32 bf16 MFMA chain waves + 32x32x16 loss waves, eight steps per tile)", "k_bwd_pair",
              "k_bwd_pair + k_grad_gemm<1 piece> (reverse scan + streaming gradient GEMM)"),
-    "wide": ("k_fwd_wide", "k_fwd_wide + k_hy_wide + k_loss_wide (float32 forward chain, R / Q register resident; H y as a split-bf16 GEMM)", "k_bwd_wide",
-             "k_bwd_wide + k_grad_gemm<3 pieces> (float32 reverse scan + split-bf16 gradient GEMM)"),
+    "wide": ("k_fwd_wide", "k_fwd_wide + k_hy_wide + k_loss_wide (float32 forward chain on the VALU, R / Q register resident; H y as a split-operand GEMM)",
+             "k_bwd_wide", "k_bwd_wide + k_grad_gemm (float32 reverse scan on the VALU + split-operand gradient GEMM)"),
+    "wide_mfma": ("k_fwd_chain16", "k_fwd_chain16 + k_hy_wide + k_loss_wide (forward chain: f16x2-split operands on the matrix cores; H y as a split-operand GEMM)",
+                  "k_bwd_chain16", "k_bwd_chain16 + k_grad_gemm (reverse chain: f16x2-split operands on the matrix cores + split-operand gradient GEMM)"),
+    "wide_mfma_fwd": ("k_fwd_chain16", "k_fwd_chain16 + k_hy_wide + k_loss_wide (forward chain on the matrix cores)",
+                      "k_bwd_wide", "k_bwd_wide + k_grad_gemm (reverse chain on the VALU: the A/B setting)"),
     "block": ("k_fwd_block", "k_fwd_block", "k_bwd_block", "k_bwd_block"),
 }
 
@@ -393,20 +499,20 @@ def kernel_records(fam, D, T, B, rank1, ktimes):
     return recs
 
 
-def roofline_record(D, T, B, variant, rank1, t_fwd, t_bwd, ms_per_step, ktimes=None):
+def roofline_record(D, T, B, variant, rank1, t_fwd, t_bwd, ms_per_step, ktimes=None, wide_chain=1):
     """The contract's roofline object for the dominant kernel + the per-pipe split of what is executed + the step's traffic."""
     N = T - 1
     units = float(B) * N
     fam = family_of(variant, D)
-    pmc_f, name_f, pmc_b, name_b = KERNEL_NAMES[fam]
+    pmc_f, name_f, pmc_b, name_b = KERNEL_NAMES[fam if fam != "wide" else {0: "wide", 1: "wide_mfma", 2: "wide_mfma_fwd"}[wide_chain]]
     pair = variant == V_PAIR
     peak = BF16_PEAK_TFLOPS if pair else FP32_PEAK_TFLOPS
-    split = executed_split(variant, D, rank1)
+    split = executed_split(variant, D, rank1, wide_chain)
     alg = {"fwd": 24.0 * D * D * units, "bwd": 56.0 * D * D * units}
     tt = {"fwd": t_fwd, "bwd": t_bwd}
     dom = "fwd" if t_fwd >= t_bwd else "bwd"
     oth = "bwd" if dom == "fwd" else "fwd"
-    doc = profile_summary(D, T, B, variant)
+    doc = profile_summary(D, T, B, variant, wide_chain)
 
     def pipes(which):
         sp = split[which]
@@ -469,16 +575,20 @@ def roofline_record(D, T, B, variant, rank1, t_fwd, t_bwd, ms_per_step, ktimes=N
             "bound": "mfma",
             "binding": ("one LDS round trip (store latency + barrier + operand burst) + 512 matrix-pipe cycles + the dependent tail per step of "
                         "ONE wave per SIMD") if pair else
-                       "instruction issue of the float32 chain kernels (two waves per SIMD); the GEMM kernels sit at what hides behind an MFMA",
+                       ("instruction issue of the float32 VALU chain kernels (two waves per SIMD); the GEMM kernels sit at what hides behind an MFMA"
+                        if wide_chain == 0 else
+                        "serial chain of ONE wave per SIMD: the matrix pipe is busy ~60 % of a step (f16x2-split products, half the A rows "
+                        "padding), the rest is the LDS round trip + barrier + dependent tail; the GEMM kernels sit at their operand builds"),
             "kernel": top["kernel"] if top else (name_f if dom == "fwd" else name_b),
             "pipe": top["pipe"] if top else None,
             "achieved": top["achieved"] if top else None, "peak": top["peak"] if top else peak, "unit": "TFLOP/s",
             "frac": top["frac"] if top else None,
-            "frac_is": "EXECUTED flops of the longest kernel on the pipe it runs on / its live launch time / that pipe's peak (`kernels` has "
-                       "every kernel and pipe of the family, HBM included)",
+            "frac_is": "EXECUTED (as issued) flops of the longest kernel on its pipe / live launch time / that pipe's peak (roofline_detail.kernels: "
+                       "every kernel and pipe, HBM included)",
             "launch_ms": top["duration_ms"] if top else tt[dom] * 1e3,
             "traffic": traffic, "traffic_source": doc["_source"] if doc is not None else None,
             "algorithmic_bytes": 4.0 * B * T,
+            "whole_step_frac_algorithmic": None,
             "kernels": krecs,
             "algorithmic": {"flops_per_step": alg["fwd"] + alg["bwd"], "whole_step_tflops": whole_alg,
                             "fwd_entry_tflops": alg["fwd"] / t_fwd / 1e12, "bwd_entry_tflops": alg["bwd"] / t_bwd / 1e12,
@@ -492,13 +602,16 @@ def roofline_record(D, T, B, variant, rank1, t_fwd, t_bwd, ms_per_step, ktimes=N
     ach = alg[dom] / tt[dom] / 1e12
     whole = (alg["fwd"] + alg["bwd"]) / (1e-3 * ms_per_step) / 1e12
     return {
-        "bound": "mfma",            # the contract's class for a compute-bound kernel (the other class is "hbm"): see `binding`
+        # compute bound, but not by the matrix cores: what binds is the instruction issue of one wave per SIMD (`binding`), so the
+        # contract's "mfma" class would mislabel it; the peak is the fp32 vector rate (= the f32-input MFMA rate)
+        "bound": "valu-issue",
         "binding": ("instruction issue of ONE wave per SIMD: fp32 VALU mat-vecs on the serial chain, rank-1 / loss products beside them on "
-                    "the matrix cores; 10 D^2 algorithmic flop per algorithmic byte, so never HBM") if not pair else
-                   "one LDS round trip (store latency + barrier + operand burst) + 512 matrix-pipe cycles + the dependent tail per step of ONE wave per SIMD",
-        "kernel": name_f if dom == "fwd" else name_b, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-        "frac_is": "ALGORITHMIC flops (SURVEY 8(d)) / launch time / peak: includes work the kernel eliminates or runs on the other pipe; "
-                   "`executed` has the per-pipe rates",
+                    "the matrix cores; 10 D^2 algorithmic flop per algorithmic byte, so never HBM"),
+        "kernel": name_f if dom == "fwd" else name_b, "pipe": "valu_fp32 (+ matrix cores for the off-chain products)",
+        "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+        "frac_is": "ALGORITHMIC flops (SURVEY 8d: 56 D^2 bwd, 24 D^2 fwd per clip-sample) / live launch time / fp32 vector peak; counts work the "
+                   "kernel eliminates or runs on the matrix cores (roofline_detail.executed: per-pipe rates)",
+        "whole_step_frac_algorithmic": whole / peak,
         "traffic": traffic, "traffic_source": doc["_source"] if doc is not None else None,
         "algorithmic_bytes": 4.0 * B * T, "launch_ms": tt[dom] * 1e3, "flops_per_launch": alg[dom],
         "executed": pipes(dom),
@@ -544,6 +657,7 @@ class Run:
         self.trainer = Trainer(self.model, self.hp, dp, device_step=not host_optimizer)
         self.host_optimizer = host_optimizer
         self.variant = int(self.backend.variant)
+        self.wide_chain = int(self.backend.wide_chain)               # CMPS_OPT_WIDE_CHAIN of this handle (matters for V_WIDE only)
 
     def step(self):
         if self.host_optimizer:
@@ -628,21 +742,29 @@ class Run:
                 "against": "oracle/cmps_oracle.c float32 (parity UNPINNED: no reference-held vectors exist)"}
 
 
-def dtype_label(variant, D, rank1):
+def dtype_label(variant, D, rank1, wide_chain=1):
+    """The arithmetic the path computes in (a label, not a precision claim); `arithmetic_note` has the long form."""
     if variant == V_PAIR:
-        return "bf16 (mat-vec operands; fp32 state and accumulate)"
-    if variant in (V_WAVE, V_WAVE32) and not (variant == V_WAVE and D <= 16):
-        tail = {1: "rank-1 gradient sums: bf16x2 split, 16 operand bits", 0: "rank-1 gradient sums: exact fp32 MFMA",
-                2: "rank-1 gradient sums: the same bf16x3 split",
-                3: "rank-1 gradient sums: f16x2 split (power-of-two scales per eight-step octet from a guaranteed bound, 24 operand bits: bf16x3's accuracy class at half the products)"}[rank1]
-        return ("f32 (fp32 FMA chains on the serial path; loss product H y: bf16x3-split operands on the matrix cores, fp32 accumulate; "
-                + tail + ")")
-    if variant == V_WIDE:
-        return ("f32 (fp32 FMA chains for every mat-vec; rank-1 gradient sums: " +
-                {1: "bf16x2-split operands (16 bits)", 2: "bf16x3-split operands (24 bits, fp32-faithful)",
-                 3: "f16x2-split operands (scaled, 24 bits: bf16x3's accuracy class at half the products)"}[rank1] +
-                " on the matrix cores, fp32 accumulate)")
+        return "bf16 operands, f32 state and accumulate"
+    if variant == V_WIDE and wide_chain != 0:
+        return "f32 (mat-vecs as f16x2-split operands on the matrix cores, f32 accumulate)"
     return "f32"
+
+
+def arithmetic_note(variant, D, rank1, wide_chain=1):
+    if variant == V_PAIR:
+        return "bf16 mat-vec operands on v_mfma_f32_16x16x32_bf16; fp32 state, identity part and accumulate"
+    split = {0: "exact fp32 MFMA", 1: "bf16x2 split (16 operand bits)", 2: "bf16x3 split (24 operand bits)",
+             3: "f16x2 split (scaled, 24 operand bits)"}[rank1]
+    if variant in (V_WAVE, V_WAVE32) and not (variant == V_WAVE and D <= 16):
+        return "fp32 FMA chains on the serial path; off-chain products on the matrix cores, fp32 accumulate: H y bf16x3 split, rank-1 sums " + split
+    if variant == V_WAVE:
+        return "fp32 FMA chains; rank-1 gradient sums as exact fp32 MFMAs (16-row layout)"
+    if variant == V_WIDE:
+        chain = {0: "serial chains: fp32 v_pk_fma (VALU)", 1: "serial chains (forward and reverse): scaled f16x2-split mat-vec operands on the "
+                 "matrix cores, fp32 identity part and accumulate", 2: "forward chain: scaled f16x2-split operands on the matrix cores; reverse chain: fp32 VALU"}[wide_chain]
+        return chain + "; H y and rank-1 gradient GEMMs: " + split + ", fp32 accumulate"
+    return "plain fp32 FMA code"
 
 
 def other_config_rows(ARGS, dp, dev):
@@ -651,17 +773,18 @@ def other_config_rows(ARGS, dp, dev):
     import torch
     rows = []
     cores = host_cores()
-    for name, D, T, B, variant, steps, cid in (
-            ("configs[0] shape: D=4, T=256, batch 8", 4, 256, 8, 0, 20, 1),
-            ("configs[1]: D=16, T=4096, batch 256", 16, 4096, 256, 0, 10, 2),
-            ("configs[4] in float32: D=128, T=16000, batch 512 (wide kernels)", 128, 16000, 512, 0, 3, 5),
-            ("configs[4] as named (bf16 operands, fp32 accumulate): pair kernels", 128, 16000, 512, V_PAIR, 3, 5)):
+    for key, name, D, T, B, variant, steps, cid in (
+            ("c0", "configs[0] shape: D=4, T=256, batch 8", 4, 256, 8, 0, 20, 1),
+            ("c1", "configs[1]: D=16, T=4096, batch 256", 16, 4096, 256, 0, 10, 2),
+            ("c4_f32", "configs[4] in float32: D=128, T=16000, batch 512 (wide kernels)", 128, 16000, 512, 0, 3, 5),
+            ("c4_bf16", "configs[4] as named (bf16 operands, fp32 accumulate): pair kernels", 128, 16000, 512, V_PAIR, 3, 5)):
         run = None
         try:
             run = Run(D, T, B, variant, ARGS.rank1, ARGS.input, dp, dev, 1, 0, ARGS.host_optimizer, config_id=cid)
             r = run.timed(steps, 2)
             ms = 1e3 * r["elapsed"] / steps
-            roof = roofline_record(D, T, B, run.variant, run.backend.effective_rank1, r["t_fwd"], r["t_bwd"], ms, run.kernel_pass(2))
+            roof = roofline_record(D, T, B, run.variant, run.backend.effective_rank1, r["t_fwd"], r["t_bwd"], ms, run.kernel_pass(2),
+                                   run.wide_chain)
             clips = min(B, 16)
             sample = make_audio_host(ARGS.input, clips, T, run.hp.delta_t, run.seed)
             run.trainer.sync_to_host()
@@ -669,8 +792,10 @@ def other_config_rows(ARGS, dp, dev):
             ref = oracle_on(run.model, sample, cores)
             cpu_s = time.perf_counter() - t0
             par = run.parity(sample, ref, run.variant == V_PAIR)
-            rows.append({"config": name, "ms_per_step": ms, "value": B * T * steps / r["elapsed"], "unit": "samples/s", "steps": steps,
-                         "kernel_variant": run.variant, "dtype": dtype_label(run.variant, D, run.backend.effective_rank1),
+            rows.append({"key": key, "config": name, "ms_per_step": ms, "value": B * T * steps / r["elapsed"], "unit": "samples/s", "steps": steps,
+                         "kernel_variant": run.variant, "dtype": dtype_label(run.variant, D, run.backend.effective_rank1, run.wide_chain),
+                         "arithmetic": arithmetic_note(run.variant, D, run.backend.effective_rank1, run.wide_chain),
+                         "wide_chain": run.wide_chain if run.variant == V_WIDE else None,
                          "fwd_ms": r["t_fwd"] * 1e3, "bwd_ms": r["t_bwd"] * 1e3, "final_loss": r["last"],
                          "dominant_kernel": roof["kernel"], "dominant_pipe": roof.get("pipe", "valu_fp32 (algorithmic flops, see roofline.frac_is)"),
                          "frac": roof["frac"], "peak": roof["peak"], "kernels": roof.get("kernels"),
@@ -679,7 +804,8 @@ def other_config_rows(ARGS, dp, dev):
                          "cpu_port": {"value": clips * T / cpu_s, "unit": "samples/s", "cores": cores, "sample": f"{clips} clips, {cpu_s:.2f} s"},
                          "parity_in_bench": par})
         except Exception as exc:                                      # a failing side configuration must not take the headline down
-            rows.append({"config": name, "error": f"{type(exc).__name__}: {exc}"})
+            rows.append({"key": key, "config": name, "error": f"{type(exc).__name__}: {exc}"})
+        emit_detail("other_config:" + key, rows[-1])                 # one line per configuration, as soon as it is known
         del run
         torch.cuda.empty_cache()
     return rows
@@ -708,7 +834,7 @@ def worker(ARGS):
 
     D, T, B = ARGS.bond_dim, ARGS.T, ARGS.batch_per_gpu
     run = Run(D, T, B, ARGS.variant, ARGS.rank1, ARGS.input, dp, dev, world, rank, ARGS.host_optimizer)
-    variant, rank1 = run.variant, run.backend.effective_rank1
+    variant, rank1, wide_chain = run.variant, run.backend.effective_rank1, run.wide_chain
     r = run.timed(ARGS.steps, ARGS.warmup)
     if not np.isfinite(r["last"]):
         raise SystemExit(f"non-finite loss {r['last']}")
@@ -723,6 +849,7 @@ def worker(ARGS):
     rccl_world = dp.measured_world_size()                        # dist.get_world_size() after a GPU all-reduce of ones
 
     out = None
+    details = []
     pair = variant == V_PAIR
     fam = family_of(variant, D)
     if rank == 0:
@@ -731,26 +858,33 @@ def worker(ARGS):
         cfg_name = BASELINE_CONFIGS.get((D, T, B), "custom shape")
         if world > 1 and (D, T, B) == (32, 16000, 1024):
             cfg_name = "BASELINE configs[3] (configs[2] per GPU)" if world == 8 else f"BASELINE configs[2] per GPU x {world}"
+        roof = roofline_record(D, T, B, variant, rank1, r["t_fwd"], r["t_bwd"], ms_per_step, ktimes, wide_chain)
+        details.append(emit_detail("roofline_detail", roof))
+        settings = collective_settings()
         out = {
             "metric": f"audio samples/sec (fwd+bwd) at D={D}, T={T}",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": ARGS.steps, "warmup": ARGS.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": dtype_label(variant, D, rank1), "data": "synthetic",
+            "dtype": dtype_label(variant, D, rank1, wide_chain), "data": "synthetic",
             "config": {"workload": f"{cfg_name}: PsiCMPS fwd+bwd scan, D={D}, T={T}, batch {B} per GPU"
                                    f" (global {B * world}), input {ARGS.input}, full optimiser step "
                                    f"({'host numpy' if ARGS.host_optimizer else 'device-resident'} chain rule + Adam)",
                        "parallelism": f"dp{world}", "kernel_variant": variant, "kernel_family": fam, "input": ARGS.input,
                        "optimizer_step": "host" if ARGS.host_optimizer else "device (cmps_psi_apply_step)",
-                       "rank1_updates": (("exact fp32 MFMA (16-row layout)" if fam == "wave16" else RANK1_LABEL[rank1])
-                                         if fam in ("wave", "wave16", "wide") else None)},
-            "roofline": roofline_record(D, T, B, variant, rank1, r["t_fwd"], r["t_bwd"], ms_per_step, ktimes),
+                       "arithmetic": arithmetic_note(variant, D, rank1, wide_chain),
+                       "rank1_updates": (("exact_f32 (16-row layout)" if fam == "wave16" else {v: k for k, v in RANK1_MODES.items()}[rank1])
+                                         if fam in ("wave", "wave16", "wide") else None),
+                       "wide_chain": ({0: "valu", 1: "mfma", 2: "mfma_fwd"}[wide_chain] if fam == "wide" else None)},
+            "roofline": compact_roofline(roof),
+            "fwd_ms": r["t_fwd"] * 1e3, "bwd_ms": r["t_bwd"] * 1e3,
             "final_loss": float(r["last"]),
             "per_rank_ms_per_step": {"min": float(np.min(per_rank_ms)), "max": float(np.max(per_rank_ms))},
             "rccl_world_size": rccl_world,
             "allreduce_us": allreduce_us,
             "collective_backend": dp.backend,                    # "nccl" (= RCCL), "gloo" (rehearsal) or None (N = 1 in process)
             "collective": {"message_bytes": 4 * (2 * D * D + 3 * D + 2), "calls_per_step": 1, "op": "all_reduce(sum), in place on the device buffer",
-                           "settings": collective_settings(), "replicas_bit_identical_after_run": replicas_ok},
+                           "settings": {k: v for k, v in sorted(settings.items()) if v is not None},
+                           "replicas_bit_identical_after_run": replicas_ok},
         }
         if ARGS.rehearse_on_one_gpu:
             out["rehearsal"] = "all ranks share cuda:0 and reduce over gloo on the host: NOT a scaling measurement"
@@ -760,7 +894,9 @@ def worker(ARGS):
         run.trainer.sync_to_host()                               # the oracle sees the variables the timed steps left behind
         cb, sample, ref = cpu_baseline(run.model, D, T, ARGS.input, seed=run.seed, clips_arg=ARGS.cpu_clips)
         out["cpu_baseline"] = cb
-        out["parity_in_bench"] = run.parity(sample, ref, pair)
+        par = run.parity(sample, ref, pair)
+        details.append(emit_detail("parity_in_bench", par))
+        out["parity_in_bench"] = compact_parity(par)
         if fam in ("wave", "wide") and not ARGS.no_precision_ab:
             ab = {}
             modes = {"exact_f32": 0, "bf16x2": 1, "bf16x3": 2, "f16x2": 3} if fam == "wave" else {"bf16x2": 1, "bf16x3": 2, "f16x2": 3}
@@ -774,20 +910,28 @@ def worker(ARGS):
                 ab[name].update({"ms_per_step": 1e3 * rr["elapsed"] / 5, "samples_per_s": B * T * 5 / rr["elapsed"],
                                  "bwd_ms": rr["t_bwd"] * 1e3, "fwd_ms": rr["t_fwd"] * 1e3})
             run.backend.set_rank1(RANK1_MODES[ARGS.rank1])
-            out["precision_ab"] = {"what": "rank-1 gradient sums (k_bwd_wave / k_grad_gemm); everything else is identical fp32 code.  All "
-                                           "modes sit in float32 reorder noise of the oracle: the label 'fp32-faithful' of bf16x3 rests on its "
-                                           "operand-bit argument (24 bits kept), not on a difference this comparison can resolve",
-                                   "headline_mode": {v: k for k, v in RANK1_MODES.items()}[rank1], "modes": ab}
+            head_mode = {v: k for k, v in RANK1_MODES.items()}[rank1]
+            details.append(emit_detail("precision_ab", {
+                "what": "rank-1 gradient sums (k_bwd_wave / k_grad_gemm); everything else is identical fp32 code.  All "
+                        "modes sit in float32 reorder noise of the oracle: the label 'fp32-faithful' of bf16x3 rests on its "
+                        "operand-bit argument (24 bits kept), not on a difference this comparison can resolve",
+                "headline_mode": head_mode, "modes": ab}))
+            out["precision_ab"] = {"headline_mode": head_mode,
+                                   "grad_err_vs_f32_oracle": {k: float(f"{v['max_rel_grad_err_vs_f32_oracle']:.3g}") for k, v in ab.items()},
+                                   "ms_per_step": {k: round(v["ms_per_step"], 3) for k, v in ab.items()}}
         if (D, T, B) == (32, 16000, 1024):
-            out["cpu_baseline"]["reference_style"] = cpu_reference_style()
+            details.append(emit_detail("reference_style", cpu_reference_style()))
             if not ARGS.no_other_configs:
                 del run
                 torch.cuda.empty_cache()
-                out["other_configs"] = other_config_rows(ARGS, dp, dev)
+                rows = other_config_rows(ARGS, dp, dev)
+                details += ["other_config:" + row["key"] for row in rows]
+                out["other_configs"] = [compact_other_config(row) for row in rows]
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        out["detail_lines"] = details                            # names of the {"detail": ...} lines printed above this one
+        print(headline_line(out), flush=True)                    # the LAST stdout line: the contract's record
     dp.barrier()
     dp.close()
 

@@ -188,12 +188,21 @@ def test_bench_runs_at_small_shapes(args):
     proc = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1"] + args,
                           capture_output=True, text=True, timeout=600)
     assert proc.returncode == 0, proc.stderr[-3000:]
-    line = json.loads(proc.stdout.strip().splitlines()[-1])
+    lines = proc.stdout.strip().splitlines()
+    # the LAST line is the contract's record and must fit the driver's record (BENCH_r04.parsed was null for a 23.5 KB line);
+    # every earlier JSON line is a {"detail": ...} object without a top-level "metric"
+    assert len(lines[-1]) < 4096, len(lines[-1])
+    line = json.loads(lines[-1])
+    earlier = [json.loads(l) for l in lines[:-1] if l.startswith("{")]
+    assert earlier and all("detail" in d and "metric" not in d for d in earlier)
+    assert sorted(line["detail_lines"]) == sorted(d["detail"] for d in earlier)
+    assert "roofline_detail" in line["detail_lines"] and "parity_in_bench" in line["detail_lines"]
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                 "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in line, key
-    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for key in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "algorithmic_bytes"):
         assert key in line["roofline"], key
+    assert "kernels" not in line["roofline"] and "workload" in line["config"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in line["cpu_baseline"], key
     assert line["steps"] == 2 and line["n_gpus"] == 1 and line["value"] > 0

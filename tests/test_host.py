@@ -276,3 +276,56 @@ def test_crc32c_native_matches_python_and_known_answer():
     data = np.random.default_rng(3).integers(0, 256, 4099, dtype=np.uint8).tobytes()
     assert t.crc32c(data) == t._crc32c_python(data)
     assert t.crc32c(b"") == 0
+
+
+def test_bench_headline_is_compact(capsys, tmp_path, monkeypatch):
+    """bench.py's LAST stdout line must fit the driver's record (BENCH_r04.json.parsed was null for a 23.5 KB line): the headline
+    formatter keeps the contract's keys, drops the per-kernel tables, and never exceeds HEADLINE_LIMIT; details are separate
+    {"detail": ...} lines without a top-level "metric"."""
+    import json
+    import bench
+    monkeypatch.setattr(bench, "DETAIL_DIR", str(tmp_path / "detail"))
+    ktimes = {"k_fwd_wave2": (13.5, 3), "k_bwd_wave": (18.6, 3), "k_reduce_slabs": (0.1, 3), "k_finalize": (0.02, 3)}
+    roof = bench.roofline_record(32, 16000, 1024, bench.V_WAVE, 3, 4.5e-3, 6.2e-3, 10.8, ktimes)
+    assert roof["bound"] == "valu-issue" and roof["kernels"]
+    name = bench.emit_detail("roofline_detail", roof)
+    printed = capsys.readouterr().out.strip().splitlines()
+    assert name == "roofline_detail" and len(printed) == 1
+    d = json.loads(printed[0])
+    assert d["detail"] == "roofline_detail" and "metric" not in d and d["data"]["kernels"]
+    assert (tmp_path / "detail" / "roofline_detail.json").exists()
+    comp = bench.compact_roofline(roof)
+    for key in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "algorithmic_bytes"):
+        assert key in comp, key
+    assert "kernels" not in comp and "executed" not in comp and "step_traffic" not in comp
+    assert comp["frac"] == pytest.approx(56 * 32 * 32 * 1024 * 15999 / 6.2e-3 / 1e12 / 157.3, rel=1e-9)
+    par = {"clips": 128, "max_rel_loss_err": 1e-6, "max_rel_loss_err_unfloored": 1e-6, "loss_err_note": "x" * 500, "max_rel_grad_err": 5e-5,
+           "grad_err_by_tensor": {"Rbar": 1e-6}, "tolerance": {"loss": 1e-5, "grad": 1e-4}, "ok": True, "against": "oracle " * 40}
+    row = {"config": "configs[4] in float32: D=128, T=16000, batch 512 (wide kernels)", "ms_per_step": 43.1234567, "value": 1.9e8,
+           "dtype": bench.dtype_label(bench.V_WIDE, 128, 3, 1), "dominant_kernel": "k_bwd_chain16", "frac": 0.43, "kernels": [roof] * 5,
+           "parity_in_bench": par}
+    out = {"metric": "audio samples/sec (fwd+bwd) at D=32, T=16000", "value": 1.5e9, "unit": "samples/s", "n_gpus": 1, "steps": 20,
+           "warmup": 5, "ms_per_step": 10.8, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": bench.dtype_label(bench.V_WAVE, 32, 3), "data": "synthetic",
+           "config": {"workload": "w" * 250, "parallelism": "dp1", "arithmetic": bench.arithmetic_note(bench.V_WAVE, 32, 3)},
+           "roofline": comp, "cpu_baseline": {"value": 1.7e6, "unit": "samples/s", "cores": 16, "kind": "port", "sample": "s" * 100},
+           "parity_in_bench": bench.compact_parity(par),
+           "other_configs": [bench.compact_other_config(row)] * 4 + [bench.compact_other_config({"config": "c", "error": "e" * 900})],
+           "collective": {"settings": {"NCCL_PROTO": "LL"}}, "detail_lines": ["roofline_detail"] * 9}
+    line = bench.headline_line(out)
+    assert len(line) < 4096 and len(line) <= bench.HEADLINE_LIMIT
+    back = json.loads(line)
+    assert back["roofline"]["frac"] == comp["frac"] and back["cpu_baseline"]["kind"] == "port" and len(back["other_configs"]) == 5
+    # too long: optional keys go, the contract's keys stay; hopeless: an error, never a silent over-long line
+    out["other_configs"] = [{"config": "c" * 300}] * 30
+    back = json.loads(bench.headline_line(out))
+    assert "other_configs" in back["dropped_for_size"] and "roofline" in back and "cpu_baseline" in back
+    out["config"]["workload"] = "w" * 5000
+    with pytest.raises(RuntimeError):
+        bench.headline_line(out)
+    # the wide family's labels follow CMPS_OPT_WIDE_CHAIN (ADVICE r4)
+    assert "matrix cores" in bench.dtype_label(bench.V_WIDE, 128, 3, 1) and bench.dtype_label(bench.V_WIDE, 128, 3, 0) == "f32"
+    assert "VALU" in bench.arithmetic_note(bench.V_WIDE, 128, 3, 0) and "f16x2" in bench.arithmetic_note(bench.V_WIDE, 128, 3, 1)
+    rw = bench.roofline_record(128, 16000, 512, bench.V_WIDE, 3, 18e-3, 25e-3, 43.0,
+                               {"k_fwd_chain16": (27.0, 2), "k_bwd_chain16": (31.0, 2), "k_grad_gemm<f16x2>": (17.0, 2)}, 1)
+    assert rw["kernel"] == "k_bwd_chain16" and rw["bound"] == "mfma" and "chain16" in bench.executed_split(bench.V_WIDE, 128, 3, 1)["bwd"]["what"]
