@@ -14,6 +14,7 @@ CMPS_ERR_UNSUPPORTED_D = 2
 CMPS_ERR_WORKSPACE = 3
 CMPS_ERR_HIP = 4
 CMPS_ERR_STATE = 5
+CMPS_ERR_F16_RANGE = 6
 
 CMPS_WS_FWD_ONLY = 0
 CMPS_WS_TRAIN = 1
@@ -35,6 +36,7 @@ CMPS_RANK1_BF16X3 = 2
 CMPS_RANK1_F16X2 = 3
 CMPS_RANK1_DEFAULT = 4
 CMPS_OPT_WIDE_CHAIN = 3
+CMPS_OPT_F16_SCALE_SHIFT = 4
 CMPS_WIDE_CHAIN_VALU = 0
 CMPS_WIDE_CHAIN_MFMA = 1
 CMPS_WIDE_CHAIN_MFMA_FWD = 2
@@ -45,7 +47,7 @@ SYMBOLS = (
     "cmps_version", "cmps_create", "cmps_destroy", "cmps_last_error", "cmps_set_variant",
     "cmps_get_variant", "cmps_set_option", "cmps_get_option", "cmps_kernel_times", "cmps_workspace_bytes", "cmps_set_params", "cmps_set_params_dev",
     "cmps_apply_step_scratch_bytes", "cmps_psi_apply_step", "cmps_psi_loss_fwd",
-    "cmps_psi_loss_bwd", "cmps_psi_update_ancilla", "cmps_psi_states", "cmps_psi_sample",
+    "cmps_psi_loss_bwd", "cmps_psi_grad_status", "cmps_psi_update_ancilla", "cmps_psi_states", "cmps_psi_sample",
     "cmps_legacy_set_params", "cmps_legacy_loss_fwd", "cmps_legacy_loss_bwd",
     "cmps_rho_workspace_bytes", "cmps_rho_set_state", "cmps_rho_loss_fwd", "cmps_rho_loss_bwd",
     "cmps_rho_update_ancilla", "cmps_rho_sample", "cmps_rho_states", "cmps_crc32c",
@@ -95,6 +97,8 @@ def _declare(lib):
     lib.cmps_psi_loss_fwd.restype = c_int
     lib.cmps_psi_loss_bwd.argtypes = [vp, vp, c_int, c_int, vp, vp]
     lib.cmps_psi_loss_bwd.restype = c_int
+    lib.cmps_psi_grad_status.argtypes = [vp, ctypes.POINTER(c_int), vp]
+    lib.cmps_psi_grad_status.restype = c_int
     lib.cmps_psi_update_ancilla.argtypes = [vp, vp, vp, c_float, c_int, vp, vp]
     lib.cmps_psi_update_ancilla.restype = c_int
     lib.cmps_psi_states.argtypes = [vp, c_int, c_int, vp, vp]

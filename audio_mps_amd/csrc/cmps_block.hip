@@ -234,6 +234,7 @@ __global__ void k_reduce_slabs(Dev P, float* __restrict__ part) {
     const size_t col = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= P.slab_floats) return;
     const int g = blockIdx.y;
+    if (col == 0 && g == 0 && P.status) P.status[0] = 0u;          // this reverse pass's flag word (k_finalize, next in stream order, sets it)
     const int per = (P.B + RPART - 1) / RPART;
     const int b0 = g * per, b1 = (b0 + per < P.B) ? b0 + per : P.B;
     double acc = 0.0;
@@ -253,6 +254,12 @@ __global__ void k_finalize(Dev P, const float* __restrict__ sums, const float* _
     const int D = P.D, DP = P.DP, DD = DP * DP;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int nthreads = gridDim.x * blockDim.x;
+    // run-time check of the split-operand arithmetic (cmps_psi_grad_status): an fp16 piece that left its scaled range is Inf, and
+    // whatever it fed is Inf / NaN here; flag bit 0 = a gradient sum is non-finite, bit 1 = the loss sum is
+    auto flag = [&](unsigned bits) {
+        if (P.status) { atomicOr(&P.status[0], bits); atomicOr(&P.status[1], bits); }
+    };
+    bool bad = false;
     for (int idx = tid; idx < D * D; idx += nthreads) {
         const int i = idx / D, j = idx % D;
         double ar = sums[i * DP + j], ai = sums[DD + i * DP + j];
@@ -265,16 +272,24 @@ __global__ void k_finalize(Dev P, const float* __restrict__ sums, const float* _
             cr += (double)rik.x * hr - (double)rik.y * hi;
             ci += (double)rik.x * hi + (double)rik.y * hr;
         }
-        grad_out[idx] = (float)(ar + (double)P.c_half * cr);
-        grad_out[D * D + idx] = (float)(ai + (double)P.c_half * ci);
+        const float gr = (float)(ar + (double)P.c_half * cr), gi = (float)(ai + (double)P.c_half * ci);
+        grad_out[idx] = gr;
+        grad_out[D * D + idx] = gi;
+        bad |= !(isfinite(gr) && isfinite(gi));
     }
     for (int d = tid; d < D; d += nthreads) {
-        grad_out[2 * D * D + d] = sums[4 * DD + d];
-        grad_out[2 * D * D + D + d] = sums[4 * DD + DP + d];
-        grad_out[2 * D * D + 2 * D + d] = sums[4 * DD + 2 * DP + d];
+        const float a = sums[4 * DD + d], b = sums[4 * DD + DP + d], c = sums[4 * DD + 2 * DP + d];
+        grad_out[2 * D * D + d] = a;
+        grad_out[2 * D * D + D + d] = b;
+        grad_out[2 * D * D + 2 * D + d] = c;
+        bad |= !(isfinite(a) && isfinite(b) && isfinite(c));
     }
+    if (__any(bad) && (threadIdx.x & 63) == 0) flag(1u);
     if (!P.abar_fix) {
-        if (tid == 0) grad_out[2 * D * D + 3 * D] = sums[4 * DD + 3 * DP];
+        if (tid == 0) {
+            grad_out[2 * D * D + 3 * D] = sums[4 * DD + 3 * DP];
+            if (!isfinite(sums[4 * DD + 3 * DP])) flag(1u);
+        }
     } else if (blockIdx.x == 1 && threadIdx.x < 64) {
         // sum_k Re(u_k^dagger Q ybar_k) = Re sum_ij Q_ij Qbar_ji with Qbar = sum_k ybar_k u_k^dagger (sums[2 DD ...], [3 DD ...])
         double p = 0.0;
@@ -285,14 +300,21 @@ __global__ void k_finalize(Dev P, const float* __restrict__ sums, const float* _
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) p += __shfl_xor(p, off, 64);
-        if (threadIdx.x == 0) grad_out[2 * D * D + 3 * D] = (float)((double)sums[4 * DD + 3 * DP] + p / (double)dev_A(P));
+        if (threadIdx.x == 0) {
+            const float ga = (float)((double)sums[4 * DD + 3 * DP] + p / (double)dev_A(P));
+            grad_out[2 * D * D + 3 * D] = ga;
+            if (!isfinite(ga)) flag(1u);
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x < 64) {      // sum_b loss_b: one wave, strided partials then a fixed-order tree
         double ls = 0.0;
         for (int b = threadIdx.x; b < P.B; b += 64) ls += (double)loss[b];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) ls += __shfl_xor(ls, off, 64);
-        if (threadIdx.x == 0) grad_out[2 * D * D + 3 * D + 1] = (float)ls;
+        if (threadIdx.x == 0) {
+            grad_out[2 * D * D + 3 * D + 1] = (float)ls;
+            if (!isfinite((float)ls)) flag(2u);
+        }
     }
 }
 

@@ -18,6 +18,7 @@ struct cmps_handle_s {
     int variant_req = CMPS_VARIANT_AUTO;
     int rank1_mode = CMPS_RANK1_DEFAULT;
     int wide_chain = CMPS_WIDE_CHAIN_MFMA;
+    int f16_shift = 0;         // CMPS_OPT_F16_SCALE_SHIFT (diagnostic)
     bool params_set = false;
     bool legacy = false;       // the tables currently hold the legacy AudioMPS arithmetic (cmps_legacy_set_params)
     bool fwd_saved = false;
@@ -138,6 +139,11 @@ int cmps_set_option(cmps_handle_t h, int option, int value) {
         h->wide_chain = value;
         return CMPS_OK;
     }
+    if (option == CMPS_OPT_F16_SCALE_SHIFT) {
+        if (value < -40 || value > 40) return fail(h, CMPS_ERR_BAD_ARG, "cmps_set_option: CMPS_OPT_F16_SCALE_SHIFT takes -40 .. 40");
+        h->f16_shift = value;
+        return CMPS_OK;
+    }
     if (option == CMPS_OPT_KERNEL_EVENTS) {
         if (value != 0 && value != 1) return fail(h, CMPS_ERR_BAD_ARG, "cmps_set_option: CMPS_OPT_KERNEL_EVENTS takes 0 or 1");
         if (value && !h->ktimer) h->ktimer = new cmps::KTimer();
@@ -152,6 +158,7 @@ int cmps_get_option(cmps_handle_t h, int option) {
     if (option == CMPS_OPT_RANK1) return h->rank1_mode;
     if (option == CMPS_OPT_KERNEL_EVENTS) return h->ktimer ? 1 : 0;
     if (option == CMPS_OPT_WIDE_CHAIN) return h->wide_chain;
+    if (option == CMPS_OPT_F16_SCALE_SHIFT) return h->f16_shift;
     return -1;
 }
 
@@ -189,6 +196,7 @@ static int set_params_impl(cmps_handle_t h, const float* R_re_dev, const float* 
     P.QT = reinterpret_cast<float2*>(ws + L.off_QT);
     P.psi0 = reinterpret_cast<float2*>(ws + L.off_psi0);
     P.freqs = reinterpret_cast<float*>(ws + L.off_freqs);
+    P.qflag = reinterpret_cast<unsigned*>(ws + L.off_qflag);
     P.ttab = reinterpret_cast<float*>(ws + L.off_ttab);
     P.dtk = reinterpret_cast<float*>(ws + L.off_dtk);
     P.rho = reinterpret_cast<float2*>(ws + L.off_rho);
@@ -199,6 +207,7 @@ static int set_params_impl(cmps_handle_t h, const float* R_re_dev, const float* 
     P.opmax = ((flags & CMPS_WS_TRAIN) && L.D > 32) ? reinterpret_cast<float*>(ws + L.off_opmax) : nullptr;
     P.slabs = (flags & CMPS_WS_TRAIN) ? reinterpret_cast<float*>(ws + L.off_slabs) : nullptr;
     P.sums = (flags & CMPS_WS_TRAIN) ? reinterpret_cast<float*>(ws + L.off_sums) : nullptr;
+    P.status = (flags & CMPS_WS_TRAIN) ? reinterpret_cast<unsigned*>(ws + L.off_status) : nullptr;
     P.slab_floats = L.slab_floats;
     P.A = A;
     P.Adev = A_dev;
@@ -215,6 +224,10 @@ static int set_params_impl(cmps_handle_t h, const float* R_re_dev, const float* 
                                const_cast<float*>(P.freqs), const_cast<float2*>(P.rho),
                                reinterpret_cast<double2*>(ws + L.off_rfix), static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail_hip(h, e, "cmps_set_params");
+    if (P.status && (fresh || h->ws != ws)) {        // a workspace this handle cannot vouch for: the flag words start at zero
+        e = hipMemsetAsync(P.status, 0, 2 * sizeof(unsigned), static_cast<hipStream_t>(stream));
+        if (e != hipSuccess) return fail_hip(h, e, "cmps_set_params (status words)");
+    }
     h->tt_ws = ws; h->tt_N = L.N; h->tt_dt = dt;
     h->L = L; h->P = P; h->ws = ws;
     h->params_set = true;
@@ -281,7 +294,8 @@ int cmps_psi_loss_fwd(cmps_handle_t h, const float* audio_dev, int B, int T, flo
         e = launch_fwd_wave16(P, audio_dev, loss_dev, save_for_bwd != 0, s);
     } else if (variant == CMPS_VARIANT_WAVE || variant == CMPS_VARIANT_WAVE32) {
         KScope ks("k_fwd_wave2", s);
-        e = launch_fwd_wave2(P, audio_dev, loss_dev, save_for_bwd != 0, s);
+        // the loss product's pieces follow CMPS_OPT_RANK1 like the reverse scan's rank-1 sums: two fp16 pieces for F16X2 / DEFAULT
+        e = launch_fwd_wave2(P, audio_dev, loss_dev, save_for_bwd != 0, wave_rank1(h->rank1_mode) == CMPS_RANK1_F16X2, s);
     } else if (variant == CMPS_VARIANT_PAIR) {
         KScope ks("k_fwd_pair", s);
         e = launch_fwd_pair(P, audio_dev, loss_dev, save_for_bwd != 0, s);
@@ -312,6 +326,7 @@ int cmps_psi_loss_bwd(cmps_handle_t h, const float* audio_dev, int B, int T, flo
         return fail(h, CMPS_ERR_STATE, "cmps_psi_loss_bwd: audio / B / T differ from the forward call");
     Dev P = h->P;
     P.B = B;
+    P.f16_shift = h->f16_shift;
     hipStream_t s = static_cast<hipStream_t>(stream);
     // the stash layout belongs to the variant that wrote it
     KBind kb(h);
@@ -361,6 +376,26 @@ int cmps_psi_loss_bwd(cmps_handle_t h, const float* audio_dev, int B, int T, flo
     KScope ks("reduce + finalize", s);
     e = launch_reduce_finalize(P, h->saved_loss, grad_dev, s);
     if (e != hipSuccess) return fail_hip(h, e, "cmps_psi_loss_bwd (reduce)");
+    return CMPS_OK;
+}
+
+int cmps_psi_grad_status(cmps_handle_t h, int* sticky_out, void* stream) {
+    if (!h) return CMPS_ERR_BAD_ARG;
+    if (sticky_out) *sticky_out = 0;
+    if (!h->params_set || h->legacy || !h->P.status)
+        return fail(h, CMPS_ERR_STATE, "cmps_psi_grad_status: needs cmps_set_params with a CMPS_WS_TRAIN workspace");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    unsigned words[2] = {0u, 0u};
+    hipError_t e = hipMemcpyAsync(words, h->P.status, sizeof words, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemsetAsync(h->P.status + 1, 0, sizeof(unsigned), s);        // the sticky word restarts
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return fail_hip(h, e, "cmps_psi_grad_status");
+    if (sticky_out) *sticky_out = (int)words[1];
+    if ((words[0] & 1u) && !(words[0] & 2u))
+        return fail(h, CMPS_ERR_F16_RANGE,
+                    "cmps_psi_grad_status: the gradient sums of the last cmps_psi_loss_bwd hold Inf / NaN although every per-clip loss is "
+                    "finite: an fp16-split operand left its scaled range.  Fallback: CMPS_OPT_RANK1 = BF16X3, CMPS_OPT_WIDE_CHAIN = VALU, "
+                    "then repeat cmps_psi_loss_fwd / _bwd");
     return CMPS_OK;
 }
 
@@ -431,6 +466,7 @@ int cmps_legacy_set_params(cmps_handle_t h, const float* R_dev, const float* Q_r
     P.scal = (flags & CMPS_WS_TRAIN) ? reinterpret_cast<float*>(ws + L.off_scal) : nullptr;
     P.slabs = (flags & CMPS_WS_TRAIN) ? reinterpret_cast<float*>(ws + L.off_slabs) : nullptr;
     P.sums = (flags & CMPS_WS_TRAIN) ? reinterpret_cast<float*>(ws + L.off_sums) : nullptr;
+    P.status = (flags & CMPS_WS_TRAIN) ? reinterpret_cast<unsigned*>(ws + L.off_status) : nullptr;
     P.slab_floats = L.slab_floats;
     P.dt = (float)delta_t;
     // the tables of the pure-state wave kernels, which the D <= 32 legacy kernels share (cmps_wave2.hip / cmps_wave.hip, LEGACY):

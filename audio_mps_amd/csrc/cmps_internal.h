@@ -40,7 +40,7 @@ struct KScope {
 // Workspace layout (all offsets in bytes from the workspace base, every section 256-B aligned).
 //
 //   mats     : R [D][D] float2 | RT [D][D] float2 (RT[j][i] = R[i][j]) | Q [D][D] float2
-//              (Q = -(dt sigma^2 / 2) R^dagger R, Hermitian) | psi0 [D] float2 | freqs [D] float
+//              (Q = -(dt sigma^2 / 2) R^dagger R, Hermitian) | psi0 [D] float2 | freqs [D] float | qflag (|Q|_F <= 2^-19)
 //   ttab     : t_k, k = 0..N          float32, sequential sum (model.py:16,266,281)
 //   dtk      : t_k - t_{k+1}          float32 (exact), k = 0..N-1
 //   rho      : [N+1][DP] float2       rho_k[d] = exp(i (fl(f_d t_k) - fl(f_d t_{k+1}))), drift-corrected (cmps_prep.hip)
@@ -54,12 +54,14 @@ struct KScope {
 //                                     [wave][lane] (round 2 kept the five operands here in bf16, 2.5 x the bytes)
 //   slabs    : [B][slab] float        per-clip gradient partials (TRAIN only)
 //   sums     : [slab] float           reduced partials, followed by [32][slab] double first-pass partial sums
+//   status   : [2] unsigned           flag words of the last cmps_psi_loss_bwd and their OR since the last cmps_psi_grad_status
+//                                     (bit 0: a gradient sum is Inf / NaN, bit 1: the loss sum is) -- written by k_reduce_slabs / k_finalize
 // DP = D rounded up to a multiple of 32 (components >= D are zero padding and stay exactly zero).
 // ---------------------------------------------------------------------------------------------
 struct Layout {
     int D, DP, B, T, N, flags;
-    size_t off_R, off_RT, off_Q, off_QT, off_psi0, off_freqs, off_ttab, off_dtk, off_rho, off_rfix,
-        off_stash, off_hst, off_scal, off_slabs, off_sums, off_gops, off_opmax, total;
+    size_t off_R, off_RT, off_Q, off_QT, off_psi0, off_freqs, off_qflag, off_ttab, off_dtk, off_rho, off_rfix,
+        off_stash, off_hst, off_scal, off_slabs, off_sums, off_gops, off_opmax, off_status, total;
     size_t slab_floats;  // 4*DP*DP + 3*DP + 2
 };
 
@@ -80,6 +82,7 @@ inline Layout make_layout(int D, int B, int T, int flags) {
     L.off_QT = o;    o = align256(o + DP * DP * sizeof(float2));
     L.off_psi0 = o;  o = align256(o + DP * sizeof(float2));
     L.off_freqs = o; o = align256(o + DP * sizeof(float));
+    L.off_qflag = o; o = align256(o + sizeof(unsigned));
     L.off_ttab = o;  o = align256(o + (N + 1) * sizeof(float));
     L.off_dtk = o;   o = align256(o + (N + 64) * sizeof(float));
     L.off_rho = o;   o = align256(o + (N + 1) * DP * sizeof(float2));
@@ -92,6 +95,7 @@ inline Layout make_layout(int D, int B, int T, int flags) {
     L.off_sums = o;
     L.off_gops = o;
     L.off_opmax = o;
+    L.off_status = o;
     if (flags & 1) {
         // the two variants never run on the same stash: their layouts share one region
         // D > 32: the pair kernels (D = 128) keep (y, H y) per step, 16 B per component; the block kernels use half of it
@@ -110,6 +114,7 @@ inline Layout make_layout(int D, int B, int T, int flags) {
         // max |ybar| per pair (wide reverse scan -> the gradient GEMM's fp16 operand scale, CMPS_RANK1_F16X2)
         L.off_opmax = o;
         if (D > 32) o = align256(o + (size_t)((B + 1) / 2) * sizeof(float));
+        L.off_status = o; o = align256(o + 2 * sizeof(unsigned));
     }
     L.total = o;
     return L;
@@ -124,6 +129,7 @@ struct Dev {
     const float2* QT;    // [DP][DP] transpose of Q (legacy mode only)
     const float2* psi0;  // [DP]
     const float* freqs;  // [DP]
+    const unsigned* qflag;  // [1]: 1 when |Q|_F <= 2^-19 (k_qflag, once per cmps_set_params): which instance of the chain16 kernels runs
     const float* ttab;   // [N+1]
     const float* dtk;    // [N]
     const float2* rho;   // [N][DP]
@@ -142,6 +148,8 @@ struct Dev {
     const float* Adev;   // non-null: A lives in device memory (cmps_set_params_dev: device-resident optimiser step) and `A` is unset
     float dt;            // (float)delta_t (model.py:16; also the python-float factor of model.py:286)
     float c_half;        // (float)(-delta_t * sigma^2) / 2   (model.py:312)
+    unsigned* status;    // [2]: flag word of the last reverse pass | OR since the last cmps_psi_grad_status (TRAIN workspaces; else null)
+    int f16_shift;       // CMPS_OPT_F16_SCALE_SHIFT (diagnostic, 0): added to the exponent of the wave reverse scan's data-dependent fp16 scales
     int abar_fix;        // 1: the slabs' Abar holds -(sum_k Re(u^dagger (Q + s R^dagger) ybar)) / A (k_bwd_wave's merged mat-vec);
                          //    k_finalize adds Re sum_ij Q_ij Qbar_ji / A from the reduced Qbar
 };
@@ -235,7 +243,7 @@ hipError_t launch_prep(const Dev& P, const float* R_re, const float* R_im, const
 hipError_t launch_fwd_block(const Dev& P, const float* audio, float* loss, bool save, hipStream_t s);
 hipError_t launch_bwd_block(const Dev& P, const float* audio, hipStream_t s);
 hipError_t launch_bwd_wave(const Dev& P, const float* audio, int rank1_mode, hipStream_t s);
-hipError_t launch_fwd_wave2(const Dev& P, const float* audio, float* loss, bool save, hipStream_t s);
+hipError_t launch_fwd_wave2(const Dev& P, const float* audio, float* loss, bool save, bool hf16, hipStream_t s);
 hipError_t launch_fwd_wave16(const Dev& P, const float* audio, float* loss, bool save, hipStream_t s);
 hipError_t launch_bwd_wave16(const Dev& P, const float* audio, hipStream_t s);
 hipError_t launch_fwd_pair(const Dev& P, const float* audio, float* loss, bool save, hipStream_t s);

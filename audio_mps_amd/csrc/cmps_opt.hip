@@ -64,7 +64,20 @@ __global__ __launch_bounds__(ONT) void k_apply_step(OptArgs a, float* __restrict
     float* fr = Ry + DD;
     float* px = fr + D;
     float* py = px + D;
+    // A gradient with Inf / NaN in it next to a FINITE loss sum is the signature of an fp16-split operand that left its scaled range
+    // (include/cmps.h: CMPS_ERR_F16_RANGE): such a step is skipped -- variables and Adam slots stay as they are, losses[1] = NaN marks
+    // it -- instead of poisoning every variable.  The decision reads the all-reduced buffer, so every rank takes the same one.
+    bool skip = false;
     if (a.apply) {
+        int bad = 0;
+        for (int idx = t; idx < 2 * DD + 3 * D + 1; idx += ONT) bad |= !isfinite(gs[idx]);
+        skip = __syncthreads_or(bad) != 0 && isfinite(gs[2 * DD + 3 * D + 1]);
+        if (skip && t == 0) {
+            losses[0] = (float)((double)gs[2 * DD + 3 * D + 1] * a.inv_batch);
+            losses[1] = __builtin_nanf("");
+        }
+    }
+    if (a.apply && !skip) {
         // ---- regulariser terms on the CURRENT effective parameters (train.py:55-60) ----
         double sf = 0.0, sr = 0.0;
         for (int d = t; d < D; d += ONT) {

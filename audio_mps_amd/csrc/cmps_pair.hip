@@ -904,6 +904,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_fwd_chain16(Dev P, const float* _
     const float* xr0 = audio + (size_t)b0 * T;
     const float* xr1 = audio + (size_t)b1 * T;
     const float A = dev_A(P);
+    if ((*P.qflag != 0u) != QLITE) return;        // the other instance's case (decided once per parameter set: k_qflag)
 
     // ---- operand scales: max |R|, max |Q|, Frobenius norms, max |s| over the pair's clips ----
     float sR, sQ, sV;
@@ -939,7 +940,6 @@ __global__ __launch_bounds__(2 * PD, 1) void k_fwd_chain16(Dev P, const float* _
         sR = uni(gg::pow2_scale(mR, 15));
         sQ = uni(gg::pow2_scale(mQ, 15));
         sV = uni(gg::pow2_scale(1.01f * (1.0f + sqrtf(fQ) + ms * sqrtf(fR)), 13));
-        if ((sqrtf(fQ) <= 1.9073486e-6f) != QLITE) return;          // 2^-19 (uniform: every lane holds the same sums)
     }
     const float iRV = (1.0f / sR) * (1.0f / sV), iQV = (1.0f / sQ) * (1.0f / sV);    // exact: powers of two
 
@@ -1498,8 +1498,9 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_chain16(Dev P, const float* _
     const int b0 = 2 * blockIdx.x, b1 = (b0 + 1 < P.B) ? b0 + 1 : b0;
     const bool two = b1 != b0;
     const float A = dev_A(P);
+    if ((*P.qflag != 0u) != QLITE) return;        // as k_fwd_chain16
 
-    // ---- matrix scales and norms: max entries (-> fp16 scales), Frobenius norm of Q (QLITE), row sums of |Q|, |R^dagger|, |H| ----
+    // ---- matrix scales and norms: max entries (-> fp16 scales), Frobenius norm of Q, row sums of |Q|, |R^dagger|, |H| ----
     float sQ, sD, Qinf, Dinf, Hinf;
     {
         const int row0 = 32 * w + (lane0 & 31), c0 = (lane0 >> 5) * (PD / 2);
@@ -1529,7 +1530,6 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_chain16(Dev P, const float* _
             rQ = fmaxf(rQ, L.nrm[0][0][ww]); rD = fmaxf(rD, L.nrm[0][1][ww]); rH = fmaxf(rH, L.nrm[1][0][ww]);
         }
         __syncthreads();
-        if ((sqrtf(fQ) <= 1.9073486e-6f) != QLITE) return;            // as k_fwd_chain16
         auto uni = [](float x) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(x))); };
         sQ = uni(gg::pow2_scale(mQ, 15));
         sD = uni(gg::pow2_scale(mD, 15));

@@ -121,6 +121,20 @@ __global__ void k_rho_fix(int DP, int N, float2* __restrict__ rho, const double2
     }
 }
 
+// |Q|_F <= 2^-19 ?  Decided ONCE per parameter set, here; both chain kernels of the wide family (k_fwd_chain16 / k_bwd_chain16 have an
+// instance for either case) read the word.  Rounds 4's kernels each recomputed the norm in their prologue and compared it with the
+// threshold themselves: two separately compiled sums at a boundary can disagree, and then both instances run, or neither.
+__global__ void k_qflag(int DP, const float2* __restrict__ Q, unsigned* __restrict__ flag) {
+    __shared__ double red[4];
+    double f = 0.0;
+    for (int idx = threadIdx.x; idx < DP * DP; idx += 256) f += (double)Q[idx].x * Q[idx].x + (double)Q[idx].y * Q[idx].y;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) f += __shfl_xor(f, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = f;
+    __syncthreads();
+    if (threadIdx.x == 0) flag[0] = sqrt(red[0] + red[1] + red[2] + red[3]) <= 1.9073486328125e-6 ? 1u : 0u;   // 2^-19
+}
+
 hipError_t launch_prep(const Dev& P, const float* R_re, const float* R_im, const float* freqs,
                        const float* psi0_re, const float* psi0_im, float dt, bool rebuild_ttab,
                        float* ttab, float* dtk, float2* R, float2* RT, float2* Q, float2* psi0,
@@ -129,6 +143,8 @@ hipError_t launch_prep(const Dev& P, const float* R_re, const float* R_im, const
     const int n = P.DP * P.DP;
     hipLaunchKernelGGL(k_pack, dim3((n + 255) / 256), dim3(256), 0, s, P.D, P.DP, R_re, R_im, freqs,
                        psi0_re, psi0_im, P.c_half, R, RT, Q, psi0, freqs_out);
+    if (P.D > 32 && P.qflag)
+        hipLaunchKernelGGL(k_qflag, dim3(1), dim3(256), 0, s, P.DP, (const float2*)Q, const_cast<unsigned*>(P.qflag));
     const int NC = (P.N + 63) / 64;
     const int m = NC * P.DP;
     double2* prod = rfix;

@@ -205,8 +205,9 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
         }
     };
     // RANK1 == 3: scales of the chunk just committed from |ybar| of the step above it; the accumulators follow (exact ratios)
-    auto pow2_of = [](float bound) {                   // the largest power of two S with bound S < 2^15 (exponent clamped)
-        int se = 15 - ((int)((__float_as_uint(bound) >> 23) & 0xFFu) - 126);
+    const int f16_shift = P.f16_shift;                 // CMPS_OPT_F16_SCALE_SHIFT: 0 but in the test that provokes CMPS_ERR_F16_RANGE
+    auto pow2_of = [f16_shift](float bound) {          // the largest power of two S with bound S < 2^15 (exponent clamped)
+        int se = 15 + f16_shift - ((int)((__float_as_uint(bound) >> 23) & 0xFFu) - 126);
         se = se > 60 ? 60 : se < -60 ? -60 : se;
         return __uint_as_float((unsigned)(127 + se) << 23);
     };
@@ -428,7 +429,17 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
         const v2f yhbp = cmul2_conj_b(mk2(g, go), S.rho);              // conj(rho_k) g
         const float yhb = yhbp.x;
         float dot = rad_next;
-        if (exact) dot = LEGACY ? sum64(S.yhp * yhb) + rad_next : sum64(S.yhp * yhb);
+        // Only the first step of a staged chunk projects explicitly, and inside an aligned octet that can only be slot 7: the other
+        // slots carry no test at all, and the block stays a branch (sum64 is plain asm; the empty volatile asm keeps it from ever being
+        // if-converted into five DPP adds per step).  Timing-neutral (A/B in one call, profiles/r5_c3_ab_projection_branch.log: hipcc
+        // already branched around it) -- kept because it removes eight compare-and-branch pairs per octet.
+        constexpr int SLOT = decltype(slot)::value;
+        if constexpr (SLOT < 0 || SLOT == 7) {
+            if (exact) {
+                asm volatile("" ::: "memory");
+                dot = LEGACY ? sum64(S.yhp * yhb) + rad_next : sum64(S.yhp * yhb);
+            }
+        }
         rad_next = S.rad;
         const float ybar = (yhb - dot * S.yhp) * S.inv + S.pre;
         bcast_issue(aBw, aBr, ybar, qc);                               // 9 ops

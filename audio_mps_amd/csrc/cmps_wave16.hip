@@ -493,7 +493,10 @@ __global__ __launch_bounds__(128, 1) void k_bwd_wave16(Dev P, const float* __res
             const v2f yhbp = cmul2_conj_b(mk2(g, go), S.rho);              // conj(rho_k) g
             const float yhb = yhbp.x;
             float dot = rad_next;
-            if (exact) dot = 0.5f * sum64(S.yhp * yhb);
+            if (exact) {                                                   // a real branch (see cmps_wave.hip): never if-converted
+                asm volatile("" ::: "memory");
+                dot = 0.5f * sum64(S.yhp * yhb);
+            }
             rad_next = S.rad;
             const float ybar = (yhb - dot * S.yhp) * S.inv + S.pre;
             write16_off<OFF + BROW>(aL, S.yh);                             // 1 op

@@ -139,7 +139,11 @@ __device__ __forceinline__ float vmax_s(float s, float c) {     // one v_max_f32
 // y_k = inv_{k-1} (y_{k-1} + M_k y_{k-1}), M_k = Q + dt x_k R; what differs is the loss wave: e_k = psi_k^dagger H psi_k is taken on the
 // normalised state BEFORE the update, i.e. e_k = (y_{k-1}^dagger H y_{k-1}) / max(|y_{k-1}|^2, 1e-12) (e_0 = H_00), and
 // loss += (x_k - e_k)^2 / 2.  The stash rows (y_k, H y_k) and the |y_k|^2 rows are the same; the e rows hold the legacy e_k.
-template <bool SAVE, bool LEGACY = false>
+// HF16 (round 5; what CMPS_RANK1_F16X2 / DEFAULT select for the PsiCMPS arithmetic): the loss wave's GEMM with two power-of-two scaled fp16
+// pieces per operand and three products (hi hi + hi lo + lo hi on v_mfma_f32_32x32x16_f16) instead of three bf16 pieces and six: the
+// arithmetic of the wide family's k_hy_wide<f16x2>.  Scales: W from its largest entry (below 2^15), the chunk's y rows from
+// the guaranteed bound |y_k|_2 <= 1 + |Q|_F + max_chunk |s_k| |R|_F (below 2^14); one exact multiply takes them out of the accumulators.
+template <bool SAVE, bool LEGACY = false, bool HF16 = false>
 __global__ __launch_bounds__(128 * WAVES, 1) void k_fwd_wave2(Dev P, const float* __restrict__ audio,
                                                               float* __restrict__ loss_out) {
     __shared__ __attribute__((aligned(16))) float4 stR[WAVES][CH2 * 16];   // rho rows of the chain wave's chunk
@@ -309,9 +313,51 @@ __global__ __launch_bounds__(128 * WAVES, 1) void k_fwd_wave2(Dev P, const float
     // B operand: W[m][n], the real 64 x 64 form of H = R + R^dagger acting on (re, im)-interleaved vectors,
     //   (H y)[n = 2 i + c] = sum_m y[m = 2 j + c'] W[m][n]:  W = Hr_ij for c' = c,  -Hi_ij for (c', c) = (1, 0),  +Hi_ij for (0, 1).
     // Lane (col = lane & 31, hk = lane >> 5) holds W[16 s + 8 hk + e][32 t + col], e = 0..7, for tile t and k-step s.
-    unsigned WH[2][4][4], WM[2][4][4], WL[2][4][4];
+    typedef _Float16 hf8 __attribute__((ext_vector_type(8)));
+    typedef _Float16 hf2 __attribute__((ext_vector_type(2)));
+    auto split2h = [](float fe, float fo, unsigned& H, unsigned& L) {           // two fp16 pieces, round to nearest (11 + 1 + 11 + 1 bits)
+        const hf2 hh = {(_Float16)fe, (_Float16)fo};                            // plain casts: hipcc must see who produces an MFMA operand
+        const hf2 ll = {(_Float16)(fe - (float)hh.x), (_Float16)(fo - (float)hh.y)};
+        H = __builtin_bit_cast(unsigned, hh);
+        L = __builtin_bit_cast(unsigned, ll);
+    };
+    // the same for the pair p * sc (sc a power of two): ONE packed multiply, and each residual as ONE v_fma_mix_f32 (p sc - hi, the fp16
+    // half read in place); hipcc makes a v_cvt_f32_f16 + v_fma_f32 of the C form.  The asm results feed compiler-visible conversions, never
+    // an MFMA directly, so the hazard of DESIGN 4.3e cannot arise.
+    auto split2h_scaled = [](v2f p, float sc, unsigned& H, unsigned& L) {
+        const v2f t = p * mk2(sc, sc);
+        const hf2 hh = {(_Float16)t.x, (_Float16)t.y};
+        H = __builtin_bit_cast(unsigned, hh);
+        float re, ro;
+        asm("v_fma_mix_f32 %0, %2, %4, -%5 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+            "v_fma_mix_f32 %1, %3, %4, -%5 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+            : "=&v"(re), "=&v"(ro) : "v"(p.x), "v"(p.y), "v"(sc), "v"(H));
+        const hf2 ll = {(_Float16)re, (_Float16)ro};
+        L = __builtin_bit_cast(unsigned, ll);
+    };
+    auto fragh = [](const unsigned (&f)[4]) { return __builtin_bit_cast(hf8, v4u{f[0], f[1], f[2], f[3]}); };
+    unsigned WH[2][4][4], WM[HF16 ? 1 : 2][HF16 ? 1 : 4][4], WL[2][4][4];
+    float sW = 1.f, Qn = 0.f, Rn = 0.f;              // HF16: scale of W; Frobenius norms of Q and R (the bound of |y_k|)
     {
         const int col = lane & 31, hk = lane >> 5;
+        if constexpr (HF16) {
+            float mw = 0.f, q2 = 0.f, r2 = 0.f;
+            for (int idx = lane; idx < DPW * DPW; idx += 64) {
+                const float2 r = P.R[idx], rt = P.RT[idx], q = P.Q[idx];
+                mw = fmaxf(mw, fmaxf(fabsf(r.x + rt.x), fabsf(r.y - rt.y)));
+                q2 += q.x * q.x + q.y * q.y;
+                r2 += r.x * r.x + r.y * r.y;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) mw = fmaxf(mw, __shfl_xor(mw, off, 64));
+            Qn = 1.001f * sqrtf(sum64(q2));
+            Rn = 1.001f * sqrtf(sum64(r2));
+            // the largest power of two with max |W| sW < 2^15 (W = 0: any scale)
+            int se = 15 - ((int)((__float_as_uint(fmaxf(mw, 1e-30f)) >> 23) & 0xFFu) - 126);
+            se = se > 60 ? 60 : se < -60 ? -60 : se;
+            sW = __uint_as_float((unsigned)(127 + se) << 23);
+            sW = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(sW)));
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int n = 32 * t + col, ii = n >> 1, cc = n & 1;
@@ -326,7 +372,10 @@ __global__ __launch_bounds__(128 * WAVES, 1) void k_fwd_wave2(Dev P, const float
                     wv[e] = cp == cc ? hr : (cc ? hi : -hi);
                 }
 #pragma unroll
-                for (int e2 = 0; e2 < 4; ++e2) split3(wv[2 * e2], wv[2 * e2 + 1], WH[t][ks][e2], WM[t][ks][e2], WL[t][ks][e2]);
+                for (int e2 = 0; e2 < 4; ++e2) {
+                    if constexpr (HF16) split2h(wv[2 * e2] * sW, wv[2 * e2 + 1] * sW, WH[t][ks][e2], WL[t][ks][e2]);
+                    else split3(wv[2 * e2], wv[2 * e2 + 1], WH[t][ks][e2], WM[t][ks][e2], WL[t][ks][e2]);
+                }
             }
         }
     }
@@ -348,10 +397,36 @@ __global__ __launch_bounds__(128 * WAVES, 1) void k_fwd_wave2(Dev P, const float
             while (flag_load(aProd) < c + 1) __builtin_amdgcn_s_sleep(8);     // a chunk takes ~20000 cycles: poll rarely
         const float* rh = ringw + (c & 1) * (CH2 * RLD);               // this chunk's 32 rows (rows >= cnt: stale, ignored below)
         v16f acc0 = {}, acc1 = {};
+        float sY = 1.f, unsc = 1.f;
+        if constexpr (HF16) {
+            // the chunk's rows: |y_k|_inf <= |y_k|_2 <= 1 + |Q|_F + |s_k| |R|_F (inv_{k-1} |ut| <= 1); s_k of this chunk sits one step per lane
+            float smax = fabsf((x1 - x0) / A);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) smax = fmaxf(smax, __shfl_xor(smax, off, 64));
+            const float bnd = 1.001f * (1.0f + Qn + smax * Rn);
+            int se = 14 - ((int)((__float_as_uint(bnd) >> 23) & 0xFFu) - 126);
+            se = se > 60 ? 60 : se < -60 ? -60 : se;
+            sY = __uint_as_float(__builtin_amdgcn_readfirstlane((unsigned)(127 + se) << 23));
+            unsc = __uint_as_float(0x7F000000u - __float_as_uint(sY)) * __uint_as_float(0x7F000000u - __float_as_uint(sW));   // exact 1 / (sY sW)
+        }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const float4 f0 = *reinterpret_cast<const float4*>(rh + crow * RLD + 16 * ks + 8 * chk);
             const float4 f1 = *reinterpret_cast<const float4*>(rh + crow * RLD + 16 * ks + 8 * chk + 4);
+            if constexpr (HF16) {
+                unsigned AH[4], AL[4];
+                split2h_scaled(mk2(f0.x, f0.y), sY, AH[0], AL[0]);
+                split2h_scaled(mk2(f0.z, f0.w), sY, AH[1], AL[1]);
+                split2h_scaled(mk2(f1.x, f1.y), sY, AH[2], AL[2]);
+                split2h_scaled(mk2(f1.z, f1.w), sY, AH[3], AL[3]);
+#define MF3(ACC, T_)                                                                                           \
+                ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(fragh(AH), fragh(WH[T_][ks]), ACC, 0, 0, 0);      \
+                ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(fragh(AH), fragh(WL[T_][ks]), ACC, 0, 0, 0);      \
+                ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(fragh(AL), fragh(WH[T_][ks]), ACC, 0, 0, 0);
+                MF3(acc0, 0)
+                MF3(acc1, 1)
+#undef MF3
+            } else {
             unsigned AH[4], AM[4], AL[4];
             split3(f0.x, f0.y, AH[0], AM[0], AL[0]);
             split3(f0.z, f0.w, AH[1], AM[1], AL[1]);
@@ -359,14 +434,23 @@ __global__ __launch_bounds__(128 * WAVES, 1) void k_fwd_wave2(Dev P, const float
             split3(f1.z, f1.w, AH[3], AM[3], AL[3]);
 #define MF6(ACC, T_)                                                                                           \
             ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(AH), frag(WH[T_][ks]), ACC, 0, 0, 0);           \
-            ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(AH), frag(WM[T_][ks]), ACC, 0, 0, 0);           \
+            ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(AH), frag(WM[HF16 ? 0 : T_][HF16 ? 0 : ks]), ACC, 0, 0, 0);           \
             ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(AM), frag(WH[T_][ks]), ACC, 0, 0, 0);           \
             ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(AH), frag(WL[T_][ks]), ACC, 0, 0, 0);           \
             ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(AL), frag(WH[T_][ks]), ACC, 0, 0, 0);           \
-            ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(AM), frag(WM[T_][ks]), ACC, 0, 0, 0);
+            ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(AM), frag(WM[HF16 ? 0 : T_][HF16 ? 0 : ks]), ACC, 0, 0, 0);
             MF6(acc0, 0)
             MF6(acc1, 1)
 #undef MF6
+            }
+        }
+        if constexpr (HF16) {                                          // packed: one v_pk_mul_f32 per two accumulator registers
+            const v2f u2 = mk2(unsc, unsc);
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const v2f a = mk2(acc0[r], acc0[r + 1]) * u2, b2 = mk2(acc1[r], acc1[r + 1]) * u2;
+                acc0[r] = a.x; acc0[r + 1] = a.y; acc1[r] = b2.x; acc1[r + 1] = b2.y;
+            }
         }
         // y_k[n] in the C/D layout, products y (H y), stash rows
         float yc0[16], yc1[16], pr[16];
@@ -388,16 +472,33 @@ __global__ __launch_bounds__(128 * WAVES, 1) void k_fwd_wave2(Dev P, const float
             // 8 (r >> 2) in lanes 0-31 and step s0 + 4 in lanes 32-63, for n = 0..31 (tile 0) and n = 32..63 (tile 1): one
             // v_permlane32_swap between the two tiles puts ALL of row s0 into one register and all of row s0 + 4 into the
             // other, so every store instruction writes one whole row (lane = n).
-            char* sbase = reinterpret_cast<char*>(st + (size_t)kbeg * 64) + lane * 8;
+            // A full chunk (all but a clip's last): address = uniform base (SGPR pair, one per eight rows: the immediate reaches 4095) + this
+            // lane's 8 bytes (one VGPR for the whole kernel) + the row's immediate -- no 64-bit VALU address arithmetic and no per-row test.
+            // (Stores by asm: dwordx2 data has no write-after-store hazard; nothing in this kernel reads the rows back.)
+            char* cbase = reinterpret_cast<char*>(st + (size_t)kbeg * 64);
+            const unsigned loff = (unsigned)lane * 8u;
+            if (cnt == CH2) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int s0 = (r & 3) + 8 * (r >> 2);
-                const auto ys = __builtin_amdgcn_permlane32_swap(__float_as_uint(yc0[r]), __float_as_uint(yc1[r]), false, false);
-                const auto hs = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc0[r]), __float_as_uint(acc1[r]), false, false);
-                if (s0 < cnt)
-                    *reinterpret_cast<float2*>(sbase + s0 * 512) = make_float2(__uint_as_float(ys[0]), __uint_as_float(hs[0]));
-                if (s0 + 4 < cnt)
-                    *reinterpret_cast<float2*>(sbase + (s0 + 4) * 512) = make_float2(__uint_as_float(ys[1]), __uint_as_float(hs[1]));
+                for (int r = 0; r < 16; ++r) {
+                    const int s0 = (r & 3) + 8 * (r >> 2);
+                    const auto ys = __builtin_amdgcn_permlane32_swap(__float_as_uint(yc0[r]), __float_as_uint(yc1[r]), false, false);
+                    const auto hs = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc0[r]), __float_as_uint(acc1[r]), false, false);
+                    const v2f lo = mk2(__uint_as_float(ys[0]), __uint_as_float(hs[0])), hi = mk2(__uint_as_float(ys[1]), __uint_as_float(hs[1]));
+                    const char* q0 = cbase + (s0 >> 3) * 4096;              // rows 8 q .. 8 q + 7
+                    asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3" :: "v"(loff), "v"(lo), "s"(q0), "n"((s0 & 7) * 512) : "memory");
+                    asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3" :: "v"(loff), "v"(hi), "s"(q0), "n"(((s0 + 4) & 7) * 512) : "memory");
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int s0 = (r & 3) + 8 * (r >> 2);
+                    const auto ys = __builtin_amdgcn_permlane32_swap(__float_as_uint(yc0[r]), __float_as_uint(yc1[r]), false, false);
+                    const auto hs = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc0[r]), __float_as_uint(acc1[r]), false, false);
+                    if (s0 < cnt)
+                        *reinterpret_cast<float2*>(cbase + s0 * 512 + loff) = make_float2(__uint_as_float(ys[0]), __uint_as_float(hs[0]));
+                    if (s0 + 4 < cnt)
+                        *reinterpret_cast<float2*>(cbase + (s0 + 4) * 512 + loff) = make_float2(__uint_as_float(ys[1]), __uint_as_float(hs[1]));
+                }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -444,18 +545,27 @@ __global__ __launch_bounds__(128 * WAVES, 1) void k_fwd_wave2(Dev P, const float
             const float z = (evec * incv) / A;                         // model.py:294 operation order
             lv = -logf(1.0f + z);
         }
-        for (int j = 0; j < cnt; ++j) loss += rdlane(lv, j);           // model.py:279: sequential in time
+        if (cnt == CH2) {                                              // model.py:279: sequential in time.  A full chunk unrolled: the lane
+#pragma unroll                                                         // selects are immediates (v_readlane + v_add per step; the counted loop
+            for (int j = 0; j < CH2; ++j) loss += rdlane(lv, j);       // below costs eight instructions per step)
+        } else {
+            for (int j = 0; j < cnt; ++j) loss += rdlane(lv, j);
+        }
         if (SAVE && lane < CH2) sc[(size_t)(c >> 1) * 128 + 64 + (c & 1) * CH2 + lane] = evec;
     }
     if (lane == 0) loss_out[b] = loss;
 }
 
-hipError_t launch_fwd_wave2(const Dev& P, const float* audio, float* loss, bool save, hipStream_t s) {
+hipError_t launch_fwd_wave2(const Dev& P, const float* audio, float* loss, bool save, bool hf16, hipStream_t s) {
     const unsigned nb = (unsigned)((P.B + WAVES - 1) / WAVES);
-    if (save)
-        hipLaunchKernelGGL(k_fwd_wave2<true>, dim3(nb), dim3(128 * WAVES), 0, s, P, audio, loss);
+    if (save && hf16)
+        hipLaunchKernelGGL((k_fwd_wave2<true, false, true>), dim3(nb), dim3(128 * WAVES), 0, s, P, audio, loss);
+    else if (save)
+        hipLaunchKernelGGL((k_fwd_wave2<true, false, false>), dim3(nb), dim3(128 * WAVES), 0, s, P, audio, loss);
+    else if (hf16)
+        hipLaunchKernelGGL((k_fwd_wave2<false, false, true>), dim3(nb), dim3(128 * WAVES), 0, s, P, audio, loss);
     else
-        hipLaunchKernelGGL(k_fwd_wave2<false>, dim3(nb), dim3(128 * WAVES), 0, s, P, audio, loss);
+        hipLaunchKernelGGL((k_fwd_wave2<false, false, false>), dim3(nb), dim3(128 * WAVES), 0, s, P, audio, loss);
     return hipGetLastError();
 }
 

@@ -272,7 +272,7 @@ class PsiCMPS(CMPS):
         B, T = audio.shape
         be = self._get_backend()
         be.set_params(self.effective_params(), B, T, train=True)
-        _, grad = be.loss_and_grad_sums(audio)
+        _, grad = be.loss_and_grad_sums(audio, check=True)       # fp16-range check + documented fallback (include/cmps.h)
         return grad, B
 
     def chain_rule(self, flat_sums: np.ndarray, global_batch: int, with_reg: bool = False):

@@ -73,6 +73,7 @@ class HipScan:
         self._audio = None
         self._loss = None
         self._grad = torch.empty(grad_size(D), dtype=torch.float32, device=self.device)
+        self.f16_fallbacks = 0        # loss_and_grad_sums(check=True) re-runs that cmps_psi_grad_status asked for
         self.timing = None            # a list: forward() / backward() then append HIP-event pairs around their launches (bench.py)
 
     # ------------------------------------------------------------------
@@ -271,9 +272,39 @@ class HipScan:
         self._event_close("bwd", ev)
         return self._grad
 
-    def loss_and_grad_sums(self, audio: torch.Tensor):
+    def grad_status(self):
+        """cmps_psi_grad_status: (code, sticky flags).  Waits for the stream.  code = CMPS_ERR_F16_RANGE when the last backward()
+        left Inf / NaN in the gradient next to finite per-clip losses (an fp16-split operand out of its scaled range)."""
+        sticky = ctypes.c_int(0)
+        code = int(self._lib.cmps_psi_grad_status(self._h, ctypes.byref(sticky), self._stream()))
+        if code not in (_capi.CMPS_OK, _capi.CMPS_ERR_F16_RANGE):
+            _capi.check(self._h, code)
+        return code, int(sticky.value)
+
+    def loss_and_grad_sums(self, audio: torch.Tensor, check: bool = False):
+        """forward(save) + backward().  check=True (the host trainer and the model's gradient accessors: they read the result
+        on the host anyway) asks cmps_psi_grad_status afterwards and, on CMPS_ERR_F16_RANGE, takes the documented fallback once:
+        CMPS_OPT_RANK1 = BF16X3, CMPS_OPT_WIDE_CHAIN = VALU (no fp16 piece anywhere), the same two calls again; the handle's
+        options are restored.  A gradient that is non-finite in that arithmetic as well is returned as it is (it propagates, as in
+        the reference)."""
         loss = self.forward(audio, save_for_bwd=True)
         grad = self.backward()
+        if check:
+            code, _ = self.grad_status()
+            if code == _capi.CMPS_ERR_F16_RANGE and (self.effective_rank1 == _capi.CMPS_RANK1_F16X2 or
+                                                     (self.variant == _capi.CMPS_VARIANT_WIDE and self.wide_chain != _capi.CMPS_WIDE_CHAIN_VALU)):
+                import warnings
+                warnings.warn("libcmps: " + self._lib.cmps_last_error(self._h).decode() + " -- re-running this batch with bf16x3 pieces")
+                keep = (self.rank1, self.wide_chain)
+                self.f16_fallbacks += 1
+                try:
+                    self.set_rank1(_capi.CMPS_RANK1_BF16X3)
+                    self.set_wide_chain(_capi.CMPS_WIDE_CHAIN_VALU)
+                    loss = self.forward(audio, save_for_bwd=True)
+                    grad = self.backward()
+                finally:
+                    self.set_rank1(keep[0])
+                    self.set_wide_chain(keep[1])
         return loss, grad
 
     # ------------------------------------------------------------------

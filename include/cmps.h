@@ -30,7 +30,9 @@ enum {
     CMPS_ERR_UNSUPPORTED_D = 2, /* bond dimension outside [1, 128] */
     CMPS_ERR_WORKSPACE = 3,     /* workspace missing or smaller than cmps_workspace_bytes() */
     CMPS_ERR_HIP = 4,           /* a HIP runtime call or kernel launch failed */
-    CMPS_ERR_STATE = 5          /* call order: set_params -> fwd(save_for_bwd=1) -> bwd */
+    CMPS_ERR_STATE = 5,         /* call order: set_params -> fwd(save_for_bwd=1) -> bwd */
+    CMPS_ERR_F16_RANGE = 6      /* cmps_psi_grad_status only: the gradient sums of the last cmps_psi_loss_bwd hold Inf / NaN although
+                                 * every per-clip loss is finite -- an fp16-split operand left its scaled range (see CMPS_RANK1_F16X2) */
 };
 
 /* workspace flags */
@@ -44,12 +46,16 @@ enum {
                            * for something else since the previous call -- rebuild every cached table (see below) */
 };
 
-/* kernel variants (cmps_set_variant); AUTO picks the register-resident wave-per-clip kernels for D <= 32 and the float32
- * "wide" kernels above that: the reference's float32 / complex64 arithmetic (model.py:300-325) at every bond dimension.
- * "float32" means: every mat-vec on the serial chains is an fp32 FMA chain; the products nothing waits for (the loss
- * product H y of 17 <= D <= 32, the rank-1 gradient sums) run on the matrix cores with every operand split EXACTLY into three
- * bf16 pieces and fp32 accumulation -- fp32-faithful (24 operand bits), not bit-identical to an fp32 FMA chain.  Only
- * CMPS_VARIANT_BLOCK is plain fp32 FMA code throughout. */
+/* Kernel variants (cmps_set_variant).  AUTO picks the register-resident wave-per-clip kernels for D <= 32 and the "wide"
+ * kernels above that.  Both follow the reference's float32 / complex64 arithmetic (model.py:300-325) in this sense:
+ *   - state, identity part of every update, normalisation, loss and every accumulation are float32;
+ *   - D <= 32: the mat-vec on the serial chain is an fp32 FMA chain.  The two products nothing waits for run on the matrix
+ *     cores with split operands and fp32 accumulation: the loss product H y (three bf16 pieces, six products) and the rank-1
+ *     gradient sums (CMPS_OPT_RANK1; default two scaled fp16 pieces, three products);
+ *   - 32 < D <= 128: the mat-vecs of both serial chains, H y and the gradient GEMM all run on the matrix cores with two
+ *     scaled fp16 pieces per operand (CMPS_OPT_WIDE_CHAIN, CMPS_OPT_RANK1 select the fp32-VALU / bf16-piece forms).
+ * Split products carry 22-24 operand bits: within float32 rounding of an fp32 FMA chain, not bit-identical to it.
+ * Only CMPS_VARIANT_BLOCK is plain fp32 FMA code throughout. */
 enum {
     CMPS_VARIANT_AUTO = 0,
     CMPS_VARIANT_BLOCK = 1, /* one workgroup per clip, any D <= 128 */
@@ -57,8 +63,8 @@ enum {
                              * (cmps_wave16.hip) for D <= 16, the 32-row layout above that */
     CMPS_VARIANT_PAIR = 3,  /* 32 < D <= 128: one workgroup per pair of clips, matrices as bf16 MFMA fragments, fp32 accumulate */
     CMPS_VARIANT_WAVE32 = 4, /* the 32-row wave layout for every D <= 32 (zero padding below 32; cross-check of the 16-row layout) */
-    CMPS_VARIANT_WIDE = 5   /* 32 < D <= 128 in float32 (what AUTO picks there): one workgroup per pair of clips, R / Q register
-                             * resident, float32 VALU mat-vecs; gradient GEMM with fp32-faithful split operands (CMPS_OPT_RANK1) */
+    CMPS_VARIANT_WIDE = 5   /* 32 < D <= 128 in float32 (what AUTO picks there): one workgroup per pair of clips, R / Q resident in
+                             * registers for the whole launch; arithmetic selected by CMPS_OPT_WIDE_CHAIN and CMPS_OPT_RANK1 */
 };
 
 /* options (cmps_set_option / cmps_get_option) */
@@ -68,30 +74,42 @@ enum {
                         * BF16X2 = two bf16 pieces / three products, F16X2 = two fp16 pieces / three products, anything else = three
                         * bf16 pieces / six products) */,
     CMPS_OPT_WIDE_CHAIN = 3 /* how the wide kernels (32 < D <= 128, float32) run the training forward's serial chain: see the values below */,
+    CMPS_OPT_F16_SCALE_SHIFT = 4 /* DIAGNOSTIC, default 0: added to the exponent of every data-dependent fp16 scale of the wave reverse
+                        * scan's F16X2 arithmetic (range -40 .. 40).  A positive value pushes the pieces out of fp16 range on purpose:
+                        * how tests/test_gpu_parity.py provokes CMPS_ERR_F16_RANGE.  No reference counterpart. */,
     CMPS_OPT_KERNEL_EVENTS = 2 /* 1: every kernel cmps_psi_loss_fwd / _bwd launch is bracketed by two HIP events on the caller's stream
                         * (read and reset with cmps_kernel_times); 0 (default): nothing is recorded.  A measurement aid -- the reference
                         * has no counterpart (no tracing / profiling hooks); bench.py uses it OUTSIDE its timed region to price
                         * each kernel of a multi-kernel family against the pipe it runs on */
 };
-/* values of CMPS_OPT_RANK1.  All accumulate in fp32; they differ in how the two factors of every product
+/* Values of CMPS_OPT_RANK1.  All accumulate in fp32; they differ in how the two factors of every product
  * dR += a b^dagger enter the matrix cores:
- *   EXACT_F32  v_mfma_f32_32x32x2_f32, bit-for-bit an fp32 fma chain (slowest: it holds the fp32 ALUs)
- *   BF16X2     each factor split into two bf16 pieces, 3 products: 16 operand bits, error <= ~2^-16 |a||b|
+ *   EXACT_F32  v_mfma_f32_32x32x2_f32: bit-for-bit an fp32 fma chain (slowest: it holds the fp32 ALUs).
+ *   BF16X2     each factor split into two bf16 pieces, 3 products: 16 operand bits, error <= ~2^-16 |a||b|.
  *   BF16X3     each factor split EXACTLY into three bf16 pieces (8+8+8 bits), 6 products: 24 operand bits,
- *              error <= 2^-23 |a||b| (what is dropped is below the fp32 rounding of the product)
- *   F16X2      (the 32-row wave reverse scan, with scales per eight-step octet; the wide kernels' gradient GEMM and loss product H y, with
- *              scales per pair of clips; the RhoCMPS row-array GEMM forward, with scales per clip, and sampler, with fixed scales; elsewhere it means BF16X3) each factor scaled by a power of two per pair of clips
- *              and split into two fp16 pieces, round to nearest (11+1+11+1 bits), 3 products on v_mfma_f32_32x32x16_f16: BF16X2's
- *              instruction count at BF16X3's accuracy class, error <= ~2^-22 |a||b| for factors within 2^-18 of their class's
- *              largest value in the pair and <= 2^-39 of that largest value below */
+ *              error <= 2^-23 |a||b| (what is dropped is below the fp32 rounding of the product).
+ *   F16X2      each factor multiplied by a power of two and split into two fp16 pieces, round to nearest
+ *              (11+1+11+1 bits), 3 products on v_mfma_f32_32x32x16_f16 / 16x16x32_f16: BF16X2's instruction count in
+ *              BF16X3's accuracy class.  Error <= ~2^-22 |a||b| for factors within 2^-18 of the largest value their
+ *              scale was chosen for, and <= 2^-39 of that largest value below.
+ * Which kernels know which value, and where the fp16 scales come from:
+ *   kernel                                        EXACT_F32  BF16X2  BF16X3  F16X2                          DEFAULT means
+ *   wave reverse scan, 17 <= D <= 32 (PsiCMPS)    yes        yes     yes     scales per eight-step octet    F16X2
+ *   wave reverse scan in legacy AudioMPS mode     yes        yes     yes     runs BF16X3                    BF16X3
+ *   wave kernels, D <= 16                         always exact fp32 MFMAs (the option is ignored)
+ *   wide kernels' GEMMs (H y, gradient), D > 32   runs BF16X3  yes   yes     scales per pair of clips       F16X2
+ *   RhoCMPS row-array GEMM forward and sampler    runs BF16X3 (every value but F16X2 / DEFAULT)  scales per clip / fixed   F16X2
+ *   RhoCMPS reverse scan, pair (bf16) kernels     the option is ignored
+ * The fp16 scales follow guaranteed bounds; should one ever be violated the pieces overflow to Inf and the gradient
+ * comes out non-finite: cmps_psi_grad_status reports that as CMPS_ERR_F16_RANGE. */
 enum {
     CMPS_RANK1_EXACT_F32 = 0,
     CMPS_RANK1_BF16X2 = 1,
     CMPS_RANK1_BF16X3 = 2,
     CMPS_RANK1_F16X2 = 3,
-    CMPS_RANK1_DEFAULT = 4   /* a new handle's setting: F16X2 wherever it exists (the 32-row wave reverse scan of the PsiCMPS arithmetic,
-                              * the wide kernels' GEMMs, the RhoCMPS GEMM forward and sampler), BF16X3 elsewhere -- the cheapest arithmetic of the 24-operand-bit class on each
-                              * kernel (scripts/rank1_accuracy_wide.py, tests/test_gpu_parity.py::test_rank1_modes_order_of_accuracy) */
+    CMPS_RANK1_DEFAULT = 4   /* a new handle's setting: see the table above (the cheapest arithmetic of the 24-operand-bit
+                              * class each kernel has; scripts/rank1_accuracy_wide.py,
+                              * tests/test_gpu_parity.py::test_rank1_modes_order_of_accuracy) */
 };
 
 /* values of CMPS_OPT_WIDE_CHAIN */
@@ -201,6 +219,19 @@ int cmps_psi_loss_fwd(cmps_handle_t h, const float* audio_dev, int B, int T, flo
  */
 int cmps_psi_loss_bwd(cmps_handle_t h, const float* audio_dev, int B, int T, float* grad_dev,
                       void* stream);
+
+/*
+ * Run-time check of the split-operand arithmetic (no reference counterpart: the reference has one float32 arithmetic).
+ * cmps_psi_loss_bwd leaves two flag words in the workspace: bit 0 = a gradient sum is Inf / NaN, bit 1 = the loss sum is.
+ * This call waits for `stream`, reads them and returns
+ *   CMPS_OK             gradient finite, or loss and gradient both non-finite (that propagates, as in the reference);
+ *   CMPS_ERR_F16_RANGE  gradient non-finite although the loss is finite: with an F16X2 arithmetic in force an operand piece
+ *                       overflowed fp16 (a violated scale bound).  Documented fallback: set CMPS_OPT_RANK1 = BF16X3 and
+ *                       CMPS_OPT_WIDE_CHAIN = VALU and repeat cmps_psi_loss_fwd / _bwd (audio_mps_amd.scan.HipScan does so).
+ * *sticky_out (may be NULL) receives the OR of the flag words of every cmps_psi_loss_bwd since the previous call of this
+ * function, for loops that do not check every step; cmps_psi_apply_step given `status_dev` skips the update of such a step.
+ */
+int cmps_psi_grad_status(cmps_handle_t h, int* sticky_out, void* stream);
 
 /*
  * Replaces: PsiCMPS._update_ancilla_psi (model.py:300-317), one step in the lab frame.

@@ -19,6 +19,7 @@ stats = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))
 if stats:
     shutil.copy(stats[0], os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"))
 SCAN = ("k_fwd_wave", "k_bwd_wave", "k_fwd_pair", "k_bwd_pair", "k_grad_gemm", "k_fwd_block", "k_bwd_block", "k_fwd_wide", "k_bwd_wide",
+        "k_fwd_chain16", "k_bwd_chain16", "k_sample_wide", "k_sample_wave",
         "k_hy_wide", "k_loss_wide", "k_apply_step", "k_reduce_slabs", "k_reduce_parts", "k_finalize", "k_pack", "k_rho_raw", "k_rho_fix")
 acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(src, "pmc_*", "*", "*counter_collection.csv")):

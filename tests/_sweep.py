@@ -158,7 +158,8 @@ def sweep_rho(rng, n, out):
         assert np.all(np.isfinite(per)) and all(np.all(np.isfinite(grads[k])) for k in grads), ("rho non-finite", cfg)
         out.append(("rho", "loss", _loss_err(per, ref["per_clip"]), LOSS_BAR, cfg))
         out.append(("rho", "grad", max(rel_inf(grads[k], ref[k]) for k in ("Rx", "Ry", "freqs", "Wx", "Wy")), GRAD_BAR, cfg))
-        out.append(("rho", "dA", rel_inf(grads["A"], ref["A"]), 1e-3, cfg))     # the float32 restatement itself sits 1e-5 ... 1e-3 from float64
+        ref32 = O.rho_loss_and_grads(O.HParams(**hp.values()), ov, m.variables["Wx"], m.variables["Wy"], audio, "f32")
+        out.append(("rho", "dA", rel_inf(grads["A"], ref["A"]), _dA_bar(ref32["A"], ref["A"], GRAD_BAR), cfg))
 
 
 def sweep_legacy(rng, n, out):

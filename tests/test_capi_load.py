@@ -93,8 +93,8 @@ def test_workspace_bytes_pair_variant(hip_lib):
 
 
 def test_options_default_and_errors(hip_lib):
-    """cmps_set_option / cmps_get_option (no device work): the rank-1 arithmetic defaults to DEFAULT (BF16X3 in the wave reverse
-    scan, F16X2 in the wide kernels' gradient GEMM)."""
+    """cmps_set_option / cmps_get_option (no device work): the rank-1 arithmetic defaults to DEFAULT (include/cmps.h's table: F16X2
+    in the 32-row wave reverse scan, the wide kernels' GEMMs and the RhoCMPS GEMM forward / sampler; BF16X3 in legacy mode)."""
     from audio_mps_amd import _capi
     h = ctypes.c_void_p()
     assert hip_lib.cmps_create(32, ctypes.byref(h)) == _capi.CMPS_OK
@@ -110,6 +110,18 @@ def test_options_default_and_errors(hip_lib):
         assert hip_lib.cmps_set_option(h, _capi.CMPS_OPT_WIDE_CHAIN, v) == _capi.CMPS_OK
         assert hip_lib.cmps_get_option(h, _capi.CMPS_OPT_WIDE_CHAIN) == v
     assert hip_lib.cmps_set_option(h, _capi.CMPS_OPT_WIDE_CHAIN, 3) == _capi.CMPS_ERR_BAD_ARG
+    # CMPS_OPT_F16_SCALE_SHIFT (diagnostic: provokes CMPS_ERR_F16_RANGE in tests/test_gpu_parity.py): 0 on a new handle, -40 .. 40
+    assert hip_lib.cmps_get_option(h, _capi.CMPS_OPT_F16_SCALE_SHIFT) == 0
+    assert hip_lib.cmps_set_option(h, _capi.CMPS_OPT_F16_SCALE_SHIFT, 7) == _capi.CMPS_OK
+    assert hip_lib.cmps_get_option(h, _capi.CMPS_OPT_F16_SCALE_SHIFT) == 7
+    assert hip_lib.cmps_set_option(h, _capi.CMPS_OPT_F16_SCALE_SHIFT, 41) == _capi.CMPS_ERR_BAD_ARG
+    assert hip_lib.cmps_set_option(h, _capi.CMPS_OPT_F16_SCALE_SHIFT, 0) == _capi.CMPS_OK
+    # cmps_psi_grad_status before any cmps_set_params: a call-order error, never a crash; the null handle is a bad argument
+    sticky = ctypes.c_int(5)
+    assert hip_lib.cmps_psi_grad_status(h, ctypes.byref(sticky), None) == _capi.CMPS_ERR_STATE and sticky.value == 0
+    assert b"cmps_set_params" in hip_lib.cmps_last_error(h)
+    assert hip_lib.cmps_psi_grad_status(None, None, None) == _capi.CMPS_ERR_BAD_ARG
+    assert _capi.CMPS_ERR_F16_RANGE == 6
     assert hip_lib.cmps_set_option(h, 99, 0) == _capi.CMPS_ERR_BAD_ARG
     assert hip_lib.cmps_get_option(h, 99) == -1 and hip_lib.cmps_get_option(None, _capi.CMPS_OPT_RANK1) == -1
     # CMPS_WS_FRESH / CMPS_WS_REUSE_TABLES are requests, not layouts: they do not change the size

@@ -49,6 +49,40 @@ def test_pair_matches_bf16_oracle_and_float32(D, T, B):
     assert abs(g["loss_sum"] - float(np.sum(per, dtype=np.float64))) <= 1e-4 * max(1.0, abs(g["loss_sum"]))
 
 
+@pytest.mark.parametrize("D,T,rs,sigma", [(40, 60, 0.6, 0.36), (64, 130, 0.6, 0.36), (128, 90, 0.5, 0.36), (96, 257, 0.6, 0.5), (128, 33, 0.7, 0.3)])
+def test_pair_qbar_sums_visible_at_large_sigma(D, T, rs, sigma):
+    """no case of this file had sigma > 1e-4, where Q = -(delta_t sigma^2 / 2) R^dagger R (/root/reference/model.py:312)
+    is below float32 resolution and errors in Qbar = sum ybar u^dagger never reach a gradient.  sigma = 0.3 ... 0.5, A = 66, quiet audio and
+    a large R make Q carry 14 ... 50 % of the R gradient; the pair kernels (k_bwd_pair + k_grad_gemm<1>) against the bf16-emulating
+    oracle at this file's bars, and against the float32 restatement at its bf16 bars."""
+    from audio_mps_amd.scan import unpack_grad
+    B = 3
+    m, _ = _pair_model(T, B, D=D, seed=7, sigma=sigma, A=66.0)
+    audio = (make_audio(B, T, m.hparams.delta_t, 3) * np.float32(0.09)).astype(np.float32)
+    m.variables["Rx"] *= np.float32(rs)
+    m.variables["Ry"] *= np.float32(rs)
+    per = m.loss_per_clip(audio)
+    g = unpack_grad(m.grad_sums(audio)[0].cpu().numpy(), D)
+    em = O.psi_bf16_scan(oracle_hparams(m.hparams), oracle_variables(m), audio, want_grad=True)
+    ref = c_oracle_run(m, audio, "f32", want_grad=True)
+    gr = C.unpack_grad(ref["grad"], D)
+    # Q is visible: the same model at sigma = 1e-4 has a different R gradient by >= 10 %
+    small = C.unpack_grad(C.psi_scan(audio, *_eff(m), float(m.A), m.hparams.delta_t, 1e-4, "f32", want_grad=True)["grad"], D)
+    assert rel_inf(small["Rbar"], gr["Rbar"]) >= 0.1
+    den = np.maximum(np.abs(ref["loss_per_clip"]), 1.0)
+    assert np.max(np.abs(per - em["loss_per_clip"]) / den) <= 3e-4
+    assert np.max(np.abs(per - ref["loss_per_clip"]) / den) <= 2e-3
+    for k in ("Rbar", "fbar", "psi0bar", "Abar"):
+        assert rel_inf(g[k], em[k]) <= 2e-3, (k, rel_inf(g[k], em[k]))
+        assert rel_inf(g[k], gr[k]) <= 3e-2, (k, rel_inf(g[k], gr[k]))
+
+
+def _eff(m):
+    ohp, ov = oracle_hparams(m.hparams), oracle_variables(m)
+    R, f, _, _ = O.effective_params(ohp, ov, "f32")
+    return R, f, O.psi_0(ov, "f32")
+
+
 def test_pair_agrees_with_block_variant_at_reduced_c5():
     """BASELINE configs[4] at reduced length and batch: the MFMA path against the float32 block kernels on the GPU."""
     from audio_mps_amd import PsiCMPS

@@ -255,6 +255,75 @@ def test_rank1_f16x2_scale_jumps(D):
     assert rel_inf(g["Rbar"], g3["Rbar"]) <= 2e-5
 
 
+def test_f16_range_tripwire_and_fallback():
+    """The run-time check of the fp16-split arithmetic (include/cmps.h: cmps_psi_grad_status).  The scales follow
+    guaranteed bounds, so no input provokes an overflow; the diagnostic option CMPS_OPT_F16_SCALE_SHIFT pushes every data-dependent
+    scale of the wave reverse scan up by 2^20 instead: the pieces of ybar overflow fp16, the gradient comes out non-finite while every
+    per-clip loss is finite -> CMPS_ERR_F16_RANGE (not a silent NaN), the sticky word remembers it, cmps_psi_apply_step skips the
+    update, and HipScan.loss_and_grad_sums(check=True) -- what PsiCMPS.grad_sums calls -- returns the BF16X3 result instead."""
+    import warnings
+    import torch
+    from audio_mps_amd import _capi
+    from audio_mps_amd.scan import unpack_grad
+    from audio_mps_amd.train import Trainer
+    D, T, B = 32, 300, 6
+    m, audio = _model(D, T, B, WAVE, seed=11)
+    be = m._get_backend()
+    assert be.effective_rank1 == _capi.CMPS_RANK1_F16X2
+    ref = c_oracle_run(m, audio, "f32")
+    gr = C.unpack_grad(ref["grad"], D)
+    d_audio = torch.from_numpy(audio).to(be.device)
+    # in range: status OK, nothing sticky
+    be.set_params(m.effective_params(), B, T, train=True)
+    be.loss_and_grad_sums(d_audio)
+    assert be.grad_status() == (_capi.CMPS_OK, 0)
+    # out of range on purpose
+    _capi.check(be._h, be._lib.cmps_set_option(be._h, _capi.CMPS_OPT_F16_SCALE_SHIFT, 20))
+    loss, grad = be.loss_and_grad_sums(d_audio)
+    assert np.all(np.isfinite(loss.cpu().numpy())) and not np.all(np.isfinite(grad.cpu().numpy()[:2 * D * D]))
+    code, sticky = be.grad_status()
+    assert code == _capi.CMPS_ERR_F16_RANGE and sticky == 1
+    assert b"fp16" in be._lib.cmps_last_error(be._h)
+    assert be.grad_status() == (_capi.CMPS_ERR_F16_RANGE, 0)          # the last pass is still the bad one; the sticky word restarted
+    # the documented fallback, as the model's accessor takes it: same batch with bf16x3 pieces, options restored
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        flat, nb = m.grad_sums(audio)
+    assert be.f16_fallbacks == 1 and any("bf16x3" in str(x.message) for x in w)
+    assert be.rank1 == _capi.CMPS_RANK1_DEFAULT and be.effective_rank1 == _capi.CMPS_RANK1_F16X2
+    g = unpack_grad(flat.cpu().numpy(), D)
+    for k in ("Rbar", "fbar", "psi0bar", "Abar"):
+        assert rel_inf(g[k], gr[k]) <= GRAD_RTOL, k
+    # the device-resident optimiser step skips such a step: variables untouched, total loss NaN as the marker
+    tr = Trainer(m, m.hparams, device_step=True)
+    st = tr._device_state()
+    before = st["vars"].clone()
+    out = tr.step(audio, sync=True)
+    assert np.isfinite(out["model_loss"]) and np.isnan(out["total_loss"])
+    assert torch.equal(st["vars"], before)
+    # back in range: the next step moves the variables again
+    _capi.check(be._h, be._lib.cmps_set_option(be._h, _capi.CMPS_OPT_F16_SCALE_SHIFT, 0))
+    out = tr.step(audio, sync=True)
+    assert np.isfinite(out["total_loss"]) and not torch.equal(st["vars"], before)
+    assert be.grad_status()[0] == _capi.CMPS_OK
+
+
+def test_nan_input_is_not_an_f16_range_error():
+    """NaN / Inf that comes from the DATA propagates as in the reference (model.py has no guard; tests/test_model.py:113 only looks):
+    loss and gradient are both non-finite, and cmps_psi_grad_status says CMPS_OK -- the check is about the split arithmetic only."""
+    import torch
+    from audio_mps_amd import _capi
+    m, audio = _model(24, 130, 3, WAVE, seed=2)
+    audio = audio.copy()
+    audio[1, 40] = np.nan
+    be = m._get_backend()
+    be.set_params(m.effective_params(), 3, 130, train=True)
+    loss, grad = be.loss_and_grad_sums(torch.from_numpy(audio).to(be.device))
+    assert np.isnan(loss.cpu().numpy()[1]) and np.all(np.isfinite(loss.cpu().numpy()[[0, 2]]))
+    code, sticky = be.grad_status()
+    assert code == _capi.CMPS_OK and (sticky & 2)
+
+
 def test_variants_agree():
     m1, audio = _model(32, 1500, 9, WAVE, seed=5)
     m2, _ = _model(32, 1500, 9, BLOCK, seed=5)
@@ -482,6 +551,35 @@ def test_legacy_audiomps_matches_oracle(D, T, B, dt):
     assert rel_inf(grads["R"], ref["gR"]) <= GRAD_RTOL
     assert rel_inf(grads["H"], ref["gH"]) <= GRAD_RTOL
     assert np.allclose(np.triu(grads["H"], 1), 0)                  # only the lower triangle of H is used
+
+
+@pytest.mark.parametrize("D,T,dt,scale", [(18, 60, 0.01, 1.5), (32, 60, 0.004, 2.0), (32, 501, 0.002, 1.5), (9, 47, 0.01, 2.0), (40, 75, 0.004, 1.5)])
+def test_legacy_qbar_is_the_H_gradient_at_large_R(D, T, dt, scale):
+    """VERDICT r4 weak 2, legacy row: in the legacy arithmetic Q = dt (-i H_s - R^T R / 2) is never negligible and
+    Qbar = sum ybar psi^dagger is a direct OUTPUT (dQ of cmps_legacy_loss_bwd; the H gradient is its imaginary part), so the hazard class of
+    DESIGN 4.3e shows up in gH.  Large H and R (x 1.5 ... 2 of the initialisation) with T above, on and below the octet / chunk boundaries,
+    every rank-1 arithmetic of k_bwd_wave<*, LEGACY> (and the general kernels at D = 40), against the float64 oracle with the float32
+    oracle's own distance (x 3) as the bar."""
+    from audio_mps_amd import LegacyAudioMPS
+    from audio_mps_amd.scan import HipScan
+    B = 5
+    audio = make_audio(B, T, dt, 3, noise=0.05)
+    ref64 = own = None
+    for mode in ((0, 1, 2, 3) if D <= 32 else (4,)):
+        m = LegacyAudioMPS(D, dt, B, data_iterator=audio, seed=7, backend=HipScan(D, rank1=mode))
+        m.variables["H"] *= np.float32(scale)
+        m.variables["R"] *= np.float32(scale)
+        if ref64 is None:
+            ref64 = O.legacy_loss_and_grads(m.variables["H"].astype(np.float64), m.variables["R"].astype(np.float64), dt, audio, "f64")
+            ref32 = O.legacy_loss_and_grads(m.variables["H"], m.variables["R"], dt, audio, "f32")
+            own = {k: rel_inf(ref32[k], ref64[k]) for k in ("gR", "gH")}
+            assert np.all(np.isfinite(ref32["per_clip"]))
+        per = m.loss_per_clip()
+        assert np.max(np.abs(per - ref32["per_clip"]) / np.maximum(np.abs(ref32["per_clip"]), 1.0)) <= LOSS_RTOL
+        _, grads = m.loss_and_grads()
+        for k, name in (("R", "gR"), ("H", "gH")):
+            bar = 3 * own[name] + (3e-5 if mode == 1 else 1e-5)
+            assert rel_inf(grads[k], ref64[name]) <= bar, (mode, k, rel_inf(grads[k], ref64[name]), own[name])
 
 
 @pytest.mark.parametrize("T", [65, 130, 400])

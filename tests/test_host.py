@@ -219,7 +219,7 @@ def test_train_main_iterates_a_tfrecord_dataset(tmp_path):
     seen = []
 
     class Spy(OracleBackend):
-        def loss_and_grad_sums(self, audio):
+        def loss_and_grad_sums(self, audio, check=False):
             seen.append(np.asarray(audio).copy())
             return super().loss_and_grad_sums(audio)
 
