@@ -467,6 +467,10 @@ int cmps_legacy_set_params(cmps_handle_t h, const float* R_dev, const float* Q_r
     P.slabs = (flags & CMPS_WS_TRAIN) ? reinterpret_cast<float*>(ws + L.off_slabs) : nullptr;
     P.sums = (flags & CMPS_WS_TRAIN) ? reinterpret_cast<float*>(ws + L.off_sums) : nullptr;
     P.status = (flags & CMPS_WS_TRAIN) ? reinterpret_cast<unsigned*>(ws + L.off_status) : nullptr;
+    P.gops = ((flags & CMPS_WS_TRAIN) && L.D > 32) ? static_cast<void*>(ws + L.off_gops) : nullptr;      // the wide kernels' ybar rows
+    P.opmax = ((flags & CMPS_WS_TRAIN) && L.D > 32) ? reinterpret_cast<float*>(ws + L.off_opmax) : nullptr;
+    P.freqs = reinterpret_cast<float*>(ws + L.off_freqs);
+    P.qflag = reinterpret_cast<unsigned*>(ws + L.off_qflag);
     P.slab_floats = L.slab_floats;
     P.dt = (float)delta_t;
     // the tables of the pure-state wave kernels, which the D <= 32 legacy kernels share (cmps_wave2.hip / cmps_wave.hip, LEGACY):
@@ -499,11 +503,17 @@ int cmps_legacy_loss_fwd(cmps_handle_t h, const float* audio_dev, int B, int T, 
         return fail(h, CMPS_ERR_WORKSPACE, "cmps_legacy_loss_fwd: save_for_bwd needs a CMPS_WS_TRAIN workspace");
     Dev P = h->P;
     P.B = B;
-    const bool wave = h->D <= 32 && h->variant_req != CMPS_VARIANT_BLOCK;     // the pure-state wave kernels in LEGACY mode (cmps_wave2.hip, cmps_wave.hip)
+    // D <= 32: the pure-state wave kernels in LEGACY mode (cmps_wave2.hip, cmps_wave.hip); above: the wide kernels in LEGACY mode
+    // (cmps_wide.hip; round 5); CMPS_VARIANT_BLOCK: the general one-workgroup-per-clip kernels (cmps_legacy.hip), the cross-check
+    const bool wave = h->D <= 32 && h->variant_req != CMPS_VARIANT_BLOCK;
+    const bool wide = h->D > 32 && h->variant_req != CMPS_VARIANT_BLOCK;
+    const bool f16 = h->rank1_mode == CMPS_RANK1_DEFAULT || h->rank1_mode == CMPS_RANK1_F16X2;
+    KBind kb(h);
     hipError_t e = wave ? launch_fwd_legacy_wave(P, audio_dev, loss_dev, save_for_bwd != 0, static_cast<hipStream_t>(stream))
+                 : wide ? launch_fwd_wide_legacy(P, audio_dev, loss_dev, save_for_bwd != 0, f16, static_cast<hipStream_t>(stream))
                         : launch_fwd_legacy(P, audio_dev, loss_dev, save_for_bwd != 0, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail_hip(h, e, "cmps_legacy_loss_fwd");
-    h->saved_variant = wave ? CMPS_VARIANT_WAVE : CMPS_VARIANT_BLOCK;
+    h->saved_variant = wave ? CMPS_VARIANT_WAVE : wide ? CMPS_VARIANT_WIDE : CMPS_VARIANT_BLOCK;
     h->fwd_saved = save_for_bwd != 0;
     h->saved_B = B; h->saved_T = T; h->saved_audio = audio_dev; h->saved_loss = loss_dev;
     return CMPS_OK;
@@ -519,9 +529,22 @@ int cmps_legacy_loss_bwd(cmps_handle_t h, const float* audio_dev, int B, int T, 
     Dev P = h->P;
     P.B = B;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipError_t e = h->saved_variant == CMPS_VARIANT_WAVE ? launch_bwd_legacy_wave(P, audio_dev, wave_rank1(h->rank1_mode), s) : launch_bwd_legacy(P, audio_dev, s);
+    KBind kb(h);
+    hipError_t e;
+    Dev Pr = P;                                                    // what the slab reduction runs over
+    if (h->saved_variant == CMPS_VARIANT_WIDE) {
+        // reverse chain, then the gradient GEMM over the rows both scans left behind; one slab per PAIR of clips
+        { KScope ks("k_bwd_wide<legacy>", s); e = launch_bwd_wide_legacy(P, audio_dev, s); }
+        if (e == hipSuccess) {
+            KScope ks("k_grad_gemm<legacy>", s);
+            e = launch_grad_wide_legacy(P, audio_dev, h->rank1_mode == CMPS_RANK1_DEFAULT || h->rank1_mode == CMPS_RANK1_F16X2, s);
+        }
+        Pr.B = (B + 1) / 2;
+    } else {
+        e = h->saved_variant == CMPS_VARIANT_WAVE ? launch_bwd_legacy_wave(P, audio_dev, wave_rank1(h->rank1_mode), s) : launch_bwd_legacy(P, audio_dev, s);
+    }
     if (e != hipSuccess) return fail_hip(h, e, "cmps_legacy_loss_bwd (scan)");
-    e = launch_reduce_only(P, s);
+    e = launch_reduce_only(Pr, s);
     if (e == hipSuccess) e = launch_finalize_legacy(P, h->saved_loss, grad_dev, s);
     if (e != hipSuccess) return fail_hip(h, e, "cmps_legacy_loss_bwd (reduce)");
     return CMPS_OK;

@@ -112,7 +112,10 @@ constexpr int free_slots(int t) {               // slots below t that take slice
 //   y_off(tid, c) / yb_off(tid, c): float offset of component c of this thread's (row, clip) inside a step's y / ybar row;
 //   rsq(m): 1 / sqrt(m) exactly as the family's reverse kernel computes it.
 // Rows of step k: y at stash + ((pair N + k) 2) 4 PD (the y half of the (y, H y) row pair), ybar at gops + (pair N + k) 4 PD.
-template <int PD, int NPC, typename ROWS, bool F16 = false>
+// LEGACY (round 5, the wide family only): the legacy AudioMPS sums -- Rbar = sum (te_k psi_k) psi_k^dagger + (s ybar) u^dagger with psi_k = u_k
+// (the normalised state the step starts from), te_k = 2 (e_k - x_k), s = dt x_k; Qbar = sum ybar u^dagger unchanged.  The first term's B
+// operand is u instead of y, its A operand te_k u_k.
+template <int PD, int NPC, typename ROWS, bool F16 = false, bool LEGACY = false>
 __global__ __launch_bounds__(2 * PD, 1) void k_grad_gemm(Dev P, const float* __restrict__ audio) {
     using namespace gg;
     static_assert(!F16 || NPC == 2, "the fp16 split has two pieces");
@@ -156,9 +159,14 @@ __global__ __launch_bounds__(2 * PD, 1) void k_grad_gemm(Dev P, const float* __r
             const float* sc = P.scal + ((size_t)(cl ? b1 : b0) * NC + idx / CH) * 128;
             const float inc = (idx + 1 < T ? xr[idx + 1] : 0.f) - xr[idx];
             const float nv = sc[idx & (CH - 1)], ev = sc[64 + (idx & (CH - 1))];
-            const float zbar = -1.0f / (1.0f + (ev * inc) / A);
-            m_s = fmaxf(m_s, fabsf(inc / A));
-            m_t = fmaxf(m_t, fabsf(2.0f * (zbar * inc / A)) * sqrtf(nv));
+            if constexpr (LEGACY) {                               // |psi_k| = 1
+                m_s = fmaxf(m_s, fabsf(P.dt * inc));
+                m_t = fmaxf(m_t, fabsf(2.0f * (ev - inc)));
+            } else {
+                const float zbar = -1.0f / (1.0f + (ev * inc) / A);
+                m_s = fmaxf(m_s, fabsf(inc / A));
+                m_t = fmaxf(m_t, fabsf(2.0f * (zbar * inc / A)) * sqrtf(nv));
+            }
             m_n = fmaxf(m_n, nv);
         }
 #pragma unroll
@@ -204,6 +212,10 @@ __global__ __launch_bounds__(2 * PD, 1) void k_grad_gemm(Dev P, const float* __r
             const float z = (ev * inc) / A;
             const float zbar = -1.0f / (1.0f + z);
             const bool on = in && (cl == 0 || two);
+            if constexpr (LEGACY)
+                tab[((cj & 1) * CH + st) * 2 + cl] =
+                    v4{on ? (P.dt * inc) * sR : 0.f, ROWS::rsq(fmaxf(nv, 1e-12f)) * sB, on ? sQ : 0.f, on ? (2.0f * (ev - inc)) * sR : 0.f};
+            else
             tab[((cj & 1) * CH + st) * 2 + cl] =
                 v4{on ? (inc / A) * sR : 0.f, ROWS::rsq(fmaxf(nv, 1e-12f)) * sB, on ? sQ : 0.f, on ? (2.0f * (zbar * inc / A)) * sR : 0.f};
         }
@@ -282,7 +294,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_grad_gemm(Dev P, const float* __r
                         val[1][j][4] = (kb + j > 0) ? ui : ps0.y;
                     } else {
                         constexpr int c = part - 2;
-                        val[c][j][0] = sk[j].w * rY[c][j + 1];
+                        val[c][j][0] = LEGACY ? sk[j].w * (F16 ? val[c][j][4] * (1.0f / sB) : val[c][j][4]) : sk[j].w * rY[c][j + 1];
                         val[c][j][1] = sk[j].x * rYB[c][j];
                         val[c][j][2] = sk[j].z * rYB[c][j];
                         val[c][j][3] = F16 ? rY[c][j + 1] * sB : rY[c][j + 1];
@@ -370,8 +382,8 @@ __global__ __launch_bounds__(2 * PD, 1) void k_grad_gemm(Dev P, const float* __r
             if constexpr (MAC) {
                 constexpr int g = t / (6 * PWV), ap = (t / PWV) % 6, cb = t % PWV;
                 constexpr int ng = g + 1;
-                if constexpr (ap == 0) Rre[cb] = mma<F16>(Areg[0], By[cb], Rre[cb]);
-                if constexpr (ap == 1) Rim[cb] = mma<F16>(Areg[1], By[cb], Rim[cb]);
+                if constexpr (ap == 0) Rre[cb] = mma<F16>(Areg[0], LEGACY ? Bu[cb] : By[cb], Rre[cb]);
+                if constexpr (ap == 1) Rim[cb] = mma<F16>(Areg[1], LEGACY ? Bu[cb] : By[cb], Rim[cb]);
                 if constexpr (ap == 2) Qre[cb] = mma<F16>(Areg[2], Bu[cb], Qre[cb]);
                 if constexpr (ap == 3) Qim[cb] = mma<F16>(Areg[3], Bu[cb], Qim[cb]);
                 if constexpr (ap == 4) Rre[cb] = mma<F16>(Areg[4], Bu[cb], Rre[cb]);

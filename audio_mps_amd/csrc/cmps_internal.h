@@ -250,6 +250,9 @@ hipError_t launch_fwd_pair(const Dev& P, const float* audio, float* loss, bool s
 hipError_t launch_bwd_pair(const Dev& P, const float* audio, hipStream_t s);
 hipError_t launch_grad_pair(const Dev& P, const float* audio, hipStream_t s);
 hipError_t launch_fwd_wide(const Dev& P, const float* audio, float* loss, bool save, bool hy_f16, bool chain_mfma, hipStream_t s);
+hipError_t launch_fwd_wide_legacy(const Dev& P, const float* audio, float* loss, bool save, bool hy_f16, hipStream_t s);
+hipError_t launch_bwd_wide_legacy(const Dev& P, const float* audio, hipStream_t s);
+hipError_t launch_grad_wide_legacy(const Dev& P, const float* audio, bool f16, hipStream_t s);
 hipError_t launch_fwd_chain16(const Dev& P, const float* audio, hipStream_t s);
 hipError_t launch_bwd_chain16(const Dev& P, const float* audio, hipStream_t s);    // cmps_pair.hip: the wide family's chain on the matrix cores
 hipError_t launch_bwd_wide(const Dev& P, const float* audio, hipStream_t s);

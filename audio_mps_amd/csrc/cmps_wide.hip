@@ -221,7 +221,12 @@ __device__ __forceinline__ StepScal step_scalars(float inc, float nv, float ev, 
 // SAVE = true (training): the kernel is the serial chain alone -- it stashes y_k and |y_k|^2 -- and H y, e_k = y_k . H y_k and
 // the loss follow as a GEMM over all (clip, step) pairs at once (k_hy_wide, k_loss_wide below): the in-kernel product costs
 // 128 of the 320 packed FMAs a wave issues per step (38 of 62 ms at configs[4]), the GEMM runs them on the matrix cores.
-template <int PD, bool SAVE>
+// LEGACY (round 5): the arithmetic of the previous-generation AudioMPS (cmps_legacy.hip has the recurrence and its
+// graph.pbtxt lines) on the same kernels, as the D <= 32 wave kernels do it (cmps_wave2.hip).  With rho = 1 and psi_0 = e_0 in the tables
+// (cmps_legacy_set_params) the chain is the same linear step y_k = inv_{k-1} (y_{k-1} + M_k y_{k-1}), M_k = Q + dt x_k R (Q a general
+// complex matrix); what differs is scalar: e_k = (y_{k-1}^dagger H y_{k-1}) / max(|y_{k-1}|^2, 1e-12) on the normalised state BEFORE the
+// update (e_0 = H_00), loss += (x_k - e_k)^2 / 2.
+template <int PD, bool SAVE, bool LEGACY = false>
 __global__ __launch_bounds__(4 * PD) void k_fwd_wide(Dev P, const float* __restrict__ audio, float* __restrict__ loss_out) {
     using G = WideGeom<PD>;
     constexpr int NW = G::NW, KC = G::KC, VSL = G::VSL, VEC4 = G::VEC4;
@@ -276,6 +281,8 @@ __global__ __launch_bounds__(4 * PD) void k_fwd_wide(Dev P, const float* __restr
     float sv0 = 0.f, sv1 = 0.f;                                   // s = x / A of the current 64 steps, lane <-> step
     float ebuf0 = 0.f, ebuf1 = 0.f, nbuf0 = 0.f, nbuf1 = 0.f;     // wave 0: e_k, |y_k|^2 of the current chunk, lane <-> step
     float loss0 = 0.f, loss1 = 0.f;
+    float nq0 = 1.f, nq1 = 1.f;                                   // LEGACY loss in the kernel: |y_{k-2}|^2 (the sums of the iteration before)
+    float fbel0 = 2.0f * P.R[0].x, fbel1 = fbel0, nbel0 = 1.f, nbel1 = 1.f;   // ... y^dagger H y and |y|^2 of the step below the chunk (psi_0 = e_0)
     float2 rho_next = P.rho[row];                                 // rho_0
     __syncthreads();
 
@@ -289,8 +296,9 @@ __global__ __launch_bounds__(4 * PD) void k_fwd_wide(Dev P, const float* __restr
         if (chain && (k & (WCH - 1)) == 0) {                      // increments of the next 64 steps, one per lane (model.py:263, 303)
             const int idx = k + lane;
             const bool in0 = idx < T, in1 = idx + 1 < T;
-            sv0 = ((in1 ? xr0[idx + 1] : 0.f) - (in0 ? xr0[idx] : 0.f)) / A;
-            sv1 = ((in1 ? xr1[idx + 1] : 0.f) - (in0 ? xr1[idx] : 0.f)) / A;
+            const float i0 = (in1 ? xr0[idx + 1] : 0.f) - (in0 ? xr0[idx] : 0.f), i1 = (in1 ? xr1[idx + 1] : 0.f) - (in0 ? xr1[idx] : 0.f);
+            sv0 = LEGACY ? P.dt * i0 : i0 / A;
+            sv1 = LEGACY ? P.dt * i1 : i1 / A;
         }
         const float2 rho_k = rho_next;
         // y_{k-1} goes out HERE, in front of the rho load: vector-memory operations retire in order, so waiting for rho_{k+1} at the
@@ -359,13 +367,24 @@ __global__ __launch_bounds__(4 * PD) void k_fwd_wide(Dev P, const float* __restr
                     const float2 t = *reinterpret_cast<const float2*>(&ee[(p * NW + ww) * 2]);
                     e0 += t.x; e1 += t.y;
                 }
-                if (lane == (ke & (WCH - 1))) { ebuf0 = e0; ebuf1 = e1; }
+                if (lane == (ke & (WCH - 1))) { ebuf0 = e0; ebuf1 = e1; if (LEGACY) { nbuf0 = nq0; nbuf1 = nq1; } }
                 if ((ke & (WCH - 1)) == WCH - 1 || ke == N - 1) {
                     const int c = ke / WCH, idx = c * WCH + lane;
                     const bool in = idx < N;
                     const float i0 = in ? xr0[idx + 1] - xr0[idx] : 0.f, i1 = in ? xr1[idx + 1] - xr1[idx] : 0.f;
-                    const float l0 = in ? -logf(1.0f + (ebuf0 * i0) / A) : 0.f;        // model.py:294 operation order
-                    const float l1 = in ? -logf(1.0f + (ebuf1 * i1) / A) : 0.f;
+                    float l0, l1;
+                    if constexpr (LEGACY) {                       // the expectation on the normalised state of the step below (graph.pbtxt:11857-12819)
+                        float f0 = __shfl_up(ebuf0, 1, 64), f1 = __shfl_up(ebuf1, 1, 64), m0 = __shfl_up(nbuf0, 1, 64), m1 = __shfl_up(nbuf1, 1, 64);
+                        if (lane == 0) { f0 = fbel0; f1 = fbel1; m0 = nbel0; m1 = nbel1; }
+                        fbel0 = wrdl(ebuf0, WCH - 1); fbel1 = wrdl(ebuf1, WCH - 1); nbel0 = wrdl(nbuf0, WCH - 1); nbel1 = wrdl(nbuf1, WCH - 1);
+                        const float v0 = 1.0f / sqrtf(fmaxf(m0, 1e-12f)), v1 = 1.0f / sqrtf(fmaxf(m1, 1e-12f));
+                        const float d0 = i0 - (f0 * v0) * v0, d1 = i1 - (f1 * v1) * v1;
+                        l0 = in ? d0 * d0 / 2.0f : 0.f;
+                        l1 = in ? d1 * d1 / 2.0f : 0.f;
+                    } else {
+                    l0 = in ? -logf(1.0f + (ebuf0 * i0) / A) : 0.f;        // model.py:294 operation order
+                    l1 = in ? -logf(1.0f + (ebuf1 * i1) / A) : 0.f;
+                    }
 #pragma unroll
                     for (int j = 0; j < WCH; ++j) {               // model.py:279: sequential in time
                         loss0 += wrdl(l0, j);
@@ -374,6 +393,7 @@ __global__ __launch_bounds__(4 * PD) void k_fwd_wide(Dev P, const float* __restr
                 }
             }
         }
+        if (LEGACY && LOSS) { nq0 = n0; nq1 = n1; }               // |y_{k-1}|^2: the e of step k - 1 is finished in the next iteration
         if (w == 0 && SAVE && k >= 1) {                           // |y_{k-1}|^2 rows of the scalar stash, one chunk per 64 steps
             const int kn = k - 1;
             if (lane == (kn & (WCH - 1))) { nbuf0 = n0; nbuf1 = n1; }
@@ -799,24 +819,44 @@ __global__ __launch_bounds__(2 * PD, 1) void k_hy_wide(Dev P) {
 
 // loss_b = sum_k -log(1 + (e_k x_k) / A), accumulated sequentially in float32 in time order (model.py:279, 294): one wavefront per
 // clip, the logarithms of 64 steps at a time (one step per lane), then 64 ordered adds
+template <bool LEGACY>
 __global__ __launch_bounds__(64) void k_loss_wide(Dev P, const float* __restrict__ audio, float* __restrict__ loss_out) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const int N = P.N, NC = (N + WCH - 1) / WCH;
     const float* xr = audio + (size_t)b * P.T;
-    const float* sc = P.scal + (size_t)b * NC * 128;
+    float* sc = P.scal + (size_t)b * NC * 128;
     const float A = dev_A(P);
     float loss = 0.f;
     float en = lane < N ? sc[64 + lane] : 0.f, x0n = lane < N ? xr[lane] : 0.f, x1n = lane < N ? xr[lane + 1] : 0.f;
+    float nn = (LEGACY && lane < N) ? sc[lane] : 1.f;
+    float f_below = LEGACY ? 2.0f * P.R[0].x : 0.f, n_below = 1.f;     // LEGACY: y^dagger H y and |y|^2 of the step below the chunk (psi_0 = e_0)
     for (int c = 0; c < NC; ++c) {
-        const float e = en, inc = x1n - x0n;
+        float e = en;
+        const float inc = x1n - x0n, nv = nn;
         const bool in = c * WCH + lane < N;
         const int idx = (c + 1) * WCH + lane;
         if (c + 1 < NC) {
             en = idx < N ? sc[(size_t)(c + 1) * 128 + 64 + lane] : 0.f;
+            if (LEGACY) nn = idx < N ? sc[(size_t)(c + 1) * 128 + lane] : 1.f;
             x0n = idx < N ? xr[idx] : 0.f;
             x1n = idx < N ? xr[idx + 1] : 0.f;
         }
-        const float lv = in ? -logf(1.0f + (e * inc) / A) : 0.f;
+        float lv;
+        if constexpr (LEGACY) {
+            // e_k = psi_k^dagger (R + R^T) psi_k on the normalised state of the step below (graph.pbtxt:11857-12661), loss += (x_k - e_k)^2 / 2
+            // (:12685-12819); the e row is REPLACED by the legacy e_k (what the reverse scan and the gradient GEMM read), as the wave kernels do
+            float fb = __shfl_up(e, 1, 64), nb = __shfl_up(nv, 1, 64);
+            if (lane == 0) { fb = f_below; nb = n_below; }
+            f_below = wrdl(e, WCH - 1);
+            n_below = wrdl(nv, WCH - 1);
+            const float invb = 1.0f / sqrtf(fmaxf(nb, 1e-12f));       // graph.pbtxt:14350-14594
+            e = (fb * invb) * invb;
+            if (in) sc[(size_t)c * 128 + 64 + lane] = e;
+            const float d = inc - e;
+            lv = in ? d * d / 2.0f : 0.f;
+        } else {
+            lv = in ? -logf(1.0f + (e * inc) / A) : 0.f;
+        }
 #pragma unroll
         for (int j = 0; j < WCH; ++j) loss += wrdl(lv, j);
     }
@@ -831,7 +871,10 @@ __global__ __launch_bounds__(64) void k_loss_wide(Dev P, const float* __restrict
 // rad_{k+1} = Re(u_{k+1}^dagger g_{k+1}) = te_{k+1} e_{k+1} (Euler: everything downstream of u_{k+1} is scale invariant except
 // the loss term of step k + 1, homogeneous of degree 2), 0 behind the last step.
 // ------------------------------------------------------------------------------------------------------------------------
-template <int PD>
+// LEGACY: Q^dagger instead of Q (the legacy Q is not Hermitian) and the legacy per-step scalars -- s = dt x_k, te_k = 2 (e_k - x_k); the
+// loss term of step k + 1 looks at the NORMALISED y_k, so it enters ybar_k with the coefficient te_{k+1} inv_k^2 on H y_k and the radial
+// part rad_{k+1} = te_{k+1} e_{k+1} (everything else downstream of psi_{k+1} is scale invariant, as in the PsiCMPS arithmetic).
+template <int PD, bool LEGACY = false>
 __global__ __launch_bounds__(4 * PD) void k_bwd_wide(Dev P, const float* __restrict__ audio) {
     using G = WideGeom<PD>;
     constexpr int NW = G::NW, KC = G::KC, VSL = G::VSL, VEC4 = G::VEC4;
@@ -860,9 +903,14 @@ __global__ __launch_bounds__(4 * PD) void k_bwd_wide(Dev P, const float* __restr
 #pragma unroll
         for (int j = 0; j < KC; ++j) {
             const float2 a = P.RT[(size_t)ra * PD + c0 + j], b = P.RT[(size_t)rb * PD + c0 + j];   // R^dagger[i][j] = conj(RT[i][j])
-            const float2 c = P.Q[(size_t)ra * PD + c0 + j], d = P.Q[(size_t)rb * PD + c0 + j];
+            if constexpr (LEGACY) {                               // Q^dagger[i][j] = conj(QT[i][j])
+                const float2 c = P.QT[(size_t)ra * PD + c0 + j], d = P.QT[(size_t)rb * PD + c0 + j];
+                MQ[0][j] = mkv2(c.x, -c.y); MQ[1][j] = mkv2(d.x, -d.y);
+            } else {
+                const float2 c = P.Q[(size_t)ra * PD + c0 + j], d = P.Q[(size_t)rb * PD + c0 + j];
+                MQ[0][j] = mkv2(c.x, c.y); MQ[1][j] = mkv2(d.x, d.y);
+            }
             MD[0][j] = mkv2(a.x, -a.y); MD[1][j] = mkv2(b.x, -b.y);
-            MQ[0][j] = mkv2(c.x, c.y); MQ[1][j] = mkv2(d.x, d.y);
         }
     }
     const int own_f = vec_float_index<PD>(row, comp, clip);
@@ -873,6 +921,7 @@ __global__ __launch_bounds__(4 * PD) void k_bwd_wide(Dev P, const float* __restr
 
     // every wave builds its own copy of a chunk's scalar rows (no cross-wave hand-over): lane <-> step
     float accA = 0.f, svA0 = 0.f, svA1 = 0.f, svB0 = 0.f, svB1 = 0.f;      // s of chunk parity 0 / 1, lane <-> step
+    float te_above0 = 0.f, te_above1 = 0.f;                       // LEGACY: te of the first step of the chunk above (no step N: 0)
     auto chunk_rows = [&](int cj) {
         const int idx = cj * WCH + lane;
         const bool in = idx < N;
@@ -884,7 +933,22 @@ __global__ __launch_bounds__(4 * PD) void k_bwd_wide(Dev P, const float* __restr
             const float x0 = idx < T ? xr[idx] : 0.f, x1 = idx + 1 < T ? xr[idx + 1] : 0.f;
             const float nv = in ? sc[(size_t)cj * 128 + lane] : 1.f;
             const float ev = in ? sc[(size_t)cj * 128 + 64 + lane] : 0.f;
-            const StepScal r = step_scalars(x1 - x0, nv, ev, A);
+            StepScal r;
+            if constexpr (LEGACY) {
+                const float inc = x1 - x0;
+                const float tev = in ? 2.0f * (ev - inc) : 0.f;   // te_k = 2 ebar_k, ebar_k = e_k - x_k (the e rows hold the legacy e_k: k_loss_wide)
+                float ten = __shfl_down(tev, 1, 64);               // te_{k+1}
+                if (lane == 63) ten = qq ? te_above1 : te_above0;
+                if (qq) te_above1 = wrdl(tev, 0); else te_above0 = wrdl(tev, 0);
+                r.s = P.dt * inc;
+                r.inv = rsq_newton(fmaxf(nv, 1e-12f));
+                r.ok = nv > 1e-12f ? 1.f : 0.f;
+                r.te = ten * r.inv * r.inv;                        // the coefficient of H y_k in ybar_k
+                r.rad = tev * ev;
+                r.zex = 0.f;
+            } else {
+                r = step_scalars(x1 - x0, nv, ev, A);
+            }
             tab[w][cj & 1][lane][qq][0] = v4f{r.s, r.inv, r.ok, r.te};
             tab[w][cj & 1][lane][qq][1] = v4f{r.rad, dtv, 0.f, 0.f};
             if (cj & 1) { if (qq) svB1 = r.s; else svB0 = r.s; } else { if (qq) svA1 = r.s; else svA0 = r.s; }
@@ -1036,22 +1100,22 @@ static hipError_t wide_lds_attr(K kernel, size_t shm) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
 }
 
-template <int PD>
+template <int PD, bool LEGACY = false>
 static hipError_t fwd_wide_t(const Dev& P, const float* audio, float* loss, bool save, bool hy_f16, bool chain_mfma, hipStream_t s) {
     const unsigned nb = (unsigned)((P.B + 1) / 2);
     hipError_t e;
     if (save) {
         // the serial chain, then H y / e_k for all (clip, step) pairs as one GEMM launch, then the sequential loss sums
         const size_t shm = WideGeom<PD>::FWD_LDS_CHAIN, shm_hy = HyGeom<PD>::LDS;
-        e = wide_lds_attr(k_fwd_wide<PD, true>, shm);
+        e = wide_lds_attr(k_fwd_wide<PD, true, LEGACY>, shm);
         if (e == hipSuccess) e = hy_f16 ? wide_lds_attr(k_hy_wide<PD, true>, shm_hy) : wide_lds_attr(k_hy_wide<PD, false>, shm_hy);
         if (e != hipSuccess) return e;
-        if (chain_mfma) {
+        if (chain_mfma && !LEGACY) {
             KScope ks("k_fwd_chain16", s);
             if ((e = launch_fwd_chain16(P, audio, s)) != hipSuccess) return e;
         } else {
             KScope ks("k_fwd_wide", s);
-            hipLaunchKernelGGL((k_fwd_wide<PD, true>), dim3(nb), dim3(4 * PD), shm, s, P, audio, loss);
+            hipLaunchKernelGGL((k_fwd_wide<PD, true, LEGACY>), dim3(nb), dim3(4 * PD), shm, s, P, audio, loss);
         }
         {
             KScope ks(hy_f16 ? "k_hy_wide<f16x2>" : "k_hy_wide<3>", s);
@@ -1059,14 +1123,31 @@ static hipError_t fwd_wide_t(const Dev& P, const float* audio, float* loss, bool
             if (hy_f16) hipLaunchKernelGGL((k_hy_wide<PD, true>), grid, dim3(2 * PD), shm_hy, s, P);
             else hipLaunchKernelGGL((k_hy_wide<PD, false>), grid, dim3(2 * PD), shm_hy, s, P);
         }
-        { KScope ks("k_loss_wide", s); hipLaunchKernelGGL(k_loss_wide, dim3((unsigned)P.B), dim3(64), 0, s, P, audio, loss); }
+        { KScope ks("k_loss_wide", s); hipLaunchKernelGGL(k_loss_wide<LEGACY>, dim3((unsigned)P.B), dim3(64), 0, s, P, audio, loss); }
     } else {
         const size_t shm = WideGeom<PD>::FWD_LDS;
-        e = wide_lds_attr(k_fwd_wide<PD, false>, shm);
+        e = wide_lds_attr(k_fwd_wide<PD, false, LEGACY>, shm);
         if (e != hipSuccess) return e;
         KScope ks("k_fwd_wide", s);
-        hipLaunchKernelGGL((k_fwd_wide<PD, false>), dim3(nb), dim3(4 * PD), shm, s, P, audio, loss);
+        hipLaunchKernelGGL((k_fwd_wide<PD, false, LEGACY>), dim3(nb), dim3(4 * PD), shm, s, P, audio, loss);
     }
+    return hipGetLastError();
+}
+
+// the legacy AudioMPS arithmetic on the wide kernels (32 < D <= 128): the fp32 VALU chain kernels in their LEGACY mode + the same GEMMs
+hipError_t launch_fwd_wide_legacy(const Dev& P, const float* audio, float* loss, bool save, bool hy_f16, hipStream_t s) {
+    if (P.DP == 128) return fwd_wide_t<128, true>(P, audio, loss, save, hy_f16, false, s);
+    if (P.DP == 96) return fwd_wide_t<96, true>(P, audio, loss, save, hy_f16, false, s);
+    if (P.DP == 64) return fwd_wide_t<64, true>(P, audio, loss, save, hy_f16, false, s);
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_bwd_wide_legacy(const Dev& P, const float* audio, hipStream_t s) {
+    const unsigned nb = (unsigned)((P.B + 1) / 2);
+    if (P.DP == 128) hipLaunchKernelGGL((k_bwd_wide<128, true>), dim3(nb), dim3(512), 0, s, P, audio);
+    else if (P.DP == 96) hipLaunchKernelGGL((k_bwd_wide<96, true>), dim3(nb), dim3(384), 0, s, P, audio);
+    else if (P.DP == 64) hipLaunchKernelGGL((k_bwd_wide<64, true>), dim3(nb), dim3(256), 0, s, P, audio);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
@@ -1095,11 +1176,25 @@ hipError_t launch_bwd_wide(const Dev& P, const float* audio, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int PD, int NPC, bool F16 = false>
+template <int PD, int NPC, bool F16 = false, bool LEGACY = false>
 static hipError_t grad_wide_t(const Dev& P, const float* audio, hipStream_t s) {
     const unsigned nb = (unsigned)((P.B + 1) / 2);
-    hipLaunchKernelGGL((k_grad_gemm<PD, NPC, WideRows<PD>, F16>), dim3(nb), dim3(2 * PD), 0, s, P, audio);   // static LDS: 2 x NPC x 160 PD + 4 KB
+    hipLaunchKernelGGL((k_grad_gemm<PD, NPC, WideRows<PD>, F16, LEGACY>), dim3(nb), dim3(2 * PD), 0, s, P, audio);   // static LDS: 2 x NPC x 160 PD + 4 KB
     return hipGetLastError();
+}
+
+// legacy mode: two fp16 pieces (CMPS_RANK1_F16X2 / DEFAULT) or three bf16 pieces (every other value)
+hipError_t launch_grad_wide_legacy(const Dev& P, const float* audio, bool f16, hipStream_t s) {
+    if (f16) {
+        if (P.DP == 128) return grad_wide_t<128, 2, true, true>(P, audio, s);
+        if (P.DP == 96) return grad_wide_t<96, 2, true, true>(P, audio, s);
+        if (P.DP == 64) return grad_wide_t<64, 2, true, true>(P, audio, s);
+    } else {
+        if (P.DP == 128) return grad_wide_t<128, 3, false, true>(P, audio, s);
+        if (P.DP == 96) return grad_wide_t<96, 3, false, true>(P, audio, s);
+        if (P.DP == 64) return grad_wide_t<64, 3, false, true>(P, audio, s);
+    }
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_grad_wide(const Dev& P, const float* audio, int pieces, hipStream_t s) {

@@ -264,7 +264,9 @@ int cmps_psi_sample(cmps_handle_t h, const float* noise_dev, int n, int length, 
  * cmps_legacy_loss_fwd / _bwd mirror cmps_psi_loss_fwd / _bwd; grad_dev [3*D*D + 1] receives sums over clips of
  *   dQ_re [D*D], dQ_im [D*D], dR (the direct real-R part) [D*D], sum_b loss_b.
  * D <= 32 runs on the wavefront-per-clip kernels of the pure-state path in their legacy mode (same rank-1 arithmetic option,
- * CMPS_OPT_RANK1); CMPS_VARIANT_BLOCK and D > 32 run the general one-workgroup-per-clip kernels.
+ * CMPS_OPT_RANK1); 32 < D <= 128 on the wide kernels in their legacy mode (fp32 VALU chains; the H y and gradient GEMMs with two fp16
+ * pieces for CMPS_RANK1_F16X2 / DEFAULT, three bf16 pieces otherwise); CMPS_VARIANT_BLOCK runs the general one-workgroup-per-clip
+ * kernels at every D (the cross-check implementation).
  */
 int cmps_legacy_set_params(cmps_handle_t h, const float* R_dev, const float* Q_re_dev, const float* Q_im_dev,
                            double delta_t, int T, int B_max, int flags, void* workspace_dev, size_t workspace_bytes,

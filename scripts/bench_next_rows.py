@@ -120,8 +120,15 @@ lm64 = LegacyAudioMPS(64, 1e-3, B, seed=1)
 lb64 = lm64._get_backend()
 lb64.legacy_set_params(lm64.variables["R"], lm64.Q, lm64.delta_t, B, T, train=True)
 ms = dev_ms(lambda: (lb64.legacy_forward(audio64, save_for_bwd=True), lb64.legacy_backward()), rounds=2)
-res["legacy_audiomps_d64"] = {"shape": f"D=64, T={T}, B={B}, fwd+bwd", "kernel": "k_fwd_legacy + k_bwd_legacy (general block kernels: one workgroup per clip)", "ms": ms,
-                              "samples_per_s": B * T / ms * 1e3, "bound": "not optimised: LDS-resident matrices, one workgroup per clip (the wide family has no legacy mode yet)"}
+res["legacy_audiomps_d64"] = {"shape": f"D=64, T={T}, B={B}, fwd+bwd", "kernel": "k_fwd_wide<LEGACY> + k_hy_wide + k_loss_wide<LEGACY> + k_bwd_wide<LEGACY> + k_grad_gemm<LEGACY> (round 5: the wide kernels in legacy mode)", "ms": ms,
+                              "samples_per_s": B * T / ms * 1e3, "bound": "serial fp32 VALU chains of one workgroup per pair of clips (128 workgroups at B = 256) + the two GEMMs"}
+from audio_mps_amd.scan import HipScan
+lm64b = LegacyAudioMPS(64, 1e-3, B, seed=1, backend=HipScan(64, variant=1))
+lb64b = lm64b._get_backend()
+lb64b.legacy_set_params(lm64b.variables["R"], lm64b.Q, lm64b.delta_t, B, T, train=True)
+ms = dev_ms(lambda: (lb64b.legacy_forward(audio64, save_for_bwd=True), lb64b.legacy_backward()), rounds=2)
+res["legacy_audiomps_d64_general_kernels"] = {"shape": f"D=64, T={T}, B={B}, fwd+bwd", "kernel": "k_fwd_legacy + k_bwd_legacy (CMPS_VARIANT_BLOCK: one workgroup per clip; what D > 32 ran on until round 4)", "ms": ms,
+                                              "samples_per_s": B * T / ms * 1e3}
 hp = HParams(minibatch_size=B, bond_dim=64, initial_rank=16)
 a = make_audio(B, T, hp.delta_t, 2)
 rm = RhoCMPS(hp, data_iterator=a, seed=2)

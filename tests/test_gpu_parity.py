@@ -537,7 +537,11 @@ def test_more_clips_than_simds():
 # next row: the legacy AudioMPS arithmetic
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("D,T,B,dt", [(5, 200, 8, 0.01), (10, 300, 4, 0.001), (32, 150, 3, 0.01), (40, 60, 2, 0.01),
-                                      (7, 2, 3, 0.01), (32, 34, 5, 0.004), (16, 1000, 9, 0.002)])      # one step; a one-step last chunk; many chunks
+                                      (7, 2, 3, 0.01), (32, 34, 5, 0.004), (16, 1000, 9, 0.002),       # one step; a one-step last chunk; many chunks
+                                      # D > 32: the wide kernels in legacy mode (round 5; cmps_wide.hip): the three padded sizes, odd batches,
+                                      # one step, T - 1 around the 64-step scalar chunks and the 4-step GEMM units
+                                      (64, 300, 4, 0.004), (96, 130, 3, 0.004), (128, 200, 5, 0.002), (33, 2, 1, 0.01), (72, 66, 2, 0.004),
+                                      (100, 65, 3, 0.002), (48, 129, 1, 0.01), (64, 1000, 6, 0.001)])
 def test_legacy_audiomps_matches_oracle(D, T, B, dt):
     from audio_mps_amd import AudioMPS, LegacyAudioMPS
     audio = make_audio(B, T, dt, D, noise=0.05)
@@ -580,6 +584,27 @@ def test_legacy_qbar_is_the_H_gradient_at_large_R(D, T, dt, scale):
         for k, name in (("R", "gR"), ("H", "gH")):
             bar = 3 * own[name] + (3e-5 if mode == 1 else 1e-5)
             assert rel_inf(grads[k], ref64[name]) <= bar, (mode, k, rel_inf(grads[k], ref64[name]), own[name])
+
+
+@pytest.mark.parametrize("D,T", [(40, 75), (64, 260), (96, 131), (128, 70)])
+@pytest.mark.parametrize("mode", [2, 4])
+def test_legacy_wide_and_general_kernels_agree(D, T, mode):
+    """32 < D <= 128 runs the wide kernels in legacy mode (k_fwd_wide / k_bwd_wide<LEGACY> + the H y and gradient GEMMs, two fp16 or three
+    bf16 pieces); CMPS_VARIANT_BLOCK keeps the general one-workgroup-per-clip kernels (cmps_legacy.hip): two independent implementations
+    of SURVEY Appendix A.  Also the forward-only path (the loss product inside the chain kernel)."""
+    from audio_mps_amd import LegacyAudioMPS
+    from audio_mps_amd.scan import HipScan
+    B, dt = 5, 0.004
+    audio = make_audio(B, T, dt, D, noise=0.05)
+    a = LegacyAudioMPS(D, dt, B, data_iterator=audio, seed=4, backend=HipScan(D, rank1=mode))
+    b = LegacyAudioMPS(D, dt, B, data_iterator=audio, seed=4, backend=HipScan(D, variant=BLOCK))
+    pa, pb = a.loss_per_clip(), b.loss_per_clip()                 # forward only (no stash)
+    assert np.max(np.abs(pa - pb) / np.maximum(np.abs(pb), 1.0)) <= LOSS_RTOL
+    la, ga = a.loss_and_grads()                                   # training forward (chain + GEMM + loss kernel) and reverse
+    lb, gb = b.loss_and_grads()
+    assert abs(float(la) - float(lb)) <= LOSS_RTOL * max(1.0, abs(float(lb)))
+    for k in ga:
+        assert rel_inf(ga[k], gb[k]) <= GRAD_RTOL, k
 
 
 @pytest.mark.parametrize("T", [65, 130, 400])
