@@ -590,6 +590,20 @@ int cmps_rho_set_state(cmps_handle_t h, const float* phi_re_dev, const float* ph
     W.slabs = train ? reinterpret_cast<float*>(ws + RL.off_slabs) : nullptr;
     W.sums = train ? reinterpret_cast<float*>(ws + RL.off_sums) : nullptr;
     W.slab_floats = RL.slab_floats;
+    W.vrank = RL.vrank;                                          // > 0: the sections of the wide (virtual-clip) path exist
+    if (RL.vrank) {
+        W.vphi = reinterpret_cast<float2*>(ws + RL.off_vphi);
+        W.vstash = reinterpret_cast<float*>(ws + RL.off_vstash);
+        W.vgops = reinterpret_cast<float*>(ws + RL.off_vgops);
+        W.vopmax = reinterpret_cast<float*>(ws + RL.off_vopmax);
+        W.vscal = reinterpret_cast<float*>(ws + RL.off_vscal);
+        W.rscal = reinterpret_cast<float*>(ws + RL.off_rscal);
+        W.vslabs = reinterpret_cast<float*>(ws + RL.off_vslabs);
+        W.vsums = reinterpret_cast<float*>(ws + RL.off_vsums);
+        W.vaudio = reinterpret_cast<float*>(ws + RL.off_vaudio);
+        W.gphi = reinterpret_cast<float*>(ws + RL.off_gphi);
+        W.vslab_floats = RL.vslab_floats;
+    }
     hipError_t e = launch_pack_phi(h->P, W, phi_re_dev, phi_im_dev, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail_hip(h, e, "cmps_rho_set_state");
     h->RL = RL; h->W = W;
@@ -616,12 +630,18 @@ int cmps_rho_loss_fwd(cmps_handle_t h, const float* audio_dev, int B, int T, flo
     // GEMMs on the matrix cores (cmps_rho_mfma.hip); CMPS_VARIANT_WAVE32 keeps the column-by-column kernel (cross-check)
     const bool wave = h->D <= 32 && h->W.rank <= 32 && h->variant_req != CMPS_VARIANT_BLOCK;
     const bool mfma = wave && h->variant_req != CMPS_VARIANT_WAVE32 && h->W.rank > 8;   // below rank ~10 the column loop is faster
+    // 32 < D <= 128, training forward (round 5): the columns as virtual clips of the wide kernels (cmps_wide.hip), when the rho workspace
+    // has the sections for it (cmps_rho_workspace_bytes: CMPS_WS_TRAIN and the column vectors fit the LDS); else the general kernels
+    const bool wide = h->D > 32 && h->W.vrank > 0 && save_for_bwd != 0 && h->variant_req != CMPS_VARIANT_BLOCK;
+    const bool f16 = h->rank1_mode == CMPS_RANK1_DEFAULT || h->rank1_mode == CMPS_RANK1_F16X2;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipError_t e = mfma ? launch_fwd_rho_mfma(P, h->W, audio_dev, loss_dev, save_for_bwd != 0, h->rank1_mode == CMPS_RANK1_DEFAULT || h->rank1_mode == CMPS_RANK1_F16X2, s)
+    KBind kb(h);
+    hipError_t e = wide ? launch_fwd_rho_wide(P, h->W, audio_dev, loss_dev, f16, s)
+                 : mfma ? launch_fwd_rho_mfma(P, h->W, audio_dev, loss_dev, save_for_bwd != 0, f16, s)
                  : wave ? launch_fwd_rho_wave(P, h->W, audio_dev, loss_dev, save_for_bwd != 0, s)
                         : launch_fwd_rho(P, h->W, audio_dev, loss_dev, save_for_bwd != 0, s);
     if (e != hipSuccess) return fail_hip(h, e, "cmps_rho_loss_fwd");
-    h->W.stash_layout = mfma ? 2 : (wave ? 1 : 0);
+    h->W.stash_layout = wide ? 3 : mfma ? 2 : (wave ? 1 : 0);
     h->rho_saved = h->rho_bwd_ok = save_for_bwd != 0;
     h->rho_saved_B = B; h->rho_saved_steps = T - 1;
     h->saved_audio = audio_dev; h->saved_loss = loss_dev;
@@ -639,6 +659,14 @@ int cmps_rho_loss_bwd(cmps_handle_t h, const float* audio_dev, int B, int T, flo
     P.B = B; P.T = T; P.N = T - 1;
     P.slabs = h->W.slabs; P.sums = h->W.sums; P.slab_floats = h->W.slab_floats;   // the reduction runs on the rho slabs
     hipStream_t s = static_cast<hipStream_t>(stream);
+    KBind kb(h);
+    if (h->W.stash_layout == 3) {                                 // the wide kernels on virtual clips: reverse chain, GEMM, reduction, closing terms
+        const int rm = h->rank1_mode == CMPS_RANK1_DEFAULT ? CMPS_RANK1_F16X2 : h->rank1_mode;
+        const hipError_t ew = launch_bwd_rho_wide(P, h->W, h->saved_loss, grad_dev,
+                                                  rm == CMPS_RANK1_F16X2 ? -2 : rm == CMPS_RANK1_BF16X2 ? 2 : 3, s);
+        if (ew != hipSuccess) return fail_hip(h, ew, "cmps_rho_loss_bwd (wide)");
+        return CMPS_OK;
+    }
     hipError_t e = h->W.stash_layout == 2 ? launch_bwd_rho_mfma(P, h->W, audio_dev, s)
                  : h->W.stash_layout == 1 ? launch_bwd_rho_wave(P, h->W, audio_dev, s) : launch_bwd_rho(P, h->W, audio_dev, s);
     if (e != hipSuccess) return fail_hip(h, e, "cmps_rho_loss_bwd (scan)");

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_grad_gemm(Dev P, const float* __r
     const int prow = 8 * (tid >> 4) + (tid & 7), pclip = (tid >> 3) & 1;
     const float* stf = reinterpret_cast<const float*>(P.stash) + (size_t)blockIdx.x * N * (8 * PD);   // uniform bases
     const float* ybs = reinterpret_cast<const float*>(P.gops) + (size_t)blockIdx.x * N * (4 * PD);
-    float2 ps0 = P.psi0[prow];
+    float2 ps0 = P.phi0 ? P.phi0[(size_t)((2 * blockIdx.x + pclip) % P.phi_rank) * PD + prow] : P.psi0[prow];   // (RhoCMPS: the column's phi_a)
     // ---- MFMA role: wave w owns the 32-row block w of Re Rbar, Im Rbar, Re Qbar, Im Qbar ----
     const int mr = lane & 31, mh = lane >> 5;
     const unsigned imask = mh ? 0x80008000u : 0u;                 // Im form: K half 1 is -a_re

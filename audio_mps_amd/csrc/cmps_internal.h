@@ -148,6 +148,12 @@ struct Dev {
     const float* Adev;   // non-null: A lives in device memory (cmps_set_params_dev: device-resident optimiser step) and `A` is unset
     float dt;            // (float)delta_t (model.py:16; also the python-float factor of model.py:286)
     float c_half;        // (float)(-delta_t * sigma^2) / 2   (model.py:312)
+    // RhoCMPS on the wide kernels (32 < D <= 128; cmps_wide.hip, round 5): the columns of every clip's rho are handed to the pure-state
+    // kernels as VIRTUAL clips (virtual clip v = clip * phi_rank + column); then the initial vector of virtual clip v is phi0[v % phi_rank]
+    // instead of psi0, dA's per-clip sum is taken once per real clip, and the reverse scan leaves every column's cotangent in gphi
+    const float2* phi0;  // [phi_rank][DP] (zero rows pad an odd rank), or null: the pure-state model
+    int phi_rank;        // columns per clip, even
+    float* gphi;         // [virtual clips][re | im][DP]
     unsigned* status;    // [2]: flag word of the last reverse pass | OR since the last cmps_psi_grad_status (TRAIN workspaces; else null)
     int f16_shift;       // CMPS_OPT_F16_SCALE_SHIFT (diagnostic, 0): added to the exponent of the wave reverse scan's data-dependent fp16 scales
     int abar_fix;        // 1: the slabs' Abar holds -(sum_k Re(u^dagger (Q + s R^dagger) ybar)) / A (k_bwd_wave's merged mat-vec);
@@ -164,7 +170,17 @@ struct Dev {
 struct RhoLayout {
     int rank;
     size_t off_phi0, off_stash, off_scal, off_slabs, off_sums, off_p1, off_cols, total, slab_floats;
+    // the wide (virtual-clip) path of 32 < D <= 128, TRAIN workspaces: vrank = rank rounded up to even (0: not available)
+    int vrank;
+    size_t off_vphi, off_vstash, off_vgops, off_vopmax, off_vscal, off_rscal, off_vslabs, off_vsums, off_vaudio, off_gphi, vslab_floats;
 };
+
+// RhoCMPS on the wide kernels: every pair of columns of a clip is one broadcast vector in LDS, two buffers (cmps_wide.hip::k_fwd_wide_rho)
+inline size_t rho_wide_lds(int D, int rank) {
+    const size_t PD = (size_t)padded_D(D), vr = (size_t)((rank + 1) / 2 * 2);
+    return 2 * (vr / 2) * (8 * (PD / 8 + 1)) * 16 + 2 * (PD / 16) * sizeof(float) + 64;
+}
+inline bool rho_wide_ok(int D, int rank, int flags) { return D > 32 && D <= 128 && (flags & 1) && rho_wide_lds(D, rank) <= 120 * 1024; }
 
 // rank * D above which the block kernels' column arrays (4 rank D complex numbers in the reverse scan) no longer fit into 160 KB of
 // LDS and live in the workspace instead (RhoDev::cols): the reference's default rank = D (model.py:62-65) from D = 72 upwards
@@ -196,6 +212,22 @@ inline RhoLayout make_rho_layout(int D, int rank, int B, int T, int flags) {
     // column arrays of the block kernels when they do not fit into LDS: [B][4][rank][D] float2 (forward 2, sampler 3, reverse 4)
     L.off_cols = o;
     if (r * (size_t)D > RHO_LDS_COLS_MAX) o = align256(o + (size_t)B * 4 * r * D * sizeof(float2));
+    L.vrank = 0;
+    if (rho_wide_ok(D, rank, flags)) {
+        const size_t vr = (size_t)((rank + 1) / 2 * 2), vB = (size_t)B * vr, vp = vB / 2, NC = (N + 63) / 64;
+        L.vrank = (int)vr;
+        L.vslab_floats = 4 * DP * DP + 3 * DP + 2;
+        L.off_vphi = o;   o = align256(o + vr * DP * sizeof(float2));
+        L.off_vstash = o; o = align256(o + vp * N * 8 * DP * sizeof(float));         // [virtual pair][step][y | H y][4 DP]
+        L.off_vgops = o;  o = align256(o + vp * N * 4 * DP * sizeof(float));         // ybar rows
+        L.off_vopmax = o; o = align256(o + vp * sizeof(float));
+        L.off_vscal = o;  o = align256(o + vB * NC * 128 * sizeof(float));           // (|y|^2 of the clip, e of the clip) per virtual clip
+        L.off_rscal = o;  o = align256(o + (size_t)B * NC * 128 * sizeof(float));    // the same per real clip
+        L.off_vslabs = o; o = align256(o + vp * L.vslab_floats * sizeof(float));
+        L.off_vsums = o;  o = align256(o + (L.vslab_floats + 64) * sizeof(float) + 32 * L.vslab_floats * sizeof(double));
+        L.off_vaudio = o; o = align256(o + vB * (size_t)T * sizeof(float));
+        L.off_gphi = o;   o = align256(o + vB * 2 * DP * sizeof(float));
+    }
     L.total = o;
     return L;
 }
@@ -204,6 +236,11 @@ struct RhoDev {
     int rank;
     int stash_layout;    // 0: [B][N][rank][DP] float2 (cmps_rho.hip)  1: [B][N][rank][64] (y own, H y own) (cmps_rho_wave.hip)
                          // 2: [B][N][rank][64] pairs (y[n], (H y)[n]), n = 2 i + {re, im} (cmps_rho_mfma.hip)
+                         // 3: the wide kernels' rows, one vector per PAIR of columns: vstash [(b vrank + a) / 2][N][y | H y][4 DP] (cmps_wide.hip)
+    int vrank;           // rank rounded up to even when the wide path's sections exist (else 0)
+    float2* vphi;        // [vrank][DP]
+    float* vstash; float* vgops; float* vopmax; float* vscal; float* rscal; float* vslabs; float* vsums; float* vaudio; float* gphi;
+    size_t vslab_floats;
     float* scal;         // [B][NC][2][64]: tr rho'_k and e_k, one step per lane (wave kernels)
     float* p1;           // [B][4][16][64]: the forward's part of Rbar (cmps_rho_mfma.hip), raw C/D tiles
     const float2* phi0;  // [rank][DP]
@@ -253,6 +290,8 @@ hipError_t launch_fwd_wide(const Dev& P, const float* audio, float* loss, bool s
 hipError_t launch_fwd_wide_legacy(const Dev& P, const float* audio, float* loss, bool save, bool hy_f16, hipStream_t s);
 hipError_t launch_bwd_wide_legacy(const Dev& P, const float* audio, hipStream_t s);
 hipError_t launch_grad_wide_legacy(const Dev& P, const float* audio, bool f16, hipStream_t s);
+hipError_t launch_fwd_rho_wide(const Dev& P, const RhoDev& W, const float* audio, float* loss, bool hy_f16, hipStream_t s);
+hipError_t launch_bwd_rho_wide(const Dev& P, const RhoDev& W, const float* loss, float* grad_out, int pieces, hipStream_t s);
 hipError_t launch_fwd_chain16(const Dev& P, const float* audio, hipStream_t s);
 hipError_t launch_bwd_chain16(const Dev& P, const float* audio, hipStream_t s);    // cmps_pair.hip: the wide family's chain on the matrix cores
 hipError_t launch_bwd_wide(const Dev& P, const float* audio, hipStream_t s);

@@ -399,6 +399,12 @@ __global__ __launch_bounds__(256) void k_states_rho(Dev P, RhoDev W, int steps, 
     const float2* st = W.stash + row * r * DP;
     const float* stw = reinterpret_cast<const float*>(W.stash) + row * r * 128;   // wave layout: [rank][64] (y own, H y own)
     auto ldY = [&](int a, int d) {
+        if (W.stash_layout == 3) {                          // the wide kernels' rows (cmps_wide.hip): one vector per pair of columns, lane order
+            const size_t vp = ((row / steps) * W.vrank + a) >> 1;
+            const float* base = W.vstash + ((vp * steps + k) * 2) * (size_t)(4 * DP);
+            const int p0 = 64 * (d >> 4) + 8 * ((((d & 15) >> 3) << 2) | (a & 1)) + (d & 7);
+            return make_float2(base[p0], base[p0 + 16]);    // component bit = q bit 1 = + 16 lanes
+        }
         return W.stash_layout == 1 ? make_float2(stw[(a * 64 + d) * 2], stw[(a * 64 + d + 32) * 2])
              : W.stash_layout == 2 ? make_float2(stw[(a * 64 + 2 * d) * 2], stw[(a * 64 + 2 * d + 1) * 2]) : st[a * DP + d];
     };

@@ -414,6 +414,147 @@ __global__ __launch_bounds__(4 * PD) void k_fwd_wide(Dev P, const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
+// RhoCMPS forward chain on the wide layout (round 5; model.py:133-144, 152-158, 172-203).  rho = sum_a phi_a phi_a^dagger is carried as
+// its columns (cmps_rho.hip has the argument): every column takes the SAME linear step y_a = inv (ut_a + (Q + s R) ut_a), coupled only through
+// the trace n = sum_a |y_a|^2 (inv = 1 / sqrt(n_{k-1})) and the expectation e = sum_a y_a^dagger H y_a.  One workgroup per clip, R and Q
+// register resident as in k_fwd_wide; the two halves of v_pk_fma_f32 carry two COLUMNS of the clip instead of two clips, and a step loops
+// over the clip's column pairs (broadcast vectors [2 buffers][pairs] in LDS), one LDS-only barrier per step.  It stashes y of the
+// column pair cp of clip b as the row of VIRTUAL pair b pairs + cp -- the row format of k_fwd_wide -- so that H y (k_hy_wide), the reverse
+// chain (k_bwd_wide: with the per-step scalars of the clip the column cotangents do not couple at all) and the gradient GEMM
+// (k_grad_gemm) run unchanged on rank x as many "clips"; |y|^2 of the clip goes to the per-clip scalar rows (rscal).
+// ------------------------------------------------------------------------------------------------------------------------
+template <int PD>
+__global__ __launch_bounds__(4 * PD) void k_fwd_wide_rho(Dev P, const float* __restrict__ audio, float* __restrict__ rscal, int npairs) {
+    using G = WideGeom<PD>;
+    constexpr int NW = G::NW, KC = G::KC, VSL = G::VSL, VEC4 = G::VEC4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char wide_lds[];
+    v4f* uvec = reinterpret_cast<v4f*>(wide_lds);                 // [2][npairs][VEC4]
+    float* nrm = reinterpret_cast<float*>(uvec + (size_t)2 * npairs * VEC4);   // [2][NW]
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int q = lane >> 3, i = lane & 7;
+    const int rowsel = q >> 2, comp = (q >> 1) & 1, clip = q & 1;   // clip = the column's parity inside its pair
+    const bool clip1 = clip != 0, im_lane = comp != 0;
+    const int row = 16 * w + 8 * rowsel + i;
+    const int N = P.N, T = P.T, NC = (N + WCH - 1) / WCH;
+    const int b = blockIdx.x;
+    const float* xr = audio + (size_t)b * T;
+    const float A = dev_A(P);
+    v2f MR[2][KC], MQ[2][KC];
+    {
+        const int ra = 16 * w + i, rb = ra + 8, c0 = q * KC;
+#pragma unroll
+        for (int j = 0; j < KC; ++j) {
+            const float2 a = P.R[(size_t)ra * PD + c0 + j], bb = P.R[(size_t)rb * PD + c0 + j];
+            const float2 c = P.Q[(size_t)ra * PD + c0 + j], d = P.Q[(size_t)rb * PD + c0 + j];
+            MR[0][j] = mkv2(a.x, a.y); MR[1][j] = mkv2(bb.x, bb.y);
+            MQ[0][j] = mkv2(c.x, c.y); MQ[1][j] = mkv2(d.x, d.y);
+        }
+    }
+    const int own_f = vec_float_index<PD>(row, comp, clip);
+    const int rd4 = q * VSL;
+    float* stash = reinterpret_cast<float*>(P.stash);
+    const size_t pos = (size_t)w * 64 + lane;
+    for (int cp = 0; cp < npairs; ++cp) {                         // ut_0 = the columns phi_a (trace 1: "inv_{-1}" = 1)
+        const float2 p0 = P.phi0[(size_t)(2 * cp + clip) * PD + row];
+        reinterpret_cast<float*>(uvec + (size_t)cp * VEC4)[own_f] = im_lane ? p0.y : p0.x;
+    }
+    float sv = 0.f, nbuf = 0.f;
+    float2 rho_next = P.rho[row];
+    __syncthreads();
+    for (int k = 0; k <= N; ++k) {
+        const int p = k & 1;
+        const bool chain = k < N;
+        if (chain && (k & (WCH - 1)) == 0) {                      // increments of the next 64 steps, one per lane (model.py:135, 175)
+            const int idx = k + lane;
+            sv = ((idx + 1 < T ? xr[idx + 1] : 0.f) - (idx < T ? xr[idx] : 0.f)) / A;
+        }
+        const float2 rho_k = rho_next;
+        if (k + 1 < N) rho_next = P.rho[(size_t)(k + 1) * PD + row];
+        float n = 1.f;                                            // tr rho'_{k-1} (published before the barrier of the previous iteration)
+        if (k >= 1) {
+            n = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) n += nrm[p * NW + ww];
+        }
+        const float inv = k >= 1 ? rsq_newton(fmaxf(n, 1e-12f)) : 1.f;       // model.py:198-203 (sqrt of the trace: columns, not the matrix)
+        if (chain) {
+            const float sk = wrdl(sv, k & (WCH - 1));
+            const v2f s2 = mkv2(sk, sk);
+            float nacc = 0.f;
+            for (int cp = 0; cp < npairs; ++cp) {
+                const v4f* uv = uvec + ((size_t)p * npairs + cp) * VEC4;
+                v2f cRe0 = mkv2(0.f, 0.f), cIm0 = cRe0, cRe1 = cRe0, cIm1 = cRe0;
+#pragma unroll
+                for (int j = 0; j < KC; ++j) {
+                    const v4f x = uv[rd4 + j];
+                    col_merged(cRe0, cIm0, cRe1, cIm1, MR[0][j], MQ[0][j], MR[1][j], MQ[1][j], s2, lo_of(x), hi_of(x));
+                }
+                const float ut = reinterpret_cast<const float*>(uv)[own_f];
+                const float acc = reduce_slices(cRe0, cIm0, cRe1, cIm1, clip1);
+                const float y = inv * (ut + acc);
+                nacc = fmaf(y, y, nacc);
+                stash[wide_stash_vec<PD>((size_t)b * npairs + cp, N, k, 0) + pos] = y;
+                const float py = partner16(y, im_lane);
+                reinterpret_cast<float*>(uvec + ((size_t)(p ^ 1) * npairs + cp) * VEC4)[own_f] =
+                    rho_k.x * y + (im_lane ? rho_k.y : -rho_k.y) * py;       // ut_{k+1} = rho_k y_k (un-normalised)
+            }
+            float nn = clip_wave_sum(nacc);
+            nn += wdpp<0x128>(nn);                                // + the columns of the other parity (lane ^ 8)
+            if (lane == 0) nrm[(p ^ 1) * NW + w] = nn;
+        }
+        if (w == 0 && k >= 1) {                                   // tr rho'_{k-1} rows of the per-clip scalar stash
+            const int kn = k - 1;
+            if (lane == (kn & (WCH - 1))) nbuf = n;
+            if ((kn & (WCH - 1)) == WCH - 1 || kn == N - 1) {
+                const int c = kn / WCH;
+                if (c * WCH + lane < N) rscal[((size_t)b * NC + c) * 128 + lane] = nbuf;
+            }
+        }
+        wide_barrier();
+    }
+}
+
+// audio [B][T] -> [B vrank][T]: every column of a clip reads the clip's samples
+__global__ void k_rho_expand_audio(const float* __restrict__ audio, float* __restrict__ vaudio, int T, int vrank) {
+    const float* src = audio + (size_t)(blockIdx.x / vrank) * T;
+    float* dst = vaudio + (size_t)blockIdx.x * T;
+    for (int t = threadIdx.x; t < T; t += blockDim.x) dst[t] = src[t];
+}
+// the clip's |y|^2 rows -> every virtual clip's rows (k_hy_wide scales its fp16 pieces from them: |y_a|^2 <= tr rho')
+__global__ void k_rho_spread_n(const float* __restrict__ rscal, float* __restrict__ vscal, int NC, int vrank) {
+    const size_t v = blockIdx.x, c = blockIdx.y;
+    vscal[(v * NC + c) * 128 + threadIdx.x] = rscal[((v / vrank) * NC + c) * 128 + threadIdx.x];
+}
+// e = sum over the clip's columns of y_a^dagger H y_a (fixed order), to the clip's row and back to every column's row
+__global__ void k_rho_merge_e(float* __restrict__ rscal, float* __restrict__ vscal, int NC, int vrank) {
+    const size_t b = blockIdx.x, c = blockIdx.y;
+    float e = 0.f;
+    for (int a = 0; a < vrank; ++a) e += vscal[((b * vrank + a) * NC + c) * 128 + 64 + threadIdx.x];
+    rscal[(b * NC + c) * 128 + 64 + threadIdx.x] = e;
+    for (int a = 0; a < vrank; ++a) vscal[((b * vrank + a) * NC + c) * 128 + 64 + threadIdx.x] = e;
+}
+// zero-padded copy of the columns: [rank][DP] -> [vrank][DP]
+__global__ void k_rho_pad_phi(const float2* __restrict__ phi0, float2* __restrict__ vphi, int rank, int vrank, int DP) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < vrank * DP) vphi[idx] = idx < rank * DP ? phi0[idx] : make_float2(0.f, 0.f);
+}
+// cotangents of the columns: dphi_a = sum over clips of the reverse chain's final g of virtual clip (b, a)
+__global__ void k_rho_phi_reduce(const float* __restrict__ gphi, int B, int vrank, int rank, int D, int DP, float* __restrict__ out_re,
+                                 float* __restrict__ out_im) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rank * D) return;
+    const int a = idx / D, d = idx % D;
+    double sr = 0.0, si = 0.0;
+    for (int b = 0; b < B; ++b) {
+        const float* g = gphi + ((size_t)b * vrank + a) * 2 * DP;
+        sr += (double)g[d];
+        si += (double)g[DP + d];
+    }
+    out_re[idx] = (float)sr;
+    out_im[idx] = (float)si;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
 // PsiCMPS.sample (model.py:242-251, 284-291) for 32 < D <= 128 (round 4: a mode of the wide chain; before, the block sampler re-read
 // both matrices from L2 every step).  One workgroup per PAIR of paths, the forward chain's lane layout and broadcast; the step is
 //   e = 2 inv^2 Re(ut^dagger R ut)  ->  inc = e dt + noise_k,  samp += inc,  s = inc / A  ->  y_k = inv (ut + Q ut + s R ut),
@@ -952,7 +1093,8 @@ __global__ __launch_bounds__(4 * PD) void k_bwd_wide(Dev P, const float* __restr
             tab[w][cj & 1][lane][qq][0] = v4f{r.s, r.inv, r.ok, r.te};
             tab[w][cj & 1][lane][qq][1] = v4f{r.rad, dtv, 0.f, 0.f};
             if (cj & 1) { if (qq) svB1 = r.s; else svB0 = r.s; } else { if (qq) svA1 = r.s; else svA0 = r.s; }
-            if (in && w == 0 && (qq == 0 || two)) accA += r.zex;
+            // (RhoCMPS on virtual clips: z = e x / A belongs to the clip, not to its columns -- counted with the clip's first column)
+            if (in && w == 0 && (qq == 0 || two) && (!P.phi0 || (2 * blockIdx.x + qq) % P.phi_rank == 0)) accA += r.zex;
         }
     };
     chunk_rows((N - 1) / WCH);
@@ -986,7 +1128,7 @@ __global__ __launch_bounds__(4 * PD) void k_bwd_wide(Dev P, const float* __restr
         const Row cur = row_at(k0);
         c3 = S0.w * cur.h;                                        // rad_N = 0
     }
-    const float2 ps = P.psi0[row];
+    const float2 ps = P.phi0 ? P.phi0[(size_t)((2 * blockIdx.x + clip) % P.phi_rank) * PD + row] : P.psi0[row];
     const float ps0 = im_lane ? ps.y : ps.x;
     int p = 0;
     __syncthreads();
@@ -1047,8 +1189,9 @@ __global__ __launch_bounds__(4 * PD) void k_bwd_wide(Dev P, const float* __restr
         const float ft = f + partner16(f, im_lane);               // + the other component's share
         if (!clip1) {
             if (!im_lane) slab[4 * DD + row] = ft;
-            slab[4 * DD + (im_lane ? 2 * PD : PD) + row] = g0;
+            slab[4 * DD + (im_lane ? 2 * PD : PD) + row] = P.gphi ? 0.f : g0;
         }
+        if (P.gphi) P.gphi[((size_t)(2 * blockIdx.x + clip) * 2 + comp) * PD + row] = g * wq;    // every column's own cotangent
     }
     {
         float t = accS * wq;
@@ -1212,6 +1355,93 @@ hipError_t launch_grad_wide(const Dev& P, const float* audio, int pieces, hipStr
         if (P.DP == 64) return grad_wide_t<64, 2>(P, audio, s);
     }
     return hipErrorInvalidValue;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// RhoCMPS on the wide kernels (32 < D <= 128; the sections of RhoLayout::vrank > 0).  P carries the tables of cmps_set_params; every
+// buffer of the virtual-clip run lives in the rho workspace.
+// ------------------------------------------------------------------------------------------------------------------------
+static Dev rho_virtual_dev(const Dev& P, const RhoDev& W) {
+    Dev V = P;
+    V.B = P.B * W.vrank;
+    V.stash = reinterpret_cast<float2*>(W.vstash);
+    V.hst = W.vstash;
+    V.stash_layout = 4;
+    V.scal = W.vscal;
+    V.gops = W.vgops;
+    V.opmax = W.vopmax;
+    V.slabs = W.vslabs;
+    V.sums = W.vsums;
+    V.slab_floats = W.vslab_floats;
+    V.phi0 = W.vphi;
+    V.phi_rank = W.vrank;
+    V.gphi = W.gphi;
+    V.status = nullptr;
+    return V;
+}
+
+template <int PD>
+static hipError_t fwd_rho_wide_t(const Dev& P, const RhoDev& W, const float* audio, float* loss, bool hy_f16, hipStream_t s) {
+    const int npairs = W.vrank / 2, NC = (P.N + WCH - 1) / WCH;
+    const size_t shm = rho_wide_lds(P.D, W.rank), shm_hy = HyGeom<PD>::LDS;
+    hipError_t e = wide_lds_attr(k_fwd_wide_rho<PD>, shm);
+    if (e == hipSuccess) e = hy_f16 ? wide_lds_attr(k_hy_wide<PD, true>, shm_hy) : wide_lds_attr(k_hy_wide<PD, false>, shm_hy);
+    if (e != hipSuccess) return e;
+    Dev V = rho_virtual_dev(P, W);
+    {
+        KScope ks("k_rho_expand_audio", s);
+        hipLaunchKernelGGL(k_rho_pad_phi, dim3((unsigned)((W.vrank * PD + 255) / 256)), dim3(256), 0, s, W.phi0, W.vphi, W.rank, W.vrank, PD);
+        hipLaunchKernelGGL(k_rho_expand_audio, dim3((unsigned)V.B), dim3(256), 0, s, audio, W.vaudio, P.T, W.vrank);
+    }
+    { KScope ks("k_fwd_wide_rho", s); hipLaunchKernelGGL(k_fwd_wide_rho<PD>, dim3((unsigned)P.B), dim3(4 * PD), shm, s, V, audio, W.rscal, npairs); }
+    { KScope ks("k_rho_spread_n", s); hipLaunchKernelGGL(k_rho_spread_n, dim3((unsigned)V.B, (unsigned)NC), dim3(64), 0, s, W.rscal, W.vscal, NC, W.vrank); }
+    {
+        KScope ks(hy_f16 ? "k_hy_wide<f16x2>" : "k_hy_wide<3>", s);
+        const dim3 grid((unsigned)(V.B / 2), (unsigned)((P.N + HCHUNK - 1) / HCHUNK));
+        if (hy_f16) hipLaunchKernelGGL((k_hy_wide<PD, true>), grid, dim3(2 * PD), shm_hy, s, V);
+        else hipLaunchKernelGGL((k_hy_wide<PD, false>), grid, dim3(2 * PD), shm_hy, s, V);
+    }
+    { KScope ks("k_rho_merge_e", s); hipLaunchKernelGGL(k_rho_merge_e, dim3((unsigned)P.B, (unsigned)NC), dim3(64), 0, s, W.rscal, W.vscal, NC, W.vrank); }
+    {
+        Dev R = P;
+        R.scal = W.rscal;
+        KScope ks("k_loss_wide", s);
+        hipLaunchKernelGGL(k_loss_wide<false>, dim3((unsigned)P.B), dim3(64), 0, s, R, audio, loss);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_fwd_rho_wide(const Dev& P, const RhoDev& W, const float* audio, float* loss, bool hy_f16, hipStream_t s) {
+    if (P.DP == 128) return fwd_rho_wide_t<128>(P, W, audio, loss, hy_f16, s);
+    if (P.DP == 96) return fwd_rho_wide_t<96>(P, W, audio, loss, hy_f16, s);
+    if (P.DP == 64) return fwd_rho_wide_t<64>(P, W, audio, loss, hy_f16, s);
+    return hipErrorInvalidValue;
+}
+
+// reverse chain + gradient GEMM on the virtual clips, the common reduction, the closing terms (k_finalize), the columns' cotangents.
+// pieces: -2 two fp16 pieces, 2 / 3 bf16 pieces (launch_grad_wide).  grad_out: the layout of cmps_rho_loss_bwd.
+hipError_t launch_bwd_rho_wide(const Dev& P, const RhoDev& W, const float* loss, float* grad_out, int pieces, hipStream_t s) {
+    Dev V = rho_virtual_dev(P, W);
+    hipError_t e;
+    { KScope ks("k_bwd_wide", s); e = launch_bwd_wide(V, W.vaudio, s); }
+    if (e != hipSuccess) return e;
+    { KScope ks("k_grad_gemm", s); e = launch_grad_wide(V, W.vaudio, pieces, s); }
+    if (e != hipSuccess) return e;
+    KScope ks("reduce + finalize", s);
+    Dev Vp = V;
+    Vp.B = V.B / 2;
+    e = launch_reduce_only(Vp, s);
+    if (e != hipSuccess) return e;
+    Dev F = V;
+    F.B = P.B;                                                    // the loss sum runs over the real clips
+    F.abar_fix = 1;
+    e = launch_finalize_only(F, loss, grad_out, s);
+    if (e != hipSuccess) return e;
+    const int D = P.D, n = W.rank * D;
+    float* dphi = grad_out + (2 * D * D + 3 * D + 2);
+    hipLaunchKernelGGL(k_rho_phi_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)W.gphi, P.B, W.vrank, W.rank, D, P.DP,
+                       dphi, dphi + n);
+    return hipGetLastError();
 }
 
 }  // namespace cmps

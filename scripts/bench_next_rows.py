@@ -136,8 +136,26 @@ rm.variables["Rx"] *= np.float32(0.5); rm.variables["Ry"] *= np.float32(0.5)
 d_a = rm._to_device(a)
 rb = rm._prepare(B, T, train=True)
 ms = dev_ms(lambda: rb.rho_loss_and_grad_sums(d_a), rounds=2)
-res["rho_cmps_d64_rank16"] = {"shape": f"D=64, rank=16, T={T}, B={B}, fwd+bwd", "kernel": "k_fwd_rho + k_bwd_rho (general block kernels: one workgroup per clip, columns in LDS)", "ms": ms,
-                              "samples_per_s": B * T / ms * 1e3, "bound": "not optimised: the row-array GEMM kernels stop at D = 32"}
+rb.kernel_events(True)
+rb.rho_loss_and_grad_sums(d_a); torch.cuda.synchronize(); rb.kernel_times()
+rb.rho_loss_and_grad_sums(d_a); torch.cuda.synchronize()
+kt = {k: round(v[0] / max(v[1], 1), 3) for k, v in rb.kernel_times().items()}
+rb.kernel_events(False)
+res["rho_cmps_d64_rank16"] = {"shape": f"D=64, rank=16, T={T}, B={B}, fwd+bwd", "kernel": "round 5: the columns as virtual clips of the wide kernels (k_fwd_wide_rho + k_hy_wide + k_bwd_wide + k_grad_gemm on 4096 virtual clips)", "ms": ms,
+                              "samples_per_s": B * T / ms * 1e3, "kernel_ms": kt, "bound": "forward chain: one workgroup per clip looping over 8 column pairs per step; reverse chain and GEMMs: 2048 independent virtual pairs"}
+for rk in (4, 32):
+    hp = HParams(minibatch_size=B, bond_dim=64, initial_rank=rk)
+    rm2 = RhoCMPS(hp, data_iterator=a, seed=2)
+    rm2.variables["Rx"] *= np.float32(0.5); rm2.variables["Ry"] *= np.float32(0.5)
+    rb2 = rm2._prepare(B, T, train=True)
+    ms2 = dev_ms(lambda: rb2.rho_loss_and_grad_sums(d_a), rounds=2)
+    res[f"rho_cmps_d64_rank{rk}"] = {"shape": f"D=64, rank={rk}, T={T}, B={B}, fwd+bwd", "ms": ms2, "samples_per_s": B * T / ms2 * 1e3}
+rmb = RhoCMPS(HParams(minibatch_size=B, bond_dim=64, initial_rank=16), data_iterator=a, seed=2, backend=HipScan(64, variant=1))
+rmb.variables["Rx"] *= np.float32(0.5); rmb.variables["Ry"] *= np.float32(0.5)
+rbb = rmb._prepare(B, T, train=True)
+ms = dev_ms(lambda: rbb.rho_loss_and_grad_sums(d_a), rounds=1)
+res["rho_cmps_d64_rank16_general_kernels"] = {"shape": f"D=64, rank=16, T={T}, B={B}, fwd+bwd", "kernel": "k_fwd_rho + k_bwd_rho (CMPS_VARIANT_BLOCK: what D > 32 ran on until round 4)", "ms": ms,
+                                              "samples_per_s": B * T / ms * 1e3}
 
 # ---- rank 3b: RhoCMPS.sample (row-array GEMM sampler, one wavefront per path), D = 32, rank 32 and 4: 64 paths x 4000 steps
 for rank in (32, 4):

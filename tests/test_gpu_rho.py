@@ -257,6 +257,64 @@ def test_rho_wave_and_block_kernels_agree(D, rank):
     assert rel_inf(ra, rb) <= 1e-5
 
 
+@pytest.mark.parametrize("D,rank,T,B,sigma,rscale", [
+    (64, 16, 260, 3, 0.2, 0.4),          # scripts/bench_next_rows.py's shape (reduced): visible damping
+    (40, 7, 131, 2, 0.3, 0.5),           # odd rank (a zero column pads the last pair), zero-padded rows (40 -> 64), one-step last chunk
+    (96, 9, 66, 3, 1e-4, 0.4),           # PD = 96
+    (128, 24, 70, 2, 0.1, 0.3),          # PD = 128
+    (48, 48, 40, 2, 1e-4, 0.5),          # the reference's default rank = D (model.py:62-65): 24 column pairs
+    (64, 1, 130, 5, 0.2, 0.5),           # rank 1
+])
+def test_rho_wide_kernels_match_oracle_and_general_kernels(D, rank, T, B, sigma, rscale):
+    """32 < D <= 128 (round 5): the training forward / reverse run the columns of rho as VIRTUAL clips of the pure-state wide kernels
+    (cmps_wide.hip: k_fwd_wide_rho, then k_hy_wide / k_bwd_wide / k_grad_gemm unchanged on rank x as many clips).  Against the oracle's
+    matrix form (/root/reference/model.py:133-203 restated) and against the general one-workgroup-per-clip kernels (CMPS_VARIANT_BLOCK):
+    loss, all six gradient tensors, the states rho_k and the purity read from the wide stash layout."""
+    from audio_mps_amd import RhoCMPS
+    from audio_mps_amd.scan import HipScan
+    m, audio = _rho_model(D, T, B, rank=rank, sigma=sigma, seed=D + rank, rscale=rscale)
+    be = m._get_backend()
+    be.kernel_events(True)
+    loss, grads = m.loss_and_grads()
+    names = set(be.kernel_times())
+    be.kernel_events(False)
+    assert {"k_fwd_wide_rho", "k_bwd_wide", "k_grad_gemm", "k_rho_merge_e"} <= names, names       # the wide path really ran
+    ohp, ov, Wx, Wy = _oracle_side(m)
+    ref = O.rho_loss_and_grads(ohp, ov, Wx, Wy, audio, "f32")
+    ref64 = O.rho_loss_and_grads(ohp, ov.astype(np.float64), Wx.astype(np.float64), Wy.astype(np.float64), audio, "f64")
+    assert abs(float(loss) - float(ref["loss"])) <= LOSS_RTOL * max(abs(float(ref["loss"])), 1.0)
+    for k in ("A", "Rx", "Ry", "freqs", "Wx", "Wy"):
+        own = rel_inf(ref[k], ref64[k])
+        e = rel_inf(grads[k], ref64[k])
+        assert e <= max(GRAD_RTOL, 3 * own), f"{k}: rel err {e} (oracle f32 vs f64: {own})"
+    blk = RhoCMPS(m.hparams, data_iterator=audio, seed=1, backend=HipScan(D, variant=1))
+    for k in m.variables:
+        blk.variables[k] = m.variables[k].copy()
+    lb, gb = blk.loss_and_grads()
+    assert abs(float(loss) - float(lb)) <= LOSS_RTOL * max(abs(float(lb)), 1.0)
+    for k in grads:
+        assert rel_inf(grads[k], gb[k]) <= (GRAD_RTOL if k != "A" else 10 * GRAD_RTOL), k
+    ra, rb = m.rho_evolve_with_data(), blk.rho_evolve_with_data()
+    np.testing.assert_allclose(np.trace(ra, axis1=2, axis2=3).real, np.ones((B, T - 1)), rtol=1e-5)
+    assert rel_inf(ra, rb) <= 2e-5
+
+
+def test_rho_wide_rank_scaling_and_batch_order():
+    """The cost of the wide path is linear in the rank (the GEMM kernels of D <= 32 cost the same at rank 4 and 32), and clips are
+    independent: permuting the batch permutes the per-clip losses (training forward) and leaves the gradient sums unchanged."""
+    import torch
+    m, audio = _rho_model(64, 300, 6, rank=8, sigma=0.1, seed=3, rscale=0.4)
+    perm = np.random.default_rng(0).permutation(6)
+    be = m._prepare(6, 300, train=True)
+    la = be.rho_forward(m._to_device(audio), save_for_bwd=True).cpu().numpy().copy()
+    ga = be.rho_backward().cpu().numpy().copy()
+    lb = be.rho_forward(m._to_device(audio[perm]), save_for_bwd=True).cpu().numpy().copy()
+    gb = be.rho_backward().cpu().numpy().copy()
+    np.testing.assert_array_equal(lb, la[perm])
+    assert rel_inf(gb, ga) <= 1e-5
+    assert np.all(np.isfinite(ga))
+
+
 @pytest.mark.parametrize("D,rank,T,B", [(32, 32, 200, 5), (32, 11, 65, 3), (24, 24, 130, 9)])
 def test_rho_gemm_and_column_kernels_agree(D, rank, T, B):
     """rank > 8 runs the scan as row-array GEMMs on the matrix cores (cmps_rho_mfma.hip, bf16 x 3 operand split);
