@@ -37,6 +37,9 @@ CMPS_RANK1_F16X2 = 3
 CMPS_RANK1_DEFAULT = 4
 CMPS_OPT_WIDE_CHAIN = 3
 CMPS_OPT_F16_SCALE_SHIFT = 4
+CMPS_OPT_RHO_BWD = 5
+CMPS_RHO_BWD_VIRTUAL = 0
+CMPS_RHO_BWD_GEMM = 1
 CMPS_WIDE_CHAIN_VALU = 0
 CMPS_WIDE_CHAIN_MFMA = 1
 CMPS_WIDE_CHAIN_MFMA_FWD = 2

@@ -19,6 +19,7 @@ struct cmps_handle_s {
     int rank1_mode = CMPS_RANK1_DEFAULT;
     int wide_chain = CMPS_WIDE_CHAIN_MFMA;
     int f16_shift = 0;         // CMPS_OPT_F16_SCALE_SHIFT (diagnostic)
+    bool rho_virtual_bwd = true;   // CMPS_OPT_RHO_BWD: the RhoCMPS GEMM forward's reverse sweep on virtual clips of k_bwd_wave (else k_bwd_rho_mfma)
     bool params_set = false;
     bool legacy = false;       // the tables currently hold the legacy AudioMPS arithmetic (cmps_legacy_set_params)
     bool fwd_saved = false;
@@ -139,6 +140,11 @@ int cmps_set_option(cmps_handle_t h, int option, int value) {
         h->wide_chain = value;
         return CMPS_OK;
     }
+    if (option == CMPS_OPT_RHO_BWD) {
+        if (value != CMPS_RHO_BWD_VIRTUAL && value != CMPS_RHO_BWD_GEMM) return fail(h, CMPS_ERR_BAD_ARG, "cmps_set_option: unknown value for CMPS_OPT_RHO_BWD");
+        h->rho_virtual_bwd = value == CMPS_RHO_BWD_VIRTUAL;
+        return CMPS_OK;
+    }
     if (option == CMPS_OPT_F16_SCALE_SHIFT) {
         if (value < -40 || value > 40) return fail(h, CMPS_ERR_BAD_ARG, "cmps_set_option: CMPS_OPT_F16_SCALE_SHIFT takes -40 .. 40");
         h->f16_shift = value;
@@ -159,6 +165,7 @@ int cmps_get_option(cmps_handle_t h, int option) {
     if (option == CMPS_OPT_KERNEL_EVENTS) return h->ktimer ? 1 : 0;
     if (option == CMPS_OPT_WIDE_CHAIN) return h->wide_chain;
     if (option == CMPS_OPT_F16_SCALE_SHIFT) return h->f16_shift;
+    if (option == CMPS_OPT_RHO_BWD) return h->rho_virtual_bwd ? CMPS_RHO_BWD_VIRTUAL : CMPS_RHO_BWD_GEMM;
     return -1;
 }
 
@@ -590,6 +597,8 @@ int cmps_rho_set_state(cmps_handle_t h, const float* phi_re_dev, const float* ph
     W.slabs = train ? reinterpret_cast<float*>(ws + RL.off_slabs) : nullptr;
     W.sums = train ? reinterpret_cast<float*>(ws + RL.off_sums) : nullptr;
     W.slab_floats = RL.slab_floats;
+    W.wslabs = (train && h->D <= 32) ? reinterpret_cast<float*>(ws + RL.off_wslabs) : nullptr;
+    W.wsums = (train && h->D <= 32) ? reinterpret_cast<float*>(ws + RL.off_wsums) : nullptr;
     W.vrank = RL.vrank;                                          // > 0: the sections of the wide (virtual-clip) path exist
     if (RL.vrank) {
         W.vphi = reinterpret_cast<float2*>(ws + RL.off_vphi);
@@ -665,6 +674,12 @@ int cmps_rho_loss_bwd(cmps_handle_t h, const float* audio_dev, int B, int T, flo
         const hipError_t ew = launch_bwd_rho_wide(P, h->W, h->saved_loss, grad_dev,
                                                   rm == CMPS_RANK1_F16X2 ? -2 : rm == CMPS_RANK1_BF16X2 ? 2 : 3, s);
         if (ew != hipSuccess) return fail_hip(h, ew, "cmps_rho_loss_bwd (wide)");
+        return CMPS_OK;
+    }
+    if (h->W.stash_layout == 2 && h->rho_virtual_bwd) {
+        // the row-array forward's rows through the pure-state wave reverse scan, one virtual clip per column (cmps_rho_wave.hip)
+        const hipError_t ew = launch_bwd_rho_virtual_wave(P, h->W, audio_dev, h->saved_loss, grad_dev, wave_rank1(h->rank1_mode), s);
+        if (ew != hipSuccess) return fail_hip(h, ew, "cmps_rho_loss_bwd (virtual clips)");
         return CMPS_OK;
     }
     hipError_t e = h->W.stash_layout == 2 ? launch_bwd_rho_mfma(P, h->W, audio_dev, s)

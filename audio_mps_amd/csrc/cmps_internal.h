@@ -171,6 +171,7 @@ struct RhoLayout {
     int rank;
     size_t off_phi0, off_stash, off_scal, off_slabs, off_sums, off_p1, off_cols, total, slab_floats;
     // the wide (virtual-clip) path of 32 < D <= 128, TRAIN workspaces: vrank = rank rounded up to even (0: not available)
+    size_t off_wslabs, off_wsums;       // D <= 32, TRAIN: one pure-state slab per (clip, column) for the wave reverse scan on virtual clips
     int vrank;
     size_t off_vphi, off_vstash, off_vgops, off_vopmax, off_vscal, off_rscal, off_vslabs, off_vsums, off_vaudio, off_gphi, vslab_floats;
 };
@@ -208,6 +209,12 @@ inline RhoLayout make_rho_layout(int D, int rank, int B, int T, int flags) {
         L.off_sums = o;  o = align256(o + (L.slab_floats + 64) * sizeof(float) + 32 * L.slab_floats * sizeof(double));
         // D <= 32: sum_k 2 ebar_k Y^T Y (real 64 x 64 form, four C/D tiles per clip), accumulated by k_fwd_rho_mfma for the reverse scan
         L.off_p1 = o;    if (D <= 32) o = align256(o + (size_t)B * 4096 * sizeof(float));
+        L.off_wslabs = L.off_wsums = o;
+        if (D <= 32) {
+            const size_t psl = 4 * DP * DP + 3 * DP + 2;
+            L.off_wslabs = o; o = align256(o + (size_t)B * r * psl * sizeof(float));
+            L.off_wsums = o;  o = align256(o + (psl + 64) * sizeof(float) + 32 * psl * sizeof(double));
+        }
     }
     // column arrays of the block kernels when they do not fit into LDS: [B][4][rank][D] float2 (forward 2, sampler 3, reverse 4)
     L.off_cols = o;
@@ -237,6 +244,7 @@ struct RhoDev {
     int stash_layout;    // 0: [B][N][rank][DP] float2 (cmps_rho.hip)  1: [B][N][rank][64] (y own, H y own) (cmps_rho_wave.hip)
                          // 2: [B][N][rank][64] pairs (y[n], (H y)[n]), n = 2 i + {re, im} (cmps_rho_mfma.hip)
                          // 3: the wide kernels' rows, one vector per PAIR of columns: vstash [(b vrank + a) / 2][N][y | H y][4 DP] (cmps_wide.hip)
+    float* wslabs; float* wsums;   // D <= 32: the wave reverse scan's slabs, one per (clip, column), and their reduction buffer
     int vrank;           // rank rounded up to even when the wide path's sections exist (else 0)
     float2* vphi;        // [vrank][DP]
     float* vstash; float* vgops; float* vopmax; float* vscal; float* rscal; float* vslabs; float* vsums; float* vaudio; float* gphi;
@@ -290,6 +298,8 @@ hipError_t launch_fwd_wide(const Dev& P, const float* audio, float* loss, bool s
 hipError_t launch_fwd_wide_legacy(const Dev& P, const float* audio, float* loss, bool save, bool hy_f16, hipStream_t s);
 hipError_t launch_bwd_wide_legacy(const Dev& P, const float* audio, hipStream_t s);
 hipError_t launch_grad_wide_legacy(const Dev& P, const float* audio, bool f16, hipStream_t s);
+hipError_t launch_bwd_rho_virtual_wave(const Dev& P, const RhoDev& W, const float* audio, const float* loss, float* grad_out, int rank1_mode,
+                                       hipStream_t s);
 hipError_t launch_fwd_rho_wide(const Dev& P, const RhoDev& W, const float* audio, float* loss, bool hy_f16, hipStream_t s);
 hipError_t launch_bwd_rho_wide(const Dev& P, const RhoDev& W, const float* loss, float* grad_out, int pieces, hipStream_t s);
 hipError_t launch_fwd_chain16(const Dev& P, const float* audio, hipStream_t s);

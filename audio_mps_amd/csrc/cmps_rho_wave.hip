@@ -269,4 +269,61 @@ hipError_t launch_bwd_rho_wave(const Dev& P, const RhoDev& W, const float* audio
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Round 5: the reverse sweep of the row-array forward (k_fwd_rho_mfma, stash layout 2) as the PURE-STATE wave reverse scan on virtual
+// clips.  Given the clip's per-step scalars (tr rho'_k, e_k: RhoDev::scal) the cotangents of the columns do not couple -- the
+// normalisation adjoint's radial part is te_{k+1} e_{k+1} for every column (Euler, as in k_bwd_wave) -- so column a of clip b is clip
+// b rank + a of k_bwd_wave (cmps_wave.hip; Dev::phi0 switches the indexing), whose cost is linear in the rank and whose rank-1 sums
+// run in the CMPS_OPT_RANK1 arithmetic (fp16 x 2 by default).  k_bwd_rho_mfma (bf16 x 3, the same cost at every rank) stays behind
+// CMPS_VARIANT_WAVE32 ... it also needs the forward's part of Rbar (RhoDev::p1), which this path ignores: k_bwd_wave forms all three sums.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_rho_phi_from_slabs(const float* __restrict__ slabs, size_t slab_floats, int B, int rank, int D, int DP,
+                                     float* __restrict__ grad_out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int DD = DP * DP, G = 2 * D * D + 3 * D + 2;
+    if (idx < 2 * D) grad_out[2 * D * D + D + idx] = 0.f;           // the pure-state layout's psi_0 entries: unused here (include/cmps.h)
+    if (idx >= rank * D) return;
+    const int a = idx / D, d = idx % D;
+    double sr = 0.0, si = 0.0;
+    for (int b = 0; b < B; ++b) {
+        const float* sl = slabs + ((size_t)b * rank + a) * slab_floats + 4 * DD;
+        sr += (double)sl[DP + d];
+        si += (double)sl[2 * DP + d];
+    }
+    grad_out[G + idx] = (float)sr;
+    grad_out[G + rank * D + idx] = (float)si;
+}
+
+hipError_t launch_bwd_rho_virtual_wave(const Dev& P, const RhoDev& W, const float* audio, const float* loss, float* grad_out, int rank1_mode,
+                                       hipStream_t s) {
+    Dev V = P;
+    V.B = P.B * W.rank;
+    V.hst = reinterpret_cast<float*>(W.stash);
+    V.stash = W.stash;
+    V.stash_layout = 3;
+    V.scal = W.scal;
+    V.slabs = W.wslabs;
+    V.sums = W.wsums;
+    V.slab_floats = (size_t)4 * P.DP * P.DP + 3 * P.DP + 2;
+    V.phi0 = W.phi0;
+    V.phi_rank = W.rank;
+    V.gphi = nullptr;
+    V.status = nullptr;
+    hipError_t e;
+    { KScope ks("k_bwd_wave", s); e = launch_bwd_wave(V, audio, rank1_mode, s); }
+    if (e != hipSuccess) return e;
+    KScope ks("reduce + finalize", s);
+    e = launch_reduce_only(V, s);
+    if (e != hipSuccess) return e;
+    Dev F = V;
+    F.B = P.B;                                                   // the loss sum runs over the real clips
+    F.abar_fix = 1;
+    e = launch_finalize_only(F, loss, grad_out, s);
+    if (e != hipSuccess) return e;
+    const int n = W.rank * P.D > 2 * P.D ? W.rank * P.D : 2 * P.D;
+    hipLaunchKernelGGL(k_rho_phi_from_slabs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)W.wslabs, V.slab_floats, P.B,
+                       W.rank, P.D, P.DP, grad_out);
+    return hipGetLastError();
+}
+
 }  // namespace cmps

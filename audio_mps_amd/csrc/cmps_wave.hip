@@ -125,9 +125,13 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
     const unsigned aRho = lds_addr(&stR[w][0]) + i * 8;
     const unsigned aScl = lds_addr(&scl[w][0]);
     const float4* rho4 = reinterpret_cast<const float4*>(P.rho);
-    const float4* sty4 = reinterpret_cast<const float4*>(P.hst + (size_t)b * N * 128);
-    const float* xrow = audio + (size_t)b * T;
-    const float* sc = P.scal + scal_off(b, NC, 0);
+    // RhoCMPS on virtual clips (round 5; Dev::phi0): wave b is column av of clip bc -- the clip's audio and per-step scalars (tr rho', e), the
+    // column's rows in the [clip][step][column] stash of k_fwd_rho_mfma (the same 512-B row format), phi_av as the initial vector
+    const int vr = P.phi0 ? P.phi_rank : 1;
+    const int bc = b / vr, av = b - bc * vr;
+    const float4* sty4 = reinterpret_cast<const float4*>(P.hst + ((size_t)bc * N * vr + av) * 128);
+    const float* xrow = audio + (size_t)bc * T;
+    const float* sc = P.scal + scal_off(bc, NC, 0);
     const float A = dev_A(P);
 
     float facc = 0.f;   // per lane: sum_k dtk * g_osig * u_own   (the two halves are added at the end)
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
         sR = nRs; sQ = nQs;
     };
     auto stage_load_all = [&](int hh) {
-        stage_load512<16>(sty4, hh * CHB, N - 1, lane, sry);
+        stage_load512<16>(sty4, hh * CHB, N - 1, lane, sry, vr);
         stage_load<8>(rho4, hh * CHB, N, lane, srr);
     };
     auto stage_commit_all = [&]() {
@@ -281,7 +285,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
         S = make_pre(yh_j, rho_j, c0_j, c1_j);
     }
     float g = 0.f, go = 0.f;                      // cotangent of u_{k+1}: split value and its osig
-    const float2 p0 = P.psi0[i];
+    const float2 p0 = P.phi0 ? P.phi0[av * DPW + i] : P.psi0[i];
     const float u0 = hb ? p0.y : p0.x, u0o = hb ? -p0.x : p0.y;
 
     // one step of the serial chain (step k = the step S describes); with have_pre, the pre stage of step
@@ -519,6 +523,10 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
         return Sn;
     };
 
+    // (a RhoCMPS column on its own has no radial identity -- Re(sum_a yhat_a^dagger g_a) = te e holds for the SUM over the clip's columns -- so
+    // the explicit projection of a staged chunk's first step is a pure-state refinement: virtual clips use the analytic value throughout,
+    // as the wide kernels do)
+    const bool proj_ok = P.phi0 == nullptr;
     // pre index j runs N-2 .. 0, one staged chunk (32 steps) at a time; the chain handles step j+1 in the
     // same iteration; per-step scalars are re-derived whenever j enters a new 64-step chunk
     for (int hh = hl; hh >= 0; --hh) {
@@ -532,14 +540,14 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
         for (; j >= jlo && (RANK1 == 0 || (j & 7) != 7); --j) {
             const int jr = j & (CHB - 1), jc = j & (CH - 1);
             own_issue(aYown + jr * 512, aRho + jr * 256, aScl + jc * 32, yh_j, rho_j, c0_j, c1_j);
-            S = chain_step(S, 0.f, 0.f, std::true_type{}, j, j == jhi, std::integral_constant<int, -1>{});
+            S = chain_step(S, 0.f, 0.f, std::true_type{}, j, proj_ok && j == jhi, std::integral_constant<int, -1>{});
         }
         // aligned octets: slot = j & 7, updates recorded and applied once per octet
 #define BWD_STEP8(P)                                                                                          \
         {                                                                                                     \
             const int jq = j - (7 - (P));                                                                     \
             own_issue_off<(P) * 512, (P) * 256, (P) * 32>(aYo8, aRo8, aSo8, yh_j, rho_j, c0_j, c1_j);         \
-            S = chain_step(S, 0.f, 0.f, std::true_type{}, jq, jq == jhi, std::integral_constant<int, (P)>{}); \
+            S = chain_step(S, 0.f, 0.f, std::true_type{}, jq, proj_ok && jq == jhi, std::integral_constant<int, (P)>{}); \
         }
         for (; j >= jlo; j -= 8) {
             if constexpr (RANK1 == 3) {
@@ -567,7 +575,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
         }
     }
     if (pend) flush_octet();
-    S = chain_step(S, u0, u0o, std::false_type{}, 0, true, std::integral_constant<int, -1>{});   // step 0: u_0 = psi_0
+    S = chain_step(S, u0, u0o, std::false_type{}, 0, proj_ok, std::integral_constant<int, -1>{});   // step 0: u_0 = psi_0
 #undef MF_HOOK
 #undef MF_HOOKB
 #undef MF_HOOK_AB
@@ -586,7 +594,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
         slab[3 * DD + o] = -Qim[r] * uQ;
     }
     const float sumS = sum64(accS);
-    const float sumA = sum64(accA);
+    const float sumA = av == 0 ? sum64(accA) : 0.f;        // (z = e x / A belongs to the clip: counted with its first column)
     // fbar_i = sum_k dtk Im(g conj(u)) = sum over both halves of g_osig * u_own (the sign lives in osig)
     const float ftot = swapadd(facc, facc);               // half 0: f(h=0) + f(h=1)
     slab[4 * DD + (hb ? 2 * DPW : DPW) + i] = g;          // cotangent of psi_0: re in [DPW, 2DPW), im in [2DPW, 3DPW)

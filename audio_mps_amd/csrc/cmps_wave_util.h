@@ -281,15 +281,16 @@ __device__ __forceinline__ void stage_load(const float4* __restrict__ tab, int r
     }
 }
 // same for 512-B rows (32 float4 each): 2*NQ rows
+// (stride: rows between consecutive steps -- 1, or the rank when the rows of a RhoCMPS column are read from the [clip][step][column] stash)
 template <int NQ>
 __device__ __forceinline__ void stage_load512(const float4* __restrict__ tab, int row0, int max_row, int lane,
-                                              v4f (&r)[NQ]) {
+                                              v4f (&r)[NQ], int stride = 1) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int e = q * 64 + lane;
         int row = row0 + (e >> 5);
         row = row < max_row ? row : max_row;
-        const float4 t = tab[(size_t)row * 32 + (e & 31)];
+        const float4 t = tab[(size_t)row * stride * 32 + (e & 31)];
         r[q] = v4f{t.x, t.y, t.z, t.w};
     }
 }

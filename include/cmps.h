@@ -74,6 +74,7 @@ enum {
                         * BF16X2 = two bf16 pieces / three products, F16X2 = two fp16 pieces / three products, anything else = three
                         * bf16 pieces / six products) */,
     CMPS_OPT_WIDE_CHAIN = 3 /* how the wide kernels (32 < D <= 128, float32) run the training forward's serial chain: see the values below */,
+    CMPS_OPT_RHO_BWD = 5 /* which reverse sweep follows the RhoCMPS row-array GEMM forward (D <= 32, rank > 8): see the values below */,
     CMPS_OPT_F16_SCALE_SHIFT = 4 /* DIAGNOSTIC, default 0: added to the exponent of every data-dependent fp16 scale of the wave reverse
                         * scan's F16X2 arithmetic (range -40 .. 40).  A positive value pushes the pieces out of fp16 range on purpose:
                         * how tests/test_gpu_parity.py provokes CMPS_ERR_F16_RANGE.  No reference counterpart. */,
@@ -110,6 +111,14 @@ enum {
     CMPS_RANK1_DEFAULT = 4   /* a new handle's setting: see the table above (the cheapest arithmetic of the 24-operand-bit
                               * class each kernel has; scripts/rank1_accuracy_wide.py,
                               * tests/test_gpu_parity.py::test_rank1_modes_order_of_accuracy) */
+};
+
+/* values of CMPS_OPT_RHO_BWD */
+enum {
+    CMPS_RHO_BWD_VIRTUAL = 0,  /* (a new handle's setting) every column of rho as one clip of the pure-state wave reverse scan (k_bwd_wave): given
+                                * the clip's per-step scalars the column cotangents do not couple; cost linear in the rank, rank-1 sums in the
+                                * CMPS_OPT_RANK1 arithmetic */
+    CMPS_RHO_BWD_GEMM = 1      /* k_bwd_rho_mfma: the cotangent array as row-array GEMMs (bf16 x 3), the same cost at every rank <= 32 */
 };
 
 /* values of CMPS_OPT_WIDE_CHAIN */

@@ -110,6 +110,12 @@ def test_options_default_and_errors(hip_lib):
         assert hip_lib.cmps_set_option(h, _capi.CMPS_OPT_WIDE_CHAIN, v) == _capi.CMPS_OK
         assert hip_lib.cmps_get_option(h, _capi.CMPS_OPT_WIDE_CHAIN) == v
     assert hip_lib.cmps_set_option(h, _capi.CMPS_OPT_WIDE_CHAIN, 3) == _capi.CMPS_ERR_BAD_ARG
+    # CMPS_OPT_RHO_BWD: the virtual-clip reverse sweep is a new handle's setting
+    assert hip_lib.cmps_get_option(h, _capi.CMPS_OPT_RHO_BWD) == _capi.CMPS_RHO_BWD_VIRTUAL == 0
+    assert hip_lib.cmps_set_option(h, _capi.CMPS_OPT_RHO_BWD, _capi.CMPS_RHO_BWD_GEMM) == _capi.CMPS_OK
+    assert hip_lib.cmps_get_option(h, _capi.CMPS_OPT_RHO_BWD) == _capi.CMPS_RHO_BWD_GEMM
+    assert hip_lib.cmps_set_option(h, _capi.CMPS_OPT_RHO_BWD, 2) == _capi.CMPS_ERR_BAD_ARG
+    assert hip_lib.cmps_set_option(h, _capi.CMPS_OPT_RHO_BWD, _capi.CMPS_RHO_BWD_VIRTUAL) == _capi.CMPS_OK
     # CMPS_OPT_F16_SCALE_SHIFT (diagnostic: provokes CMPS_ERR_F16_RANGE in tests/test_gpu_parity.py): 0 on a new handle, -40 .. 40
     assert hip_lib.cmps_get_option(h, _capi.CMPS_OPT_F16_SCALE_SHIFT) == 0
     assert hip_lib.cmps_set_option(h, _capi.CMPS_OPT_F16_SCALE_SHIFT, 7) == _capi.CMPS_OK

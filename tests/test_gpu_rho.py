@@ -299,6 +299,39 @@ def test_rho_wide_kernels_match_oracle_and_general_kernels(D, rank, T, B, sigma,
     assert rel_inf(ra, rb) <= 2e-5
 
 
+@pytest.mark.parametrize("D,rank,T,B,sigma,rscale", [(32, 32, 200, 5, 0.3, 0.4), (32, 11, 65, 3, 1e-4, None), (24, 24, 130, 9, 0.2, 0.5),
+                                                    (20, 9, 257, 2, 0.4, 0.6), (32, 17, 40, 7, 0.1, 0.3)])
+def test_rho_reverse_on_virtual_clips_matches_gemm_reverse_and_oracle(D, rank, T, B, sigma, rscale):
+    """D <= 32, rank > 8 (round 5; CMPS_OPT_RHO_BWD): the reverse sweep that follows the row-array GEMM forward is, by default, the
+    pure-state wave reverse scan k_bwd_wave on one VIRTUAL clip per column (cmps_rho_wave.hip) -- given the clip's per-step scalars the
+    column cotangents do not couple.  Against k_bwd_rho_mfma (CMPS_RHO_BWD_GEMM, the round 1-4 reverse sweep: a different formulation,
+    cotangent array as GEMMs) and against the matrix-form oracle; every rank-1 arithmetic of the wave scan."""
+    from audio_mps_amd import _capi
+    m, audio = _rho_model(D, T, B, rank=rank, sigma=sigma, seed=D + T, rscale=rscale)
+    be = m._get_backend()
+    ohp, ov, Wx, Wy = _oracle_side(m)
+    ref = O.rho_loss_and_grads(ohp, ov, Wx, Wy, audio, "f32")
+    ref64 = O.rho_loss_and_grads(ohp, ov.astype(np.float64), Wx.astype(np.float64), Wy.astype(np.float64), audio, "f64")
+    assert be._lib.cmps_get_option(be._h, _capi.CMPS_OPT_RHO_BWD) == _capi.CMPS_RHO_BWD_VIRTUAL
+    be.kernel_events(True)
+    loss, gv = m.loss_and_grads()
+    names = set(be.kernel_times())
+    be.kernel_events(False)
+    assert "k_bwd_wave" in names, names
+    _capi.check(be._h, be._lib.cmps_set_option(be._h, _capi.CMPS_OPT_RHO_BWD, _capi.CMPS_RHO_BWD_GEMM))
+    _, gg_ = m.loss_and_grads()
+    _capi.check(be._h, be._lib.cmps_set_option(be._h, _capi.CMPS_OPT_RHO_BWD, _capi.CMPS_RHO_BWD_VIRTUAL))
+    for k in ("A", "Rx", "Ry", "freqs", "Wx", "Wy"):
+        own = rel_inf(ref[k], ref64[k])
+        assert rel_inf(gv[k], ref64[k]) <= max(GRAD_RTOL, 3 * own), (k, rel_inf(gv[k], ref64[k]), own)
+        assert rel_inf(gv[k], gg_[k]) <= max(GRAD_RTOL, 3 * own), (k, rel_inf(gv[k], gg_[k]))
+    for mode in (0, 1, 2):
+        be.set_rank1(mode)
+        _, gm = m.loss_and_grads()
+        for k in ("Rx", "Ry", "Wx", "Wy"):
+            assert rel_inf(gm[k], ref64[k]) <= max(GRAD_RTOL, 3 * rel_inf(ref[k], ref64[k])) + (3e-5 if mode == 1 else 0.0), (mode, k)
+
+
 def test_rho_wide_rank_scaling_and_batch_order():
     """The cost of the wide path is linear in the rank (the GEMM kernels of D <= 32 cost the same at rank 4 and 32), and clips are
     independent: permuting the batch permutes the per-clip losses (training forward) and leaves the gradient sums unchanged."""
