@@ -19,6 +19,7 @@ struct cmps_handle_s {
     int rank1_mode = CMPS_RANK1_DEFAULT;
     int wide_chain = CMPS_WIDE_CHAIN_MFMA;
     int f16_shift = 0;         // CMPS_OPT_F16_SCALE_SHIFT (diagnostic)
+    bool rho_fwd_grad1 = false;    // the last GEMM forward accumulated RhoDev::p1
     bool rho_virtual_bwd = true;   // CMPS_OPT_RHO_BWD: the RhoCMPS GEMM forward's reverse sweep on virtual clips of k_bwd_wave (else k_bwd_rho_mfma)
     bool params_set = false;
     bool legacy = false;       // the tables currently hold the legacy AudioMPS arithmetic (cmps_legacy_set_params)
@@ -638,7 +639,9 @@ int cmps_rho_loss_fwd(cmps_handle_t h, const float* audio_dev, int B, int T, flo
     // D <= 32 (and rank <= 32): one wavefront per clip, unless the block variant was asked for -- the forward as row-array
     // GEMMs on the matrix cores (cmps_rho_mfma.hip); CMPS_VARIANT_WAVE32 keeps the column-by-column kernel (cross-check)
     const bool wave = h->D <= 32 && h->W.rank <= 32 && h->variant_req != CMPS_VARIANT_BLOCK;
-    const bool mfma = wave && h->variant_req != CMPS_VARIANT_WAVE32 && h->W.rank > 8;   // below rank ~10 the column loop is faster
+    // the row-array GEMM forward costs the same at every rank; with the virtual-clip reverse sweep behind it (3.75 + 0.11 rank ms at T = 1000,
+    // B = 256 against 1.65 rank ms for the column kernels: scripts/bench_next_rows.py) it wins from rank 3, with k_bwd_rho_mfma from rank 9
+    const bool mfma = wave && h->variant_req != CMPS_VARIANT_WAVE32 && h->W.rank > (h->rho_virtual_bwd && save_for_bwd ? 2 : 8);
     // 32 < D <= 128, training forward (round 5): the columns as virtual clips of the wide kernels (cmps_wide.hip), when the rho workspace
     // has the sections for it (cmps_rho_workspace_bytes: CMPS_WS_TRAIN and the column vectors fit the LDS); else the general kernels
     const bool wide = h->D > 32 && h->W.vrank > 0 && save_for_bwd != 0 && h->variant_req != CMPS_VARIANT_BLOCK;
@@ -646,11 +649,12 @@ int cmps_rho_loss_fwd(cmps_handle_t h, const float* audio_dev, int B, int T, flo
     hipStream_t s = static_cast<hipStream_t>(stream);
     KBind kb(h);
     hipError_t e = wide ? launch_fwd_rho_wide(P, h->W, audio_dev, loss_dev, f16, s)
-                 : mfma ? launch_fwd_rho_mfma(P, h->W, audio_dev, loss_dev, save_for_bwd != 0, f16, s)
+                 : mfma ? launch_fwd_rho_mfma(P, h->W, audio_dev, loss_dev, save_for_bwd != 0, f16, !h->rho_virtual_bwd, s)
                  : wave ? launch_fwd_rho_wave(P, h->W, audio_dev, loss_dev, save_for_bwd != 0, s)
                         : launch_fwd_rho(P, h->W, audio_dev, loss_dev, save_for_bwd != 0, s);
     if (e != hipSuccess) return fail_hip(h, e, "cmps_rho_loss_fwd");
     h->W.stash_layout = wide ? 3 : mfma ? 2 : (wave ? 1 : 0);
+    h->rho_fwd_grad1 = mfma && !h->rho_virtual_bwd;               // the forward's part of Rbar exists (k_bwd_rho_mfma needs it)
     h->rho_saved = h->rho_bwd_ok = save_for_bwd != 0;
     h->rho_saved_B = B; h->rho_saved_steps = T - 1;
     h->saved_audio = audio_dev; h->saved_loss = loss_dev;
@@ -676,6 +680,8 @@ int cmps_rho_loss_bwd(cmps_handle_t h, const float* audio_dev, int B, int T, flo
         if (ew != hipSuccess) return fail_hip(h, ew, "cmps_rho_loss_bwd (wide)");
         return CMPS_OK;
     }
+    if (h->W.stash_layout == 2 && !h->rho_virtual_bwd && !h->rho_fwd_grad1)
+        return fail(h, CMPS_ERR_STATE, "cmps_rho_loss_bwd: CMPS_OPT_RHO_BWD changed between the forward and the reverse call");
     if (h->W.stash_layout == 2 && h->rho_virtual_bwd) {
         // the row-array forward's rows through the pure-state wave reverse scan, one virtual clip per column (cmps_rho_wave.hip)
         const hipError_t ew = launch_bwd_rho_virtual_wave(P, h->W, audio_dev, h->saved_loss, grad_dev, wave_rank1(h->rank1_mode), s);

@@ -275,7 +275,7 @@ hipError_t launch_fwd_legacy_wave(const Dev& P, const float* audio, float* loss,
 hipError_t launch_bwd_legacy_wave(const Dev& P, const float* audio, int rank1_mode, hipStream_t s);
 hipError_t launch_legacy_tables(const Dev& P, float2* psi0, float* dtk, float2* rho, hipStream_t s);
 hipError_t launch_fwd_rho_wave(const Dev& P, const RhoDev& W, const float* audio, float* loss, bool save, hipStream_t s);
-hipError_t launch_fwd_rho_mfma(const Dev& P, const RhoDev& W, const float* audio, float* loss, bool save, bool f16, hipStream_t s);
+hipError_t launch_fwd_rho_mfma(const Dev& P, const RhoDev& W, const float* audio, float* loss, bool save, bool f16, bool grad1, hipStream_t s);
 hipError_t launch_bwd_rho_mfma(const Dev& P, const RhoDev& W, const float* audio, hipStream_t s);
 hipError_t launch_sample_rho_mfma(const Dev& P, const RhoDev& W, const float* noise, int n, int length, float* out, bool save,
                                   bool f16, hipStream_t s);

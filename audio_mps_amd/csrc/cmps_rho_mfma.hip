@@ -94,7 +94,9 @@ __device__ __forceinline__ float dpp_nb(float x) {      // the value of lane n ^
 
 }  // namespace
 
-template <bool SAVE, bool F16>
+// GRAD1: also accumulate the forward's part of Rbar, sum_k 2 ebar_k Y^T Y (RhoDev::p1), which k_bwd_rho_mfma adds to its own sums; the
+// virtual-clip reverse sweep (round 5, k_bwd_wave per column: cmps_rho_wave.hip) forms all three rank-1 sums itself and runs without it
+template <bool SAVE, bool F16, bool GRAD1 = true>
 __global__ __launch_bounds__(64 * WAVES, 1) void k_fwd_rho_mfma(Dev P, RhoDev W, const float* __restrict__ audio,
                                                                 float* __restrict__ loss_out) {
     __shared__ __attribute__((aligned(16))) float Urow[WAVES][32 * RRLD];
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_fwd_rho_mfma(Dev P, RhoDev W,
                     if (s0 + 4 < r) sbase[(size_t)(s0 + 4) * 64] = make_float2(__uint_as_float(ys[1]), __uint_as_float(hs[1]));
                 }
             }
-            if (SAVE) {
+            if (SAVE && GRAD1) {
                 // 2 ebar_k with the reverse scan's own operations (cmps_rho_wave.hip: zbv, tev)
                 const float inck = rdlane(incv, kk);
                 const float zb = -1.0f / (1.0f + (e * inck) / A);
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_fwd_rho_mfma(Dev P, RhoDev W,
         }
     }
     if (lane == 0) loss_out[b] = loss;
-    if (SAVE) {
+    if (SAVE && GRAD1) {
         float* p1 = W.p1 + (size_t)b * 4096 + lane;
 #pragma unroll
         for (int ta = 0; ta < 2; ++ta)
@@ -771,10 +773,12 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_sample_rho_mfma(Dev P, RhoDev
     }
 }
 
-hipError_t launch_fwd_rho_mfma(const Dev& P, const RhoDev& W, const float* audio, float* loss, bool save, bool f16, hipStream_t s) {
+hipError_t launch_fwd_rho_mfma(const Dev& P, const RhoDev& W, const float* audio, float* loss, bool save, bool f16, bool grad1, hipStream_t s) {
     const unsigned nb = (unsigned)((P.B + WAVES - 1) / WAVES);
-    if (save && f16) hipLaunchKernelGGL((k_fwd_rho_mfma<true, true>), dim3(nb), dim3(64 * WAVES), 0, s, P, W, audio, loss);
-    else if (save) hipLaunchKernelGGL((k_fwd_rho_mfma<true, false>), dim3(nb), dim3(64 * WAVES), 0, s, P, W, audio, loss);
+    if (save && f16 && grad1) hipLaunchKernelGGL((k_fwd_rho_mfma<true, true, true>), dim3(nb), dim3(64 * WAVES), 0, s, P, W, audio, loss);
+    else if (save && f16) hipLaunchKernelGGL((k_fwd_rho_mfma<true, true, false>), dim3(nb), dim3(64 * WAVES), 0, s, P, W, audio, loss);
+    else if (save && grad1) hipLaunchKernelGGL((k_fwd_rho_mfma<true, false, true>), dim3(nb), dim3(64 * WAVES), 0, s, P, W, audio, loss);
+    else if (save) hipLaunchKernelGGL((k_fwd_rho_mfma<true, false, false>), dim3(nb), dim3(64 * WAVES), 0, s, P, W, audio, loss);
     else if (f16) hipLaunchKernelGGL((k_fwd_rho_mfma<false, true>), dim3(nb), dim3(64 * WAVES), 0, s, P, W, audio, loss);
     else hipLaunchKernelGGL((k_fwd_rho_mfma<false, false>), dim3(nb), dim3(64 * WAVES), 0, s, P, W, audio, loss);
     return hipGetLastError();

@@ -74,7 +74,8 @@ enum {
                         * BF16X2 = two bf16 pieces / three products, F16X2 = two fp16 pieces / three products, anything else = three
                         * bf16 pieces / six products) */,
     CMPS_OPT_WIDE_CHAIN = 3 /* how the wide kernels (32 < D <= 128, float32) run the training forward's serial chain: see the values below */,
-    CMPS_OPT_RHO_BWD = 5 /* which reverse sweep follows the RhoCMPS row-array GEMM forward (D <= 32, rank > 8): see the values below */,
+    CMPS_OPT_RHO_BWD = 5 /* which reverse sweep follows the RhoCMPS row-array GEMM forward (D <= 32; the forward runs from rank 3 with
+                        * CMPS_RHO_BWD_VIRTUAL, from rank 9 with CMPS_RHO_BWD_GEMM, the column-by-column kernels below that): see the values below */,
     CMPS_OPT_F16_SCALE_SHIFT = 4 /* DIAGNOSTIC, default 0: added to the exponent of every data-dependent fp16 scale of the wave reverse
                         * scan's F16X2 arithmetic (range -40 .. 40).  A positive value pushes the pieces out of fp16 range on purpose:
                         * how tests/test_gpu_parity.py provokes CMPS_ERR_F16_RANGE.  No reference counterpart. */,

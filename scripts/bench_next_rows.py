@@ -106,10 +106,10 @@ for rank in (4, 32):
                                                               rm.variables["freqs"], np.zeros(32, np.float32), np.zeros(32, np.float32),
                                                               scaled_R=True, scaled_freqs=True), rm.variables["Wx"], rm.variables["Wy"], a[:4, :200])
     cpu = 4 * 200 / (time.perf_counter() - t0)
-    res[f"rho_cmps_rank{rank}"] = {"shape": f"D=32, rank={rank}, T={T}, B={B}, fwd+bwd", "kernel": ("k_fwd_rho_mfma<f16x2> + k_bwd_rho_mfma (wave per clip, row-array GEMMs; forward fp16 x 2 operands, reverse bf16 x 3)" if rank > 8 else
+    res[f"rho_cmps_rank{rank}"] = {"shape": f"D=32, rank={rank}, T={T}, B={B}, fwd+bwd", "kernel": ("k_fwd_rho_mfma<f16x2> (wave per clip, row-array GEMMs, fp16 x 2 operands) + round 5: k_bwd_wave on one virtual clip per column (CMPS_OPT_RHO_BWD)" if rank > 8 else
                                               "k_fwd_rho_wave + k_bwd_rho_wave (wave per clip, column by column)"), "ms": ms,
                                    "samples_per_s": B * T / ms * 1e3, "cpu_numpy_samples_per_s": cpu,
-                                   "bound": ("matrix pipe + operand splitting: 144 (forward, training) + 144 (reverse) 32x32x16 bf16 MFMAs per step, independent of the rank up to 32"
+                                   "bound": ("forward: 256 waves on 1024 SIMDs, dependent trip registers -> LDS -> MFMA per step, the same cost at every rank <= 32; reverse: the pure-state wave scan on B x rank virtual clips, linear in the rank"
                                              if rank > 8 else
                                              "straight-line wave-per-clip kernels, 3 r D^2 complex MACs + 6 r exact fp32 MFMAs per step (issue / LDS latency)")}
 
