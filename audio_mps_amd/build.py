@@ -38,31 +38,49 @@ def _flags():
     return ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Xarch_host", "-msse4.2", "-Wall", "-Wno-unused-function"]
 
 
+def _stamp_text(flags) -> str:
+    """Everything a compile depends on besides the sources: the common flags AND the per-source ones."""
+    return " ".join(flags) + " | " + " ; ".join(f"{k}: {' '.join(v)}" for k, v in sorted(EXTRA_FLAGS.items()))
+
+
 def build(force: bool = False, verbose: bool = False, extra_flags=(), jobs: int | None = None) -> str:
     """One object per source, compiled in parallel (a source is recompiled when it or any header is newer than its
-    object, or when the flags changed), then one link.  ``force`` recompiles everything."""
-    if not force and not needs_build() and not extra_flags:
+    object, or when the flags changed), then one link.  ``force`` recompiles everything.
+
+    ``extra_flags`` (diagnostic -DCMPS_DIAG ... builds, whose results are documented as wrong) never touch the shipped
+    library: they compile into their own object directory and link ``lib/libcmps_diag_<hash>.so``, whose path is returned
+    (select it with CMPS_LIB).  The shipped library is rebuilt whenever its stamped flags differ from the current ones."""
+    import hashlib
+    flags = _flags() + list(extra_flags)
+    obj_dir, lib_path = OBJ_DIR, LIB_PATH
+    if extra_flags:
+        tag = hashlib.sha1(" ".join(extra_flags).encode()).hexdigest()[:10]
+        obj_dir, lib_path = OBJ_DIR + "_diag_" + tag, os.path.join(LIB_DIR, f"libcmps_diag_{tag}.so")
+    stamp = os.path.join(obj_dir, "flags.txt")
+    same_flags = os.path.exists(stamp) and open(stamp).read() == _stamp_text(flags)
+    if not force and not extra_flags and same_flags and not needs_build():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    os.makedirs(OBJ_DIR, exist_ok=True)
+    os.makedirs(obj_dir, exist_ok=True)
     hipcc = _hipcc()
-    flags = _flags() + list(extra_flags)
-    stamp = os.path.join(OBJ_DIR, "flags.txt")
-    same_flags = os.path.exists(stamp) and open(stamp).read() == " ".join(flags)
     hdr_t = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS if os.path.exists(os.path.join(CSRC, h)))
     todo, objs = [], []
     for s in SOURCES:
-        src, obj = os.path.join(CSRC, s), os.path.join(OBJ_DIR, s.replace(".hip", ".o"))
+        src, obj = os.path.join(CSRC, s), os.path.join(obj_dir, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or not same_flags or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
             todo.append((src, obj))
 
     def compile_one(job):
         src, obj = job
-        cmd = [hipcc] + flags + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
+        tmp = f"{obj}.{os.getpid()}.tmp"                      # concurrent ranks never write the same file; the rename is atomic
+        cmd = [hipcc] + flags + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", tmp]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
-        return src, subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if proc.returncode == 0:
+            os.replace(tmp, obj)
+        return src, proc
 
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=jobs or min(6, os.cpu_count() or 2)) as pool:
@@ -72,12 +90,14 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), jobs: int 
             if verbose and proc.stdout:
                 print(proc.stdout, file=sys.stderr)
     with open(stamp, "w") as f:
-        f.write(" ".join(flags))
-    proc = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs,
+        f.write(_stamp_text(flags))
+    tmp_lib = f"{lib_path}.{os.getpid()}.tmp"
+    proc = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp_lib] + objs,
                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if proc.returncode != 0:
         raise RuntimeError("hipcc link failed:\n" + proc.stdout)
-    return LIB_PATH
+    os.replace(tmp_lib, lib_path)
+    return lib_path
 
 
 if __name__ == "__main__":

@@ -79,6 +79,20 @@ def _normalize_psi_host(p: np.ndarray) -> np.ndarray:
 
 
 # --------------------------------------------------------------------------------------------------
+class _VarDict(dict):
+    """model.variables: a plain dict whose item assignment invalidates a live device-resident copy of the variables (see CMPS.variables)."""
+
+    def __init__(self, model):
+        super().__init__()
+        self._model = model
+
+    def __setitem__(self, key, value):
+        owner = self._model._owner() if hasattr(self._model, "_device_owner") else None
+        if owner is not None and getattr(owner, "_dev", None) is not None and not getattr(owner, "_syncing_back", False):
+            owner.drop_device_state()              # device -> host for everything else, then forget the device copy
+        super().__setitem__(key, value)
+
+
 class CMPS:
     """Continuous Matrix Product State: the trainable variables and the effective parameters
     (model.py:5-52).  ``self.R`` (complex64 [D,D], diagonal removed as at model.py:42), ``self.freqs``,
@@ -96,7 +110,8 @@ class CMPS:
         self.data_iterator = data_iterator
         D = self.bond_d
         rng = np.random.default_rng(seed)
-        self._variables: Dict[str, np.ndarray] = {}
+        self._device_owner = None
+        self._variables: Dict[str, np.ndarray] = _VarDict(self)
         self._device_owner = None      # a Trainer whose device-resident optimiser state is newer than self._variables (see `variables`)
         self.variables["A"] = np.asarray(np.float32(hparams.A))   # model.py:19
         # --- R (model.py:31-42)
@@ -123,13 +138,19 @@ class CMPS:
             self._c_h = _rsqrt32(self.h_reg)
         self._rng = rng
 
+    def _owner(self):
+        ref = self._device_owner
+        return ref() if ref is not None else None
+
     @property
     def variables(self) -> Dict[str, np.ndarray]:
         """The raw trainable variables (host copies).  While a Trainer runs the device-resident optimiser step the current values
         live on the GPU; reading this attribute then brings them back first (Trainer._lazy_sync: one device -> host copy, only after
         steps that changed them), so loss / sample / effective_params / summaries never see stale parameters.
-        Values written here while a device-resident state is live are not pushed to it: restore() / a new Trainer rebuild it."""
-        owner = self._device_owner
+        ASSIGNING an entry (``m.variables["Rx"] = ...``, ``m.variables["Rx"] *= c``) while a device-resident state is live brings that
+        state back and drops it, so the Trainer's next step starts from the host values (ADVICE r4: such writes used to be ignored);
+        the Trainer is held by a weak reference."""
+        owner = self._owner()
         if owner is not None:
             owner._lazy_sync()
         return self._variables

@@ -112,6 +112,9 @@ class HipScan:
         exact fp32, two bf16 pieces, two fp16 pieces (also for DEFAULT) and three bf16 pieces.  (The 16-row kernels of D <= 16 always
         use exact fp32 MFMAs and the legacy mode maps the fp16 form to three bf16 pieces: this property describes the 32-row kernel.)"""
         mode, wide = self.rank1, self.variant == _capi.CMPS_VARIANT_WIDE
+        if getattr(self, "_legacy_buf", None) is not None and not wide:        # a handle in legacy mode (legacy_set_params): the wave
+            # reverse scan's legacy instance has no fp16 form -- F16X2 / DEFAULT run three bf16 pieces (include/cmps.h's table)
+            return mode if mode in (_capi.CMPS_RANK1_EXACT_F32, _capi.CMPS_RANK1_BF16X2) else _capi.CMPS_RANK1_BF16X3
         if wide:
             return {0: _capi.CMPS_RANK1_BF16X3, 4: _capi.CMPS_RANK1_F16X2}.get(mode, mode)
         if mode == _capi.CMPS_RANK1_DEFAULT:

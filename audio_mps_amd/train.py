@@ -133,7 +133,8 @@ class Trainer:
             st["losses"] = torch.zeros(2, dtype=torch.float32, device=be.device)
             self._dev = st
             self._dirty = False
-            self.model._device_owner = self                        # model.variables now syncs lazily from the device state
+            import weakref
+            self.model._device_owner = weakref.ref(self)           # model.variables now syncs lazily from the device state
             self._apply(None, 1)                                   # effective parameters of the current variables
         return self._dev
 
@@ -181,10 +182,25 @@ class Trainer:
             self.history.append(out)
         return out
 
+    def drop_device_state(self):
+        """Bring the device-resident state back and forget it: the next device step re-uploads variables and Adam slots from the host
+        (called when model.variables is assigned to while the state is live)."""
+        if self._dev is not None:
+            self.sync_to_host()
+            self._dev = None
+            self._dirty = False
+
     def sync_to_host(self):
         """Device-resident state -> model.variables and the host AdamOptimizer's slots (checkpoints, sampling, inspection)."""
         if self._dev is None:
             return
+        self._syncing_back = True              # (the assignments below must not drop the state they are reading)
+        try:
+            self._sync_to_host()
+        finally:
+            self._syncing_back = False
+
+    def _sync_to_host(self):
         D = self.model.bond_d
         shapes = {"A": (), "Rx": (D, D), "Ry": (D, D), "freqs": (D,), "psi_x": (D,), "psi_y": (D,)}
         self._dirty = False

@@ -164,9 +164,9 @@ def test_config3_reduced_batch():
 
 @pytest.mark.parametrize("mode", [0, 1, 2, 3])
 def test_rank1_modes(mode):
-    """cmps_set_option(CMPS_OPT_RANK1): exact fp32 MFMA, bf16x2 split and bf16x3 split of the rank-1 gradient updates
-    (k_bwd_wave<0|1|2>) all stay inside the gradient bar; a new handle's DEFAULT means BF16X3 here (24 operand bits, fp32-faithful
-    products).
+    """cmps_set_option(CMPS_OPT_RANK1): exact fp32 MFMA, the bf16x2 and bf16x3 splits and the scaled fp16x2 split of the rank-1 gradient
+    updates (k_bwd_wave<0|1|2|3>) all stay inside the gradient bar; a new handle's DEFAULT means F16X2 here (include/cmps.h's table; the
+    forward's loss product follows the same option: two fp16 pieces for F16X2 / DEFAULT, three bf16 pieces otherwise).
     T = 3000 spans many aligned octets plus an unaligned top (2999 steps) and a chunk boundary."""
     from audio_mps_amd import _capi
     m, audio = _model(32, 3000, 10, WAVE, seed=17)

@@ -235,3 +235,21 @@ def test_model_accessors_follow_the_device_resident_state():
     assert float(m_dev.loss) == pytest.approx(float(m_host.loss), rel=1e-5, abs=1e-6)
     t_dev.step(sync=False)
     assert t_dev._dirty
+    # ASSIGNING to model.variables while the device state is live is honoured -- the state comes back, is dropped, and the
+    # next device step starts from the host values (such writes used to be silently overwritten by the next sync)
+    t_host.step()
+    for mm in (m_dev, m_host):
+        mm.variables["Rx"] *= np.float32(0.5)
+        mm.variables["freqs"] = (mm.variables["freqs"] + np.float32(0.25)).astype(np.float32)
+    assert t_dev._dev is None and not t_dev._dirty
+    for _ in range(2):
+        t_dev.step(sync=False)
+        t_host.step()
+    np.testing.assert_allclose(m_dev.R, m_host.R, rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(m_dev.freqs, m_host.freqs, rtol=2e-5, atol=1e-4)
+    import gc, weakref
+    ref = weakref.ref(t_dev)
+    del t_dev
+    gc.collect()
+    assert ref() is None and m_dev._owner() is None                # the model does not keep its Trainer (and the GPU buffers) alive
+    assert np.all(np.isfinite(m_dev.variables["Rx"]))
