@@ -146,7 +146,10 @@ __device__ __forceinline__ float vmax_s(float s, float c) {     // one v_max_f32
 template <bool SAVE, bool LEGACY = false, bool HF16 = false>
 __global__ __launch_bounds__(128 * WAVES, 1) void k_fwd_wave2(Dev P, const float* __restrict__ audio,
                                                               float* __restrict__ loss_out) {
-    __shared__ __attribute__((aligned(16))) float4 stR[WAVES][CH2 * 16];   // rho rows of the chain wave's chunk
+    // rho rows of the chain wave's chunk, two buffers (round 5): the next chunk's rows are fetched in two halves of 16 rows and committed
+    // into the OTHER buffer while the current one is being read, so only 16 registers ride through the chunk instead of 32 -- with 32
+    // hipcc spilled four of them to scratch memory and reloaded them behind an s_waitcnt vmcnt(0) at every chunk end (ISA of round 4)
+    __shared__ __attribute__((aligned(16))) float4 stR[WAVES][2][CH2 * 16];
     __shared__ __attribute__((aligned(16))) float2 bcU[WAVES][DPW];
     __shared__ __attribute__((aligned(16))) float ring[WAVES][RING][RLD];   // y_k, n = 2 i + {re, im}, rows padded (RLD)
     __shared__ __attribute__((aligned(16))) float pe[WAVES][CH2 * PE2_LD]; // y_k[n] (H y_k)[n], [step][column]
@@ -180,13 +183,16 @@ __global__ __launch_bounds__(128 * WAVES, 1) void k_fwd_wave2(Dev P, const float
         }
         const unsigned aUw = lds_addr(&bcU[w][0]) + i * 8 + h * 4, aUr = lds_addr(&bcU[w][0]) + h * 128;
         const unsigned aYw = aRing + i * 8 + h * 4;
-        const unsigned aRho = lds_addr(&stR[w][0]) + i * 8;
+        unsigned aRho = lds_addr(&stR[w][0][0]) + i * 8;
         const float4* rho4 = reinterpret_cast<const float4*>(P.rho);
-        v4f sr[8];
-        stage_load<8>(rho4, 0, N, lane, sr);
+        v4f sr[4];
+        {
+            v4f s8[8];
+            stage_load<8>(rho4, 0, N, lane, s8);
+            stage_commit<8>(stR[w][0], lane, s8);
+        }
         float xa0 = lane < T ? xrow[lane] : 0.f;
         float xa1 = lane + 1 < T ? xrow[lane + 1] : 0.f;
-        stage_commit<8>(stR[w], lane, sr);
         const float2 p0 = P.psi0[i];
         float u = hb ? p0.y : p0.x;
         v4f qu[8];
@@ -209,9 +215,10 @@ __global__ __launch_bounds__(128 * WAVES, 1) void k_fwd_wave2(Dev P, const float
         for (int c = 0; c < NC2; ++c) {
             const int kbeg = c * CH2;
             const int cnt = (N - kbeg) < CH2 ? (N - kbeg) : CH2;
+            const int cn = c + 1 < NC2 ? c + 1 : NC2 - 1;
+            float4* nxt = stR[w][(c + 1) & 1];                         // the buffer the next chunk will read
             {
-                const int cn = c + 1 < NC2 ? c + 1 : NC2 - 1;
-                stage_load<8>(rho4, cn * CH2, N, lane, sr);
+                stage_load<4>(rho4, cn * CH2, N, lane, sr);            // rows 0 .. 15 of the next chunk
                 const int idx = cn * CH2 + lane;
                 xa0 = idx < T ? xrow[idx] : 0.f;
                 xa1 = idx + 1 < T ? xrow[idx + 1] : 0.f;
@@ -266,11 +273,15 @@ __global__ __launch_bounds__(128 * WAVES, 1) void k_fwd_wave2(Dev P, const float
                 CHAIN_STEPC(0)
                 if (SAVE && c > 0 && lane < CH2) sc[(size_t)((c - 1) >> 1) * 128 + ((c - 1) & 1) * CH2 + lane] = nvec;
                 CHAIN_STEPC(1) CHAIN_STEPC(2) CHAIN_STEPC(3) CHAIN_STEPC(4) CHAIN_STEPC(5) CHAIN_STEPC(6) CHAIN_STEPC(7)
+                stage_commit<4>(nxt, lane, sr);                        // (requested eight steps ago)
+                stage_load<4>(rho4, cn * CH2 + 16, N, lane, sr);       // rows 16 .. 31
                 CHAIN_STEPC(8) CHAIN_STEPC(9) CHAIN_STEPC(10) CHAIN_STEPC(11) CHAIN_STEPC(12) CHAIN_STEPC(13) CHAIN_STEPC(14)
                 CHAIN_STEPC(15) CHAIN_STEPC(16) CHAIN_STEPC(17) CHAIN_STEPC(18) CHAIN_STEPC(19) CHAIN_STEPC(20) CHAIN_STEPC(21)
-                CHAIN_STEPC(22) CHAIN_STEPC(23) CHAIN_STEPC(24) CHAIN_STEPC(25) CHAIN_STEPC(26) CHAIN_STEPC(27) CHAIN_STEPC(28)
+                CHAIN_STEPC(22) CHAIN_STEPC(23)
+                stage_commit<4>(nxt + 4 * 64, lane, sr);
+                CHAIN_STEPC(24) CHAIN_STEPC(25) CHAIN_STEPC(26) CHAIN_STEPC(27) CHAIN_STEPC(28)
                 CHAIN_STEPC(29) CHAIN_STEPC(30) CHAIN_STEPC(31)
-            } else {                                                   // the clip's last, partial chunk
+            } else {                                                   // the clip's last, partial chunk (nothing follows it)
                 CHAIN_STEP(0)
                 if (SAVE && c > 0 && lane < CH2) sc[(size_t)((c - 1) >> 1) * 128 + ((c - 1) & 1) * CH2 + lane] = nvec;
                 for (int kk = 1; kk < cnt; ++kk) CHAIN_STEP(kk)
@@ -280,7 +291,7 @@ __global__ __launch_bounds__(128 * WAVES, 1) void k_fwd_wave2(Dev P, const float
             lds_wait_hi_t<0>(qu, rho);                                 // everything of this chunk has landed
             flag_store(aProd, c + 1, lane);                            // publish (ordered behind the chunk's y rows)
             if (c + 1 < NC2) {
-                stage_commit<8>(stR[w], lane, sr);
+                aRho = lds_addr(&stR[w][(c + 1) & 1][0]) + i * 8;     // both halves of the next chunk are in place
                 sv = LEGACY ? P.dt * (xa1 - xa0) : (xa1 - xa0) / A;    // the next chunk's s_k
                 FORM_M(rdlane(sv, 0))                                  // the last in-loop FORM_M used the stale lane 0
                 bcast_issue_tab(aUw, aUr, u, aRho, qu, rho);
