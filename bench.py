@@ -372,8 +372,9 @@ def kernel_counters(doc, kernel):
 def executed_split(variant, D, rank1, wide_chain=1):
     if variant in (V_WAVE, V_WAVE32) and not (variant == V_WAVE and D <= 16):
         prod = {0: 1, 1: 3, 2: 6, 3: 3}[rank1]
-        return {"fwd": {"valu_fp32": 12, "mfma_fp32_equiv": 8, "mfma_products": 6, "eliminated": 4,
-                        "what": "merged (Q + s R) u mat-vec 8 + forming it 4 on the VALU; H y as a bf16x3 GEMM over 32-step chunks"},
+        return {"fwd": {"valu_fp32": 12, "mfma_fp32_equiv": 8, "mfma_products": 3 if rank1 == 3 else 6, "eliminated": 4,
+                        "what": "merged (Q + s R) u mat-vec 8 + forming it 4 on the VALU; H y as a split-operand GEMM over 32-step chunks "
+                                "(f16x2: 3 products; bf16x3: 6)"},
                 "bwd": {"valu_fp32": 12, "mfma_fp32_equiv": 24, "mfma_products": prod, "eliminated": 20,
                         "what": "merged (Q + s R^dagger) ybar 8 + forming it 4 on the VALU; H y read from the forward's stash (16 "
                                 "eliminated), the merge (4 eliminated); three rank-1 sums on the matrix cores"}}
@@ -441,8 +442,10 @@ def kernel_work_model(fam, D, DP, rank1):
     prod = {0: 1, 1: 3, 2: 6, 3: 3}[rank1]
     rp = "mfma_f32" if rank1 == 0 else "mfma_bf16"
     if fam == "wave":
+        hyp = 3 if rank1 == 3 else 6
         return {"k_fwd_wave2": [("valu_fp32", 12 * D * D, "merged (Q + s R) u mat-vec 8 + forming it 4"),
-                                ("mfma_bf16", 8 * 6 * D * D, "H y as a bf16x3-split GEMM over 32-step chunks: 6 piece products"),
+                                ("mfma_bf16", 8 * hyp * D * D, f"H y as a split-operand GEMM over 32-step chunks: {hyp} piece products (f16x2 for "
+                                                               "CMPS_RANK1_F16X2 / DEFAULT, bf16x3 otherwise; fp16 and bf16 MFMAs have the same dense peak)"),
                                 ("hbm", 512.0, "stash rows written: 512 B per (clip, step)")],
                 "k_bwd_wave": [("valu_fp32", 12 * D * D, "merged (Q + s R^dagger) ybar mat-vec 8 + forming it 4"),
                                (rp, 24 * prod * D * D, f"three rank-1 sums, {prod} product(s) per float32 product"),
@@ -757,7 +760,8 @@ def arithmetic_note(variant, D, rank1, wide_chain=1):
     split = {0: "exact fp32 MFMA", 1: "bf16x2 split (16 operand bits)", 2: "bf16x3 split (24 operand bits)",
              3: "f16x2 split (scaled, 24 operand bits)"}[rank1]
     if variant in (V_WAVE, V_WAVE32) and not (variant == V_WAVE and D <= 16):
-        return "fp32 FMA chains on the serial path; off-chain products on the matrix cores, fp32 accumulate: H y bf16x3 split, rank-1 sums " + split
+        hy = "f16x2 split" if rank1 == 3 else "bf16x3 split"
+        return "fp32 FMA chains on the serial path; off-chain products on the matrix cores, fp32 accumulate: H y " + hy + ", rank-1 sums " + split
     if variant == V_WAVE:
         return "fp32 FMA chains; rank-1 gradient sums as exact fp32 MFMAs (16-row layout)"
     if variant == V_WIDE:
