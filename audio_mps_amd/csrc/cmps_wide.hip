@@ -128,6 +128,20 @@ __device__ __forceinline__ void col_two(v2f& rRe0, v2f& rIm0, v2f& rRe1, v2f& rI
         : "v"(r0), "v"(q0), "v"(r1), "v"(q1), "v"(xre), "v"(xim));
 #undef WIDE_CMAC
 }
+// acc(two rows) += M[row][col] * x[col] for both packed vectors, ONE matrix for both (k_fwd_wide_rho: the two vectors are columns of the
+// same clip, so M_k = Q + s_k R is the same for both and is formed once per step, not per column pair): m = (re, im)
+__device__ __forceinline__ void col_single(v2f& aRe0, v2f& aIm0, v2f& aRe1, v2f& aIm1, v2f m0, v2f m1, v2f xre, v2f xim) {
+    asm("v_pk_fma_f32 %0, %4, %6, %0 op_sel_hi:[0,1,1]\n\t"                                    // Re += m_re x_re
+        "v_pk_fma_f32 %2, %5, %6, %2 op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %1, %4, %7, %1 op_sel_hi:[0,1,1]\n\t"                                    // Im += m_re x_im
+        "v_pk_fma_f32 %3, %5, %7, %3 op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %0, %4, %7, %0 op_sel:[1,0,0] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"         // Re -= m_im x_im
+        "v_pk_fma_f32 %2, %5, %7, %2 op_sel:[1,0,0] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_pk_fma_f32 %1, %4, %6, %1 op_sel:[1,0,0]\n\t"                                       // Im += m_im x_re
+        "v_pk_fma_f32 %3, %5, %6, %3 op_sel:[1,0,0]"
+        : "+v"(aRe0), "+v"(aIm0), "+v"(aRe1), "+v"(aIm1)
+        : "v"(m0), "v"(m1), "v"(xre), "v"(xim));
+}
 // acc(two rows) += H[row][col .. col + 1] * y[col .. col + 1] for both clips; h = (re, im, re, im) of two adjacent columns
 __device__ __forceinline__ void col_pair_plain(v2f& aRe0, v2f& aIm0, v2f& aRe1, v2f& aIm1, v4f h0, v4f h1, v4f ya, v4f yb) {
     asm("v_pk_fma_f32 %0, %4, %8, %0 op_sel_hi:[0,1,1]\n\t"                                    // Re += h_re y_re
@@ -480,6 +494,12 @@ __global__ __launch_bounds__(4 * PD) void k_fwd_wide_rho(Dev P, const float* __r
         if (chain) {
             const float sk = wrdl(sv, k & (WCH - 1));
             const v2f s2 = mkv2(sk, sk);
+            v2f MM[2][KC];                                        // M_k = Q + s_k R: once per step, shared by every column of the clip
+#pragma unroll
+            for (int j = 0; j < KC; ++j) {
+                MM[0][j] = __builtin_elementwise_fma(MR[0][j], s2, MQ[0][j]);
+                MM[1][j] = __builtin_elementwise_fma(MR[1][j], s2, MQ[1][j]);
+            }
             float nacc = 0.f;
             for (int cp = 0; cp < npairs; ++cp) {
                 const v4f* uv = uvec + ((size_t)p * npairs + cp) * VEC4;
@@ -487,7 +507,7 @@ __global__ __launch_bounds__(4 * PD) void k_fwd_wide_rho(Dev P, const float* __r
 #pragma unroll
                 for (int j = 0; j < KC; ++j) {
                     const v4f x = uv[rd4 + j];
-                    col_merged(cRe0, cIm0, cRe1, cIm1, MR[0][j], MQ[0][j], MR[1][j], MQ[1][j], s2, lo_of(x), hi_of(x));
+                    col_single(cRe0, cIm0, cRe1, cIm1, MM[0][j], MM[1][j], lo_of(x), hi_of(x));
                 }
                 const float ut = reinterpret_cast<const float*>(uv)[own_f];
                 const float acc = reduce_slices(cRe0, cIm0, cRe1, cIm1, clip1);
