@@ -38,6 +38,7 @@ CMPS_RANK1_DEFAULT = 4
 CMPS_OPT_WIDE_CHAIN = 3
 CMPS_OPT_F16_SCALE_SHIFT = 4
 CMPS_OPT_RHO_BWD = 5
+CMPS_OPT_BWD_WAVES = 6
 CMPS_RHO_BWD_VIRTUAL = 0
 CMPS_RHO_BWD_GEMM = 1
 CMPS_WIDE_CHAIN_VALU = 0

@@ -12,7 +12,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libcmps.so")
 OBJ_DIR = os.path.join(_HERE, "obj")
-SOURCES = ["cmps_capi.hip", "cmps_prep.hip", "cmps_opt.hip", "cmps_block.hip", "cmps_wave.hip", "cmps_wave2.hip", "cmps_wave16.hip", "cmps_pair.hip", "cmps_wide.hip", "cmps_legacy.hip", "cmps_rho.hip", "cmps_rho_wave.hip", "cmps_rho_mfma.hip"]
+SOURCES = ["cmps_capi.hip", "cmps_prep.hip", "cmps_opt.hip", "cmps_block.hip", "cmps_wave.hip", "cmps_wave_bwd2.hip", "cmps_wave2.hip", "cmps_wave16.hip", "cmps_pair.hip", "cmps_wide.hip", "cmps_legacy.hip", "cmps_rho.hip", "cmps_rho_wave.hip", "cmps_rho_mfma.hip"]
 # per-source flags: the pair kernels place plain VALU between MFMAs themselves (cmps_pair.hip::mfma_valu_pipeline); the compiler's
 # SLP packing into v_pk_* (expensive beside MFMAs, and a v_mov shuffle per operand) is switched off there
 EXTRA_FLAGS = {"cmps_pair.hip": ["-fno-slp-vectorize"]}

@@ -19,6 +19,7 @@ struct cmps_handle_s {
     int rank1_mode = CMPS_RANK1_DEFAULT;
     int wide_chain = CMPS_WIDE_CHAIN_MFMA;
     int f16_shift = 0;         // CMPS_OPT_F16_SCALE_SHIFT (diagnostic)
+    int bwd_waves = 2;             // CMPS_OPT_BWD_WAVES
     bool rho_fwd_grad1 = false;    // the last GEMM forward accumulated RhoDev::p1
     bool rho_virtual_bwd = true;   // CMPS_OPT_RHO_BWD: the RhoCMPS GEMM forward's reverse sweep on virtual clips of k_bwd_wave (else k_bwd_rho_mfma)
     bool params_set = false;
@@ -141,6 +142,11 @@ int cmps_set_option(cmps_handle_t h, int option, int value) {
         h->wide_chain = value;
         return CMPS_OK;
     }
+    if (option == CMPS_OPT_BWD_WAVES) {
+        if (value != 1 && value != 2) return fail(h, CMPS_ERR_BAD_ARG, "cmps_set_option: CMPS_OPT_BWD_WAVES takes 1 or 2");
+        h->bwd_waves = value;
+        return CMPS_OK;
+    }
     if (option == CMPS_OPT_RHO_BWD) {
         if (value != CMPS_RHO_BWD_VIRTUAL && value != CMPS_RHO_BWD_GEMM) return fail(h, CMPS_ERR_BAD_ARG, "cmps_set_option: unknown value for CMPS_OPT_RHO_BWD");
         h->rho_virtual_bwd = value == CMPS_RHO_BWD_VIRTUAL;
@@ -166,6 +172,7 @@ int cmps_get_option(cmps_handle_t h, int option) {
     if (option == CMPS_OPT_KERNEL_EVENTS) return h->ktimer ? 1 : 0;
     if (option == CMPS_OPT_WIDE_CHAIN) return h->wide_chain;
     if (option == CMPS_OPT_F16_SCALE_SHIFT) return h->f16_shift;
+    if (option == CMPS_OPT_BWD_WAVES) return h->bwd_waves;
     if (option == CMPS_OPT_RHO_BWD) return h->rho_virtual_bwd ? CMPS_RHO_BWD_VIRTUAL : CMPS_RHO_BWD_GEMM;
     return -1;
 }
@@ -376,8 +383,10 @@ int cmps_psi_loss_bwd(cmps_handle_t h, const float* audio_dev, int B, int T, flo
     const bool w16 = h->saved_variant == CMPS_VARIANT_WAVE && h->D <= 16;
     hipError_t e;
     {
-        KScope ks(!wave ? "k_bwd_block" : w16 ? "k_bwd_wave16" : "k_bwd_wave", s);
-        e = !wave ? launch_bwd_block(P, audio_dev, s) : w16 ? launch_bwd_wave16(P, audio_dev, s) : launch_bwd_wave(P, audio_dev, wave_rank1(h->rank1_mode), s);
+        const bool two = wave && !w16 && h->bwd_waves == 2 && wave_rank1(h->rank1_mode) == CMPS_RANK1_F16X2 && h->f16_shift == 0;
+        KScope ks(!wave ? "k_bwd_block" : w16 ? "k_bwd_wave16" : two ? "k_bwd_wave2w" : "k_bwd_wave", s);
+        e = !wave ? launch_bwd_block(P, audio_dev, s) : w16 ? launch_bwd_wave16(P, audio_dev, s)
+          : two ? launch_bwd_wave2w(P, audio_dev, s) : launch_bwd_wave(P, audio_dev, wave_rank1(h->rank1_mode), s);
     }
     if (e != hipSuccess) return fail_hip(h, e, "cmps_psi_loss_bwd (scan)");
     P.abar_fix = wave ? 1 : 0;

@@ -288,6 +288,7 @@ hipError_t launch_prep(const Dev& P, const float* R_re, const float* R_im, const
 hipError_t launch_fwd_block(const Dev& P, const float* audio, float* loss, bool save, hipStream_t s);
 hipError_t launch_bwd_block(const Dev& P, const float* audio, hipStream_t s);
 hipError_t launch_bwd_wave(const Dev& P, const float* audio, int rank1_mode, hipStream_t s);
+hipError_t launch_bwd_wave2w(const Dev& P, const float* audio, hipStream_t s);    // cmps_wave_bwd2.hip: two waves per clip (F16X2 sums)
 hipError_t launch_fwd_wave2(const Dev& P, const float* audio, float* loss, bool save, bool hf16, hipStream_t s);
 hipError_t launch_fwd_wave16(const Dev& P, const float* audio, float* loss, bool save, hipStream_t s);
 hipError_t launch_bwd_wave16(const Dev& P, const float* audio, hipStream_t s);

@@ -21,6 +21,9 @@ rank1 = int(sys.argv[6]) if len(sys.argv) > 6 else None      # cmps_set_option(C
 be = HipScan(D, variant=variant, rank1=rank1)
 if len(sys.argv) > 7:                                         # cmps_set_option(CMPS_OPT_WIDE_CHAIN): 0 VALU chain, 1 fp16 x 2 on the matrix cores
     be.set_wide_chain(int(sys.argv[7]))
+if os.environ.get("CMPS_BWD_WAVES"):                          # cmps_set_option(CMPS_OPT_BWD_WAVES)
+    from audio_mps_amd import _capi
+    _capi.check(be._h, be._lib.cmps_set_option(be._h, _capi.CMPS_OPT_BWD_WAVES, int(os.environ["CMPS_BWD_WAVES"])))
 m = PsiCMPS(hp, seed=0, backend=be)
 be.set_params(m.effective_params(), B, T, train=True)
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]

@@ -255,6 +255,47 @@ def test_rank1_f16x2_scale_jumps(D):
     assert rel_inf(g["Rbar"], g3["Rbar"]) <= 2e-5
 
 
+@pytest.mark.parametrize("D,T,B,sigma,rscale", [
+    (32, 2, 3, 1e-4, None), (32, 3, 2, 1e-4, None), (32, 8, 5, 1e-4, None), (32, 9, 4, 1e-4, None), (32, 10, 4, 1e-4, None),
+    (32, 16, 4, 1e-4, None), (32, 17, 1, 1e-4, None), (32, 33, 6, 1e-4, None), (32, 34, 5, 1e-4, None), (32, 65, 5, 1e-4, None),
+    (32, 66, 7, 1e-4, None), (32, 129, 3, 1e-4, None), (32, 130, 9, 1e-4, None), (32, 700, 6, 1e-4, None), (24, 257, 5, 1e-4, None),
+    (17, 131, 4, 1e-4, None), (32, 501, 5, 0.36, 0.69), (18, 60, 5, 0.36, 0.69), (32, 2000, 12, 1e-4, None), (32, 500, 4, 1.0, 0.1)])
+def test_two_wave_reverse_scan_matches_oracle_and_one_wave(D, T, B, sigma, rscale):
+    """CMPS_OPT_BWD_WAVES = 2 (round 5, cmps_wave_bwd2.hip; the default): the reverse scan as a chain wave + a gradient wave per clip.  T - 1 around
+    every boundary of the hand-over (one step, a lone top octet, (N - 1) & 7 = 0 ... 7, 32-step chunks, 64-step scalar chunks), ragged
+    batches (a partly filled last workgroup), Q visible (sigma = 0.36, large R): against the oracle at the usual bars and against the
+    one-wave kernel (same chain, the sums in the same fp16 x 2 class)."""
+    from audio_mps_amd import _capi
+    from audio_mps_amd.scan import unpack_grad
+    kw = {"A": 66.0} if sigma == 0.36 else {}
+    m, audio = _model(D, T, B, WAVE, sigma=sigma, seed=D + T, rscale=rscale, **kw)
+    if sigma == 0.36:
+        audio = (audio * np.float32(0.09)).astype(np.float32)
+        m.data_iterator = audio
+    be = m._get_backend()
+    assert be._lib.cmps_get_option(be._h, _capi.CMPS_OPT_BWD_WAVES) == 2          # the default since round 5
+    _capi.check(be._h, be._lib.cmps_set_option(be._h, _capi.CMPS_OPT_BWD_WAVES, 1))
+    be.kernel_events(True)
+    g1 = unpack_grad(m.grad_sums(audio)[0].cpu().numpy(), D)
+    assert "k_bwd_wave" in set(be.kernel_times())
+    be.kernel_events(False)
+    _capi.check(be._h, be._lib.cmps_set_option(be._h, _capi.CMPS_OPT_BWD_WAVES, 2))
+    be.kernel_events(True)
+    flat = m.grad_sums(audio)[0].cpu().numpy()
+    names = set(be.kernel_times())
+    be.kernel_events(False)
+    assert "k_bwd_wave2w" in names, names
+    assert np.all(np.isfinite(flat))
+    g2 = unpack_grad(flat, D)
+    ref = c_oracle_run(m, audio, "f32")
+    gr = C.unpack_grad(ref["grad"], D)
+    g64 = C.unpack_grad(c_oracle_run(m, audio, "f64")["grad"], D)
+    for k in ("Rbar", "fbar", "psi0bar", "Abar"):
+        own = rel_inf(gr[k], g64[k])
+        assert rel_inf(g2[k], gr[k]) <= max(GRAD_RTOL, 3 * own), (k, rel_inf(g2[k], gr[k]), own)
+        assert rel_inf(g2[k], g1[k]) <= max(GRAD_RTOL, 3 * own), (k, rel_inf(g2[k], g1[k]))
+
+
 def test_f16_range_tripwire_and_fallback():
     """The run-time check of the fp16-split arithmetic (include/cmps.h: cmps_psi_grad_status).  The scales follow
     guaranteed bounds, so no input provokes an overflow; the diagnostic option CMPS_OPT_F16_SCALE_SHIFT pushes every data-dependent

@@ -298,7 +298,8 @@ def test_bench_headline_is_compact(capsys, tmp_path, monkeypatch):
     for key in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "algorithmic_bytes"):
         assert key in comp, key
     assert "kernels" not in comp and "executed" not in comp and "step_traffic" not in comp
-    assert comp["frac"] == pytest.approx(56 * 32 * 32 * 1024 * 15999 / 6.2e-3 / 1e12 / 157.3, rel=1e-9)
+    assert comp["frac_algorithmic"] == pytest.approx(56 * 32 * 32 * 1024 * 15999 / 6.2e-3 / 1e12 / 157.3, rel=1e-9)
+    assert comp["frac"] == pytest.approx(12 * 32 * 32 * 1024 * 15999 / 6.2e-3 / 1e12 / 157.3, rel=1e-9)       # the executed VALU work: bounded by 1
     par = {"clips": 128, "max_rel_loss_err": 1e-6, "max_rel_loss_err_unfloored": 1e-6, "loss_err_note": "x" * 500, "max_rel_grad_err": 5e-5,
            "grad_err_by_tensor": {"Rbar": 1e-6}, "tolerance": {"loss": 1e-5, "grad": 1e-4}, "ok": True, "against": "oracle " * 40}
     row = {"config": "configs[4] in float32: D=128, T=16000, batch 512 (wide kernels)", "ms_per_step": 43.1234567, "value": 1.9e8,
