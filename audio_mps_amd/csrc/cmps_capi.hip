@@ -693,7 +693,7 @@ int cmps_rho_loss_bwd(cmps_handle_t h, const float* audio_dev, int B, int T, flo
         return fail(h, CMPS_ERR_STATE, "cmps_rho_loss_bwd: CMPS_OPT_RHO_BWD changed between the forward and the reverse call");
     if (h->W.stash_layout == 2 && h->rho_virtual_bwd) {
         // the row-array forward's rows through the pure-state wave reverse scan, one virtual clip per column (cmps_rho_wave.hip)
-        const hipError_t ew = launch_bwd_rho_virtual_wave(P, h->W, audio_dev, h->saved_loss, grad_dev, wave_rank1(h->rank1_mode), s);
+        const hipError_t ew = launch_bwd_rho_virtual_wave(P, h->W, audio_dev, h->saved_loss, grad_dev, wave_rank1(h->rank1_mode), h->bwd_waves, s);
         if (ew != hipSuccess) return fail_hip(h, ew, "cmps_rho_loss_bwd (virtual clips)");
         return CMPS_OK;
     }

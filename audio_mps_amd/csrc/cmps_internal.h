@@ -299,7 +299,7 @@ hipError_t launch_fwd_wide(const Dev& P, const float* audio, float* loss, bool s
 hipError_t launch_fwd_wide_legacy(const Dev& P, const float* audio, float* loss, bool save, bool hy_f16, hipStream_t s);
 hipError_t launch_bwd_wide_legacy(const Dev& P, const float* audio, hipStream_t s);
 hipError_t launch_grad_wide_legacy(const Dev& P, const float* audio, bool f16, hipStream_t s);
-hipError_t launch_bwd_rho_virtual_wave(const Dev& P, const RhoDev& W, const float* audio, const float* loss, float* grad_out, int rank1_mode,
+hipError_t launch_bwd_rho_virtual_wave(const Dev& P, const RhoDev& W, const float* audio, const float* loss, float* grad_out, int rank1_mode, int bwd_waves,
                                        hipStream_t s);
 hipError_t launch_fwd_rho_wide(const Dev& P, const RhoDev& W, const float* audio, float* loss, bool hy_f16, hipStream_t s);
 hipError_t launch_bwd_rho_wide(const Dev& P, const RhoDev& W, const float* loss, float* grad_out, int pieces, hipStream_t s);

@@ -295,7 +295,7 @@ __global__ void k_rho_phi_from_slabs(const float* __restrict__ slabs, size_t sla
 }
 
 hipError_t launch_bwd_rho_virtual_wave(const Dev& P, const RhoDev& W, const float* audio, const float* loss, float* grad_out, int rank1_mode,
-                                       hipStream_t s) {
+                                       int bwd_waves, hipStream_t s) {
     Dev V = P;
     V.B = P.B * W.rank;
     V.hst = reinterpret_cast<float*>(W.stash);
@@ -310,7 +310,8 @@ hipError_t launch_bwd_rho_virtual_wave(const Dev& P, const RhoDev& W, const floa
     V.gphi = nullptr;
     V.status = nullptr;
     hipError_t e;
-    { KScope ks("k_bwd_wave", s); e = launch_bwd_wave(V, audio, rank1_mode, s); }
+    const bool two = bwd_waves == 2 && rank1_mode == 3 && P.f16_shift == 0;      // 3 = CMPS_RANK1_F16X2: as cmps_psi_loss_bwd chooses
+    { KScope ks(two ? "k_bwd_wave2w" : "k_bwd_wave", s); e = two ? launch_bwd_wave2w(V, audio, s) : launch_bwd_wave(V, audio, rank1_mode, s); }
     if (e != hipSuccess) return e;
     KScope ks("reduce + finalize", s);
     e = launch_reduce_only(V, s);

@@ -79,7 +79,8 @@ enum {
     CMPS_OPT_BWD_WAVES = 6 /* the reverse scan of 17 <= D <= 32 (PsiCMPS arithmetic, F16X2 sums): 2 (default) = two wavefronts per clip on one
                         * SIMD, a chain wave and a gradient wave (k_bwd_wave2w, cmps_wave_bwd2.hip); 1 = one wavefront per clip (k_bwd_wave,
                         * the round-4 kernel: the A/B setting).  Same float32 tolerances; every other CMPS_OPT_RANK1 value, a non-zero
-                        * CMPS_OPT_F16_SCALE_SHIFT, the legacy mode and the RhoCMPS columns run one wavefront whatever this says */,
+                        * CMPS_OPT_F16_SCALE_SHIFT and the legacy mode run one wavefront whatever this says; the RhoCMPS reverse sweep on virtual clips
+                        * (CMPS_OPT_RHO_BWD) follows it */,
     CMPS_OPT_F16_SCALE_SHIFT = 4 /* DIAGNOSTIC, default 0: added to the exponent of every data-dependent fp16 scale of the wave reverse
                         * scan's F16X2 arithmetic (range -40 .. 40).  A positive value pushes the pieces out of fp16 range on purpose:
                         * how tests/test_gpu_parity.py provokes CMPS_ERR_F16_RANGE.  No reference counterpart. */,

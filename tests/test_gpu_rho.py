@@ -303,7 +303,7 @@ def test_rho_wide_kernels_match_oracle_and_general_kernels(D, rank, T, B, sigma,
                                                     (20, 9, 257, 2, 0.4, 0.6), (32, 17, 40, 7, 0.1, 0.3)])
 def test_rho_reverse_on_virtual_clips_matches_gemm_reverse_and_oracle(D, rank, T, B, sigma, rscale):
     """D <= 32, rank > 8 (round 5; CMPS_OPT_RHO_BWD): the reverse sweep that follows the row-array GEMM forward is, by default, the
-    pure-state wave reverse scan k_bwd_wave on one VIRTUAL clip per column (cmps_rho_wave.hip) -- given the clip's per-step scalars the
+    pure-state wave reverse scan (k_bwd_wave2w, or k_bwd_wave) on one VIRTUAL clip per column (cmps_rho_wave.hip) -- given the clip's per-step scalars the
     column cotangents do not couple.  Against k_bwd_rho_mfma (CMPS_RHO_BWD_GEMM, the round 1-4 reverse sweep: a different formulation,
     cotangent array as GEMMs) and against the matrix-form oracle; every rank-1 arithmetic of the wave scan."""
     from audio_mps_amd import _capi
@@ -317,7 +317,15 @@ def test_rho_reverse_on_virtual_clips_matches_gemm_reverse_and_oracle(D, rank, T
     loss, gv = m.loss_and_grads()
     names = set(be.kernel_times())
     be.kernel_events(False)
-    assert "k_bwd_wave" in names, names
+    assert "k_bwd_wave2w" in names, names                       # F16X2 sums: the two-wave scan (CMPS_OPT_BWD_WAVES = 2, the default)
+    _capi.check(be._h, be._lib.cmps_set_option(be._h, _capi.CMPS_OPT_BWD_WAVES, 1))
+    be.kernel_events(True)
+    _, g1 = m.loss_and_grads()
+    assert "k_bwd_wave" in set(be.kernel_times())
+    be.kernel_events(False)
+    _capi.check(be._h, be._lib.cmps_set_option(be._h, _capi.CMPS_OPT_BWD_WAVES, 2))
+    for k in ("A", "Rx", "Ry", "freqs", "Wx", "Wy"):
+        assert rel_inf(g1[k], ref64[k]) <= max(GRAD_RTOL, 3 * rel_inf(ref[k], ref64[k])), ("one wave", k)
     _capi.check(be._h, be._lib.cmps_set_option(be._h, _capi.CMPS_OPT_RHO_BWD, _capi.CMPS_RHO_BWD_GEMM))
     _, gg_ = m.loss_and_grads()
     _capi.check(be._h, be._lib.cmps_set_option(be._h, _capi.CMPS_OPT_RHO_BWD, _capi.CMPS_RHO_BWD_VIRTUAL))
