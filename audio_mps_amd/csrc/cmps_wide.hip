@@ -699,6 +699,18 @@ struct HyGeom {
     static constexpr int FBUF = HU * 4 * FROW;                    // floats of one float32 unit buffer
     static constexpr size_t LDS = (size_t)2 * 3 * PIECE + (size_t)5 * FBUF * 4 + 2 * (PD / 32) * 16 * 4;   // pieces x2, y x3, H y x2, e
 };                                                                // (the fp16 form has two pieces per buffer and leaves the third unused)
+// Where row (step j, clip, component) = 4 j + c, c = 2 clip + comp, of a unit sits in its LDS buffers.  Consecutive slots are 4 banks
+// apart (PROW, FROW = 4 mod 64 dwords).  That suits the MFMA-side ds_read_b128 accesses (a 16-lane group = 16 rows x 16 B fills the 64
+// banks) but not the build / write-out side, where a lane group touches the FOUR rows of one step with 8 - 16 consecutive dwords each and
+// stores bank modulo 32: rows 4 banks apart overlap 2- to 4-way (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.30,
+// profiles/r5_c5wide_pmc_summary.json).  slot = 8 (j >> 1) + 2 c + (j & 1): the rows of a step sit two slots = 8 banks apart (stores
+// of 8 dwords per row conflict-free, the 16-dword H y reads 2-way), and the row sets of the ds_read_b128 lane groups ({0-3, 12-15, 20-27},
+// {4-11, 16-19, 28-31}: MI355X_MICROARCH.md, LDS) still map to sixteen different slots modulo 16.
+#ifdef CMPS_DIAG_HY_NO_SLOT
+__device__ __forceinline__ constexpr int hy_slot(int row) { return row; }
+#else
+__device__ __forceinline__ constexpr int hy_slot(int row) { return 8 * (row >> 3) + 2 * (row & 3) + ((row >> 2) & 1); }
+#endif
 
 }  // namespace
 
@@ -853,7 +865,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_hy_wide(Dev P) {
             sh[1] = pack_hi16(__float_as_uint(sr0), __float_as_uint(sr1));
             sh[2] = pack_hi16(__float_as_uint(q0), __float_as_uint(q1));
         } else {
-            const int rowi = (j * 2 + pclip) * 2 + pcomp;
+            const int rowi = hy_slot((j * 2 + pclip) * 2 + pcomp);
             unsigned char* d = pcs + (size_t)(u & 1) * 3 * PIECE + rowi * PROW + prow * 2;     // rows prow, prow + 1: one dword per piece
             *reinterpret_cast<unsigned*>(d) = sh[0];
             *reinterpret_cast<unsigned*>(d + PIECE) = sh[1];
@@ -873,7 +885,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_hy_wide(Dev P) {
         constexpr int S_W0 = 0, S_E0 = S_W0 + 9, S_P0 = S_E0 + 9, S_F0 = S_P0 + 24, NS = S_F0 + 8;
         const unsigned char* pb = pcs + (size_t)PAR * 3 * PIECE;
         const int up3 = u3 == 0 ? 2 : u3 - 1, un3 = u3 == 2 ? 0 : u3 + 1;    // (u - 1) % 3, (u + 1) % 3
-        const int rowi = (cs * 2 + cc) * 2 + cf;
+        const int rowi = hy_slot((cs * 2 + cc) * 2 + cf);
         const float* yr = yf + (size_t)up3 * FBUF + rowi * FROW + 32 * w + 4 * mh;
         float* hr = hf + (size_t)(1 - PAR) * FBUF + rowi * FROW + 32 * w + 4 * mh;
         const int kw = k_lo + HU * (u - 2);                        // first step of the unit being written out
@@ -882,7 +894,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_hy_wide(Dev P) {
         auto read_b = [&](int t, int buf) {
             const int part = (16 * t) / PD, j0 = (16 * t) % PD + 8 * mh;
             const int comp = part == 0 ? cf : 1 - cf;              // Re form: [y_re; y_im]; Im form: [y_im; y_re] (sign: see the epilogue)
-            const unsigned char* src = pb + ((cs * 2 + cc) * 2 + comp) * PROW + j0 * 2;
+            const unsigned char* src = pb + hy_slot((cs * 2 + cc) * 2 + comp) * PROW + j0 * 2;
             Bq[buf][0] = __builtin_bit_cast(bf8w, *reinterpret_cast<const u4w*>(src));
             Bq[buf][1] = __builtin_bit_cast(bf8w, *reinterpret_cast<const u4w*>(src + PIECE));
             if constexpr (!F16) Bq[buf][2] = __builtin_bit_cast(bf8w, *reinterpret_cast<const u4w*>(src + 2 * PIECE));
@@ -892,7 +904,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_hy_wide(Dev P) {
             if constexpr (I < S_E0) {                             // unit u - 2: H y rows and e out (lane order: coalesced)
                 if constexpr (I < 8) {
                     constexpr int j = I;
-                    const float2 v = *reinterpret_cast<const float2*>(&hb[((j * 2 + pclip) * 2 + pcomp) * FROW + prow]);
+                    const float2 v = *reinterpret_cast<const float2*>(&hb[hy_slot((j * 2 + pclip) * 2 + pcomp) * FROW + prow]);
                     const bool ok = u >= 2 && kw + j < k_hi;
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2w, v), rs_st, ok ? voff_h : 0x7fffffff,
                                                           ok ? (kw + j) * (8 * PD * 4) : 0, 0);
