@@ -31,13 +31,15 @@ namespace {
 struct Pre2 {
     float yh, yho, yhp, un, pre;
     v2f rho;
-    float inv, s, ten, dtk, rad;
+    v2f sd;                                    // (s_k, dt_k): kept as a pair so that v_pk_fma can read s from its low half
+    float inv, ten, rad;
 };
 
 constexpr int RING_SLOT = 256;                 // bytes: one value of one step, 64 lanes
 constexpr int RING_VAL = 8 * RING_SLOT;        // one value, eight steps
 constexpr int RING_HALF = 3 * RING_VAL;        // (ybar, yhat, u) of one octet
 constexpr int SPIN_MAX = 1 << 22;              // bound of every wait loop
+constexpr int MT = 4;                          // entries of M_{k-1} formed in the tail of step k (chain_step: inside its two lane exchanges)
 
 __device__ __forceinline__ int flag_load2(unsigned addr) {
     int v;
@@ -46,6 +48,14 @@ __device__ __forceinline__ int flag_load2(unsigned addr) {
 }
 __device__ __forceinline__ void flag_store2(unsigned addr_l, int v) {       // addr_l: the flag in lane 0, a sink word in the other lanes
     asm volatile("ds_write_b32 %0, %1" : : "v"(addr_l), "v"(v) : "memory");
+}
+// v_permlane32_swap_b32 a, b (a's upper half <-> b's lower half) needs two wait states behind the VALU writes of a and b; hipcc fills
+// them with s_nop 1 although independent work is at hand.  Here they hold two entries of the next step's matrix M = Q + s R^dagger.
+__device__ __forceinline__ void swap_fill(float& a, float& b, v2f& m0, v2f r0, v2f q0, v2f& m1, v2f r1, v2f q1, v2f s2) {
+    asm("v_pk_fma_f32 %2, %4, %8, %5 op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %3, %6, %8, %7 op_sel_hi:[1,0,1]\n\t"
+        "v_permlane32_swap_b32 %0, %1"
+        : "+v"(a), "+v"(b), "=&v"(m0), "=&v"(m1) : "v"(r0), "v"(q0), "v"(r1), "v"(q1), "v"(s2));
 }
 template <int OFF>
 __device__ __forceinline__ void ring_write(unsigned addr, float v) {
@@ -173,12 +183,12 @@ __global__ __launch_bounds__(128 * WAVES, 1) void k_bwd_wave2w(Dev P, const floa
             sct[w][c & 1][lane] = make_float2(sv, tev * nv);      // what the gradient wave needs of the row (it may lag two octets behind)
             if (idx < N) accA += zbar * ex;
         };
-        auto make_pre = [&](v2f yh2, v2f rho, v4f c0, v4f c1) -> Pre2 {
+        // (sfill: the pair whose low half is s of the step whose matrix entries 10, 11 ride in the lane exchange: the CURRENT step's)
+        auto make_pre = [&](v2f yh2, v2f rho, v4f c0, v4f c1, v2f sfill) -> Pre2 {
             const float yown = yh2.x, hown = yh2.y;
             Pre2 S;
             S.rho = rho;
-            S.s = c0.x;
-            S.dtk = c0.y;
+            S.sd = __builtin_shufflevector(c0, c0, 0, 1);
             S.inv = c0.z;
             S.ten = c0.w;
             const float te = c1.x;
@@ -187,7 +197,11 @@ __global__ __launch_bounds__(128 * WAVES, 1) void k_bwd_wave2w(Dev P, const floa
             S.pre = te * hown;
             S.yh = S.inv * yown;
             S.yhp = invok * yown;
-            S.yho = osig_of(S.yh, hb);
+            {
+                float ya = S.yh, yb = S.yh;                                   // osig_of
+                swap_fill(ya, yb, MM[10], MRd[10], MQ[10], MM[11], MRd[11], MQ[11], sfill);
+                S.yho = hb ? -ya : yb;
+            }
             const v2f un = cmul2(mk2(S.yh, S.yho), rho);
             S.un = un.x;
             return S;
@@ -206,7 +220,12 @@ __global__ __launch_bounds__(128 * WAVES, 1) void k_bwd_wave2w(Dev P, const floa
             const int jr = (N - 1) & (CHB - 1), jc = (N - 1) & (CH - 1);
             own_issue(aYown + jr * 512, aRho + jr * 256, aScl + jc * 32, yh_j, rho_j, c0_j, c1_j);
             lds_wait_own<0>(yh_j, rho_j, c0_j, c1_j);
-            S = make_pre(yh_j, rho_j, c0_j, c1_j);
+            S = make_pre(yh_j, rho_j, c0_j, c1_j, __builtin_shufflevector(c0_j, c0_j, 0, 1));    // (first step: its own row)
+        }
+        {   // the first step's tail-formed matrix entries (chain_step)
+            const v2f s2 = mk2(S.sd.x, S.sd.x);
+#pragma unroll
+            for (int m = 16 - MT; m < 16; ++m) MM[m] = __builtin_elementwise_fma(MRd[m], s2, MQ[m]);
         }
         float g = 0.f, go = 0.f;                      // cotangent of u_{k+1}: split value and its osig
         const float2 p0 = P.phi0 ? P.phi0[av * DPW + i] : P.psi0[i];
@@ -217,7 +236,7 @@ __global__ __launch_bounds__(128 * WAVES, 1) void k_bwd_wave2w(Dev P, const floa
         // ring slot `aslot` (an LDS address with the value / slot offsets folded in by the caller)
         auto chain_step = [&](const Pre2& S, float uk, auto have_pre, bool exact, unsigned aslot, auto slot_off) -> Pre2 {
             constexpr int SO = decltype(slot_off)::value;        // constant part of the slot address (the aligned octets: the whole slot)
-            facc += S.dtk * (go * S.un);
+            facc += S.sd.y * (go * S.un);
             const v2f yhbp = cmul2_conj_b(mk2(g, go), S.rho);              // conj(rho_k) g
             const float yhb = yhbp.x;
             float dot = rad_next;
@@ -228,15 +247,21 @@ __global__ __launch_bounds__(128 * WAVES, 1) void k_bwd_wave2w(Dev P, const floa
             rad_next = S.rad;
             const float ybar = (yhb - dot * S.yhp) * S.inv + S.pre;
             bcast_issue(aBw, aBr, ybar, qc);                               // 9 ops
-            {   // M_k = Q + s_k R^dagger, in the shadow of the broadcast
-                const v2f s2 = mk2(S.s, S.s);
+            {   // M_k = Q + s_k R^dagger, in the shadow of the broadcast (entries 10, 11: inside this step's pre stage, make_pre; the last MT: in
+                // the tail of the step before)
+                const v2f s2 = mk2(S.sd.x, S.sd.x);
 #pragma unroll
-                for (int m = 0; m < 16; ++m) MM[m] = __builtin_elementwise_fma(MRd[m], s2, MQ[m]);
+                for (int m = 0; m < 16 - MT - 2; ++m) MM[m] = __builtin_elementwise_fma(MRd[m], s2, MQ[m]);
             }
             Pre2 Sn = S;
+            if constexpr (!decltype(have_pre)::value) {                     // no pre stage to carry entries 10, 11 (step 0)
+                const v2f s2 = mk2(S.sd.x, S.sd.x);
+                MM[10] = __builtin_elementwise_fma(MRd[10], s2, MQ[10]);
+                MM[11] = __builtin_elementwise_fma(MRd[11], s2, MQ[11]);
+            }
             if constexpr (decltype(have_pre)::value) {
                 lds_wait_own<9>(yh_j, rho_j, c0_j, c1_j);
-                Sn = make_pre(yh_j, rho_j, c0_j, c1_j);
+                Sn = make_pre(yh_j, rho_j, c0_j, c1_j, S.sd);
                 uk = Sn.un;
             }
             // the gradient wave's operands of this step (behind the broadcast: the counted waits below only get stricter)
@@ -248,10 +273,17 @@ __global__ __launch_bounds__(128 * WAVES, 1) void k_bwd_wave2w(Dev P, const floa
             mv1_lo(MM, qc, am);
             lds_wait_hi<3>(qc);
             mv1_hi(MM, qc, am);
-            const float md = swapadd(am.x, am.y);
+            // the tail is one dependency chain with two lane exchanges in it (VALU write -> permlane read: wait states the compiler fills
+            // with s_nop): MT entries of the NEXT step's matrix go there (the mat-vec above has consumed this step's)
+            const v2f sn2 = __builtin_shufflevector(c0_j, c0_j, 0, 1);     // (s, dtk) of the next step's row: only the low half is read
+            float sx = am.x, sy = am.y;                                    // swapadd (cmps_wave_util.h)
+            swap_fill(sx, sy, MM[12], MRd[12], MQ[12], MM[13], MRd[13], MQ[13], sn2);
+            const float md = sx + sy;
             accS += md * uk;
             g = ybar + md;
-            go = osig_of(g, hb);
+            float ga = g, gb = g;                                          // osig_of
+            swap_fill(ga, gb, MM[14], MRd[14], MQ[14], MM[15], MRd[15], MQ[15], sn2);
+            go = hb ? -ga : gb;
             return Sn;
         };
         // hand an octet over: (wait until the gradient wave has left this half: octets o - 2 and below consumed) ... written ... publish
