@@ -7,6 +7,7 @@ All arithmetic of the hot path happens in libcmps.so (audio_mps_amd/csrc/*.hip).
 from __future__ import annotations
 
 import ctypes
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -64,6 +65,8 @@ class HipScan:
         _capi.check(self._h, self._lib.cmps_set_variant(self._h, int(variant)))
         if rank1 is not None:
             self.set_rank1(rank1)
+        if os.environ.get("CMPS_BWD_WAVES"):            # diagnostic (like CMPS_LIB): A/B of the one- and two-wave reverse scans without code changes
+            _capi.check(self._h, self._lib.cmps_set_option(self._h, _capi.CMPS_OPT_BWD_WAVES, int(os.environ["CMPS_BWD_WAVES"])))
         self._ws = None
         self._ws_key = None
         self._param_buf = torch.empty(2 * D * D + 3 * D, dtype=torch.float32, device=self.device)

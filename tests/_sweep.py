@@ -157,8 +157,13 @@ def sweep_rho(rng, n, out):
         cfg = (D, r, T, B, round(rs, 4), round(amp, 4), round(hp.sigma, 5))
         assert np.all(np.isfinite(per)) and all(np.all(np.isfinite(grads[k])) for k in grads), ("rho non-finite", cfg)
         out.append(("rho", "loss", _loss_err(per, ref["per_clip"]), LOSS_BAR, cfg))
-        out.append(("rho", "grad", max(rel_inf(grads[k], ref[k]) for k in ("Rx", "Ry", "freqs", "Wx", "Wy")), GRAD_BAR, cfg))
         ref32 = O.rho_loss_and_grads(O.HParams(**hp.values()), ov, m.variables["Wx"], m.variables["Wy"], audio, "f32")
+        # per tensor against max(bar, 2 x the float32 oracle's own distance from float64): at tiny R / long clips the frequency gradient of
+        # ANY float32 evaluation sits 1 - 2e-4 from float64 (seeds 31, 32: 1.1e-4 ... 2.0e-4 for the oracle and for every kernel setting
+        # alike, scripts/dev_rho_sweep_cases.py); the record is the tensor closest to (or furthest above) its bar
+        worst = max(((rel_inf(grads[k], ref[k]), max(GRAD_BAR, 2.0 * rel_inf(ref32[k], ref[k]))) for k in ("Rx", "Ry", "freqs", "Wx", "Wy")),
+                    key=lambda eb: eb[0] / eb[1])
+        out.append(("rho", "grad", worst[0], worst[1], cfg))
         out.append(("rho", "dA", rel_inf(grads["A"], ref["A"]), _dA_bar(ref32["A"], ref["A"], GRAD_BAR), cfg))
 
 
