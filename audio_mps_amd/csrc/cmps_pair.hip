@@ -141,7 +141,10 @@ struct ChainLane {
     unsigned lo[KH], hi[KH];      // LDS byte addresses (parity 0 image) of the A operand of local K-step tau: K < D (array re / im) and K >= D (-im / re)
     int wr1, wr2;                 // byte offsets of the rows this lane writes: own array; -im (Im lanes) or the dummy row (Re lanes)
 };
-template <int PD>
+// STACK (the chain16 kernels, round 5): A rows 4 f + 2 / 4 f + 3 carry the LO fp16 piece of the own / partner form (read from the piece-1
+// image, VEC bytes behind the piece-0 image) instead of repeating row 4 f: one MFMA then multiplies BOTH pieces of the vector with a
+// matrix piece (registers 0, 1: hi piece; 2, 3: lo piece; the caller adds them), one LDS read per K-step feeds it.
+template <int PD, bool STACK = false>
 __device__ __forceinline__ ChainLane<PD / 32> chain_lane(int w, int lane, unsigned img0) {
     constexpr int VROW = PairLds<PD>::VROW, KH = PD / 32;
     ChainLane<KH> g;
@@ -149,10 +152,11 @@ __device__ __forceinline__ ChainLane<PD / 32> chain_lane(int w, int lane, unsign
     g.ia = 32 * w + 2 * g.j; g.ib = g.ia + 1;
     // A rows 4 f (register 0 of the result: this lane's own form) and 4 f + 1 (register 1: the Re <-> Im PARTNER's form, so that no
     // lane ever has to fetch its partner's value from 16 lanes away); the other rows repeat row 4 f (their results are not used)
-    const int af = ((lane >> 2) & 3) ^ ((lane & 3) == 1 ? 1 : 0), aq = af >> 1, kg = lane >> 4;
+    const int af = ((lane >> 2) & 3) ^ ((STACK ? (lane & 1) == 1 : (lane & 3) == 1) ? 1 : 0), aq = af >> 1, kg = lane >> 4;
     const bool ac1 = (af & 1) != 0;                                   // c1 = [u_im; u_re], c0 = [u_re; -u_im]
-    const unsigned rd_lo = img0 + ((ac1 ? 1 : 0) * 2 + aq) * VROW + 16 * kg;
-    const unsigned rd_hi = img0 + ((ac1 ? 0 : 2) * 2 + aq) * VROW + 16 * kg;
+    const unsigned pc1 = (STACK && (lane & 2)) ? 8u * VROW : 0u;      // the piece-1 image (Chain16Lds: VEC = 8 VROW bytes behind piece 0)
+    const unsigned rd_lo = img0 + pc1 + ((ac1 ? 1 : 0) * 2 + aq) * VROW + 16 * kg;
+    const unsigned rd_hi = img0 + pc1 + ((ac1 ? 0 : 2) * 2 + aq) * VROW + 16 * kg;
 #pragma unroll
     for (int t = 0; t < KH; ++t) {
         g.lo[t] = rd_lo + 64 * ((t + w) % KH);
@@ -780,8 +784,8 @@ hipError_t launch_fwd_pair(const Dev& P, const float* audio, float* loss, bool s
 // float32-faithful forward chain on the matrix cores (round 4): the training forward of the WIDE family (CMPS_VARIANT_WIDE / AUTO
 // above D = 32) when CMPS_OPT_WIDE_CHAIN = MFMA.  Lane layout, K order and step structure of k_fwd_pair's chain waves, with every
 // operand split into TWO fp16 pieces (round to nearest: hi = f16(x), lo = f16(x - hi), 11 + 1 + 11 + 1 bits) and the three products
-// hi hi' + hi lo' + lo hi' on v_mfma_f32_16x16x32_f16, as in k_grad_gemm's F16 mode (cmps_grad_gemm.h): 12 MFMAs per K-step, 6 D / 8
-// per step and wave.  fp16 has 5 exponent bits, so the operands are scaled by powers of two chosen ONCE per launch from guaranteed
+// hi hi' + hi lo' + lo hi' on v_mfma_f32_16x16x32_f16, as in k_grad_gemm's F16 mode (cmps_grad_gemm.h).  Round 4: 12 MFMAs per K-step (8
+// in the QLITE instance); round 5: both pieces of the vector STACKED in the A rows (kstep_st): 8 (6), one operand read instead of two.  fp16 has 5 exponent bits, so the operands are scaled by powers of two chosen ONCE per launch from guaranteed
 // bounds: R and Q each by its largest entry (to 2^15), the broadcast vector ut_k = rho_{k-1} y_{k-1} by 1 + |Q|_F + max|s| |R|_F
 // (to 2^13): y_k = (1 + Q + s_k R) ut_k / |ut_k|, so |ut_{k+1}| = |y_k| <= 1 + |Q + s_k R|_2.  Only the small correction (Q + s R) ut
 // goes through the split; the identity part and everything after the mat-vec is float32, as in every kernel of the family.
@@ -828,48 +832,38 @@ __device__ __forceinline__ void load_frags_f16(u4 (&fh)[PD / 8], u4 (&fl)[PD / 8
         }
 }
 
-// one K-step: both pieces of the A operand (vector forms) against both pieces of R and Q, two tiles: 12 MFMAs, the four accumulators in
-// rotation (a dependent MFMA is four instructions = 64 cycles behind its predecessor)
 struct NoSlot { template <typename I> __device__ __forceinline__ void operator()(I) const {} };
-template <int W, bool FIRST, bool SLOTS = false, bool QLITE = false, bool PIPE = false, typename Slot = NoSlot>
-__device__ __forceinline__ void kstep12(const u4& rh0, const u4& rl0, const u4& rh1, const u4& rl1, const u4& qh0, const u4& ql0, const u4& qh1,
-                                        const u4& ql1, u4& v0, u4& v1, f4& aR0, f4& aR1, f4& aQ0, f4& aQ1, Slot&& slot = NoSlot{}) {
-    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(v0), "+v"(v1) : "n"(W) : "memory");
+// One K-step: the A operand (vector forms, both fp16 pieces STACKED in its rows: chain_lane<PD, true>) against both pieces of R and the
+// pieces of Q, two tiles, the four accumulators in rotation.  Round 4 read the two pieces as two operands and issued 12 MFMAs (8 in the QLITE
+// instance); stacked it is 8 (6) -- v R_hi and v R_lo give hi hi' + lo hi' + hi lo' (+ lo lo', 2^-22 of the product: kept, it costs nothing) in registers
+// 0 + 2 (own form) and 1 + 3 (partner) of the accumulator -- and one operand read instead of two.
+template <int W, bool FIRST, bool QLITE = false, bool PIPE = false, typename Slot = NoSlot>
+__device__ __forceinline__ void kstep_st(const u4& rh0, const u4& rl0, const u4& rh1, const u4& rl1, const u4& qh0, const u4& ql0, const u4& qh1,
+                                         const u4& ql1, u4& v, f4& aR0, f4& aR1, f4& aQ0, f4& aQ1, Slot&& slot = NoSlot{}) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(W) : "memory");
     if constexpr (FIRST) { aR0 = f4{0.f, 0.f, 0.f, 0.f}; aR1 = aR0; aQ0 = aR0; aQ1 = aR0; }
-    const h8 a0 = __builtin_bit_cast(h8, v0), a1 = __builtin_bit_cast(h8, v1);
-#define C16_MMA(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, __builtin_bit_cast(h8, B), ACC, 0, 0, 0)
-    // PIPE (the reverse scan, whose slots carry ~150 instructions of off-chain work per step): the slots' code first, then the MFMAs,
-    // interleaved by a (1 MFMA, 2 VALU) sched_group_barrier pipeline instead of walls around every slot: -0.6 ms of 16.7 at C5, three
-    // interleaved A/B rounds (profiles/r4_c5wide_chain16_ablations.log); no gain for the forward, whose slots hold LDS reads only
-    if constexpr (SLOTS && PIPE) {
+    const h8 a = __builtin_bit_cast(h8, v);
+#define C16_MMA(ACC, B) ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, __builtin_bit_cast(h8, B), ACC, 0, 0, 0)
+    if constexpr (PIPE) {               // the reverse scan: the slots' code first, then the MFMAs, interleaved 1 MFMA : 2 VALU by a sched_group_barrier pipeline instead of walls around every slot (-0.6 ms of 16.7 at C5 in round 4; no gain for the forward, whose slots hold LDS reads only)
         slot(ic<0>{}); slot(ic<1>{}); slot(ic<2>{}); slot(ic<3>{}); slot(ic<4>{}); slot(ic<5>{});
-        C16_MMA(aR0, a0, rh0); C16_MMA(aQ0, a0, qh0); C16_MMA(aR1, a0, rh1); C16_MMA(aQ1, a0, qh1);
-        C16_MMA(aR0, a0, rl0); if constexpr (!QLITE) C16_MMA(aQ0, a0, ql0); C16_MMA(aR1, a0, rl1); if constexpr (!QLITE) C16_MMA(aQ1, a0, ql1);
-        C16_MMA(aR0, a1, rh0); if constexpr (!QLITE) C16_MMA(aQ0, a1, qh0); C16_MMA(aR1, a1, rh1); if constexpr (!QLITE) C16_MMA(aQ1, a1, qh1);
-        mfma_valu_pipeline<QLITE ? 8 : 12>();
+        C16_MMA(aR0, rh0); C16_MMA(aQ0, qh0); C16_MMA(aR1, rh1); C16_MMA(aQ1, qh1);
+        C16_MMA(aR0, rl0); if constexpr (!QLITE) C16_MMA(aQ0, ql0); C16_MMA(aR1, rl1); if constexpr (!QLITE) C16_MMA(aQ1, ql1);
+        mfma_valu_pipeline<QLITE ? 6 : 8>();
         __builtin_amdgcn_sched_barrier(0);
         return;
     }
-    if constexpr (SLOTS) {              // the own K-steps: the step's LDS reads are issued one by one behind pairs of MFMAs
-        if constexpr (QLITE) {          // |Q|_F below 2^-19: its cross products are below the float32 rounding of u + Q u (the caller's test)
-            C16_MMA(aR0, a0, rh0); C16_MMA(aQ0, a0, qh0); __builtin_amdgcn_sched_barrier(0); slot(ic<0>{}); __builtin_amdgcn_sched_barrier(0);
-            C16_MMA(aR1, a0, rh1); C16_MMA(aQ1, a0, qh1); __builtin_amdgcn_sched_barrier(0); slot(ic<1>{}); __builtin_amdgcn_sched_barrier(0);
-            C16_MMA(aR0, a0, rl0); C16_MMA(aR1, a0, rl1); __builtin_amdgcn_sched_barrier(0); slot(ic<2>{}); slot(ic<3>{}); __builtin_amdgcn_sched_barrier(0);
-            C16_MMA(aR0, a1, rh0); C16_MMA(aR1, a1, rh1); __builtin_amdgcn_sched_barrier(0); slot(ic<4>{}); slot(ic<5>{}); __builtin_amdgcn_sched_barrier(0);
-            return;
-        }
-        C16_MMA(aR0, a0, rh0); C16_MMA(aQ0, a0, qh0); __builtin_amdgcn_sched_barrier(0); slot(ic<0>{}); __builtin_amdgcn_sched_barrier(0);
-        C16_MMA(aR1, a0, rh1); C16_MMA(aQ1, a0, qh1); __builtin_amdgcn_sched_barrier(0); slot(ic<1>{}); __builtin_amdgcn_sched_barrier(0);
-        C16_MMA(aR0, a0, rl0); C16_MMA(aQ0, a0, ql0); __builtin_amdgcn_sched_barrier(0); slot(ic<2>{}); __builtin_amdgcn_sched_barrier(0);
-        C16_MMA(aR1, a0, rl1); C16_MMA(aQ1, a0, ql1); __builtin_amdgcn_sched_barrier(0); slot(ic<3>{}); __builtin_amdgcn_sched_barrier(0);
-        C16_MMA(aR0, a1, rh0); C16_MMA(aQ0, a1, qh0); __builtin_amdgcn_sched_barrier(0); slot(ic<4>{}); __builtin_amdgcn_sched_barrier(0);
-        C16_MMA(aR1, a1, rh1); C16_MMA(aQ1, a1, qh1); __builtin_amdgcn_sched_barrier(0); slot(ic<5>{}); __builtin_amdgcn_sched_barrier(0);
-        return;
+    C16_MMA(aR0, rh0); C16_MMA(aQ0, qh0); __builtin_amdgcn_sched_barrier(0); slot(ic<0>{}); slot(ic<1>{}); __builtin_amdgcn_sched_barrier(0);
+    C16_MMA(aR1, rh1); C16_MMA(aQ1, qh1); __builtin_amdgcn_sched_barrier(0); slot(ic<2>{}); slot(ic<3>{}); __builtin_amdgcn_sched_barrier(0);
+    if constexpr (QLITE) {
+        C16_MMA(aR0, rl0); C16_MMA(aR1, rl1); __builtin_amdgcn_sched_barrier(0); slot(ic<4>{}); slot(ic<5>{}); __builtin_amdgcn_sched_barrier(0);
+    } else {
+        C16_MMA(aR0, rl0); C16_MMA(aQ0, ql0); __builtin_amdgcn_sched_barrier(0); slot(ic<4>{}); __builtin_amdgcn_sched_barrier(0);
+        C16_MMA(aR1, rl1); C16_MMA(aQ1, ql1); __builtin_amdgcn_sched_barrier(0); slot(ic<5>{}); __builtin_amdgcn_sched_barrier(0);
     }
-    static_assert(SLOTS, "every K-step of the chain16 kernels carries slots");
 #undef C16_MMA
 }
-
+// own + partner sums of a stacked accumulator: (hi-piece rows) + (lo-piece rows)
+__device__ __forceinline__ f2 st_sum(const f4& c) { return f2{c[0], c[1]} + f2{c[2], c[3]}; }
 
 // single 16-byte LDS reads (asm volatile statements keep their order; the data is valid after a matching counted wait)
 template <int OFF, typename V>
@@ -890,7 +884,7 @@ __device__ __forceinline__ int wide_pos(int row, int comp, int clip) {
 
 // QLITE: the instance for |Q|_F <= 2^-19 (train.py's sigma = 1e-4 puts Q = -(dt sigma^2 / 2) R^dagger R near 1e-12): Q enters with its
 // hi piece against the vector's hi piece only -- what is dropped is below 2^-11 |Q|_F |u| <= 2^-30 |u|, under the float32 rounding of
-// u + Q u -- 8 instead of 12 MFMAs per K-step.  Both instances are launched; each finds |Q|_F in its prologue and the one whose case
+// u + Q u -- 8 instead of 12 MFMAs per K-step (round 5, stacked pieces: 6 instead of 8: Q's lo fragments are not multiplied).  Both instances are launched; each finds |Q|_F in its prologue and the one whose case
 // it is not returns at once (the norm lives on the device: the host cannot choose).
 template <int PD, bool QLITE>
 __global__ __launch_bounds__(2 * PD, 1) void k_fwd_chain16(Dev P, const float* __restrict__ audio) {
@@ -959,7 +953,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_fwd_chain16(Dev P, const float* _
     }
     int lane_c = lane;
     asm volatile("" : "+v"(lane_c));
-    const ChainLane<KH> g = chain_lane<PD>(w, lane_c, lds_addr_of(&L.vec[0][0][0]));
+    const ChainLane<KH> g = chain_lane<PD, true>(w, lane_c, lds_addr_of(&L.vec[0][0][0]));
     const int q = g.q, ia = g.ia, ib = g.ib;
     const bool odd = g.odd;
     const float sg = odd ? 1.f : -1.f;
@@ -970,7 +964,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_fwd_chain16(Dev P, const float* _
     float sv0 = 0.f, sv1 = 0.f;
     float nbuf0 = 0.f, nbuf1 = 0.f;                                   // wave 0: |y_k|^2 of the current 64-step chunk, lane <-> step
     float* stash = reinterpret_cast<float*>(P.stash) + (size_t)blockIdx.x * N * (8 * PD) + wide_pos(ia, odd ? 1 : 0, q);
-    u4 o00, o01, o10, o11;                                            // the wave's own K-steps: [K half][piece]
+    u4 o0, o1;                                                        // the wave's own K-steps: [K half] (both pieces stacked in the A rows)
     float n0p = 1.f, n1p = 1.f;                                       // |y|^2 of both clips as the last step's tail read them
     // |y_kn|^2 rows of the scalar stash (wave 0; lane <-> step, one row of 64 steps per chunk), a step late and off the chain's tail
     auto book = [&](int kn) {
@@ -995,8 +989,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_fwd_chain16(Dev P, const float* _
         *reinterpret_cast<unsigned*>(b1p + g.wr2) = lo ^ 0x80008000u;
     };
     write_image(0, ua.x, ub.x);
-    rd_own<0>(g.lo[0], g.hi[0], o00, o10);
-    rd_own<VEC>(g.lo[0], g.hi[0], o01, o11);
+    rd_own<0>(g.lo[0], g.hi[0], o0, o1);
     rho_stage<PD>(P, RS, 0, 0, 64 * w + lane_c);
     __syncthreads();
 
@@ -1026,34 +1019,34 @@ __global__ __launch_bounds__(2 * PD, 1) void k_fwd_chain16(Dev P, const float* _
         const unsigned ax0 = a_nrm + 32 * p;                                                                               \
         const unsigned ax2 = a_rho + 8 * PD * (((k / RCH) & 1) * RCH + (k & (RCH - 1)));                                   \
         f4 xn0, xn1, rh, cR0, cR1, cQ0, cQ1;                                                                               \
-        u4 v[4 * KH - 4];                                                                                                  \
+        u4 v[2 * KH - 2];                                                                                                  \
         /* the step's LDS reads (the other waves' K ranges, both pieces; three table rows) are issued two per K-step behind pairs of    \
            MFMAs, two K-steps ahead of their use: the four waves' 60 KB per step then pass the LDS (128 B / clk) spread over the step  \
            instead of in one burst behind the barrier (which took ~390 cycles with the matrix pipe idle, ~200 even when interleaved    \
            with the own K-steps' MFMAs).  K-step index 0, 1 = the own K ranges; index i + 2 = rest K-step i, operands v[2 i], v[2 i + 1]. */ \
         auto rd_slot = [&](auto kidx_c, auto sl_c) {                                                                       \
             constexpr int kidx = decltype(kidx_c)::value, sl = decltype(sl_c)::value, NR = 2 * KH - 2;                     \
-            if constexpr (kidx < NR && (sl == 0 || sl == 2)) {                                                             \
-                constexpr int n = 2 * kidx + sl / 2, half = n / NR, t = 1 + (n % NR) / 2, pc = n & 1;                      \
-                rd128<p * 2 * VEC + pc * VEC>(half ? g.hi[t] : g.lo[t], v[n]);                                             \
+            if constexpr (kidx < NR && sl == 0) {                                                                          \
+                constexpr int half = kidx / (KH - 1), t = 1 + kidx % (KH - 1);                                             \
+                rd128<p * 2 * VEC>(half ? g.hi[t] : g.lo[t], v[kidx]);                                                     \
             }                                                                                                              \
             if constexpr (kidx == NR && sl == 0) rd128<0>(ax0, xn0);                                                       \
             if constexpr (kidx == NR && sl == 2) rd128<16>(ax0, xn1);                                                      \
             if constexpr (kidx == NR && sl == 4) rd128<0>(ax2, rh);                                                        \
             if constexpr (kidx == 1 && sl == 5) book(k - 2);           /* wave 0: |y_{k-2}|^2 into the scalar stash's rows */ \
         };                                                                                                                 \
-        kstep12<15, true, true, QLITE>(FRh[0], FRl[0], FRh[KS], FRl[KS], FQh[0], QL_(0), FQh[KS], QL_(KS), o00, o01, cR0, cR1, cQ0, cQ1, \
-                                [&](auto sl) { rd_slot(ic<0>{}, sl); });                                                   \
-        kstep12<15, false, true, QLITE>(FRh[KH], FRl[KH], FRh[KS + KH], FRl[KS + KH], FQh[KH], QL_(KH), FQh[KS + KH], QL_(KS + KH), o10, o11, cR0, cR1, cQ0, cQ1, \
-                                 [&](auto sl) { rd_slot(ic<1>{}, sl); });                                                  \
+        kstep_st<15, true, QLITE>(FRh[0], FRl[0], FRh[KS], FRl[KS], FQh[0], QL_(0), FQh[KS], QL_(KS), o0, cR0, cR1, cQ0, cQ1,             \
+                                  [&](auto sl) { rd_slot(ic<0>{}, sl); });                                                 \
+        kstep_st<15, false, QLITE>(FRh[KH], FRl[KH], FRh[KS + KH], FRl[KS + KH], FQh[KH], QL_(KH), FQh[KS + KH], QL_(KS + KH), o1, cR0, cR1, cQ0, cQ1, \
+                                   [&](auto sl) { rd_slot(ic<1>{}, sl); });                                                \
         C16_STAMP(1)                                                                                                       \
         gg::static_for<0, 2 * KH - 2>([&](auto ic_) {                                                                      \
             constexpr int I = decltype(ic_)::value, NR = 2 * KH - 2;                                                       \
             constexpr int T_ = I < KH - 1 ? 1 + I : KH + 1 + (I - (KH - 1));                                               \
-            /* in flight behind this K-step's operands: the reads issued during the K-step before (two operands, or the three tables) */ \
-            kstep12<(I + 1 < NR ? 2 : 3), false, true, QLITE>(FRh[T_], FRl[T_], FRh[KS + T_], FRl[KS + T_], FQh[T_], QL_(T_), FQh[KS + T_], \
-                                                       QL_(KS + T_), v[2 * I], v[2 * I + 1], cR0, cR1, cQ0, cQ1,             \
-                                                       [&](auto sl) { rd_slot(ic<I + 2>{}, sl); });                         \
+            /* in flight behind this K-step's operand: the reads issued during the K-step before (one operand, or the three tables) */ \
+            kstep_st<(I + 1 < NR ? 1 : 3), false, QLITE>(FRh[T_], FRl[T_], FRh[KS + T_], FRl[KS + T_], FQh[T_], QL_(T_), FQh[KS + T_],  \
+                                                         QL_(KS + T_), v[I], cR0, cR1, cQ0, cQ1,                             \
+                                                         [&](auto sl) { rd_slot(ic<I + 2>{}, sl); });                       \
         });                                                                                                                \
         C16_STAMP(2)                                                                                                       \
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xn0), "+v"(xn1), "+v"(rh) :: "memory");                                  \
@@ -1064,16 +1057,15 @@ __global__ __launch_bounds__(2 * PD, 1) void k_fwd_chain16(Dev P, const float* _
         if (k == 0) inv = 1.f;                                                                                             \
         const float s0 = rdl(sv0, k & (PCH - 1)), s1 = rdl(sv1, k & (PCH - 1));                                            \
         const float sr = (q ? s1 : s0) * iRV;                                                                              \
-        const f2 ya = inv * (ua + (f2{cQ0[0], cQ0[1]} * iQV + sr * f2{cR0[0], cR0[1]}));                                    \
-        const f2 yb = inv * (ub + (f2{cQ1[0], cQ1[1]} * iQV + sr * f2{cR1[0], cR1[1]}));                                    \
+        const f2 ya = inv * (ua + (st_sum(cQ0) * iQV + sr * st_sum(cR0)));                                                  \
+        const f2 yb = inv * (ub + (st_sum(cQ1) * iQV + sr * st_sum(cR1)));                                                  \
         const f2 n2 = ya * ya + yb * yb;                                                                                   \
         float nn = n2.x + n2.y;                                                                                            \
         const f2 ta = f2{sg * rh.y, -(sg * rh.y)} * __builtin_shufflevector(ya, ya, 1, 0);                                  \
         const f2 tb = f2{sg * rh.w, -(sg * rh.w)} * __builtin_shufflevector(yb, yb, 1, 0);                                  \
         ua = rh.x * ya + ta;   ub = rh.z * yb + tb;                   /* ut_{k+1} = rho_k y_k (un-normalised), own and partner */ \
         write_image(p ^ 1, ua.x, ub.x);                                                                                    \
-        rd_own<(p ^ 1) * 2 * VEC>(g.lo[0], g.hi[0], o00, o10);        /* (same wave, in order: no wait between store and read) */ \
-        rd_own<(p ^ 1) * 2 * VEC + VEC>(g.lo[0], g.hi[0], o01, o11);                                                       \
+        rd_own<(p ^ 1) * 2 * VEC>(g.lo[0], g.hi[0], o0, o1);          /* (same wave, in order: no wait between store and read) */ \
         nn = row_sum16(nn);                                                                                                \
         if (lane_c == 0 || lane_c == 32) L.nrm[p ^ 1][q][w] = nn;                                                          \
         if (k < N) *reinterpret_cast<float2*>(stash + (size_t)k * (8 * PD)) = make_float2(ya.x, yb.x);                      \
@@ -1474,7 +1466,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_pair(Dev P, const float* __re
 // ------------------------------------------------------------------------------------------------
 // float32-faithful reverse chain on the matrix cores (round 4): the wide family's reverse scan when CMPS_OPT_WIDE_CHAIN = MFMA.
 // k_bwd_pair's lane layout and step structure with k_bwd_wide's arithmetic (its per-step scalars, rows, slab and Abar conventions)
-// and k_fwd_chain16's operands: two fp16 pieces per value, three products (Q: one in the QLITE instance), 12 (8) MFMAs per K-step.
+// and k_fwd_chain16's operands: two fp16 pieces per value, three products (Q: one in the QLITE instance); round 5: 8 (6) MFMAs per K-step (kstep_st).
 // What is new here is the scale of the broadcast vector: ybar_k has no a-priori size (in the forward |ut| <= 1 + |M|), and an fp16
 // overflow would be silent.  Every step derives a power of two per clip from a GUARANTEED bound, identical in all lanes and known
 // before the image is written:
@@ -1553,7 +1545,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_chain16(Dev P, const float* _
     }
     int lane = lane0;
     asm volatile("" : "+v"(lane));
-    const ChainLane<KH> g = chain_lane<PD>(w, lane, lds_addr_of(&L.vec[0][0][0]));
+    const ChainLane<KH> g = chain_lane<PD, true>(w, lane, lds_addr_of(&L.vec[0][0][0]));
     const int q = g.q, ia = g.ia, ib = g.ib;
     const bool odd = g.odd;
     const float wq = (q == 0 || two) ? 1.f : 0.f;
@@ -1621,7 +1613,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_chain16(Dev P, const float* _
     float facca = 0.f, faccb = 0.f, accS = 0.f;
     unsigned ymxb = 0u;                                 // max |ybar| of this lane over the clip (float bits), for the gradient GEMM's scale
     float sda = 0.f, sdb = 0.f;                         // ((Q + s R^dagger) ybar) rows of the step before: its Abar term is added a step late
-    u4 o00, o01, o10, o11;
+    u4 o0, o1;                                          // the wave's own K-steps: [K half] (both pieces stacked in the A rows)
     float4 rh, rhp;
     f4 S0, S1, SP0, SP1;
     float c3a, c3b;                                     // te_k (H y_k) - ok_k yhat_k rad_{k+1} inv_k
@@ -1701,8 +1693,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_chain16(Dev P, const float* _
         const float hbb = rh.z * gb.x - sgn * rh.w * gb.y;                                                                         \
         const float yba = fmaf(hba, S0.y, c3a), ybb = fmaf(hbb, S0.y, c3b);                                                        \
         write_image(p, yba * sS, ybb * sS);                                                                                        \
-        rd_own<p * 2 * VEC>(g.lo[0], g.hi[0], o00, o10);                                                                           \
-        rd_own<p * 2 * VEC + VEC>(g.lo[0], g.hi[0], o01, o11);                                                                     \
+        rd_own<p * 2 * VEC>(g.lo[0], g.hi[0], o0, o1);                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                                                         \
         C16_STAMP(1)                                                                                                               \
         /* ---- behind the stores: ybar out (for the gradient GEMM) ---- */                                                        \
@@ -1714,7 +1705,7 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_chain16(Dev P, const float* _
         lds_barrier();                                                                                                             \
         C16_STAMP(3)                                                                                                               \
         f4 cQ0, cQ1, cD0, cD1, nS0, nS1;                                                                                           \
-        u4 v[4 * KH - 4];                                                                                                          \
+        u4 v[2 * KH - 2];                                                                                                          \
         float4 nrh;                                                                                                                \
         f2 uka, ukb;                                                                                                               \
         float ypa, ypb, pypa, pypb, pyba, pybb, sSn;                                                                         \
@@ -1723,9 +1714,9 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_chain16(Dev P, const float* _
         const float invp = SP0.y;                                                                                                  \
         auto slot = [&](auto kidx_c, auto sl_c) {                                                                                  \
             constexpr int kidx = decltype(kidx_c)::value, sl = decltype(sl_c)::value;                                              \
-            if constexpr (kidx < NR && (sl == 0 || sl == 2)) {       /* operands of rest K-step kidx */                            \
-                constexpr int n = 2 * kidx + sl / 2, half = n / NR, t = 1 + (n % NR) / 2, pc = n & 1;                              \
-                rd128<p * 2 * VEC + pc * VEC>(half ? g.hi[t] : g.lo[t], v[n]);                                                     \
+            if constexpr (kidx < NR && sl == 0) {                    /* operand of rest K-step kidx */                             \
+                constexpr int half = kidx / (KH - 1), t = 1 + kidx % (KH - 1);                                                     \
+                rd128<p * 2 * VEC>(half ? g.hi[t] : g.lo[t], v[kidx]);                                                             \
             }                                                                                                                      \
             if constexpr (kidx == NR && sl == 0) rd128<0>(ax0, nS0);  /* scalar rows of step k - 2 */                              \
             if constexpr (kidx == NR && sl == 2) rd128<16>(ax0, nS1);                                                              \
@@ -1783,15 +1774,17 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_chain16(Dev P, const float* _
                 PAIR_PIN1(sSn);                                                                                                    \
             }                                                                                                                      \
         };                                                                                                                         \
-        kstep12<15, true, true, QLITE, true>(FDh[0], FDl[0], FDh[KS], FDl[KS], FQh[0], QL_(0), FQh[KS], QL_(KS), o00, o01, cD0, cD1, cQ0, cQ1, \
-                                       [&](auto sl) { slot(ic<0>{}, sl); });                                                       \
-        kstep12<15, false, true, QLITE, true>(FDh[KH], FDl[KH], FDh[KS + KH], FDl[KS + KH], FQh[KH], QL_(KH), FQh[KS + KH], QL_(KS + KH), o10, o11, \
-                                        cD0, cD1, cQ0, cQ1, [&](auto sl) { slot(ic<1>{}, sl); });                                  \
+        kstep_st<15, true, QLITE, true>(FDh[0], FDl[0], FDh[KS], FDl[KS], FQh[0], QL_(0), FQh[KS], QL_(KS), o0, cD0, cD1, cQ0, cQ1,          \
+                                        [&](auto sl) { slot(ic<0>{}, sl); });                                                      \
+        kstep_st<15, false, QLITE, true>(FDh[KH], FDl[KH], FDh[KS + KH], FDl[KS + KH], FQh[KH], QL_(KH), FQh[KS + KH], QL_(KS + KH), o1,   \
+                                         cD0, cD1, cQ0, cQ1, [&](auto sl) { slot(ic<1>{}, sl); });                                 \
         gg::static_for<0, NR>([&](auto ic_) {                                                                                      \
             constexpr int I = decltype(ic_)::value;                                                                                \
             constexpr int T_ = I < KH - 1 ? 1 + I : KH + 1 + (I - (KH - 1));                                                       \
-            kstep12<(I == 0 ? 4 : 2), false, true, QLITE, true>(FDh[T_], FDl[T_], FDh[KS + T_], FDl[KS + T_], FQh[T_], QL_(T_), FQh[KS + T_], \
-                                                              QL_(KS + T_), v[2 * I], v[2 * I + 1], cD0, cD1, cQ0, cQ1,            \
+            /* in flight behind this K-step's operand: what the K-step before issued -- the next operand (behind the first one also   \
+               the two ymx rows), or the two table rows */                                                                        \
+            kstep_st<(I == 0 ? 3 : I + 1 < NR ? 1 : 2), false, QLITE, true>(FDh[T_], FDl[T_], FDh[KS + T_], FDl[KS + T_], FQh[T_], QL_(T_),     \
+                                                              FQh[KS + T_], QL_(KS + T_), v[I], cD0, cD1, cQ0, cQ1,               \
                                                               [&](auto sl) { slot(ic<I + 2>{}, sl); });                            \
         });                                                                                                                        \
         C16_STAMP(4)                                                                                                               \
@@ -1800,8 +1793,8 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_chain16(Dev P, const float* _
         if (k == 0) { uka = ps0a; ukb = ps0b; }                      /* u_0 = psi_0 */                                             \
         {   /* g = ybar + (Q + s R^dagger) ybar, (own, partner) pairs; the accumulators carry the scales sQ sS and sD sS */           \
             const float cq = iQ * iS, cd = S0.x * (iD * iS);                                                                       \
-            const f2 da = f2{cQ0[0], cQ0[1]} * cq + cd * f2{cD0[0], cD0[1]};                                                       \
-            const f2 db = f2{cQ1[0], cQ1[1]} * cq + cd * f2{cD1[0], cD1[1]};                                                       \
+            const f2 da = st_sum(cQ0) * cq + cd * st_sum(cD0);                                                                     \
+            const f2 db = st_sum(cQ1) * cq + cd * st_sum(cD1);                                                                     \
             ga = f2{yba, pyba} + da;                                                                                               \
             gb = f2{ybb, pybb} + db;                                                                                               \
             sda = da.x; sdb = db.x;                                                                                                \

@@ -464,9 +464,9 @@ def kernel_work_model(fam, D, DP, rank1):
         gp = 6 if rank1 == 2 else 3
         gname = {1: "k_grad_gemm<2>", 2: "k_grad_gemm<3>", 3: "k_grad_gemm<f16x2>"}[rank1]
         return {"k_fwd_wide": [("valu_fp32", 12 * D * D, "merged (Q + s R) u, v_pk_fma_f32"), ("hbm", 8.0 * DP, "y rows written: 16 DP B per pair-step")],
-                "k_fwd_chain16": [("mfma_bf16", 128 * DP * DP, "(Q + s R) u as f16x2-split operands on v_mfma_f32_16x16x32_f16: DP / 32 waves x DP / 16 K-steps x 8 "
-                                                                 "MFMAs per pair and step (R three products, Q one: the |Q|_F <= 2^-19 instance; 12 otherwise), as "
-                                                                 "issued (8 of the 16 A rows carry forms)"),
+                "k_fwd_chain16": [("mfma_bf16", 96 * DP * DP, "(Q + s R) u as f16x2-split operands on v_mfma_f32_16x16x32_f16: DP / 32 waves x DP / 16 K-steps x 6 "
+                                                                "MFMAs per pair and step (round 5: both pieces of the vector stacked in the 16 A rows, so v R_hi + v R_lo are "
+                                                                "the three products and all rows carry data; Q one: the |Q|_F <= 2^-19 instance; 8 otherwise), as issued"),
                                   ("hbm", 8.0 * DP, "y rows written: 16 DP B per pair-step")],
                 ("k_hy_wide<3>" if rank1 in (1, 2) else "k_hy_wide<f16x2>"):
                     [("mfma_bf16", 8 * (6 if rank1 in (1, 2) else 3) * D * D,
@@ -474,7 +474,7 @@ def kernel_work_model(fam, D, DP, rank1):
                      ("hbm", 16.0 * DP, "y rows read + H y rows written")],
                 "k_loss_wide": [("hbm", 8.0, "e_k, |y_k|^2 scalars")],
                 "k_bwd_wide": [("valu_fp32", 12 * D * D, "merged (Q + s R^dagger) ybar"), ("hbm", 24.0 * DP, "y, H y rows read, ybar rows written")],
-                "k_bwd_chain16": [("mfma_bf16", 128 * DP * DP, "(Q + s R^dagger) ybar as f16x2-split operands on v_mfma_f32_16x16x32_f16, as issued (see k_fwd_chain16)"),
+                "k_bwd_chain16": [("mfma_bf16", 96 * DP * DP, "(Q + s R^dagger) ybar as f16x2-split operands on v_mfma_f32_16x16x32_f16, as issued (see k_fwd_chain16)"),
                                   ("hbm", 24.0 * DP, "y, H y rows read, ybar rows written")],
                 gname: [("mfma_bf16", 24 * gp * D * D, f"three rank-1 sums as GEMMs, {gp} piece products (fp16 and bf16 MFMAs have the same dense peak)"),
                         ("hbm", 16.0 * DP, "y and ybar rows read: 32 DP B per pair-step")]}
