@@ -154,9 +154,16 @@ __device__ __forceinline__ ChainLane<PD / 32> chain_lane(int w, int lane, unsign
     // lane ever has to fetch its partner's value from 16 lanes away); the other rows repeat row 4 f (their results are not used)
     const int af = ((lane >> 2) & 3) ^ ((STACK ? (lane & 1) == 1 : (lane & 3) == 1) ? 1 : 0), aq = af >> 1, kg = lane >> 4;
     const bool ac1 = (af & 1) != 0;                                   // c1 = [u_im; u_re], c0 = [u_re; -u_im]
-    const unsigned pc1 = (STACK && (lane & 2)) ? 8u * VROW : 0u;      // the piece-1 image (Chain16Lds: VEC = 8 VROW bytes behind piece 0)
-    const unsigned rd_lo = img0 + pc1 + ((ac1 ? 1 : 0) * 2 + aq) * VROW + 16 * kg;
-    const unsigned rd_hi = img0 + pc1 + ((ac1 ? 0 : 2) * 2 + aq) * VROW + 16 * kg;
+    // The piece-1 image lies VEC = 8 VROW bytes (a multiple of the 256-B bank row) behind piece 0, so the same array of both pieces falls on
+    // the same banks.  A 16-lane group of the operand's ds_read_b128 touches sixteen different 16-byte pieces now -- (own, partner) x (piece
+    // 0, 1) x four (form, K group) pairs -- and has exactly sixteen slots: the piece-1 image therefore stores array KIND k (re | im | -im |
+    // dummy) in the place of kind 3 - k, which puts its four arrays of either K half on the bank slots the piece-0 reads leave free
+    // (measured before this: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.38 / 0.31 in the two chain kernels, every operand read 2-way).
+    const bool p1 = STACK && (lane & 2);
+    const unsigned pc1 = p1 ? 8u * VROW : 0u;
+    const int kind_lo = ac1 ? 1 : 0, kind_hi = ac1 ? 0 : 2;
+    const unsigned rd_lo = img0 + pc1 + ((p1 ? 3 - kind_lo : kind_lo) * 2 + aq) * VROW + 16 * kg;
+    const unsigned rd_hi = img0 + pc1 + ((p1 ? 3 - kind_hi : kind_hi) * 2 + aq) * VROW + 16 * kg;
 #pragma unroll
     for (int t = 0; t < KH; ++t) {
         g.lo[t] = rd_lo + 64 * ((t + w) % KH);
@@ -985,8 +992,8 @@ __global__ __launch_bounds__(2 * PD, 1) void k_fwd_chain16(Dev P, const float* _
         unsigned char* b1p = L.vec[par][1];
         *reinterpret_cast<unsigned*>(b0p + g.wr1) = hi;
         *reinterpret_cast<unsigned*>(b0p + g.wr2) = hi ^ 0x80008000u;
-        *reinterpret_cast<unsigned*>(b1p + g.wr1) = lo;
-        *reinterpret_cast<unsigned*>(b1p + g.wr2) = lo ^ 0x80008000u;
+        *reinterpret_cast<unsigned*>(b1p + g.wr2) = lo;               // piece 1: array kind k in the place of kind 3 - k (chain_lane)
+        *reinterpret_cast<unsigned*>(b1p + g.wr1) = lo ^ 0x80008000u;
     };
     write_image(0, ua.x, ub.x);
     rd_own<0>(g.lo[0], g.hi[0], o0, o1);
@@ -1662,8 +1669,8 @@ __global__ __launch_bounds__(2 * PD, 1) void k_bwd_chain16(Dev P, const float* _
         unsigned char* b1p = L.vec[par][1];
         *reinterpret_cast<unsigned*>(b0p + g.wr1) = hi;
         *reinterpret_cast<unsigned*>(b0p + g.wr2) = hi ^ 0x80008000u;
-        *reinterpret_cast<unsigned*>(b1p + g.wr1) = lo;
-        *reinterpret_cast<unsigned*>(b1p + g.wr2) = lo ^ 0x80008000u;
+        *reinterpret_cast<unsigned*>(b1p + g.wr2) = lo;               // piece 1: array kind k in the place of kind 3 - k (chain_lane)
+        *reinterpret_cast<unsigned*>(b1p + g.wr1) = lo ^ 0x80008000u;
     };
 #if defined(CMPS_DIAG) && defined(C16_TIMING)              // diagnostic builds only: s_memtime stamps of a step's phases
     unsigned long long tS[7] = {0, 0, 0, 0, 0, 0, 0}, tAcc[6] = {0, 0, 0, 0, 0, 0}, tN = 0;
