@@ -294,7 +294,11 @@ __global__ __launch_bounds__(128 * WAVES, 1) void k_bwd_wave2w(Dev P, const floa
             asm volatile("ds_read_b32 %0, %1" : "=v"(cons_seen) : "v"(aCons) : "memory");
         };
         auto wait_free = [&](int o) {
-            if (o >= 2 && __builtin_amdgcn_readfirstlane(cons_seen) < o - 1) {
+            // (the register is valid only behind the counted waits of the steps since peek_cons: a volatile asm keeps its place among them,
+            // the readfirstlane builtin could be scheduled right behind the read)
+            int seen;
+            asm volatile("s_nop 0\n\tv_readfirstlane_b32 %0, %1" : "=s"(seen) : "v"(cons_seen));
+            if (o >= 2 && seen < o - 1) {
                 int spin = 0;
                 while (flag_load2(aCons) < o - 1 && ++spin < SPIN_MAX) __builtin_amdgcn_s_sleep(1);
             }
