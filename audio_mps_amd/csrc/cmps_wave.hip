@@ -487,7 +487,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_bwd_wave(Dev P, const float* 
             mv1_hi(MM, qc, am);
         }
         MF_HOOK(4)
-        const float md = swapadd(am.x, am.y);
+        const float md = swapadd_after_asm(am.x, am.y);
         accS += md * uk;
         g = ybar + md;
         MF_HOOKB(4)

@@ -78,7 +78,7 @@ __device__ __forceinline__ v2f mv16r(const v2f (&M)[4], const v4f (&q)[2], float
 }
 // (partial.x, partial.y) of the four K-quarters -> split16 total in every lane
 __device__ __forceinline__ float combine16(float px, float py) {
-    const float s1 = swapadd(px, py);      // lanes 0-31: Re over quarters (q, q+2); lanes 32-63: Im
+    const float s1 = swapadd_after_asm(px, py);      // lanes 0-31: Re over quarters (q, q+2); lanes 32-63: Im
     const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(s1), __float_as_uint(s1), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);      // + the neighbouring 16-lane row
 }

@@ -140,6 +140,14 @@ __device__ __forceinline__ float swapadd(float px, float py) {
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(px), __float_as_uint(py), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);     // half 0: sum of x's; half 1: sum of y's
 }
+// The same directly behind an asm block that wrote px / py (the mat-vec chains): hipcc's hazard recogniser does not see VALU writes inside
+// inline asm and left ONE instruction between the chain's last v_pk_fma_f32 and the exchange in k_bwd_wave / k_fwd_wave16, where its own
+// code keeps two wait states (s_nop 1) -- found by scripts/check_mfma_hazards.py's round-5 check.  No wrong result was ever observed (a
+// lone wave issues every ~5 cycles), but the distance is now written out.
+__device__ __forceinline__ float swapadd_after_asm(float px, float py) {
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(px), "+v"(py));
+    return px + py;
+}
 // split value x -> osig (see header): half 0 gets the partner's value, half 1 minus the partner's value
 __device__ __forceinline__ float osig_of(float x, bool hbit) {
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);

@@ -19,6 +19,12 @@ compiler-placed readers in this library sit at 8, 12 and 18).
 Third distance of the same kind (the wave reductions are asm DPP chains): a DPP instruction may not read, as its permuted operand,
 a VGPR that a VALU instruction wrote fewer than two wait states earlier.
 
+Round 5 added two hand-written sequences of the same kind to k_bwd_wave2w (cmps_wave_bwd2.hip), and two checks for them:
+  * v_permlane32_swap / v_permlane16_swap may not read a VGPR that a VALU instruction wrote fewer than two wait states earlier (the
+    chain step's three exchanges are asm with two v_pk_fma_f32 in those slots; hipcc pads its own with s_nop 1);
+  * the staged stash rows are asm loads (global_load_dwordx4 with a scalar base), which hipcc's s_waitcnt insertion does not count:
+    on every path from such a load, nothing may touch its destination registers before an s_waitcnt vmcnt(0).
+
 usage: check_mfma_hazards.py [libcmps.so]      exit code 1 when a violation is found
 """
 import os
@@ -174,7 +180,33 @@ def check(funcs):
                 need -= 1
                 j += 1
 
+        def walk_until_vmcnt0(i, dst):
+            """instructions behind i, in layout order, that touch dst before an s_waitcnt vmcnt(0).  Layout order = every `if` body entered:
+            the load and its commit sit under the same run-time condition eight steps apart, so a walk over branch edges would report the
+            infeasible path that takes the first and skips the second"""
+            for j in range(i + 1, len(ins)):
+                a, op, args = ins[j]
+                if op == "s_waitcnt" and re.search(r"vmcnt\(0\)", args):
+                    return
+                if op in ("s_endpgm", "s_setpc_b64"):
+                    return
+                touched = set()
+                for t in (args.split(",") if args else []):
+                    touched |= regs(t)
+                if touched & dst:
+                    yield j
+                    return
+
         for i, (a, op, args) in enumerate(ins):
+            if op.startswith(("v_permlane32_swap", "v_permlane16_swap")) and args:      # fourth distance: VALU write -> lane-exchange read
+                toks = args.split(",")
+                for j in walk(i, NEED, vregs(toks[0]) | vregs(toks[1]), set()):
+                    bad.append((name, ins[j], ins[i]))
+                continue
+            if op == "global_load_dwordx4" and "k_bwd_wave2w" in name and re.search(r"s\[\d+:\d+\]", args):      # asm loads: see the header
+                for j in walk_until_vmcnt0(i, regs(args.split(",")[0])):
+                    bad.append((name, ins[i], ins[j]))
+                continue
             if "_dpp" in op and args:                     # third distance: VALU write -> DPP read of the permuted operand (src0), 2 wait states
                 toks = args.split(",")
                 if len(toks) >= 2:
