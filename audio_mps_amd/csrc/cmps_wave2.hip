@@ -211,7 +211,7 @@ __global__ __launch_bounds__(128 * WAVES, 1) void k_fwd_wave2(Dev P, const float
             _Pragma("unroll") for (int m = 0; m < 16; ++m) MM[m] = __builtin_elementwise_fma(MR[m], s2_, MQ[m]); \
         }
         FORM_M(rdlane(sv, 0))
-        bcast_issue_tab(aUw, aUr, u, aRho, qu, rho);
+        bcast_issue_tab_sync(aUw, aUr, u, aRho, qu, rho);
         for (int c = 0; c < NC2; ++c) {
             const int kbeg = c * CH2;
             const int cnt = (N - kbeg) < CH2 ? (N - kbeg) : CH2;
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(128 * WAVES, 1) void k_fwd_wave2(Dev P, const float
                 aRho = lds_addr(&stR[w][(c + 1) & 1][0]) + i * 8;     // both halves of the next chunk are in place
                 sv = LEGACY ? P.dt * (xa1 - xa0) : (xa1 - xa0) / A;    // the next chunk's s_k
                 FORM_M(rdlane(sv, 0))                                  // the last in-loop FORM_M used the stale lane 0
-                bcast_issue_tab(aUw, aUr, u, aRho, qu, rho);
+                bcast_issue_tab_sync(aUw, aUr, u, aRho, qu, rho);      // (its registers cross the back-edge: the wait sits inside)
             }
         }
 #undef FORM_M

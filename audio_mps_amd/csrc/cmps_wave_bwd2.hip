@@ -424,11 +424,13 @@ __global__ __launch_bounds__(128 * WAVES, 1) void k_bwd_wave2w(Dev P, const floa
                          : "v"(ab), "v"(ap), "n"(t), "n"(t + 1), "n"(8 + t), "n"(8 + t + 1), "n"(16 + t), "n"(16 + t + 1) : "memory");   // units of 256 B
         }
         asm volatile("ds_read_b64 %0, %1" : "=&v"(stv) : "v"(aSct) : "memory");
+        // every loaded register passes through a statement that HOLDS the wait (only the first one stalls): registers pinned by separate empty
+        // statements may be copied by the compiler in front of the wait that makes them valid -- it happened in k_bwd_wave3's first form
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(yb[0]), "+v"(yb[1]), "+v"(yb[2]), "+v"(yb[3]), "+v"(yb[4]), "+v"(yb[5]), "+v"(yb[6]), "+v"(yb[7]) :: "memory");
-        asm volatile("" : "+v"(yh[0]), "+v"(yh[1]), "+v"(yh[2]), "+v"(yh[3]), "+v"(yh[4]), "+v"(yh[5]), "+v"(yh[6]), "+v"(yh[7]));
-        asm volatile("" : "+v"(yhq[0]), "+v"(yhq[1]), "+v"(yhq[2]), "+v"(yhq[3]), "+v"(yhq[4]), "+v"(yhq[5]), "+v"(yhq[6]), "+v"(yhq[7]));
-        asm volatile("" : "+v"(uu[0]), "+v"(uu[1]), "+v"(uu[2]), "+v"(uu[3]), "+v"(uu[4]), "+v"(uu[5]), "+v"(uu[6]), "+v"(uu[7]));
-        asm volatile("" : "+v"(uq[0]), "+v"(uq[1]), "+v"(uq[2]), "+v"(uq[3]), "+v"(uq[4]), "+v"(uq[5]), "+v"(uq[6]), "+v"(uq[7]), "+v"(stv));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(yh[0]), "+v"(yh[1]), "+v"(yh[2]), "+v"(yh[3]), "+v"(yh[4]), "+v"(yh[5]), "+v"(yh[6]), "+v"(yh[7]) :: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(yhq[0]), "+v"(yhq[1]), "+v"(yhq[2]), "+v"(yhq[3]), "+v"(yhq[4]), "+v"(yhq[5]), "+v"(yhq[6]), "+v"(yhq[7]) :: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(uu[0]), "+v"(uu[1]), "+v"(uu[2]), "+v"(uu[3]), "+v"(uu[4]), "+v"(uu[5]), "+v"(uu[6]), "+v"(uu[7]) :: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(uq[0]), "+v"(uq[1]), "+v"(uq[2]), "+v"(uq[3]), "+v"(uq[4]), "+v"(uq[5]), "+v"(uq[6]), "+v"(uq[7]), "+v"(stv) :: "memory");
         flag_store2(aConsL, o + 1);            // every ring read has landed: the half is free
         // a1 = ten yhat, a2 = s ybar (the scalars of slot t sit in lane t of the octet's scalar rows)
         float a1[8], a2[8], mQ = 0.f, mR = 0.f;

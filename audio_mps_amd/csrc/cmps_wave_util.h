@@ -200,6 +200,22 @@ __device__ __forceinline__ void bcast_issue_tab(unsigned wr, unsigned rd, float 
                    "=&v"(t)
                  : "v"(wr), "v"(mine), "v"(rd), "v"(tab) : "memory");
 }
+// The same with the wait inside the statement: for a broadcast whose registers cross a loop back-edge before the counted wait of the next
+// step.  hipcc may copy loop-carried registers at the back-edge, and it takes an asm statement's outputs for valid when the statement
+// ends: in k_fwd_wave2<no stash> it copied the broadcast registers between the chunk-end issue and the next chunk's first wait
+// (scripts/check_mfma_hazards.py, round 5; the 50 instructions in between had always covered the LDS latency).
+__device__ __forceinline__ void bcast_issue_tab_sync(unsigned wr, unsigned rd, float mine, unsigned tab,
+                                                     v4f (&o)[8], v2f& t) {
+    asm volatile("ds_write_b32 %9, %10\n\t"
+                 "ds_read_b128 %0, %11\n\tds_read_b128 %1, %11 offset:16\n\t"
+                 "ds_read_b128 %2, %11 offset:32\n\tds_read_b128 %3, %11 offset:48\n\t"
+                 "ds_read_b128 %4, %11 offset:64\n\tds_read_b128 %5, %11 offset:80\n\t"
+                 "ds_read_b128 %6, %11 offset:96\n\tds_read_b128 %7, %11 offset:112\n\t"
+                 "ds_read_b64 %8, %12\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]),
+                   "=&v"(t)
+                 : "v"(wr), "v"(mine), "v"(rd), "v"(tab) : "memory");
+}
 // the same with a compile-time offset on the table address
 template <int TOFF>
 __device__ __forceinline__ void bcast_issue_tab_off(unsigned wr, unsigned rd, float mine, unsigned tab, v4f (&o)[8], v2f& t) {

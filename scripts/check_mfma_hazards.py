@@ -22,8 +22,10 @@ a VGPR that a VALU instruction wrote fewer than two wait states earlier.
 Round 5 added two hand-written sequences of the same kind to k_bwd_wave2w (cmps_wave_bwd2.hip), and two checks for them:
   * v_permlane32_swap / v_permlane16_swap may not read a VGPR that a VALU instruction wrote fewer than two wait states earlier (the
     chain step's three exchanges are asm with two v_pk_fma_f32 in those slots; hipcc pads its own with s_nop 1);
-  * the staged stash rows are asm loads (global_load_dwordx4 with a scalar base), which hipcc's s_waitcnt insertion does not count:
-    on every path from such a load, nothing may touch its destination registers before an s_waitcnt vmcnt(0).
+  * no instruction may read the destination of a ds_read / global_load / buffer_load before SOME s_waitcnt on its counter has been issued
+    behind it (layout order).  The asm loads are awaited by waits in later statements, which hipcc's own s_waitcnt insertion does not
+    know about: a copy of a loaded register that the compiler places in front of the wait -- pair re-packing in k_bwd_wave3's first form,
+    loop-carried copies of the broadcast registers in k_fwd_wave2<no stash> -- reads whatever the register held before.
 
 usage: check_mfma_hazards.py [libcmps.so]      exit code 1 when a violation is found
 """
@@ -180,22 +182,26 @@ def check(funcs):
                 need -= 1
                 j += 1
 
-        def walk_until_vmcnt0(i, dst):
-            """instructions behind i, in layout order, that touch dst before an s_waitcnt vmcnt(0).  Layout order = every `if` body entered:
-            the load and its commit sit under the same run-time condition eight steps apart, so a walk over branch edges would report the
-            infeasible path that takes the first and skips the second"""
-            for j in range(i + 1, len(ins)):
+        def read_before_any_wait(i, dst, counter):
+            """instructions behind i, in layout order, that READ dst before any s_waitcnt on `counter` (lgkmcnt / vmcnt) has been issued: a load
+            whose result the compiler copied or used in front of the wait that makes it valid (inline-asm loads with the wait in a later
+            statement: k_bwd_wave3's first form copied five such registers)"""
+            for j in range(i + 1, min(i + 400, len(ins))):
                 a, op, args = ins[j]
-                if op == "s_waitcnt" and re.search(r"vmcnt\(0\)", args):
+                if op == "s_waitcnt" and counter in args:
                     return
-                if op in ("s_endpgm", "s_setpc_b64"):
-                    return
+                if op in ("s_endpgm", "s_setpc_b64", "s_barrier") or op.startswith(("s_cbranch", "s_branch")) or j in preds:
+                    return                                # straight-line code only: what another path does with the register is not this load's
+                toks = args.split(",") if args else []
+                srcs = toks[1:] if (op.startswith(("v_", "ds_read", "global_load", "buffer_load")) and not op.startswith("v_cmp")) else toks
                 touched = set()
-                for t in (args.split(",") if args else []):
+                for t in srcs:
                     touched |= regs(t)
                 if touched & dst:
                     yield j
                     return
+                if toks and op.startswith(("v_", "ds_read", "global_load")) and regs(toks[0]) & dst:
+                    return                                # overwritten: the load's value is dead
 
         for i, (a, op, args) in enumerate(ins):
             if op.startswith(("v_permlane32_swap", "v_permlane16_swap")) and args:      # fourth distance: VALU write -> lane-exchange read
@@ -203,10 +209,13 @@ def check(funcs):
                 for j in walk(i, NEED, vregs(toks[0]) | vregs(toks[1]), set()):
                     bad.append((name, ins[j], ins[i]))
                 continue
-            if op == "global_load_dwordx4" and "k_bwd_wave2w" in name and re.search(r"s\[\d+:\d+\]", args):      # asm loads: see the header
-                for j in walk_until_vmcnt0(i, regs(args.split(",")[0])):
+            if op.startswith(("global_load_dword", "buffer_load_dword")) and args:      # (asm loads included: hipcc does not count those)
+                for j in read_before_any_wait(i, regs(args.split(",")[0]), "vmcnt"):
                     bad.append((name, ins[i], ins[j]))
                 continue
+            if op.startswith("ds_read") and args:
+                for j in read_before_any_wait(i, regs(args.split(",")[0]), "lgkmcnt"):
+                    bad.append((name, ins[i], ins[j]))
             if "_dpp" in op and args:                     # third distance: VALU write -> DPP read of the permuted operand (src0), 2 wait states
                 toks = args.split(",")
                 if len(toks) >= 2:
