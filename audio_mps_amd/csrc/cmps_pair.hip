@@ -456,7 +456,14 @@ constexpr int LOSS_SLEEP = PAIR_LOSS_SLEEP;
 template <int D>
 struct FwdRing {
     static constexpr int BROW = D * 2 + 16, FROW = D * 4 + 16;         // padded rows (bank spread for the loss waves' reads)
-    __attribute__((aligned(16))) unsigned char b[2 * FB][2][4][BROW];  // [slot][clip][re | im | -im | dummy] bf16
+    // [slot][row][BROW] bf16 + 64 B per slot.  Row of (clip, kind = re | im | -im | dummy): brow().  A 16-lane group of the loss waves'
+    // ds_read_b128 holds sixteen (step, clip, component) columns; with the rows in [clip][kind] order and slots 8 BROW apart they fell on
+    // eight 16-byte bank slots (every read 2-way: the kernel's SQ_LDS_BANK_CONFLICT fraction 0.15).  Clip 1's rows reversed and 64 B between
+    // slots: sixteen different slots for either operand half (brute-forced over row orders and paddings, the chain waves' 4-byte stores
+    // keep their 2-way overlap: there is no layout without either).
+    static constexpr int BSLOT = 8 * BROW + 64;
+    static __device__ __forceinline__ constexpr int brow(int clip, int kind) { return clip ? 7 - kind : kind; }
+    __attribute__((aligned(16))) unsigned char b[2 * FB][BSLOT];
     __attribute__((aligned(16))) unsigned char f[2 * FB][2][2][FROW];  // [slot][clip][re | im] float32
     __attribute__((aligned(16))) float nrm[2 * FB][2][4];              // [slot][clip][chain wave]: partial |y|^2
     __attribute__((aligned(16))) float ee[2][2 * FB][4];               // [batch parity][step in batch * 2 + clip][loss wave]
@@ -514,7 +521,7 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
         const bool odd = g.odd;
         const float sg = odd ? 1.f : -1.f;                             // (rho y)_own = rho_re y_own + sg rho_im y_partner
         // the ring rows of this lane within a slot: bf16 (own array, and -im / dummy), float32
-        const int rb1 = (q * 4 + (odd ? 1 : 0)) * BROW + ia * 2, rb2 = (q * 4 + (odd ? 2 : 3)) * BROW + ia * 2;
+        const int rb1 = FwdRing<PD>::brow(q, odd ? 1 : 0) * BROW + ia * 2, rb2 = FwdRing<PD>::brow(q, odd ? 2 : 3) * BROW + ia * 2;
         const int rf = (q * 2 + (odd ? 1 : 0)) * FROW + ia * 4;
         const unsigned a_nrm = lds_addr_of(&RG.nrm[0][q][0]);        // + 32 slot
         const unsigned a_rho = lds_addr_of(&RS.row[0][0][ia]);        // + 8 PD (32 buffer + row)
@@ -601,7 +608,7 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
             __builtin_amdgcn_sched_barrier(0);                                                                             \
             if (lane_c == 0 || lane_c == 32) RG.nrm[hb_ * FB + (J)][q][w] = nn;                                           \
             {   /* y_k for the loss waves: bf16 images and float32 */                                                      \
-                unsigned char* rbase = &RG.b[hb_ * FB + (J)][0][0][0];                                                     \
+                unsigned char* rbase = &RG.b[hb_ * FB + (J)][0];                                                           \
                 *reinterpret_cast<unsigned*>(rbase + rb1) = pky;                                                           \
                 *reinterpret_cast<unsigned*>(rbase + rb2) = pky ^ 0x80008000u;                                             \
                 *reinterpret_cast<float2*>(&RG.f[hb_ * FB + (J)][0][0][0] + rf) = make_float2(yna, ynb);                   \
@@ -657,7 +664,7 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
     }
     // byte offsets of this lane inside a ring slot: B operand rows (H_re part: own component; H_im part: -im for Re columns,
     // re for Im columns), the float32 rows of its column
-    const int ob1 = (clip * 4 + comp) * BROW + 16 * hk, ob2 = (clip * 4 + (comp ? 0 : 2)) * BROW + 16 * hk;
+    const int ob1 = FwdRing<PD>::brow(clip, comp) * BROW + 16 * hk, ob2 = FwdRing<PD>::brow(clip, comp ? 0 : 2) * BROW + 16 * hk;
     const int of = (clip * 2 + comp) * FROW + (32 * w + 4 * hk) * 4;
     float* stash = reinterpret_cast<float*>(P.stash);
     float* sc_c = SAVE ? P.scal + ((size_t)(clip ? b1 : b0) * NC) * 128 : nullptr;
@@ -679,7 +686,7 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
         const int pb = bt - 1, pe = bt - 2;
         const bool mul = pb >= 0 && FB * pb < N;
         const bool fin = pe >= 0 && FB * pe < N;
-        const unsigned char* bslot = &RG.b[(pb & 1) * FB + sb][0][0][0];
+        const unsigned char* bslot = &RG.b[(pb & 1) * FB + sb][0];
         const unsigned char* fslot = &RG.f[(pb & 1) * FB + sb][0][0][0];
         const int step_b = FB * pb + sb, step_e = FB * pe + sb;       // this lane's step in either batch
 #if defined(CMPS_DIAG) && defined(PABL_LOSS_NO_READS)     // diagnostic builds only (scripts/ablate.py)
