@@ -467,6 +467,7 @@ struct FwdRing {
     __attribute__((aligned(16))) unsigned char f[2 * FB][2][2][FROW];  // [slot][clip][re | im] float32
     __attribute__((aligned(16))) float nrm[2 * FB][2][4];              // [slot][clip][chain wave]: partial |y|^2
     __attribute__((aligned(16))) float ee[2][2 * FB][4];               // [batch parity][step in batch * 2 + clip][loss wave]
+    __attribute__((aligned(16))) float sinc[2][2][PCH];                // [chunk parity][clip][step]: s_k = x_k / A of a 64-step chunk (loss wave 0 -> chain waves)
 };
 
 typedef float f16t __attribute__((ext_vector_type(16)));
@@ -553,13 +554,16 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
             constexpr int p = (J) & 1;                                                                                     \
             const int k = FB * bt + (J);                                                                                   \
             if ((J) == 0 && (bt & (PCH / FB - 1)) == 0) {              /* increments of the next 64 steps, one per lane */  \
-                const int idx = k + lane_c;                                                                                \
-                const bool in0 = idx < T, in1 = idx + 1 < T;                                                               \
-                sv0 = ((in1 ? xr0[idx + 1] : 0.f) - (in0 ? xr0[idx] : 0.f)) / A;         /* model.py:263, 303 */            \
-                sv1 = ((in1 ? xr1[idx + 1] : 0.f) - (in0 ? xr1[idx] : 0.f)) / A;                                           \
+                if (bt == 0) {                                                                                             \
+                    const int idx = k + lane_c;                                                                            \
+                    const bool in0 = idx < T, in1 = idx + 1 < T;                                                           \
+                    sv0 = ((in1 ? xr0[idx + 1] : 0.f) - (in0 ? xr0[idx] : 0.f)) / A;     /* model.py:263, 303 */            \
+                    sv1 = ((in1 ? xr1[idx + 1] : 0.f) - (in0 ? xr1[idx] : 0.f)) / A;                                       \
+                } else {                                               /* left in LDS a chunk ago by loss wave 0 (below) */ \
+                    sv0 = RG.sinc[(bt / (PCH / FB)) & 1][0][lane_c];                                                       \
+                    sv1 = RG.sinc[(bt / (PCH / FB)) & 1][1][lane_c];                                                       \
+                }                                                                                                          \
             }                                                                                                              \
-            if ((J) == 0 && (bt & (RCH / FB - 1)) == 0)                /* next chunk of rho into the other buffer */        \
-                rho_stage<PD>(P, RS, k / RCH + 1, (k / RCH + 1) & 1, 64 * w + lane_c);                                     \
             const int hb_ = bt & 1;                                    /* the ring half of this block */                   \
             /* |y_{k-1}|^2 partials (published by the previous step; nothing at k = 0) and rho_k of this lane's rows */     \
             const int nslot = (J) > 0 ? hb_ * FB + (J) - 1 : (hb_ ^ 1) * FB + FB - 1;                                      \
@@ -683,6 +687,16 @@ __global__ __launch_bounds__(4 * PD, 1) void k_fwd_pair(Dev P, const float* __re
         for (int jj = 0; jj < FB; ++jj) lds_barrier();
         continue;
 #endif
+        // the next chunk of rho into the other buffer -- here, not in the chain waves (round 5): the loads are consumed at once, a memory
+        // latency every 32 steps that cost the chain 2.4 % (ablation: profiles/r5_c5_ablations.log); the step's barrier publishes the rows
+        // 32 steps before the chain reads them
+        if ((bt & (RCH / FB - 1)) == 0) rho_stage<PD>(P, RS, (FB * bt) / RCH + 1, ((FB * bt) / RCH + 1) & 1, 64 * w + lane);
+        if (w == 0 && (bt & (PCH / FB - 1)) == 0) {                   // and the increments of the next 64-step chunk (the same expressions)
+            const int cn = bt / (PCH / FB) + 1, idx = cn * PCH + lane;
+            const bool in0 = idx < T, in1 = idx + 1 < T;
+            RG.sinc[cn & 1][0][lane] = ((in1 ? xr0[idx + 1] : 0.f) - (in0 ? xr0[idx] : 0.f)) / A;
+            RG.sinc[cn & 1][1][lane] = ((in1 ? xr1[idx + 1] : 0.f) - (in0 ? xr1[idx] : 0.f)) / A;
+        }
         const int pb = bt - 1, pe = bt - 2;
         const bool mul = pb >= 0 && FB * pb < N;
         const bool fin = pe >= 0 && FB * pe < N;
